@@ -1,0 +1,10 @@
+"""closed_chain_motion_planner_amd — MI355X-native batched closed-chain constraint projector.
+
+Only the projector hot path of jkw0701/closed_chain_motion_planner: the C-ABI library
+`libccmp.so` (include/ccmp.h, csrc/) and this thin host mirror of the reference's constraint
+interface.  Importing the package needs neither a GPU nor the built library; using it does.
+"""
+from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem  # noqa: F401
+from .constraint import ArmModel, Context, KinematicChainConstraint, load_config  # noqa: F401
+
+__version__ = "0.1.0"

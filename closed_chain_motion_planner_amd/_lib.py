@@ -1,0 +1,129 @@
+"""ctypes binding of libccmp.so (include/ccmp.h).  Fails loudly when the library is missing:
+there is no CPU implementation of the hot path in this package."""
+import ctypes as C
+import os
+
+from .build import LIBPATH
+
+
+class CcmpError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        super().__init__("%s failed: %s (%d)%s" % (what, _strerror(code), code, (" — " + detail) if detail else ""))
+
+
+class CcmpProblem(C.Structure):
+    """ccmp_problem of include/ccmp.h (row-major matrices)."""
+
+    _fields_ = [
+        ("axis", C.c_double * 42),
+        ("offset", C.c_double * 42),
+        ("ee", C.c_double * 6),
+        ("R_tool", C.c_double * 18),
+        ("base_R", C.c_double * 18),
+        ("base_p", C.c_double * 6),
+        ("init_R", C.c_double * 9),
+        ("init_p", C.c_double * 3),
+        ("lb", C.c_double * 7),
+        ("ub", C.c_double * 7),
+        ("joint_eps", C.c_double),
+        ("tol_pos", C.c_double),
+        ("tol_rot", C.c_double),
+        ("step", C.c_double),
+        ("delta", C.c_double),
+        ("lambda_", C.c_double),
+        ("start_joint", C.c_double * 14),
+        ("obj_start_R", C.c_double * 9),
+        ("obj_start_p", C.c_double * 3),
+        ("obj_goal_R", C.c_double * 9),
+        ("obj_goal_p", C.c_double * 3),
+        ("t_o7_R", C.c_double * 18),
+        ("t_o7_p", C.c_double * 6),
+        ("max_iter", C.c_int32),
+        ("jacobian_mode", C.c_int32),
+        ("arm_index", C.c_int32 * 2),
+    ]
+
+    def copy(self):
+        return CcmpProblem.from_buffer_copy(bytes(self))
+
+
+CCMP_JAC_FD = 0
+CCMP_JAC_ANALYTIC = 1
+
+# every symbol include/ccmp.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "ccmp_problem_from_yaml", "ccmp_problem_init", "ccmp_set_start", "ccmp_set_tolerance", "ccmp_set_calibration",
+    "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_device", "ccmp_ctx_num_cus",
+    "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
+    "ccmp_sample_project_batch", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid",
+    "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_detmath_probe", "ccmp_strerror",
+    "ccmp_last_hip_error", "ccmp_version", "ccmp_problem_sizeof",
+]
+
+_lib = None
+
+
+def lib():
+    """The loaded libccmp.so; raises if it has not been built (python -m closed_chain_motion_planner_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise ImportError(
+            "libccmp.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIBPATH)
+    L = C.CDLL(LIBPATH)
+    dp, u8p, u16p, vp = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.c_void_p
+    pp = C.POINTER(CcmpProblem)
+    sig = {
+        "ccmp_problem_from_yaml": ([C.c_char_p, pp], C.c_int),
+        "ccmp_problem_init": ([pp, C.c_char_p, C.c_int, C.c_char_p, C.c_int, dp, dp, dp, dp, dp], C.c_int),
+        "ccmp_set_start": ([pp, dp], C.c_int),
+        "ccmp_set_tolerance": ([pp, C.c_double, C.c_double], C.c_int),
+        "ccmp_set_calibration": ([pp, C.c_int, dp], C.c_int),
+        "ccmp_ctx_create": ([C.c_int, C.POINTER(vp)], C.c_int),
+        "ccmp_ctx_destroy": ([vp], None),
+        "ccmp_ctx_set_waves_per_cu": ([vp, C.c_int], C.c_int),
+        "ccmp_ctx_device": ([vp], C.c_int),
+        "ccmp_ctx_num_cus": ([vp], C.c_int),
+        "ccmp_function_batch": ([vp, pp, vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_project_batch": ([vp, pp, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_is_satisfied_batch": ([vp, pp, vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_joint_valid_batch": ([vp, pp, vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_sample_project_batch": ([vp, pp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_ambient_uniform_batch": ([vp, pp, C.c_uint64, C.c_uint64, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_enforce_bounds_batch": ([vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_compact_valid": ([vp, vp, vp, C.c_size_t, vp, vp, vp], C.c_int),
+        "ccmp_project_host": ([vp, pp, dp, dp, u8p, u16p, C.c_size_t], C.c_int),
+        "ccmp_function_host": ([vp, pp, dp, dp, C.c_size_t], C.c_int),
+        "ccmp_is_satisfied_host": ([vp, pp, dp, u8p, C.c_size_t], C.c_int),
+        "ccmp_detmath_probe": ([vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_strerror": ([C.c_int], C.c_char_p),
+        "ccmp_last_hip_error": ([], C.c_char_p),
+        "ccmp_version": ([], C.c_int),
+        "ccmp_problem_sizeof": ([], C.c_size_t),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = library out of date with the header
+        fn.argtypes = args
+        fn.restype = res
+    if L.ccmp_problem_sizeof() != C.sizeof(CcmpProblem):
+        raise ImportError("ccmp_problem layout mismatch between libccmp.so and the Python binding")
+    _lib = L
+    return L
+
+
+def _strerror(code):
+    try:
+        return lib().ccmp_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return "error"
+
+
+def check(code, what):
+    if code != 0:
+        detail = ""
+        if code == -2:
+            detail = lib().ccmp_last_hip_error().decode()
+        raise CcmpError(code, what, detail)

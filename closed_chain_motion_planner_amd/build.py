@@ -1,0 +1,68 @@
+"""Builds libccmp.so (HIP kernels for gfx950 + the C-ABI host code) in-tree with hipcc.
+
+Three translation units with deliberately different floating-point flags:
+  ccmp_kernels_fd.hip    -ffp-contract=off -DCCMP_USE_FMA   canonical, bit-reproducible arithmetic
+  ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   host set-up in the same rounding model
+  ccmp_kernels_fast.hip  -ffp-contract=fast                 analytic fast mode, no bitwise claim
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libccmp.so")
+ARCH = "gfx950"
+
+_UNITS = [
+    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
+    ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=fast"]),
+    ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
+]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", os.path.join("..", "..", "include", "ccmp.h")]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libccmp.so cannot be built (no CPU fallback exists)")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def build_library(force=False, verbose=False):
+    """Compile (if stale) and return the path of libccmp.so."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = hipcc_path()
+    headers = [os.path.join(CSRC, h) for h in _HEADERS]
+    objs = []
+    relink = force
+    for src, flags in _UNITS:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(objdir, src + ".o")
+        objs.append(op)
+        if force or _stale(op, [sp] + headers):
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            relink = True
+    if relink or _stale(LIBPATH, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIBPATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIBPATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

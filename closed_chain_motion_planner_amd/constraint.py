@@ -1,0 +1,297 @@
+"""Host-side mirror of the reference's constraint interface for the projector hot path.
+
+Names, argument meaning and error behaviour follow
+include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:21-137 of the reference
+(`KinematicChainConstraint`) and src/kinematics/grasping_point.cpp:34-65 (`loadConfig`), so that the
+parity tests read like tests of the reference class.  All arithmetic happens in libccmp.so on the
+GPU; PyTorch is used only to own device memory and streams.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem, check
+
+__all__ = ["Context", "KinematicChainConstraint", "ArmModel", "load_config", "CCMP_JAC_FD", "CCMP_JAC_ANALYTIC"]
+
+
+def _torch():
+    import torch  # deferred: importing the package must not need a GPU
+
+    return torch
+
+
+class Context:
+    """ccmp_ctx: one per (process, device)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(_lib.lib().ccmp_ctx_create(int(device), C.byref(self._h)), "ccmp_ctx_create")
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def num_cus(self):
+        return _lib.lib().ccmp_ctx_num_cus(self._h)
+
+    def set_waves_per_cu(self, w):
+        check(_lib.lib().ccmp_ctx_set_waves_per_cu(self._h, int(w)), "ccmp_ctx_set_waves_per_cu")
+
+    def close(self):
+        if self._h:
+            _lib.lib().ccmp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ArmModel:
+    """The two fields of the reference's `ArmModel` (panda_model.h:7-23) the projector reads."""
+
+    def __init__(self, name, index):
+        self.name = str(name)
+        self.index = int(index)
+
+
+def load_config(yaml_path):
+    """`grasping_point::loadConfig` + `ConstrainedProblem` set-up: a ready ccmp_problem."""
+    P = CcmpProblem()
+    check(_lib.lib().ccmp_problem_from_yaml(str(yaml_path).encode(), C.byref(P)), "ccmp_problem_from_yaml(%s)" % yaml_path)
+    return P
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _stream_handle(stream):
+    if stream is None:
+        return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)
+
+
+class KinematicChainConstraint:
+    """`KinematicChainConstraint : ompl::base::Constraint` (co-dimension 2) backed by libccmp.
+
+    Single-state methods (`project`, `function`, `isSatisfied`, `jointValid`) keep the reference
+    signatures on numpy vectors and run a batch of one on the GPU; the `*_batch` methods take
+    (B,14) float64 CUDA tensors.
+    """
+
+    def __init__(self, links=14, ctx=None, device=0, problem=None):
+        if int(links) != 14:
+            raise ValueError("KinematicChainConstraint: the dual-Panda chain has 14 links")
+        self.n_ = 14
+        self.ctx = ctx if ctx is not None else Context(device)
+        self._arms = [None, None]
+        self._base_max_iterations = 50  # ompl::base::Constraint::maxIterations_ default; never read by project()
+        if problem is not None:
+            self.problem = problem.copy()
+        else:
+            self.problem = None
+
+    # -- construction helpers -----------------------------------------------------------------
+    @classmethod
+    def from_yaml(cls, yaml_path, ctx=None, device=0):
+        return cls(14, ctx=ctx, device=device, problem=load_config(yaml_path))
+
+    def getCoDimension(self):
+        return 2
+
+    def getAmbientDimension(self):
+        return 14
+
+    def setArmModels(self, arm1, arm2):
+        """ConstraintFunction.h:122-126.  Callers pass arms in std::map (alphabetical) order, as
+        ConstrainedPlanningCommon.cpp:126 does."""
+        self._arms = [arm1, arm2]
+        q0 = np.zeros(14)
+        if self.problem is not None:
+            q0 = np.array(self.problem.start_joint[:], dtype=np.float64)
+        P = CcmpProblem()
+        check(_lib.lib().ccmp_problem_init(C.byref(P), arm1.name.encode(), arm1.index, arm2.name.encode(), arm2.index,
+                                           _dptr(q0), None, None, None, None), "ccmp_problem_init")
+        if self.problem is not None:  # keep tolerances / mode chosen earlier
+            P.tol_pos, P.tol_rot, P.jacobian_mode = self.problem.tol_pos, self.problem.tol_rot, self.problem.jacobian_mode
+        self.problem = P
+
+    def setInitialPosition(self, init_joint):
+        """ConstraintFunction.h:31-40."""
+        self._need_problem()
+        q0 = np.ascontiguousarray(init_joint, dtype=np.float64)
+        if q0.shape != (14,):
+            raise ValueError("init_joint must have 14 entries")
+        check(_lib.lib().ccmp_set_start(C.byref(self.problem), _dptr(q0)), "ccmp_set_start")
+
+    def setTolerance(self, tolerance1, tolerance2):
+        """ConstraintFunction.h:104-112: non-positive tolerances raise (ompl::Exception there)."""
+        self._need_problem()
+        rc = _lib.lib().ccmp_set_tolerance(C.byref(self.problem), float(tolerance1), float(tolerance2))
+        if rc != 0:
+            raise ValueError("ompl::base::Constraint::setProjectionTolerance(): tolerance must be positive.")
+
+    def setMaxIterations(self, n):
+        """Sets the *base-class* field, which the reference's project() override never reads
+        (ConstrainedPlanningCommon.cpp:129 vs ConstraintFunction.h:26,68): the cap stays 250."""
+        self._base_max_iterations = int(n)
+
+    def setJacobianMode(self, mode):
+        self._need_problem()
+        if mode not in (CCMP_JAC_FD, CCMP_JAC_ANALYTIC):
+            raise ValueError("mode must be CCMP_JAC_FD or CCMP_JAC_ANALYTIC")
+        self.problem.jacobian_mode = mode
+
+    def _need_problem(self):
+        if self.problem is None:
+            raise RuntimeError("call setArmModels()/from_yaml() first")
+
+    # -- batched API (CUDA tensors) -------------------------------------------------------------
+    def _check_q(self, q):
+        torch = _torch()
+        if not (isinstance(q, torch.Tensor) and q.is_cuda and q.dtype == torch.float64 and q.dim() == 2
+                and q.shape[1] == 14 and q.is_contiguous()):
+            raise ValueError("expected a contiguous (B,14) float64 CUDA tensor")
+        if q.device.index != self.ctx.device:
+            raise ValueError("tensor is on cuda:%s, context on cuda:%d" % (q.device.index, self.ctx.device))
+
+    def project_batch(self, q, out=None, want_iters=True, stream=None):
+        """ok[i], q_out[i], iters[i] = project(q[i]); q_out may alias q (in place, like the reference)."""
+        self._need_problem()
+        self._check_q(q)
+        torch = _torch()
+        B = q.shape[0]
+        if out is None:
+            out = torch.empty_like(q)
+        else:
+            self._check_q(out)
+        ok = torch.empty(B, dtype=torch.uint8, device=q.device)
+        it = torch.empty(B, dtype=torch.int16, device=q.device) if want_iters else None
+        check(_lib.lib().ccmp_project_batch(self.ctx.handle, C.byref(self.problem), q.data_ptr(), out.data_ptr(),
+                                            ok.data_ptr(), it.data_ptr() if it is not None else None, B,
+                                            _stream_handle(stream)), "ccmp_project_batch")
+        return out, ok, it
+
+    def sample_project_batch(self, seed, first_index, B, want_iters=True, want_ambient=False, stream=None):
+        """`jy_ProjectedStateSampler::sampleUniform` x B (jy_ProjectedStateSpace.cpp:10-15)."""
+        self._need_problem()
+        torch = _torch()
+        dev = torch.device("cuda", self.ctx.device)
+        out = torch.empty((B, 14), dtype=torch.float64, device=dev)
+        ok = torch.empty(B, dtype=torch.uint8, device=dev)
+        it = torch.empty(B, dtype=torch.int16, device=dev) if want_iters else None
+        amb = torch.empty((B, 14), dtype=torch.float64, device=dev) if want_ambient else None
+        check(_lib.lib().ccmp_sample_project_batch(self.ctx.handle, C.byref(self.problem), int(seed), int(first_index),
+                                                   out.data_ptr(), ok.data_ptr(),
+                                                   it.data_ptr() if it is not None else None,
+                                                   amb.data_ptr() if amb is not None else None, B,
+                                                   _stream_handle(stream)), "ccmp_sample_project_batch")
+        return out, ok, it, amb
+
+    def ambient_uniform_batch(self, seed, first_index, B, stream=None):
+        self._need_problem()
+        torch = _torch()
+        out = torch.empty((B, 14), dtype=torch.float64, device=torch.device("cuda", self.ctx.device))
+        check(_lib.lib().ccmp_ambient_uniform_batch(self.ctx.handle, C.byref(self.problem), int(seed), int(first_index),
+                                                    out.data_ptr(), B, _stream_handle(stream)),
+              "ccmp_ambient_uniform_batch")
+        return out
+
+    def function_batch(self, q, stream=None):
+        self._need_problem()
+        self._check_q(q)
+        torch = _torch()
+        f = torch.empty((q.shape[0], 2), dtype=torch.float64, device=q.device)
+        check(_lib.lib().ccmp_function_batch(self.ctx.handle, C.byref(self.problem), q.data_ptr(), f.data_ptr(),
+                                             q.shape[0], _stream_handle(stream)), "ccmp_function_batch")
+        return f
+
+    def is_satisfied_batch(self, q, stream=None):
+        self._need_problem()
+        self._check_q(q)
+        torch = _torch()
+        ok = torch.empty(q.shape[0], dtype=torch.uint8, device=q.device)
+        check(_lib.lib().ccmp_is_satisfied_batch(self.ctx.handle, C.byref(self.problem), q.data_ptr(), ok.data_ptr(),
+                                                 q.shape[0], _stream_handle(stream)), "ccmp_is_satisfied_batch")
+        return ok
+
+    def joint_valid_batch(self, q, stream=None):
+        self._need_problem()
+        self._check_q(q)
+        torch = _torch()
+        ok = torch.empty(q.shape[0], dtype=torch.uint8, device=q.device)
+        check(_lib.lib().ccmp_joint_valid_batch(self.ctx.handle, C.byref(self.problem), q.data_ptr(), ok.data_ptr(),
+                                                q.shape[0], _stream_handle(stream)), "ccmp_joint_valid_batch")
+        return ok
+
+    def enforce_bounds_batch(self, q, stream=None):
+        """KinematicChainSpace::enforceBounds in place (KinematicChain.h:118-130)."""
+        self._check_q(q)
+        check(_lib.lib().ccmp_enforce_bounds_batch(self.ctx.handle, q.data_ptr(), q.shape[0], _stream_handle(stream)),
+              "ccmp_enforce_bounds_batch")
+        return q
+
+    def compact_valid(self, q, ok, stream=None):
+        """Rows of q with ok != 0, in order (what the host tree consumes)."""
+        self._check_q(q)
+        torch = _torch()
+        out = torch.empty_like(q)
+        cnt = torch.zeros(1, dtype=torch.int64, device=q.device)
+        check(_lib.lib().ccmp_compact_valid(self.ctx.handle, q.data_ptr(), ok.data_ptr(), q.shape[0], out.data_ptr(),
+                                            cnt.data_ptr(), _stream_handle(stream)), "ccmp_compact_valid")
+        return out, cnt
+
+    # -- single-state API with the reference's signatures ------------------------------------------
+    def project(self, x):
+        """bool project(Eigen::Ref<VectorXd> x) const — x (numpy, 14) is modified in place."""
+        self._need_problem()
+        if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.shape == (14,) and x.flags.c_contiguous):
+            raise ValueError("x must be a contiguous float64 numpy vector of 14 entries (modified in place)")
+        ok = np.zeros(1, dtype=np.uint8)
+        check(_lib.lib().ccmp_project_host(self.ctx.handle, C.byref(self.problem), _dptr(x), _dptr(x),
+                                           ok.ctypes.data_as(C.POINTER(C.c_uint8)), None, 1), "ccmp_project_host")
+        return bool(ok[0])
+
+    def function(self, x, out=None):
+        self._need_problem()
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(14)
+        f = np.empty(2) if out is None else out
+        check(_lib.lib().ccmp_function_host(self.ctx.handle, C.byref(self.problem), _dptr(x), _dptr(f), 1),
+              "ccmp_function_host")
+        return f
+
+    def isSatisfied(self, x):
+        self._need_problem()
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(14)
+        ok = np.zeros(1, dtype=np.uint8)
+        check(_lib.lib().ccmp_is_satisfied_host(self.ctx.handle, C.byref(self.problem), _dptr(x),
+                                                ok.ctypes.data_as(C.POINTER(C.c_uint8)), 1), "ccmp_is_satisfied_host")
+        return bool(ok[0])
+
+    def jointValid(self, q):
+        self._need_problem()
+        torch = _torch()
+        t = torch.as_tensor(np.ascontiguousarray(q, dtype=np.float64).reshape(1, 14)).to("cuda:%d" % self.ctx.device)
+        return bool(self.joint_valid_batch(t).cpu()[0])
+
+    def project_host(self, q):
+        """(B,14) numpy in -> (q_out, ok, iters) numpy out through the host-pointer entry point."""
+        self._need_problem()
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B = q.shape[0]
+        out = np.empty_like(q)
+        ok = np.zeros(B, dtype=np.uint8)
+        it = np.zeros(B, dtype=np.uint16)
+        check(_lib.lib().ccmp_project_host(self.ctx.handle, C.byref(self.problem), _dptr(q), _dptr(out),
+                                           ok.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                           it.ctypes.data_as(C.POINTER(C.c_uint16)), B), "ccmp_project_host")
+        return out, ok, it

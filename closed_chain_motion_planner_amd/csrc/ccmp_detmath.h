@@ -1,0 +1,187 @@
+/* ccmp_detmath.h — bit-reproducible elementary functions (sincos, atan) and the FMA macro that
+ * defines this project's canonical rounding model.
+ *
+ * Why this file exists
+ * --------------------
+ * The reference projector (include/closed_chain_motion_planner/base/constraints/
+ * ConstraintFunction.h:57-82) differentiates its residual by finite differences with a step of
+ * sqrt(DBL_EPSILON) and stops at the first iterate under tolerance.  A 1-ulp difference in one
+ * sin() is amplified ~7e7 times in the Jacobian and then grows along the Newton trajectory
+ * (measured: the same algorithm run with glibc sin/cos and with the sin/cos below ends > 1e-6 rad
+ * apart on ~20 % of uniform samples and stops at a different iteration on ~11 %).  Agreement "to
+ * 1e-6 rad" between a GPU kernel and a CPU restatement therefore needs *bitwise identical*
+ * arithmetic.  Vendor libraries (glibc libm on the host, ocml on the device) cannot give that.
+ * This header can: only IEEE-754 double + - * / sqrt fma and comparisons, in a fixed order.
+ *
+ * Rounding model
+ * --------------
+ * CCMP_FMA(a,b,c) is a*b+c.  With CCMP_USE_FMA it is one fused operation (v_fma_f64 on gfx950,
+ * vfmadd on x86 with -mfma, libm fma() otherwise — all exact); without it, a rounded multiply
+ * followed by a rounded add.  Every translation unit that must agree bitwise is compiled with
+ * -ffp-contract=off so that only the FMAs written here and in ccmp_kin.h exist.
+ * The "fast" analytic kernel compiles the same source with contraction on and no bitwise claim.
+ *
+ * Algorithms: the classical Sun fdlibm scheme (published algorithm and minimax coefficients):
+ * Cody-Waite reduction by pi/2 split into 33-bit pieces (exact products for |x| < 2^20*pi/2),
+ * degree-13/14 kernels on [-pi/4, pi/4] in branch-free form, 4-interval atan reduction with one
+ * division.  Accuracy (tests/test_detmath.py, against glibc): <= 1 ulp sin/cos, <= 2 ulp atan.
+ */
+#ifndef CCMP_DETMATH_H
+#define CCMP_DETMATH_H
+
+#if defined(__HIPCC__)
+#define CCMP_HD __host__ __device__ __forceinline__
+#else
+#define CCMP_HD static inline
+#endif
+
+#if defined(CCMP_USE_FMA)
+#define CCMP_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#define CCMP_FMA(a, b, c) ((a) * (b) + (c))
+#endif
+
+/* Largest |x| the pi/2 reduction is exact for (2^20 * pi/2).  Beyond it sincos returns NaN:
+ * a Newton iterate that large is a diverged sample, never a valid projection. */
+#define CCMP_SINCOS_MAX 1647099.0
+
+CCMP_HD double ccmp_sqrt(double x) { return __builtin_sqrt(x); } /* IEEE correctly rounded on both sides */
+CCMP_HD double ccmp_abs(double x) { return __builtin_fabs(x); }
+
+/* sin(x+y) and cos(x+y), |x| <= pi/4 (+ a hair), y the tail of the reduced argument. */
+CCMP_HD double ccmp_kernel_sin(double x, double y)
+{
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = x * x;
+  double w = z * z;
+  double p1 = CCMP_FMA(z, S4, S3);
+  p1 = CCMP_FMA(z, p1, S2);
+  double p2 = CCMP_FMA(z, S6, S5);
+  double r = CCMP_FMA(z * w, p2, p1);
+  double v = z * x;
+  double in = CCMP_FMA(-v, r, 0.5 * y);
+  double t2 = CCMP_FMA(z, in, -y);
+  double t3 = CCMP_FMA(-v, S1, t2);
+  return x - t3;
+}
+
+CCMP_HD double ccmp_kernel_cos(double x, double y)
+{
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = x * x;
+  double w = z * z;
+  double q1 = CCMP_FMA(z, C3, C2);
+  q1 = CCMP_FMA(z, q1, C1);
+  q1 = z * q1;
+  double q2 = CCMP_FMA(z, C6, C5);
+  q2 = CCMP_FMA(z, q2, C4);
+  double r = CCMP_FMA(w * w, q2, q1);
+  double hz = 0.5 * z;
+  double w1 = 1.0 - hz;
+  return w1 + (((1.0 - w1) - hz) + CCMP_FMA(z, r, -(x * y)));
+}
+
+/* Simultaneous sine and cosine.  NaN for non-finite or |x| >= CCMP_SINCOS_MAX. */
+CCMP_HD void ccmp_sincos(double x, double *s_out, double *c_out)
+{
+  const double invpio2 = 6.36619772367581382433e-01;
+  const double pio2_1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
+  const double pio2_2 = 6.07710050630396597660e-11;  /* second 33 bits */
+  const double pio2_2t = 2.02226624879595063154e-21; /* pi/2 - (pio2_1 + pio2_2) */
+  double t = ccmp_abs(x);
+  if (!(t < CCMP_SINCOS_MAX)) {
+    double nan = (x - x) / (x - x); /* NaN for inf, NaN and out-of-range finite x alike */
+    *s_out = nan;
+    *c_out = nan;
+    return;
+  }
+  /* n = nearest multiple of pi/2; fn*pio2_1 is exact (33 + 20 bits) */
+  int n = (int)CCMP_FMA(t, invpio2, 0.5);
+  double fn = (double)n;
+  double r = CCMP_FMA(-fn, pio2_1, t);
+  double w = fn * pio2_2;
+  double tt = r;
+  r = tt - w;
+  w = CCMP_FMA(fn, pio2_2t, -((tt - r) - w));
+  double y0 = r - w;
+  double y1 = (r - y0) - w;
+  double ks = ccmp_kernel_sin(y0, y1);
+  double kc = ccmp_kernel_cos(y0, y1);
+  /* quadrant of |x|; then sin is odd, cos is even */
+  double s = (n & 1) ? kc : ks;
+  double c = (n & 1) ? ks : kc;
+  if (n & 2) s = -s;
+  if ((n + 1) & 2) c = -c;
+  *s_out = x < 0.0 ? -s : s;
+  *c_out = c;
+}
+
+/* atan(x) for any double (NaN propagates). */
+CCMP_HD double ccmp_atan(double x)
+{
+  const double hi0 = 4.63647609000806093515e-01, lo0 = 2.26987774529616870924e-17; /* atan(0.5) */
+  const double hi1 = 7.85398163397448278999e-01, lo1 = 3.06161699786838301793e-17; /* atan(1)   */
+  const double hi2 = 9.82793723247329054082e-01, lo2 = 1.39033110312309984516e-17; /* atan(1.5) */
+  const double hi3 = 1.57079632679489655800e+00, lo3 = 6.12323399573676603587e-17; /* atan(inf) */
+  const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01,
+               a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
+               a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02,
+               a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
+               a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02,
+               a10 = 1.62858201153657823623e-02;
+  int neg = x < 0.0;
+  double ax = ccmp_abs(x);
+  if (ax >= 7.378697629483821e19) { /* 2^66: atan saturates (also catches +-inf) */
+    double z = hi3 + lo3;
+    return neg ? -z : z;
+  }
+  /* interval selection expressed as one quotient num/den so every lane runs one divide */
+  double num, den, hi, lo;
+  int direct = 0;
+  if (ax < 0.4375) {
+    num = ax; den = 1.0; hi = 0.0; lo = 0.0; direct = 1;
+  } else if (ax < 0.6875) {
+    num = CCMP_FMA(2.0, ax, -1.0); den = 2.0 + ax; hi = hi0; lo = lo0;
+  } else if (ax < 1.1875) {
+    num = ax - 1.0; den = ax + 1.0; hi = hi1; lo = lo1;
+  } else if (ax < 2.4375) {
+    num = ax - 1.5; den = CCMP_FMA(1.5, ax, 1.0); hi = hi2; lo = lo2;
+  } else { /* also the NaN path: every comparison above is false */
+    num = -1.0; den = ax; hi = hi3; lo = lo3;
+  }
+  double t = num / den;
+  double z = t * t;
+  double w = z * z;
+  double s1 = CCMP_FMA(w, a10, a8);
+  s1 = CCMP_FMA(w, s1, a6);
+  s1 = CCMP_FMA(w, s1, a4);
+  s1 = CCMP_FMA(w, s1, a2);
+  s1 = CCMP_FMA(w, s1, a0);
+  s1 = z * s1;
+  double s2 = CCMP_FMA(w, a9, a7);
+  s2 = CCMP_FMA(w, s2, a5);
+  s2 = CCMP_FMA(w, s2, a3);
+  s2 = CCMP_FMA(w, s2, a1);
+  s2 = w * s2;
+  double res;
+  if (direct)
+    res = CCMP_FMA(-t, s1 + s2, t);
+  else
+    res = hi - (CCMP_FMA(t, s1 + s2, -lo) - t);
+  return neg ? -res : res;
+}
+
+/* atan2(y, x) restricted to y >= 0, x >= 0 — the only quadrant the residual's
+ * angularDistance needs (2*atan2(|vec|, |w|), ConstraintFunction.h:94-97 via Eigen).
+ * atan2(0,0) = 0 as in C. */
+CCMP_HD double ccmp_atan2_nn(double y, double x)
+{
+  if (x == 0.0 && y == 0.0) return 0.0;
+  return ccmp_atan(y / x); /* x == 0 < y gives +inf -> pi/2 */
+}
+
+#endif /* CCMP_DETMATH_H */

@@ -1,0 +1,427 @@
+// ccmp_kernels_fd.hip — gfx950 kernels in the canonical (bit-reproducible) rounding model.
+//
+// Built with -ffp-contract=off -DCCMP_USE_FMA: the only fused operations are the CCMP_FMA calls in
+// ccmp_detmath.h / ccmp_kin.h / this file, the same ones oracle/ccmp_oracle.c (det build) performs,
+// so every kernel here is expected to agree with the CPU oracle BIT FOR BIT.
+//
+// Hot kernel: project_fd_kernel — KinematicChainConstraint::project with the reference's
+// finite-difference Jacobian (include/closed_chain_motion_planner/base/constraints/
+// ConstraintFunction.h:57-82 + OMPL's default Constraint::jacobian).
+//
+// Work decomposition: one wavefront = 10 independent samples x 6 lanes.
+// The 6 lanes of a group are the 6 evaluation points of OMPL's 7-point central stencil
+// (+h,+2h,+3h,-h,-2h,-3h) of ONE Jacobian column; the wave walks the 14 columns in lock-step, so
+// arm/joint indices are wave-uniform and every kinematic constant is an SGPR operand.  A perturbed
+// evaluation reuses the unperturbed prefix of the chain (bit-identical to recomputing it) from LDS
+// and recomputes only the suffix.  Joint state, sines/cosines, prefix frames, tool poses and the
+// 2x14 Jacobian of each sample are staged in LDS (one 265-double record per group; odd stride =>
+// the 10 groups hit distinct banks, lanes of a group broadcast).  Groups pull samples from a
+// global atomic queue, so a group whose sample converges early refills while its neighbours keep
+// iterating (iteration counts spread 15..250).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ccmp_kin.h"
+#include "ccmp_solve.h"
+
+using namespace ccmp;
+
+namespace {
+
+constexpr int kGroup = 6;             // lanes per sample = stencil evaluations per column
+constexpr int kGroupsPerWave = 10;    // 60 of 64 lanes busy
+// LDS record layout (in doubles)
+constexpr int kX = 0;                 // x[14]           current iterate
+constexpr int kSC = 14;               // sc[14][2]       sin, cos of every joint of x
+constexpr int kPre = 42;              // pre[14][12]     chain frame in front of joint col: R(9), o(3) incl. offset_col
+constexpr int kEE = 210;              // ee[2][12]       world tool pose of each arm at x: R(9), p(3)
+constexpr int kJ = 234;               // J[2][14]
+constexpr int kRec = 265;             // 262 used; odd stride keeps groups on distinct LDS banks
+
+__device__ __forceinline__ double shfl_f64(double v, int src_lane)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, lo);
+  hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, hi);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src_lane)
+{
+  int lo = (int)(v & 0xffffffffull), hi = (int)(v >> 32);
+  lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, lo);
+  hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, hi);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// MODE 0: project q_in -> q_out.  MODE 1: sampleUniform = ambient sample -> project -> enforceBounds.
+template <int MODE>
+__global__ __launch_bounds__(64) void project_fd_kernel(const ccmp_consts K, const double *__restrict__ q_in,
+                                                        double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
+                                                        uint16_t *__restrict__ iters_out,
+                                                        double *__restrict__ q_ambient,
+                                                        unsigned long long B, unsigned long long *queue,
+                                                        unsigned long long seed, unsigned long long first_index)
+{
+  __shared__ double lds[kGroupsPerWave * kRec];
+  const int lane = threadIdx.x;
+  const int g = lane / kGroup;                // 0..10; lanes 60..63 form the idle "group 10"
+  const int r = lane - kGroup * g;            // evaluation point 0..5 inside the group
+  const bool live = g < kGroupsPerWave;
+  const int leader = live ? kGroup * g : 0;
+  double *rec = lds + (live ? g : 0) * kRec;  // idle lanes alias group 0 for reads, never write
+  const bool plus = r < 3;                    // y1 side of the stencil; r>=3 is the y2 side
+  const int nstep = (plus ? r : r - 3) + 1;   // how many h-steps this lane's point is away
+  const int partner = live ? (plus ? lane + 3 : lane - 3) : lane;
+
+  unsigned long long idx = 0;
+  int iter = 0, updates = 0;
+  double norm1 = 0.0, norm2 = 0.0;
+  bool active = false, drained = false;
+
+  for (;;) {
+    // ---- refill: groups without a sample pull the next index from the global queue ----------
+    {
+      const bool want = live && !active && !drained;
+      unsigned long long t = 0;
+      if (want && r == 0) t = atomicAdd(queue, 1ull);
+      t = shfl_u64(t, leader);
+      if (want) {
+        if (t < B) {
+          idx = t; active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+          for (int e = r; e < 14; e += kGroup) {
+            double v;
+            if (MODE == 0) v = q_in[idx * 14 + e];
+            else {
+              v = ambient_uniform(K, seed, first_index + idx, e);
+              if (q_ambient) q_ambient[idx * 14 + e] = v;
+            }
+            rec[kX + e] = v;
+          }
+        } else drained = true;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+    __syncthreads();
+
+    // ---- phase 1: function(x) — sines/cosines, both chains (prefix frames kept), residual ----
+    for (int e = r; e < 14; e += kGroup) {
+      double s, c;
+      ccmp_sincos(rec[kX + e], &s, &c);
+      if (live) { rec[kSC + 2 * e] = s; rec[kSC + 2 * e + 1] = c; }
+    }
+    __syncthreads();
+    double f0, f1;
+    {
+      double T[2][12];
+#pragma unroll
+      for (int arm = 0; arm < 2; arm++) {
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+        for (int i = 0; i < 7; i++) {
+          const int col = arm * 7 + i;
+          double Rj[9], Rn[9];
+          mulvec_acc(R, K.offset[arm][i], o);
+          if (live && r == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) rec[kPre + col * 12 + k] = R[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) rec[kPre + col * 12 + 9 + k] = o[k];
+          }
+          rot_sc(K.axis[arm][i], K.aprod[arm][i], rec[kSC + 2 * col], rec[kSC + 2 * col + 1], Rj);
+          mul33(R, Rj, Rn);
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = Rn[k];
+        }
+        tool_pose(K, arm, R, o, &T[arm][0], &T[arm][9]);
+        if (live && r == 0) {
+#pragma unroll
+          for (int k = 0; k < 12; k++) rec[kEE + arm * 12 + k] = T[arm][k];
+        }
+      }
+      double f[2];
+      chain_residual(K, &T[0][0], &T[0][9], &T[1][0], &T[1][9], f, nullptr, nullptr);
+      f0 = f[0]; f1 = f[1];
+    }
+
+    // ---- loop condition of ConstraintFunction.h:68, quirks included ---------------------------
+    // while (((norm1 = f[0] > tol1) || (norm2 = f[1]) > tol2) && iter++ < maxIterations)
+    bool cont = false;
+    if (active) {
+      const bool c1 = f0 > K.tol_pos;
+      norm1 = c1 ? 1.0 : 0.0;
+      bool resid = c1;
+      if (!c1) { norm2 = f1; resid = f1 > K.tol_rot; }
+      if (resid) { cont = iter < K.max_iter; iter++; }
+    }
+    // ---- finished groups: jointValid, write-back --------------------------------------------
+    {
+      const bool fin = active && !cont;
+      bool bad = false;
+      if (fin) {
+        for (int e = r; e < 14; e += kGroup) {
+          const double v = rec[kX + e];
+          const int jj = e < 7 ? e : e - 7;
+          if (v < K.lbe[jj]) bad = true;
+          if (v > K.ube[jj]) bad = true;
+          q_out[idx * 14 + e] = (MODE == 1) ? wrap_pi(v) : v;
+        }
+      }
+      const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);
+      if (fin && r == 0) {
+        const bool gbad = ((badmask >> leader) & 0x3Full) != 0ull;
+        ok_out[idx] = (uint8_t)((!gbad) && (norm1 < K.tol_pos) && (norm2 < K.tol_rot));
+        if (iters_out) iters_out[idx] = (uint16_t)updates;
+      }
+      if (fin) active = false;
+    }
+    if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue; // nobody iterates: straight to refill
+    __syncthreads(); // prefix frames / tool poses written by r==0 are visible to the group
+
+    // ---- phase 2: OMPL's default Constraint::jacobian, one column per step --------------------
+    for (int col = 0; col < 14; col++) {
+      const int arm = col >= 7 ? 1 : 0;
+      const int j = col - 7 * arm;
+      const double xj = rec[kX + col];
+      const double axj = ccmp_abs(xj);
+      const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1); // sqrt(eps)*max(1,|x_j|)
+      const double hh = plus ? h : -h;
+      double y = xj + hh;                 // y1[j] += h   /  y2[j] -= h
+      if (nstep >= 2) y = y + hh;
+      if (nstep >= 3) y = y + hh;
+      double R[9], o[3], s, c;
+#pragma unroll
+      for (int k = 0; k < 9; k++) R[k] = rec[kPre + col * 12 + k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) o[k] = rec[kPre + col * 12 + 9 + k];
+      ccmp_sincos(y, &s, &c);
+      {
+        double Rj[9], Rn[9];
+        rot_sc(K.axis[arm][j], K.aprod[arm][j], s, c, Rj);
+        mul33(R, Rj, Rn);
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = Rn[k];
+      }
+      for (int i = j + 1; i < 7; i++)
+        joint_step(K, arm, i, rec[kSC + 2 * (arm * 7 + i)], rec[kSC + 2 * (arm * 7 + i) + 1], R, o);
+      double Tw[12], To[12], t[2];
+      tool_pose(K, arm, R, o, &Tw[0], &Tw[9]);
+#pragma unroll
+      for (int k = 0; k < 12; k++) To[k] = rec[kEE + (1 - arm) * 12 + k];
+      if (arm == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);
+      else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], t, nullptr, nullptr);
+      // m_s = (t1 - t2) / (y1[j] - y2[j]) with the stored perturbed values
+      const double tp0 = shfl_f64(t[0], partner), tp1 = shfl_f64(t[1], partner), yp = shfl_f64(y, partner);
+      const double den = plus ? (y - yp) : (yp - y);
+      const double m0 = (plus ? (t[0] - tp0) : (tp0 - t[0])) / den;
+      const double m1 = (plus ? (t[1] - tp1) : (tp1 - t[1])) / den;
+      const double m10 = shfl_f64(m0, leader), m20 = shfl_f64(m0, leader + 1), m30 = shfl_f64(m0, leader + 2);
+      const double m11 = shfl_f64(m1, leader), m21 = shfl_f64(m1, leader + 1), m31 = shfl_f64(m1, leader + 2);
+      if (live && r == 0) {
+        rec[kJ + col] = CCMP_FMA(0.1, m30, CCMP_FMA(-0.6, m20, 1.5 * m10));
+        rec[kJ + 14 + col] = CCMP_FMA(0.1, m31, CCMP_FMA(-0.6, m21, 1.5 * m11));
+      }
+    }
+    __syncthreads();
+
+    // ---- Newton update: x -= 0.30 * J.jacobiSvd().solve(f) --------------------------------------
+    {
+      double Jr[28], dx[14];
+#pragma unroll
+      for (int k = 0; k < 28; k++) Jr[k] = rec[kJ + k];
+      solve_minnorm(Jr, f0, f1, dx);
+      if (cont) {
+#pragma unroll
+        for (int e = 0; e < 14; e++)
+          if (e % kGroup == r) rec[kX + e] = CCMP_FMA(-K.step, dx[e], rec[kX + e]);
+        updates++;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- simple per-lane kernels (one sample per lane; all bit-identical to the oracle) -------------
+__global__ void function_kernel(const ccmp_consts K, const double *__restrict__ q, double *__restrict__ f, size_t B)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double x[14], out[2];
+#pragma unroll
+  for (int e = 0; e < 14; e++) x[e] = q[i * 14 + e];
+  residual(K, x, out);
+  f[2 * i] = out[0];
+  f[2 * i + 1] = out[1];
+}
+
+// KinematicChainConstraint::isSatisfied (ConstraintFunction.h:114-120)
+__global__ void is_satisfied_kernel(const ccmp_consts K, const double *__restrict__ q, uint8_t *__restrict__ ok, size_t B)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double x[14], f[2];
+#pragma unroll
+  for (int e = 0; e < 14; e++) x[e] = q[i * 14 + e];
+  residual(K, x, f);
+  const bool finite = (f[0] - f[0] == 0.0) && (f[1] - f[1] == 0.0);
+  ok[i] = (uint8_t)(finite && f[0] <= K.tol_pos && f[1] <= K.tol_rot);
+}
+
+// KinematicChainConstraint::jointValid (ConstraintFunction.h:43-55)
+__global__ void joint_valid_kernel(const ccmp_consts K, const double *__restrict__ q, uint8_t *__restrict__ ok, size_t B)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  bool good = true;
+  for (int e = 0; e < 14; e++) {
+    const double v = q[i * 14 + e];
+    const int jj = e < 7 ? e : e - 7;
+    if (v < K.lbe[jj]) good = false;
+    if (v > K.ube[jj]) good = false;
+  }
+  ok[i] = (uint8_t)good;
+}
+
+__global__ void ambient_uniform_kernel(const ccmp_consts K, unsigned long long seed, unsigned long long first,
+                                       double *__restrict__ q, size_t n /* = 14*B */)
+{
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  q[t] = ambient_uniform(K, seed, first + t / 14, (int)(t % 14));
+}
+
+__global__ void enforce_bounds_kernel(double *__restrict__ q, size_t n)
+{
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  q[t] = wrap_pi(q[t]);
+}
+
+__global__ void detmath_probe_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                     double *__restrict__ out, size_t n)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  ccmp_sincos(x[i], &s, &c);
+  out[5 * i + 0] = s;
+  out[5 * i + 1] = c;
+  out[5 * i + 2] = ccmp_atan2_nn(ccmp_abs(x[i]), ccmp_abs(y[i]));
+  out[5 * i + 3] = ccmp_sqrt(ccmp_abs(x[i]));
+  out[5 * i + 4] = x[i] / y[i];
+}
+
+// Stable stream compaction of valid rows: block-local scan + one atomic per block would reorder
+// blocks, so this is the ordered two-pass form: (1) per-block counts, (2) single-block exclusive
+// scan of the counts, (3) scatter.  B/256 counts fit one block's loop comfortably (1024 at 262144).
+__global__ void compact_count_kernel(const uint8_t *__restrict__ ok, size_t B, unsigned int *__restrict__ block_counts)
+{
+  __shared__ unsigned int wsum[4];
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool v = i < B && ok[i] != 0;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__builtin_popcountll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void compact_scan_kernel(unsigned int *__restrict__ block_counts, size_t nblocks,
+                                    unsigned long long *__restrict__ total)
+{
+  // one 1024-thread block; each thread owns a contiguous chunk
+  __shared__ unsigned long long part[1024];
+  const size_t per = (nblocks + 1023) / 1024;
+  const size_t lo = (size_t)threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
+  unsigned long long s = 0;
+  for (size_t k = lo; k < hi; k++) s += block_counts[k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int k = 0; k < 1024; k++) { unsigned long long v = part[k]; part[k] = run; run += v; }
+    *total = run;
+  }
+  __syncthreads();
+  unsigned long long run = part[threadIdx.x];
+  for (size_t k = lo; k < hi; k++) { unsigned int v = block_counts[k]; block_counts[k] = (unsigned int)run; run += v; }
+}
+__global__ void compact_scatter_kernel(const double *__restrict__ q, const uint8_t *__restrict__ ok, size_t B,
+                                       const unsigned int *__restrict__ block_offsets, double *__restrict__ out)
+{
+  __shared__ unsigned int wsum[4];
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool v = i < B && ok[i] != 0;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wsum[w] = (unsigned)__builtin_popcountll(m);
+  __syncthreads();
+  unsigned int base = block_offsets[blockIdx.x];
+  for (int k = 0; k < w; k++) base += wsum[k];
+  if (v) {
+    const unsigned int pos = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+    for (int e = 0; e < 14; e++) out[(size_t)pos * 14 + e] = q[i * 14 + e];
+  }
+}
+
+} // namespace
+
+// ---- launchers (called from ccmp_api.cpp) --------------------------------------------------------
+extern "C" {
+
+hipError_t ccmp_launch_project_fd(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
+                                  uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
+                                  unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st)
+{
+  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess) return e;
+  if (mode == 0)
+    hipLaunchKernelGGL(project_fd_kernel<0>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                       (unsigned long long)B, queue, seed, first);
+  else
+    hipLaunchKernelGGL(project_fd_kernel<1>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                       (unsigned long long)B, queue, seed, first);
+  return hipGetLastError();
+}
+
+hipError_t ccmp_launch_function(const ccmp_consts *K, const double *q, double *f, size_t B, hipStream_t st)
+{
+  hipLaunchKernelGGL(function_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, *K, q, f, B);
+  return hipGetLastError();
+}
+hipError_t ccmp_launch_is_satisfied(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, hipStream_t st)
+{
+  hipLaunchKernelGGL(is_satisfied_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, *K, q, ok, B);
+  return hipGetLastError();
+}
+hipError_t ccmp_launch_joint_valid(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, hipStream_t st)
+{
+  hipLaunchKernelGGL(joint_valid_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, *K, q, ok, B);
+  return hipGetLastError();
+}
+hipError_t ccmp_launch_ambient_uniform(const ccmp_consts *K, unsigned long long seed, unsigned long long first,
+                                       double *q, size_t B, hipStream_t st)
+{
+  size_t n = B * 14;
+  hipLaunchKernelGGL(ambient_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *K, seed, first, q, n);
+  return hipGetLastError();
+}
+hipError_t ccmp_launch_enforce_bounds(double *q, size_t B, hipStream_t st)
+{
+  size_t n = B * 14;
+  hipLaunchKernelGGL(enforce_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q, n);
+  return hipGetLastError();
+}
+hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st)
+{
+  hipLaunchKernelGGL(detmath_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, out, n);
+  return hipGetLastError();
+}
+hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, unsigned int *block_counts,
+                               unsigned long long *total, hipStream_t st)
+{
+  const size_t nblocks = (B + 255) / 256;
+  hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, ok, B, block_counts);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, block_counts, nblocks, total);
+  hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, q, ok, B, block_counts, out);
+  return hipGetLastError();
+}
+
+} // extern "C"

@@ -1,0 +1,239 @@
+/* ccmp_kin.h — dual-Panda kinematics and the closed-chain residual, host+device, in the project's
+ * canonical rounding model (ccmp_detmath.h): every a*b+c that is fused is written CCMP_FMA, sums
+ * run left to right, and the translation units that must agree bitwise are built with
+ * -ffp-contract=off.  The same functions compute init_chain_ on the host at set-up and run inside
+ * the gfx950 kernels.
+ *
+ * Reference behaviour restated here (paths relative to the reference checkout):
+ *   PandaModel::getTransform / getRotation / getTranslation   src/kinematics/panda_rbdl.cpp:24-42
+ *   PandaModel::initModel (modified-DH tables -> axes/offsets) src/kinematics/panda_rbdl.cpp:73-160
+ *   KinematicChainConstraint::function                         include/.../constraints/ConstraintFunction.h:84-102
+ * and the Eigen / RBDL arithmetic those call.
+ */
+#ifndef CCMP_KIN_H
+#define CCMP_KIN_H
+#include <stdint.h>
+
+#include "ccmp_detmath.h"
+
+/* Kernel-side constants derived from ccmp_problem (ccmp_api.cpp: make_consts).  Passed by value
+ * as a kernel argument: every lane reads the same entry at the same time, so the compiler keeps
+ * them in SGPRs (scalar loads from the kernarg segment), never in VGPRs. */
+struct ccmp_consts {
+  double axis[2][7][3];
+  double aprod[2][7][6]; /* a0a0 a0a1 a0a2 a1a1 a1a2 a2a2 of each axis */
+  double offset[2][7][3];
+  double ee[2][3];
+  double R_tool[2][9];
+  double base_R[2][9];
+  double base_p[2][3];
+  double init_p[3];
+  double init_q[4]; /* Quaterniond(init_chain_.linear()) as (x,y,z,w) */
+  double lbe[7];    /* lb + eps */
+  double ube[7];    /* ub - eps */
+  double lb[7];
+  double span[7];   /* ub - lb (sampler) */
+  double tol_pos, tol_rot, step;
+  int32_t max_iter;
+  int32_t pad;
+};
+
+namespace ccmp {
+
+/* a0*b0 + a1*b1 + a2*b2, accumulated left to right */
+CCMP_HD double dot3(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+  return CCMP_FMA(a2, b2, CCMP_FMA(a1, b1, a0 * b0));
+}
+/* c + a0*b0 + a1*b1 + a2*b2, accumulated left to right onto c */
+CCMP_HD double dot3acc(double c, double a0, double b0, double a1, double b1, double a2, double b2)
+{
+  return CCMP_FMA(a2, b2, CCMP_FMA(a1, b1, CCMP_FMA(a0, b0, c)));
+}
+
+/* C = A B (row-major 3x3) */
+CCMP_HD void mul33(const double *A, const double *B, double *C)
+{
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      C[3 * i + j] = dot3(A[3 * i], B[j], A[3 * i + 1], B[3 + j], A[3 * i + 2], B[6 + j]);
+}
+/* C = A^T B */
+CCMP_HD void mulT33(const double *A, const double *B, double *C)
+{
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      C[3 * i + j] = dot3(A[i], B[j], A[3 + i], B[3 + j], A[6 + i], B[6 + j]);
+}
+/* r += A v */
+CCMP_HD void mulvec_acc(const double *A, const double *v, double *r)
+{
+#pragma unroll
+  for (int i = 0; i < 3; i++) r[i] = dot3acc(r[i], A[3 * i], v[0], A[3 * i + 1], v[1], A[3 * i + 2], v[2]);
+}
+/* r = A^T v */
+CCMP_HD void mulTvec(const double *A, const double *v, double *r)
+{
+#pragma unroll
+  for (int i = 0; i < 3; i++) r[i] = dot3(A[i], v[0], A[3 + i], v[1], A[6 + i], v[2]);
+}
+
+/* Rotation by angle with sine s, cosine c about unit axis a; ap = {a0a0,a0a1,a0a2,a1a1,a1a2,a2a2}.
+ * RBDL Xrot(angle, axis) transposed (RBDL keeps world->body; panda_rbdl.cpp:32 transposes back). */
+CCMP_HD void rot_sc(const double *a, const double *ap, double s, double c, double *R)
+{
+  double t = 1.0 - c;
+  double a0s = a[0] * s, a1s = a[1] * s, a2s = a[2] * s;
+  R[0] = CCMP_FMA(ap[0], t, c);
+  R[1] = CCMP_FMA(ap[1], t, -a2s);
+  R[2] = CCMP_FMA(ap[2], t, a1s);
+  R[3] = CCMP_FMA(ap[1], t, a2s);
+  R[4] = CCMP_FMA(ap[3], t, c);
+  R[5] = CCMP_FMA(ap[4], t, -a0s);
+  R[6] = CCMP_FMA(ap[2], t, -a1s);
+  R[7] = CCMP_FMA(ap[4], t, a0s);
+  R[8] = CCMP_FMA(ap[5], t, c);
+}
+
+/* One joint of the chain: o += R*offset_i (joint origin), then R = R*Rot(axis_i, q_i). */
+CCMP_HD void joint_step(const ccmp_consts &K, int arm, int i, double s, double c, double *R, double *o)
+{
+  double Rj[9], Rn[9];
+  mulvec_acc(R, K.offset[arm][i], o);
+  rot_sc(K.axis[arm][i], K.aprod[arm][i], s, c, Rj);
+  mul33(R, Rj, Rn);
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = Rn[k];
+}
+
+/* Body-7 frame (R,o) -> world pose of the hand frame: getTranslation/getRotation
+ * (panda_rbdl.cpp:24-33) then t_wb * (ConstraintFunction.h:89-90). */
+CCMP_HD void tool_pose(const ccmp_consts &K, int arm, const double *R, const double *o, double *Rw, double *pw)
+{
+  double pf[3] = {o[0], o[1], o[2]}, Rf[9];
+  mulvec_acc(R, K.ee[arm], pf);
+  mul33(R, K.R_tool[arm], Rf);
+  mul33(K.base_R[arm], Rf, Rw);
+  pw[0] = K.base_p[arm][0]; pw[1] = K.base_p[arm][1]; pw[2] = K.base_p[arm][2];
+  mulvec_acc(K.base_R[arm], pf, pw);
+}
+
+/* Full FK of one arm (world pose of its hand frame). */
+CCMP_HD void fk_arm(const ccmp_consts &K, int arm, const double *q, double *Rw, double *pw)
+{
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+  for (int i = 0; i < 7; i++) {
+    double s, c;
+    ccmp_sincos(q[i], &s, &c);
+    joint_step(K, arm, i, s, c, R, o);
+  }
+  tool_pose(K, arm, R, o, Rw, pw);
+}
+
+/* Eigen Quaterniond(Matrix3d) — trace / major-diagonal branches; out (x,y,z,w). */
+CCMP_HD void quat_of(const double *m, double *q)
+{
+  double t = (m[0] + m[4]) + m[8];
+  if (t > 0.0) {
+    t = ccmp_sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = (m[4] > m[0]) ? 1 : 0;
+    double mii = i ? m[4] : m[0];
+    if (m[8] > mii) i = 2;
+    if (i == 0) { /* j=1, k=2 */
+      t = ccmp_sqrt(((m[0] - m[4]) - m[8]) + 1.0);
+      q[0] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (m[7] - m[5]) * t;
+      q[1] = (m[3] + m[1]) * t;
+      q[2] = (m[6] + m[2]) * t;
+    } else if (i == 1) { /* j=2, k=0 */
+      t = ccmp_sqrt(((m[4] - m[8]) - m[0]) + 1.0);
+      q[1] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (m[2] - m[6]) * t;
+      q[2] = (m[7] + m[5]) * t;
+      q[0] = (m[1] + m[3]) * t;
+    } else { /* i=2, j=0, k=1 */
+      t = ccmp_sqrt(((m[8] - m[0]) - m[4]) + 1.0);
+      q[2] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (m[3] - m[1]) * t;
+      q[0] = (m[2] + m[6]) * t;
+      q[1] = (m[5] + m[7]) * t;
+    }
+  }
+}
+
+/* current_chain = t_w72.inverse() * t_w71, then (|dp|, angularDistance) against init_chain_
+ * (ConstraintFunction.h:92-101).  dq (nullable) receives q_c * conj(q_0) as (x,y,z,w) and pc
+ * (nullable) the chain translation — the analytic Jacobian needs both. */
+CCMP_HD void chain_residual(const ccmp_consts &K, const double *R1, const double *p1, const double *R2,
+                            const double *p2, double *f, double *dq, double *pc_out)
+{
+  double Rc[9], ti[3], pc[3], qc[4];
+  mulT33(R2, R1, Rc);
+  mulTvec(R2, p2, ti);
+  mulTvec(R2, p1, pc);
+#pragma unroll
+  for (int k = 0; k < 3; k++) pc[k] = pc[k] + (-ti[k]);
+  quat_of(Rc, qc);
+  double ax = qc[0], ay = qc[1], az = qc[2], aw = qc[3];
+  double bx = -K.init_q[0], by = -K.init_q[1], bz = -K.init_q[2], bw = K.init_q[3];
+  double dw = CCMP_FMA(-az, bz, CCMP_FMA(-ay, by, CCMP_FMA(-ax, bx, aw * bw)));
+  double dx = CCMP_FMA(-az, by, CCMP_FMA(ay, bz, CCMP_FMA(ax, bw, aw * bx)));
+  double dy = CCMP_FMA(-ax, bz, CCMP_FMA(az, bx, CCMP_FMA(ay, bw, aw * by)));
+  double dz = CCMP_FMA(-ay, bx, CCMP_FMA(ax, by, CCMP_FMA(az, bw, aw * bz)));
+  double vn = ccmp_sqrt(dot3(dx, dx, dy, dy, dz, dz));
+  f[1] = 2.0 * ccmp_atan2_nn(vn, ccmp_abs(dw));
+  double e0 = pc[0] - K.init_p[0], e1 = pc[1] - K.init_p[1], e2 = pc[2] - K.init_p[2];
+  f[0] = ccmp_sqrt(dot3(e0, e0, e1, e1, e2, e2));
+  if (dq) { dq[0] = dx; dq[1] = dy; dq[2] = dz; dq[3] = dw; }
+  if (pc_out) { pc_out[0] = pc[0]; pc_out[1] = pc[1]; pc_out[2] = pc[2]; }
+}
+
+/* KinematicChainConstraint::function for one state. */
+CCMP_HD void residual(const ccmp_consts &K, const double *x, double *f)
+{
+  double R1[9], p1[3], R2[9], p2[3];
+  fk_arm(K, 0, x, R1, p1);
+  fk_arm(K, 1, x + 7, R2, p2);
+  chain_residual(K, R1, p1, R2, p2, f, nullptr, nullptr);
+}
+
+/* KinematicChainSpace::enforceBounds for one value (KinematicChain.h:118-130). */
+CCMP_HD double wrap_pi(double q)
+{
+  const double pi = 3.14159265358979323846;
+  double v = __builtin_fmod(q, 2.0 * pi);
+  if (v < -pi) v += 2.0 * pi;
+  else if (v >= pi) v -= 2.0 * pi;
+  return v;
+}
+
+CCMP_HD uint64_t splitmix64(uint64_t z)
+{
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+/* dimension j of ambient sample `index`: RNG::uniformReal(low, high) = (high-low)*u + low */
+CCMP_HD double ambient_uniform(const ccmp_consts &K, uint64_t seed, uint64_t index, int j)
+{
+  uint64_t r = splitmix64(seed ^ (index * 14ULL + (uint64_t)j));
+  double u = (double)(r >> 11) * 1.1102230246251565e-16; /* 2^-53 */
+  return CCMP_FMA(K.span[j % 7], u, K.lb[j % 7]);
+}
+
+} /* namespace ccmp */
+#endif /* CCMP_KIN_H */

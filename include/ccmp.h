@@ -1,0 +1,153 @@
+/* ccmp.h — C ABI of libccmp: batched closed-chain constraint projector for AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE hot path of jkw0701/closed_chain_motion_planner: the Newton
+ * retraction KinematicChainConstraint::project() and its sample/extend callers.  The reference has
+ * no FFI layer (the path sits behind OMPL's C++ virtuals); every entry point below therefore names
+ * the reference C++ member it replaces (paths relative to the reference checkout).  The C++ adapter
+ * that keeps the OMPL surface source-compatible is include/ccmp_ompl_adapter.hpp; the binding a
+ * maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the ABI; every function returns CCMP_OK (0) or a negative code
+ *   - all pointers are caller-owned; *_batch calls take DEVICE pointers and are asynchronous on
+ *     the caller's HIP stream (NULL = the ctx's own stream); *_host calls take host pointers and
+ *     are synchronous
+ *   - state layout everywhere: row-major double q[B][14]; first 7 = the alphabetically first arm
+ *     name, next 7 = the second (std::map order, src/base/constraints/ConstrainedPlanningCommon.cpp:89-91)
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     CCMP_ENODEV
+ */
+#ifndef CCMP_H
+#define CCMP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCMP_VERSION 100
+
+enum {
+  CCMP_OK = 0,
+  CCMP_EINVAL = -1, /* bad argument (also: non-positive tolerance, ConstraintFunction.h:106-108) */
+  CCMP_EHIP = -2,   /* a HIP runtime call failed; see ccmp_last_hip_error()                      */
+  CCMP_EIO = -3,    /* cannot read the YAML file                                                 */
+  CCMP_EPARSE = -4, /* YAML key missing or malformed                                             */
+  CCMP_ENODEV = -5, /* no HIP device / device index out of range                                 */
+  CCMP_ENOMEM = -6
+};
+
+enum { CCMP_JAC_FD = 0, CCMP_JAC_ANALYTIC = 1 };
+
+/* Everything the kernels need besides q.  POD; matrices row-major.  Built by
+ * ccmp_problem_from_yaml / ccmp_problem_init, or filled by hand. */
+typedef struct ccmp_problem {
+  double axis[2][7][3];   /* joint axes in the parent body frame; src/kinematics/panda_rbdl.cpp:117-122 */
+  double offset[2][7][3]; /* joint origin relative to the parent joint origin; panda_rbdl.cpp:128-130   */
+  double ee[2][3];        /* rot_ee*(0,0,0.107); panda_rbdl.cpp:124-126                                 */
+  double R_tool[2][9];    /* rot_ee*Rz(-pi/4); panda_rbdl.cpp:31                                        */
+  double base_R[2][9];    /* t_wb per arm; src/kinematics/grasping_point.cpp:11-20                      */
+  double base_p[2][3];
+  double init_R[9];       /* init_chain_; ConstraintFunction.h:39                                       */
+  double init_p[3];
+  double lb[7];           /* ConstraintFunction.h:27-28 == KinematicChain.h:75-100                      */
+  double ub[7];
+  double joint_eps;       /* 0.001; ConstraintFunction.h:45                                             */
+  double tol_pos;         /* tolerance1_ = 1e-3; ConstrainedPlanningCommon.cpp:120                      */
+  double tol_rot;         /* tolerance2_ = 5e-3; ConstrainedPlanningCommon.cpp:121                      */
+  double step;            /* 0.30; ConstraintFunction.h:71                                              */
+  double delta;           /* 0.25; ConstrainedPlanningCommon.cpp:118                                    */
+  double lambda;          /* 2.0;  ConstrainedPlanningCommon.cpp:119                                    */
+  double start_joint[14]; /* config/<obj>.yaml: start_joint                                             */
+  double obj_start_R[9];  /* t_wo_start; grasping_point.cpp:38-43                                       */
+  double obj_start_p[3];
+  double obj_goal_R[9];   /* t_wo_goal; grasping_point.cpp:45-50                                        */
+  double obj_goal_p[3];
+  double t_o7_R[2][9];    /* t_o7 per arm; ConstrainedPlanningCommon.cpp:110-111                        */
+  double t_o7_p[2][3];
+  int32_t max_iter;       /* 250; ConstraintFunction.h:26 (setMaxIterations(1000) never reaches it)     */
+  int32_t jacobian_mode;  /* CCMP_JAC_FD (reference arithmetic, default) or CCMP_JAC_ANALYTIC           */
+  int32_t arm_index[2];   /* 0 panda_left, 1 panda_right, 2 panda_top; grasping_point.cpp:59-63         */
+} ccmp_problem;
+
+/* ---- problem set-up (host, once per planning problem) ------------------------------------------ */
+/* replaces grasping_point::loadConfig (grasping_point.cpp:34-65) + ConstrainedProblem::_setEnvironment
+ * + setConstrainedOptions (ConstrainedPlanningCommon.cpp:85-132): reads the reference's YAML
+ * unchanged (keys start_joint, t_wo_{start,goal}_{pos,quat}, arm1/arm2.{name,index}). */
+int ccmp_problem_from_yaml(const char *yaml_path, ccmp_problem *out);
+/* the same from explicit values; obj_* may be NULL (identity pose) */
+int ccmp_problem_init(ccmp_problem *out, const char *arm1_name, int arm1_index, const char *arm2_name,
+                      int arm2_index, const double start_joint[14], const double obj_start_pos[3],
+                      const double obj_start_quat_xyzw[4], const double obj_goal_pos[3],
+                      const double obj_goal_quat_xyzw[4]);
+/* KinematicChainConstraint::setInitialPosition (ConstraintFunction.h:31-40) and the t_o7 of
+ * ConstrainedPlanningCommon.cpp:110-111 */
+int ccmp_set_start(ccmp_problem *p, const double q0[14]);
+/* KinematicChainConstraint::setTolerance (ConstraintFunction.h:104-112): CCMP_EINVAL where the
+ * reference throws ompl::Exception */
+int ccmp_set_tolerance(ccmp_problem *p, double tolerance1, double tolerance2);
+/* PandaModel::initModel(dh) with calibration offsets (panda_rbdl.cpp:80-148; columns a,d,theta,alpha) */
+int ccmp_set_calibration(ccmp_problem *p, int arm_slot, const double dh_offsets[7][4]);
+
+/* ---- execution context -------------------------------------------------------------------------- */
+typedef struct ccmp_ctx ccmp_ctx;
+int ccmp_ctx_create(int device, ccmp_ctx **out);
+void ccmp_ctx_destroy(ccmp_ctx *ctx);
+/* persistent waves per CU for the projector kernels (0 = built-in default) */
+int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
+int ccmp_ctx_device(const ccmp_ctx *ctx);
+int ccmp_ctx_num_cus(const ccmp_ctx *ctx);
+
+/* ---- the hot path: device pointers, asynchronous on `hip_stream` -------------------------------- */
+/* KinematicChainConstraint::function (ConstraintFunction.h:84-102): f[i] = (|dp|, angle) */
+int ccmp_function_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, double *f, size_t B,
+                        void *hip_stream);
+/* KinematicChainConstraint::project (ConstraintFunction.h:57-82): q_out[i] = final iterate whether
+ * or not ok[i]; ok[i] = the reference's return value; iters[i] (nullable) = Newton updates done.
+ * q_in == q_out is allowed (in place, as the reference). */
+int ccmp_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, double *q_out,
+                       uint8_t *ok, uint16_t *iters, size_t B, void *hip_stream);
+/* KinematicChainConstraint::isSatisfied (ConstraintFunction.h:114-120) */
+int ccmp_is_satisfied_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok,
+                            size_t B, void *hip_stream);
+/* KinematicChainConstraint::jointValid (ConstraintFunction.h:43-55) */
+int ccmp_joint_valid_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B,
+                           void *hip_stream);
+/* jy_ProjectedStateSampler::sampleUniform (src/base/jy_ProjectedStateSpace.cpp:10-15): ambient
+ * uniform sample (counter-based: sample i, dim j uses splitmix64(seed ^ ((first_index+i)*14+j))) ->
+ * project (result kept in ok[], the reference ignores it) -> enforceBounds (KinematicChain.h:118-130).
+ * q_ambient (nullable) receives the un-projected samples. */
+int ccmp_sample_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
+                              double *q_out, uint8_t *ok, uint16_t *iters, double *q_ambient, size_t B,
+                              void *hip_stream);
+/* the ambient sampler alone (RealVectorStateSampler::sampleUniform over KinematicChain.h:75-100) */
+int ccmp_ambient_uniform_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
+                               double *q_out, size_t B, void *hip_stream);
+/* KinematicChainSpace::enforceBounds (KinematicChain.h:118-130), in place */
+int ccmp_enforce_bounds_batch(ccmp_ctx *ctx, double *q, size_t B, void *hip_stream);
+/* stable compaction of the rows with ok != 0 (what the host tree consumes); *count_dev is a device
+ * uint64 */
+int ccmp_compact_valid(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t B, double *q_valid,
+                       uint64_t *count_dev, void *hip_stream);
+
+/* ---- host-pointer conveniences (H2D, kernel, D2H; synchronous) ---------------------------------- */
+int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, double *q_out, uint8_t *ok,
+                      uint16_t *iters, size_t B);
+int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, double *f, size_t B);
+int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B);
+
+/* ---- diagnostics ---------------------------------------------------------------------------------- */
+/* runs ccmp_detmath.h's sincos/atan2/sqrt/div on the device: out[i] = {sin,cos,atan2_nn(|x|,|y|),
+ * sqrt(|x|), x/y} — used by tests to prove the device arithmetic is bit-identical to the host's */
+int ccmp_detmath_probe(ccmp_ctx *ctx, const double *x_dev, const double *y_dev, double *out_dev, size_t n,
+                       void *hip_stream);
+const char *ccmp_strerror(int code);
+const char *ccmp_last_hip_error(void);
+int ccmp_version(void);
+size_t ccmp_problem_sizeof(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCMP_H */

@@ -1,0 +1,672 @@
+/* ccmp_oracle.c — CPU restatement of the reference projector.  TEST INFRASTRUCTURE ONLY.
+ * See ccmp_oracle.h for scope, sources and pin status.  Plain C99, FP64 throughout,
+ * built with -ffp-contract=off so that the arithmetic below is exactly what is written.
+ *
+ * Operation order matters: the HIP FD-faithful kernel performs the same IEEE operations in the
+ * same order (sums left to right, products as parenthesised) so that, in the detmath build, the
+ * two agree bit for bit.  Do not "simplify" expressions here without changing the kernel.
+ */
+#include "ccmp_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef ORC_DETMATH
+/* elementary functions + rounding model of csrc/ccmp_detmath.h (the checker may read product
+ * code; the product may not read the checker).  Built with -DCCMP_USE_FMA: FMA(a,b,c) is fused. */
+#include "ccmp_detmath.h"
+#define ORC_SINCOS(x, s, c) ccmp_sincos((x), (s), (c))
+#define ORC_ATAN2_NN(y, x) ccmp_atan2_nn((y), (x))
+#define FMA(a, b, c) CCMP_FMA(a, b, c)
+#else
+/* what a stock x86-64 build of the reference does: glibc sin/cos/atan2, no fused operations */
+#define ORC_SINCOS(x, s, c) do { *(s) = sin(x); *(c) = cos(x); } while (0)
+#define ORC_ATAN2_NN(y, x) atan2((y), (x))
+#define FMA(a, b, c) ((a) * (b) + (c))
+#endif
+/* a0*b0 + a1*b1 + a2*b2, accumulated left to right (optionally onto c) */
+#define DOT3(a0, b0, a1, b1, a2, b2) FMA(a2, b2, FMA(a1, b1, (a0) * (b0)))
+#define DOT3ACC(c, a0, b0, a1, b1, a2, b2) FMA(a2, b2, FMA(a1, b1, FMA(a0, b0, c)))
+
+#define ORC_PI 3.14159265358979323846
+#define ORC_PI_2 1.57079632679489661923
+
+void orc_sincos(double x, double *s, double *c) { ORC_SINCOS(x, s, c); }
+double orc_atan2_nn(double y, double x) { return ORC_ATAN2_NN(y, x); }
+int orc_is_detmath(void)
+{
+#ifdef ORC_DETMATH
+  return 1;
+#else
+  return 0;
+#endif
+}
+size_t orc_problem_sizeof(void) { return sizeof(orc_problem); }
+
+/* ---- tiny fixed-size linear algebra, explicit evaluation order ---------------------------- */
+static void m3_mul(const double A[9], const double B[9], double C[9])
+{
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      C[3 * i + j] = DOT3(A[3 * i], B[j], A[3 * i + 1], B[3 + j], A[3 * i + 2], B[6 + j]);
+}
+static void m3t_mul(const double A[9], const double B[9], double C[9]) /* A^T B */
+{
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      C[3 * i + j] = DOT3(A[i], B[j], A[3 + i], B[3 + j], A[6 + i], B[6 + j]);
+}
+static void m3_vec(const double A[9], const double v[3], double r[3])
+{
+  for (int i = 0; i < 3; i++) r[i] = DOT3(A[3 * i], v[0], A[3 * i + 1], v[1], A[3 * i + 2], v[2]);
+}
+static void m3t_vec(const double A[9], const double v[3], double r[3])
+{
+  for (int i = 0; i < 3; i++) r[i] = DOT3(A[i], v[0], A[3 + i], v[1], A[6 + i], v[2]);
+}
+/* r += A v, each component accumulated left to right onto r */
+static void m3_vec_acc(const double A[9], const double v[3], double r[3])
+{
+  for (int i = 0; i < 3; i++) r[i] = DOT3ACC(r[i], A[3 * i], v[0], A[3 * i + 1], v[1], A[3 * i + 2], v[2]);
+}
+static void m3_identity(double R[9])
+{
+  for (int i = 0; i < 9; i++) R[i] = 0.0;
+  R[0] = R[4] = R[8] = 1.0;
+}
+
+/* Rotation about a fixed axis; RBDL Xrot(angle, axis) transposed (RBDL stores world->body).
+ * Entry formula order follows RBDL: axis_i*axis_j*(1-c) +- axis_k*s. */
+static void rot_axis(const double a[3], double q, double R[9])
+{
+  double s, c;
+  ORC_SINCOS(q, &s, &c);
+  double t = 1.0 - c;
+  double a0s = a[0] * s, a1s = a[1] * s, a2s = a[2] * s;
+  R[0] = FMA(a[0] * a[0], t, c);
+  R[1] = FMA(a[0] * a[1], t, -a2s);
+  R[2] = FMA(a[0] * a[2], t, a1s);
+  R[3] = FMA(a[1] * a[0], t, a2s);
+  R[4] = FMA(a[1] * a[1], t, c);
+  R[5] = FMA(a[1] * a[2], t, -a0s);
+  R[6] = FMA(a[2] * a[0], t, -a1s);
+  R[7] = FMA(a[2] * a[1], t, a0s);
+  R[8] = FMA(a[2] * a[2], t, c);
+}
+
+/* Eigen Quaternion::toRotationMatrix (no normalisation); q = (x,y,z,w). */
+static void quat_xyzw_to_R(const double q[4], double R[9])
+{
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  double twx = tx * w, twy = ty * w, twz = tz * w;
+  double txx = tx * x, txy = ty * x, txz = tz * x;
+  double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+/* Eigen Quaterniond(Matrix3d): trace / major-diagonal branches. out = (x,y,z,w). */
+static void R_to_quat(const double m[9], double q[4])
+{
+  double t = (m[0] + m[4]) + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(((m[4 * i] - m[4 * j]) - m[4 * k]) + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+    q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+  }
+}
+
+/* ---- setup ---------------------------------------------------------------------------------- */
+/* PandaModel::transformDH, panda_rbdl.cpp:150-160 */
+static void transform_dh(double a, double d, double alpha, double theta, double R[9], double p[3])
+{
+  double st, ct, sa, ca;
+  ORC_SINCOS(theta, &st, &ct);
+  ORC_SINCOS(alpha, &sa, &ca);
+  R[0] = ct;      R[1] = -1 * st; R[2] = 0.0;
+  R[3] = st * ca; R[4] = ct * ca; R[5] = -1 * sa;
+  R[6] = st * sa; R[7] = ct * sa; R[8] = ca;
+  p[0] = a; p[1] = -1 * sa * d; p[2] = ca * d;
+}
+
+/* PandaModel::initModel(dh), panda_rbdl.cpp:80-148 (kinematic part only) */
+void orc_panda_constants(const double dh_off[7][4], double axis[7][3], double offset[7][3],
+                         double ee[3], double R_tool[9])
+{
+  const double dh_al[7] = {0.0, -1.0 * ORC_PI_2, ORC_PI_2, ORC_PI_2, -1.0 * ORC_PI_2, ORC_PI_2, ORC_PI_2};
+  const double dh_a[7] = {0.0, 0.0, 0.0, 0.0825, -0.0825, 0.0, 0.088};
+  const double dh_d[7] = {0.333, 0.0, 0.316, 0.0, 0.384, 0.0, 0.0};
+  double TR[9], Tp[3] = {0, 0, 0}, gpos[7][3];
+  m3_identity(TR);
+  for (int i = 0; i < 7; i++) {
+    double a_off = dh_off ? dh_off[i][0] : 0.0, d_off = dh_off ? dh_off[i][1] : 0.0;
+    double q_off = dh_off ? dh_off[i][2] : 0.0, al_off = dh_off ? dh_off[i][3] : 0.0;
+    double R[9], p[3], NR[9], Rp[3];
+    transform_dh(dh_a[i] + a_off, dh_d[i] + d_off, dh_al[i] + al_off, q_off, R, p);
+    m3_mul(TR, R, NR);   /* T = T * DH : linear */
+    m3_vec(TR, p, Rp);   /*             translation = TR*p + Tp */
+    for (int k = 0; k < 3; k++) Tp[k] = Rp[k] + Tp[k];
+    memcpy(TR, NR, sizeof NR);
+    for (int k = 0; k < 3; k++) {
+      axis[i][k] = TR[3 * k + 2]; /* column 2 */
+      gpos[i][k] = Tp[k];
+    }
+  }
+  const double ee0[3] = {0.0, 0.0, 0.107};
+  m3_vec(TR, ee0, ee); /* ee_position_ = rot_ee_ * (0,0,0.107) */
+  for (int k = 0; k < 3; k++) offset[0][k] = gpos[0][k];
+  for (int i = 1; i < 7; i++)
+    for (int k = 0; k < 3; k++) offset[i][k] = gpos[i][k] - gpos[i - 1][k];
+  /* M = rot_ee_ * AngleAxisd(-pi/4, UnitZ), panda_rbdl.cpp:31 */
+  double s, c, Rz[9];
+  ORC_SINCOS(-ORC_PI / 4., &s, &c);
+  Rz[0] = c; Rz[1] = -s; Rz[2] = 0.0; Rz[3] = s; Rz[4] = c; Rz[5] = 0.0; Rz[6] = 0.0; Rz[7] = 0.0; Rz[8] = 1.0;
+  m3_mul(TR, Rz, R_tool);
+}
+
+/* grasping_point::grasping_point, grasping_point.cpp:5-20 */
+void orc_base_frame(int arm_index, double R[9], double p[3])
+{
+  m3_identity(R);
+  if (arm_index == 0) { p[0] = 0; p[1] = 0.3; p[2] = 1.006; }
+  else if (arm_index == 1) { p[0] = 0; p[1] = -0.3; p[2] = 1.006; }
+  else { p[0] = 1.35; p[1] = 0.3; p[2] = 1.006; R[0] = -1; R[4] = -1; }
+}
+
+/* PandaModel::getTransform (panda_rbdl.cpp:24-42) followed by t_wb * (ConstraintFunction.h:89-90) */
+void orc_fk(const orc_problem *P, int arm, const double q[7], double Rw[9], double pw[3])
+{
+  double R[9], o[3] = {0, 0, 0};
+  m3_identity(R);
+  for (int i = 0; i < 7; i++) {
+    double Rj[9], Rn[9];
+    m3_vec_acc(R, P->offset[arm][i], o);           /* r_i = r_{i-1} + E_{i-1}^T * X_T.r      */
+    rot_axis(P->axis[arm][i], q[i], Rj);           /* X_J = Xrot(q_i, axis_i)                */
+    m3_mul(R, Rj, Rn);
+    memcpy(R, Rn, sizeof Rn);
+  }
+  double Rf[9];
+  m3_vec_acc(R, P->ee[arm], o);                    /* CalcBodyToBaseCoordinates(ee): o + R*ee */
+  m3_mul(R, P->R_tool[arm], Rf);                   /* CalcBodyWorldOrientation^T * M         */
+  m3_mul(P->base_R[arm], Rf, Rw);                  /* t_wb * T                               */
+  for (int k = 0; k < 3; k++) pw[k] = P->base_p[arm][k];
+  m3_vec_acc(P->base_R[arm], o, pw);               /* base_p + base_R * p                    */
+}
+
+/* current_chain = t_w72.inverse() * t_w71 (ConstraintFunction.h:92, Eigen Isometry ops) */
+static void chain_of(const double R1[9], const double p1[3], const double R2[9], const double p2[3],
+                     double Rc[9], double pc[3])
+{
+  double ti[3], tp[3];
+  m3t_mul(R2, R1, Rc);
+  m3t_vec(R2, p2, ti);
+  for (int k = 0; k < 3; k++) ti[k] = -ti[k]; /* inverse().translation = -(R^T p) */
+  m3t_vec(R2, p1, tp);
+  for (int k = 0; k < 3; k++) pc[k] = tp[k] + ti[k];
+}
+
+/* residual of a chain against init_chain_; also returns d = q_c * conj(q_0) for the analytic J */
+static void residual_of_chain(const orc_problem *P, const double Rc[9], const double pc[3], double f[2],
+                              double dquat[4])
+{
+  double qc[4], q0[4];
+  R_to_quat(Rc, qc);
+  R_to_quat(P->init_R, q0);
+  /* d = qc * conj(q0), Eigen quaternion product with b = (w0, -x0, -y0, -z0) */
+  double ax = qc[0], ay = qc[1], az = qc[2], aw = qc[3];
+  double bx = -q0[0], by = -q0[1], bz = -q0[2], bw = q0[3];
+  double dw = FMA(-az, bz, FMA(-ay, by, FMA(-ax, bx, aw * bw)));
+  double dx = FMA(-az, by, FMA(ay, bz, FMA(ax, bw, aw * bx)));
+  double dy = FMA(-ax, bz, FMA(az, bx, FMA(ay, bw, aw * by)));
+  double dz = FMA(-ay, bx, FMA(ax, by, FMA(az, bw, aw * bz)));
+  double vn = sqrt(DOT3(dx, dx, dy, dy, dz, dz));
+  f[1] = 2.0 * ORC_ATAN2_NN(vn, fabs(dw)); /* angularDistance, Eigen >= 3.3 */
+  double e0 = pc[0] - P->init_p[0], e1 = pc[1] - P->init_p[1], e2 = pc[2] - P->init_p[2];
+  f[0] = sqrt(DOT3(e0, e0, e1, e1, e2, e2));
+  if (dquat) { dquat[0] = dx; dquat[1] = dy; dquat[2] = dz; dquat[3] = dw; }
+}
+
+/* KinematicChainConstraint::function, ConstraintFunction.h:84-102 */
+void orc_function(const orc_problem *P, const double x[14], double f[2])
+{
+  double R1[9], p1[3], R2[9], p2[3], Rc[9], pc[3];
+  orc_fk(P, 0, x, R1, p1);
+  orc_fk(P, 1, x + 7, R2, p2);
+  chain_of(R1, p1, R2, p2, Rc, pc);
+  residual_of_chain(P, Rc, pc, f, NULL);
+}
+
+/* setInitialPosition (ConstraintFunction.h:31-40) + t_o7 (ConstrainedPlanningCommon.cpp:102-111) */
+void orc_set_start(orc_problem *P, const double q0[14])
+{
+  double R1[9], p1[3], R2[9], p2[3];
+  memcpy(P->start_joint, q0, 14 * sizeof(double));
+  orc_fk(P, 0, q0, R1, p1);
+  orc_fk(P, 1, q0 + 7, R2, p2);
+  chain_of(R1, p1, R2, p2, P->init_R, P->init_p);
+  /* t_o7 = t_wo_start.inverse() * t_w7a */
+  chain_of(R1, p1, P->obj_start_R, P->obj_start_p, P->t_o7_R[0], P->t_o7_p[0]);
+  chain_of(R2, p2, P->obj_start_R, P->obj_start_p, P->t_o7_R[1], P->t_o7_p[1]);
+}
+
+int orc_problem_init(orc_problem *P, const char *name1, int index1, const char *name2, int index2,
+                     const double start_joint[14], const double obj_start_pos[3],
+                     const double obj_start_quat_xyzw[4], const double obj_goal_pos[3],
+                     const double obj_goal_quat_xyzw[4])
+{
+  static const double lb[7] = {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973};
+  static const double ub[7] = {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973};
+  memset(P, 0, sizeof *P);
+  if (index1 < 0 || index1 > 2 || index2 < 0 || index2 > 2) return -1;
+  /* std::map<std::string,int> iteration order = alphabetical (ConstrainedPlanningCommon.cpp:13-14,89-91) */
+  int idx[2];
+  if (strcmp(name1, name2) <= 0) { idx[0] = index1; idx[1] = index2; }
+  else { idx[0] = index2; idx[1] = index1; }
+  for (int a = 0; a < 2; a++) {
+    P->arm_index[a] = idx[a];
+    orc_panda_constants(NULL, P->axis[a], P->offset[a], P->ee[a], P->R_tool[a]);
+    orc_base_frame(idx[a], P->base_R[a], P->base_p[a]);
+  }
+  memcpy(P->lb, lb, sizeof lb);
+  memcpy(P->ub, ub, sizeof ub);
+  P->joint_eps = 0.001;
+  P->tol_pos = 0.001;
+  P->tol_rot = 0.005;
+  P->step = 0.30;
+  P->delta = 0.25;
+  P->lambda = 2.0;
+  P->max_iter = 250;
+  P->jacobian_mode = ORC_JAC_FD;
+  m3_identity(P->obj_start_R);
+  m3_identity(P->obj_goal_R);
+  if (obj_start_quat_xyzw) quat_xyzw_to_R(obj_start_quat_xyzw, P->obj_start_R);
+  if (obj_goal_quat_xyzw) quat_xyzw_to_R(obj_goal_quat_xyzw, P->obj_goal_R);
+  if (obj_start_pos) memcpy(P->obj_start_p, obj_start_pos, 3 * sizeof(double));
+  if (obj_goal_pos) memcpy(P->obj_goal_p, obj_goal_pos, 3 * sizeof(double));
+  orc_set_start(P, start_joint);
+  return 0;
+}
+
+/* ---- Jacobians ------------------------------------------------------------------------------ */
+/* ompl::base::Constraint::jacobian (default; the reference does not override it): 7-point
+ * central stencil, 6 residual evaluations per column, h = sqrt(eps)*max(1,|x_j|), divided by the
+ * *stored* perturbed difference. */
+void orc_jacobian_fd(const orc_problem *P, const double x[14], double J[28])
+{
+  double y1[14], y2[14], t1[2], t2[2];
+  memcpy(y1, x, sizeof y1);
+  memcpy(y2, x, sizeof y2);
+  for (int j = 0; j < 14; j++) {
+    const double ax = fabs(x[j]);
+    const double h = 1.4901161193847656e-08 /* sqrt(DBL_EPSILON) = 2^-26 */ * (ax >= 1 ? ax : 1);
+    double m[3][2];
+    for (int s = 0; s < 3; s++) {
+      y1[j] += h;
+      y2[j] -= h;
+      orc_function(P, y1, t1);
+      orc_function(P, y2, t2);
+      const double den = y1[j] - y2[j];
+      m[s][0] = (t1[0] - t2[0]) / den;
+      m[s][1] = (t1[1] - t2[1]) / den;
+    }
+    for (int r = 0; r < 2; r++) J[r * 14 + j] = FMA(0.1, m[2][r], FMA(-0.6, m[1][r], 1.5 * m[0][r]));
+    y1[j] = y2[j] = x[j];
+  }
+}
+
+/* Per-joint world frames of one arm: z_i (rotation axis) and o_i (joint origin) in world coords. */
+static void fk_frames(const orc_problem *P, int arm, const double q[7], double z[7][3], double ow[7][3],
+                      double Rw[9], double pw[3])
+{
+  double R[9], o[3] = {0, 0, 0};
+  m3_identity(R);
+  for (int i = 0; i < 7; i++) {
+    double Rj[9], Rn[9], zl[3];
+    m3_vec_acc(R, P->offset[arm][i], o);
+    m3_vec(R, P->axis[arm][i], zl);
+    m3_vec(P->base_R[arm], zl, z[i]);
+    for (int k = 0; k < 3; k++) ow[i][k] = P->base_p[arm][k];
+    m3_vec_acc(P->base_R[arm], o, ow[i]);
+    rot_axis(P->axis[arm][i], q[i], Rj);
+    m3_mul(R, Rj, Rn);
+    memcpy(R, Rn, sizeof Rn);
+  }
+  double Rf[9];
+  m3_vec_acc(R, P->ee[arm], o);
+  m3_mul(R, P->R_tool[arm], Rf);
+  m3_mul(P->base_R[arm], Rf, Rw);
+  for (int k = 0; k < 3; k++) pw[k] = P->base_p[arm][k];
+  m3_vec_acc(P->base_R[arm], o, pw);
+}
+
+/* Exact derivative of the residual: row0 = u^T dp_c/dq, row1 = n^T dw_c/dq.
+ * Not what the reference computes (it differentiates numerically); used for the CPU "analytic"
+ * baseline and to cross-check the FD stencil. */
+void orc_jacobian_analytic(const orc_problem *P, const double x[14], double J[28])
+{
+  double z[2][7][3], o[2][7][3], R1[9], p1[3], R2[9], p2[3], Rc[9], pc[3], f[2], d[4];
+  fk_frames(P, 0, x, z[0], o[0], R1, p1);
+  fk_frames(P, 1, x + 7, z[1], o[1], R2, p2);
+  chain_of(R1, p1, R2, p2, Rc, pc);
+  residual_of_chain(P, Rc, pc, f, d);
+  double u[3] = {0, 0, 0}, n[3] = {0, 0, 0}, a[3], b[3];
+  if (f[0] > 0.0)
+    for (int k = 0; k < 3; k++) u[k] = (pc[k] - P->init_p[k]) / f[0];
+  double vn = sqrt(DOT3(d[0], d[0], d[1], d[1], d[2], d[2]));
+  if (vn > 0.0) {
+    double sg = d[3] < 0.0 ? -1.0 : 1.0;
+    for (int k = 0; k < 3; k++) n[k] = sg * d[k] / vn;
+  }
+  m3_vec(R2, u, a); /* world direction of the position-error gradient */
+  m3_vec(R2, n, b); /* world direction of the rotation-error gradient */
+  for (int arm = 0; arm < 2; arm++) {
+    double sgn = arm == 0 ? 1.0 : -1.0;
+    for (int i = 0; i < 7; i++) {
+      const double *zi = z[arm][i];
+      double r[3] = {p1[0] - o[arm][i][0], p1[1] - o[arm][i][1], p1[2] - o[arm][i][2]};
+      double cx = zi[1] * r[2] - zi[2] * r[1];
+      double cy = zi[2] * r[0] - zi[0] * r[2];
+      double cz = zi[0] * r[1] - zi[1] * r[0];
+      J[0 * 14 + arm * 7 + i] = sgn * DOT3(a[0], cx, a[1], cy, a[2], cz);
+      J[1 * 14 + arm * 7 + i] = sgn * DOT3(b[0], zi[0], b[1], zi[1], b[2], zi[2]);
+    }
+  }
+}
+
+/* Eigen::JacobiSVD<MatrixXd>(j, ThinU|ThinV).solve(f) for the 2x14 j (ConstraintFunction.h:71):
+ * minimum-norm least-squares solution, singular values <= 2*eps*sigma_max treated as zero.
+ * Realised as a one-sided (Hestenes) Jacobi SVD on the two rows — two fixed sweeps, the second
+ * is a polish — which keeps kappa*eps accuracy without forming (J J^T)^-1 explicitly. */
+void orc_solve_minnorm(const double J[28], const double f[2], double dx[14])
+{
+  double r0[14], r1[14], g0 = f[0], g1 = f[1];
+  memcpy(r0, J, sizeof r0);
+  memcpy(r1, J + 14, sizeof r1);
+  double a = 0, d = 0, b = 0;
+  for (int sweep = 0; sweep < 2; sweep++) {
+    a = 0; d = 0; b = 0;
+    for (int j = 0; j < 14; j++) {
+      a = FMA(r0[j], r0[j], a);
+      d = FMA(r1[j], r1[j], d);
+      b = FMA(r0[j], r1[j], b);
+    }
+    if (b != 0.0) {
+      double zeta = (d - a) / (2.0 * b);
+      double t = 1.0 / (fabs(zeta) + sqrt(FMA(zeta, zeta, 1.0)));
+      if (zeta < 0.0) t = -t;
+      double c = 1.0 / sqrt(FMA(t, t, 1.0));
+      double s = c * t;
+      for (int j = 0; j < 14; j++) {
+        double v0 = r0[j], v1 = r1[j];
+        r0[j] = FMA(c, v0, -(s * v1));
+        r1[j] = FMA(s, v0, c * v1);
+      }
+      double h0 = g0, h1 = g1;
+      g0 = FMA(c, h0, -(s * h1));
+      g1 = FMA(s, h0, c * h1);
+    }
+  }
+  a = 0; d = 0;
+  for (int j = 0; j < 14; j++) { a = FMA(r0[j], r0[j], a); d = FMA(r1[j], r1[j], d); }
+  double s0 = sqrt(a), s1 = sqrt(d);
+  double smax = s0 > s1 ? s0 : s1;
+  double thr = smax * (2.0 * 2.220446049250313e-16); /* diagSize * epsilon */
+  if (thr < 2.2250738585072014e-308) thr = 2.2250738585072014e-308;
+  double k0 = s0 > thr ? g0 / a : 0.0;
+  double k1 = s1 > thr ? g1 / d : 0.0;
+  for (int j = 0; j < 14; j++) dx[j] = FMA(k1, r1[j], k0 * r0[j]);
+}
+
+/* ---- the projector --------------------------------------------------------------------------- */
+/* KinematicChainConstraint::jointValid, ConstraintFunction.h:43-55 */
+int orc_joint_valid(const orc_problem *P, const double q[14])
+{
+  double eps = P->joint_eps;
+  for (int arm = 0; arm < 2; arm++)
+    for (int i = 0; i < 7; i++) {
+      if (q[arm * 7 + i] < P->lb[i] + eps) return 0;
+      if (q[arm * 7 + i] > P->ub[i] - eps) return 0;
+    }
+  return 1;
+}
+
+/* KinematicChainConstraint::project, ConstraintFunction.h:57-82 — including the precedence
+ * quirk at :68 (norm1 receives the boolean f[0] > tol1; norm2 receives f[1] only when that is
+ * false), iter++ evaluated only when the residual test holds, x left at the last iterate. */
+int orc_project(const orc_problem *P, double x[14], int32_t *iters)
+{
+  unsigned int iter = 0;
+  int32_t updates = 0;
+  double norm1 = 0, norm2 = 0;
+  double f[2], J[28], dx[14];
+  orc_function(P, x, f);
+  while (((norm1 = (double)(f[0] > P->tol_pos)) != 0.0 || (norm2 = f[1]) > P->tol_rot) &&
+         iter++ < (unsigned int)P->max_iter) {
+    if (P->jacobian_mode == ORC_JAC_ANALYTIC) orc_jacobian_analytic(P, x, J);
+    else orc_jacobian_fd(P, x, J);
+    orc_solve_minnorm(J, f, dx);
+    for (int i = 0; i < 14; i++) x[i] = FMA(-P->step, dx[i], x[i]); /* x -= 0.30*dx */
+    orc_function(P, x, f);
+    updates++;
+  }
+  if (iters) *iters = updates;
+  return orc_joint_valid(P, x) && (norm1 < P->tol_pos) && (norm2 < P->tol_rot);
+}
+
+/* KinematicChainConstraint::isSatisfied, ConstraintFunction.h:114-120 */
+int orc_is_satisfied(const orc_problem *P, const double x[14])
+{
+  double f[2];
+  orc_function(P, x, f);
+  return isfinite(f[0]) && isfinite(f[1]) && f[0] <= P->tol_pos && f[1] <= P->tol_rot;
+}
+
+/* ---- state space: KinematicChain.h:118-130,145-171; RealVectorStateSpace::distance ---------- */
+void orc_enforce_bounds(double x[14])
+{
+  for (int i = 0; i < 14; i++) {
+    double v = fmod(x[i], 2.0 * ORC_PI);
+    if (v < -ORC_PI) v += 2.0 * ORC_PI;
+    else if (v >= ORC_PI) v -= 2.0 * ORC_PI;
+    x[i] = v;
+  }
+}
+
+void orc_interpolate(const double from[14], const double to[14], double t, double out[14])
+{
+  for (int i = 0; i < 14; i++) {
+    double diff = to[i] - from[i];
+    if (fabs(diff) <= ORC_PI) out[i] = FMA(diff, t, from[i]);
+    else {
+      if (diff > 0.0) diff = 2.0 * ORC_PI - diff;
+      else diff = -2.0 * ORC_PI - diff;
+      double v = FMA(-diff, t, from[i]);
+      if (v > ORC_PI) v -= 2.0 * ORC_PI;
+      else if (v < -ORC_PI) v += 2.0 * ORC_PI;
+      out[i] = v;
+    }
+  }
+}
+
+double orc_distance(const double a[14], const double b[14])
+{
+  double dist = 0.0;
+  for (int i = 0; i < 14; i++) {
+    double diff = a[i] - b[i];
+    dist = FMA(diff, diff, dist);
+  }
+  return sqrt(dist);
+}
+
+/* ---- sampler: jy_ProjectedStateSpace.cpp:10-15 with the counter-based generator of
+ * SURVEY.md §8d standing in for OMPL's (time-seeded, unreproducible) RNG ---------------------- */
+uint64_t orc_splitmix64(uint64_t z)
+{
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+void orc_ambient_uniform(const orc_problem *P, uint64_t seed, uint64_t index, double q[14])
+{
+  for (int j = 0; j < 14; j++) {
+    uint64_t r = orc_splitmix64(seed ^ (index * 14ULL + (uint64_t)j));
+    double u = (double)(r >> 11) * 1.1102230246251565e-16; /* 2^-53 */
+    q[j] = FMA(P->ub[j % 7] - P->lb[j % 7], u, P->lb[j % 7]); /* RNG::uniformReal(low, high) */
+  }
+}
+
+int orc_sample_uniform(const orc_problem *P, uint64_t seed, uint64_t index, double q[14], int32_t *iters)
+{
+  orc_ambient_uniform(P, seed, index, q);
+  int ok = orc_project(P, q, iters); /* return value ignored by the reference sampler */
+  orc_enforce_bounds(q);
+  return ok;
+}
+
+/* ---- jy_ProjectedStateSpace::discreteGeodesic, jy_ProjectedStateSpace.cpp:32-96 -------------- */
+int orc_discrete_geodesic(const orc_problem *P, const double from[14], const double to[14],
+                          int interpolate, orc_valid_fn valid, void *user, double *out,
+                          int max_states, int *n_states, int64_t *newton_iters)
+{
+  int n = 0;
+  int64_t its = 0;
+  if (out && max_states > 0) { memcpy(out, from, 14 * sizeof(double)); n = 1; }
+  const double tolerance = P->delta;
+  double dist, step = 0, total = 0;
+  if ((dist = orc_distance(from, to)) <= tolerance) {
+    if (n_states) *n_states = n;
+    if (newton_iters) *newton_iters = 0;
+    return 1;
+  }
+  const double max = dist * P->lambda;
+  double previous[14], scratch[14];
+  memcpy(previous, from, sizeof previous);
+  do {
+    orc_interpolate(previous, to, P->delta / dist, scratch);
+    int32_t it = 0;
+    int proj = orc_project(P, scratch, &it);
+    its += it;
+    if (!proj || !(interpolate || !valid || valid(scratch, user)) ||
+        (step = orc_distance(previous, scratch)) > P->lambda * P->delta)
+      break;
+    total += step;
+    if (total > max) break;
+    const double newDist = orc_distance(scratch, to);
+    if (newDist >= dist) break;
+    dist = newDist;
+    memcpy(previous, scratch, sizeof previous);
+    if (out && n < max_states) { memcpy(out + 14 * n, scratch, 14 * sizeof(double)); n++; }
+  } while (dist >= tolerance);
+  if (n_states) *n_states = n;
+  if (newton_iters) *newton_iters = its;
+  return dist <= tolerance;
+}
+
+/* IKTask::compute_t_wo, ik_task.cpp:10-14: t_wb * FK(q_left) * t_o7.inverse() for panda_left
+ * (always arm slot 0: "panda_left" sorts first). */
+void orc_compute_t_wo(const orc_problem *P, const double q_left[7], double R[9], double p[3])
+{
+  double Rw[9], pw[3], Ri[9], pi_[3], tmp[3];
+  orc_fk(P, 0, q_left, Rw, pw);
+  /* inverse of t_o7 */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Ri[3 * i + j] = P->t_o7_R[0][3 * j + i];
+  m3t_vec(P->t_o7_R[0], P->t_o7_p[0], pi_);
+  for (int k = 0; k < 3; k++) pi_[k] = -pi_[k];
+  m3_mul(Rw, Ri, R);
+  (void)tmp;
+  for (int k = 0; k < 3; k++) p[k] = pw[k];
+  m3_vec_acc(Rw, pi_, p);
+}
+
+/* ---- batch drivers ---------------------------------------------------------------------------- */
+typedef struct {
+  const orc_problem *P;
+  const double *q_in;
+  double *q_out;
+  double *f;
+  uint8_t *ok;
+  int32_t *iters;
+  uint64_t seed, first;
+  size_t lo, hi;
+  int kind; /* 0 project, 1 function, 2 sample+project */
+} orc_job;
+
+static void *orc_worker(void *arg)
+{
+  orc_job *j = (orc_job *)arg;
+  for (size_t i = j->lo; i < j->hi; i++) {
+    if (j->kind == 1) { orc_function(j->P, j->q_in + 14 * i, j->f + 2 * i); continue; }
+    double x[14];
+    int32_t it = 0;
+    int ok;
+    if (j->kind == 0) { memcpy(x, j->q_in + 14 * i, sizeof x); ok = orc_project(j->P, x, &it); }
+    else ok = orc_sample_uniform(j->P, j->seed, j->first + i, x, &it);
+    memcpy(j->q_out + 14 * i, x, sizeof x);
+    if (j->ok) j->ok[i] = (uint8_t)ok;
+    if (j->iters) j->iters[i] = it;
+  }
+  return NULL;
+}
+
+static void orc_run(orc_job proto, size_t B, int nthreads)
+{
+  if (nthreads < 1) nthreads = 1;
+  if ((size_t)nthreads > B) nthreads = B ? (int)B : 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+  orc_job *jobs = (orc_job *)malloc(sizeof(orc_job) * nthreads);
+  for (int t = 0; t < nthreads; t++) {
+    jobs[t] = proto;
+    jobs[t].lo = B * (size_t)t / (size_t)nthreads;
+    jobs[t].hi = B * (size_t)(t + 1) / (size_t)nthreads;
+    if (nthreads == 1) { orc_worker(&jobs[t]); }
+    else pthread_create(&th[t], NULL, orc_worker, &jobs[t]);
+  }
+  if (nthreads > 1)
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  free(th);
+  free(jobs);
+}
+
+void orc_function_batch(const orc_problem *P, const double *q, double *f, size_t B, int nthreads)
+{
+  orc_job j; memset(&j, 0, sizeof j);
+  j.P = P; j.q_in = q; j.f = f; j.kind = 1;
+  orc_run(j, B, nthreads);
+}
+
+void orc_project_batch(const orc_problem *P, const double *q_in, double *q_out, uint8_t *ok,
+                       int32_t *iters, size_t B, int nthreads)
+{
+  orc_job j; memset(&j, 0, sizeof j);
+  j.P = P; j.q_in = q_in; j.q_out = q_out; j.ok = ok; j.iters = iters; j.kind = 0;
+  orc_run(j, B, nthreads);
+}
+
+void orc_sample_project_batch(const orc_problem *P, uint64_t seed, uint64_t first_index,
+                              double *q_out, uint8_t *ok, int32_t *iters, size_t B, int nthreads)
+{
+  orc_job j; memset(&j, 0, sizeof j);
+  j.P = P; j.q_out = q_out; j.ok = ok; j.iters = iters; j.seed = seed; j.first = first_index; j.kind = 2;
+  orc_run(j, B, nthreads);
+}

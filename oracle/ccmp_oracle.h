@@ -1,0 +1,129 @@
+/* ccmp_oracle.h — CPU restatement of the reference's closed-chain constraint projector.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under closed_chain_motion_planner_amd/ or include/ may
+ * include, link or call this; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and there only as the checker / the reported CPU baseline.
+ *
+ * What it restates (all paths relative to /root/reference):
+ *   include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:21-137
+ *   src/kinematics/panda_rbdl.cpp:24-42,73-160          (FK over RBDL, modified-DH tables)
+ *   src/kinematics/grasping_point.cpp:5-33              (base frames)
+ *   src/base/constraints/ConstrainedPlanningCommon.cpp:85-132 (arm order, t_o7, parameters)
+ *   src/base/jy_ProjectedStateSpace.cpp:10-96           (sampler, discreteGeodesic)
+ *   include/closed_chain_motion_planner/kinematics/KinematicChain.h:69-171 (bounds, wrap, interpolate)
+ *   src/base/constraints/ik_task.cpp:10-14              (compute_t_wo)
+ * plus the un-vendored, un-pinned third-party arithmetic the reference calls:
+ *   OMPL  ompl::base::Constraint::jacobian  (default 7-point central-difference stencil)
+ *   Eigen JacobiSVD(2x14, ThinU|ThinV).solve, Quaterniond(Matrix3d), angularDistance, Isometry3d
+ *   RBDL  Xrot / CalcBodyToBaseCoordinates / CalcBodyWorldOrientation
+ *
+ * PARITY PIN STATUS: the reference has no tests and cannot be built here (needs Eigen, OMPL,
+ * RBDL, ROS — none installed, no network).  FK + residual + tolerances + delta are pinned by the
+ * reference's recorded outputs (debug/Wine_Bottle_path.txt, debug/dumbbell_path.txt, config
+ * start_joint rows; tests/golden/).  The Newton trajectory, FD Jacobian and SVD solve are
+ * "parity unpinned": no reference artefact records them.
+ *
+ * Two builds of the same source (oracle/Makefile):
+ *   libccmp_oracle_libm.so  sin/cos/atan2 from glibc  — what the reference would call
+ *   libccmp_oracle_det.so   sin/cos/atan from csrc/ccmp_detmath.h, -ffp-contract=off —
+ *                           the op-for-op sequence the HIP FD-faithful kernel also runs, so the
+ *                           two can be compared bit for bit.
+ */
+#ifndef CCMP_ORACLE_H
+#define CCMP_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout-compatible with ccmp_problem (include/ccmp.h); tests assert sizeof/offsets agree so the
+ * same bytes can be handed to both sides.  Matrices are row-major. */
+typedef struct orc_problem {
+  double axis[2][7][3];   /* joint axes in the parent body frame (base-aligned at q=0) */
+  double offset[2][7][3]; /* joint origin relative to the parent joint origin           */
+  double ee[2][3];        /* rot_ee*(0,0,0.107), panda_rbdl.cpp:124-126                 */
+  double R_tool[2][9];    /* rot_ee*Rz(-pi/4),   panda_rbdl.cpp:31                      */
+  double base_R[2][9];    /* t_wb per arm, grasping_point.cpp:11-20                     */
+  double base_p[2][3];
+  double init_R[9];       /* init_chain_, ConstraintFunction.h:39                       */
+  double init_p[3];
+  double lb[7];           /* ConstraintFunction.h:27-28                                 */
+  double ub[7];
+  double joint_eps;       /* 0.001, ConstraintFunction.h:45                             */
+  double tol_pos;         /* 1e-3,  ConstrainedPlanningCommon.cpp:120                   */
+  double tol_rot;         /* 5e-3,  ConstrainedPlanningCommon.cpp:121                   */
+  double step;            /* 0.30,  ConstraintFunction.h:71                             */
+  double delta;           /* 0.25,  ConstrainedPlanningCommon.cpp:118                   */
+  double lambda;          /* 2.0,   ConstrainedPlanningCommon.cpp:119                   */
+  double start_joint[14];
+  double obj_start_R[9];  /* t_wo_start, grasping_point.cpp:38-43                       */
+  double obj_start_p[3];
+  double obj_goal_R[9];
+  double obj_goal_p[3];
+  double t_o7_R[2][9];    /* t_o7 per arm, ConstrainedPlanningCommon.cpp:110-111        */
+  double t_o7_p[2][3];
+  int32_t max_iter;       /* 250, ConstraintFunction.h:26                               */
+  int32_t jacobian_mode;  /* 0 = finite-difference (reference), 1 = analytic            */
+  int32_t arm_index[2];   /* 0 left, 1 right, 2 top                                     */
+} orc_problem;
+
+enum { ORC_JAC_FD = 0, ORC_JAC_ANALYTIC = 1 };
+
+/* --- setup ------------------------------------------------------------------------------- */
+/* Panda constants from the modified-DH tables (panda_rbdl.cpp:73-148); dh_off may be NULL
+ * (= the zero calibration the reference ships with). */
+void orc_panda_constants(const double dh_off[7][4], double axis[7][3], double offset[7][3],
+                         double ee[3], double R_tool[9]);
+void orc_base_frame(int arm_index, double R[9], double p[3]);
+/* Fill every field with the reference defaults; arms are given as (name,index) pairs and ordered
+ * alphabetically by name exactly as the reference's std::map does.  obj_* may be NULL (identity). */
+int orc_problem_init(orc_problem *P, const char *name1, int index1, const char *name2, int index2,
+                     const double start_joint[14], const double obj_start_pos[3],
+                     const double obj_start_quat_xyzw[4], const double obj_goal_pos[3],
+                     const double obj_goal_quat_xyzw[4]);
+void orc_set_start(orc_problem *P, const double q0[14]); /* setInitialPosition + t_o7 */
+
+/* --- the path ------------------------------------------------------------------------------ */
+void orc_fk(const orc_problem *P, int arm, const double q[7], double R[9], double p[3]); /* world pose */
+void orc_function(const orc_problem *P, const double x[14], double f[2]);
+void orc_jacobian_fd(const orc_problem *P, const double x[14], double J[28]);       /* J[r*14+j] */
+void orc_jacobian_analytic(const orc_problem *P, const double x[14], double J[28]);
+void orc_solve_minnorm(const double J[28], const double f[2], double dx[14]);
+int orc_project(const orc_problem *P, double x[14], int32_t *iters); /* 1 = true, 0 = false */
+int orc_joint_valid(const orc_problem *P, const double x[14]);
+int orc_is_satisfied(const orc_problem *P, const double x[14]);
+
+/* --- callers / space ----------------------------------------------------------------------- */
+void orc_enforce_bounds(double x[14]);
+void orc_interpolate(const double from[14], const double to[14], double t, double out[14]);
+double orc_distance(const double a[14], const double b[14]);
+uint64_t orc_splitmix64(uint64_t z);
+void orc_ambient_uniform(const orc_problem *P, uint64_t seed, uint64_t index, double q[14]);
+/* sampleUniform = ambient sample -> project (result ignored) -> enforceBounds */
+int orc_sample_uniform(const orc_problem *P, uint64_t seed, uint64_t index, double q[14], int32_t *iters);
+/* discreteGeodesic; valid(state, user) may be NULL (= always valid).  Returns the bool of the
+ * reference; *n_states counts states written to out (first one is `from`), capped at max_states. */
+typedef int (*orc_valid_fn)(const double q[14], void *user);
+int orc_discrete_geodesic(const orc_problem *P, const double from[14], const double to[14],
+                          int interpolate, orc_valid_fn valid, void *user, double *out,
+                          int max_states, int *n_states, int64_t *newton_iters);
+void orc_compute_t_wo(const orc_problem *P, const double q_left[7], double R[9], double p[3]);
+
+/* --- batch drivers (pthreads; for parity runs and the CPU baseline timing) ------------------ */
+void orc_function_batch(const orc_problem *P, const double *q, double *f, size_t B, int nthreads);
+void orc_project_batch(const orc_problem *P, const double *q_in, double *q_out, uint8_t *ok,
+                       int32_t *iters, size_t B, int nthreads);
+void orc_sample_project_batch(const orc_problem *P, uint64_t seed, uint64_t first_index,
+                              double *q_out, uint8_t *ok, int32_t *iters, size_t B, int nthreads);
+/* elementary functions of this build (libm or detmath) exposed for tests */
+void orc_sincos(double x, double *s, double *c);
+double orc_atan2_nn(double y, double x);
+int orc_is_detmath(void);
+size_t orc_problem_sizeof(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(HERE, "golden")
+OBJECTS = ("Wine_Bottle", "dumbbell", "stefan")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def config_path(obj):
+    return os.path.join(GOLDEN, "config", obj + ".yaml")
+
+
+def load_cfg(obj):
+    with open(config_path(obj)) as f:
+        return yaml.safe_load(f)
+
+
+def load_path_rows(obj):
+    return np.loadtxt(os.path.join(GOLDEN, "paths", obj + "_path.txt"))
+
+
+@pytest.fixture(scope="session")
+def oracle_det():
+    from oracle_binding import Oracle
+
+    return Oracle("det")
+
+
+@pytest.fixture(scope="session")
+def oracle_libm():
+    from oracle_binding import Oracle
+
+    return Oracle("libm")
+
+
+@pytest.fixture(scope="session")
+def ccmp_built():
+    """libccmp.so, built in-tree (hipcc cross-compiles without a GPU)."""
+    from closed_chain_motion_planner_amd.build import build_library
+
+    return build_library()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(ccmp_built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from closed_chain_motion_planner_amd import Context
+
+    return Context(0)
+
+
+NCPU = max(1, min(16, os.cpu_count() or 1))

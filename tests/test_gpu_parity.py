@@ -1,0 +1,194 @@
+"""GPU parity proper: the HIP path, called through the C-ABI, against the CPU oracle.
+
+FD-faithful mode (the default, reference arithmetic) must agree with the det-build oracle BIT FOR
+BIT — joints, ok flags and iteration counts — because the reference's Newton iteration amplifies
+ulp-level differences past the 1e-6 rad bar.  The 1e-6 rad tolerance of the
+north star is asserted as well; bitwise equality implies it.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import NCPU, OBJECTS, config_path, load_cfg, load_path_rows
+
+pytestmark = pytest.mark.gpu
+
+TOL_RAD = 1e-6  # north_star: "projected joints match the reference CPU projector ... to 1e-6 rad"
+
+
+def _constraint(obj, ctx, mode=0):
+    from closed_chain_motion_planner_amd import KinematicChainConstraint
+
+    c = KinematicChainConstraint.from_yaml(config_path(obj), ctx=ctx)
+    c.setJacobianMode(mode)
+    return c
+
+
+def _oracle_problem(oracle, c):
+    return oracle.problem_from_bytes(bytes(c.problem))
+
+
+def test_device_arithmetic_is_bitwise_host(gpu_ctx, oracle_det):
+    """sincos / atan2 / sqrt / divide on gfx950 == the same source on the host, bit for bit."""
+    import torch
+    from closed_chain_motion_planner_amd import _lib
+
+    rng = np.random.default_rng(7)
+    n = 200000
+    x = np.concatenate([rng.uniform(-8, 8, n // 2), rng.standard_normal(n // 4) * 1e3, rng.uniform(-1e-3, 1e-3, n // 4)])
+    y = np.concatenate([rng.uniform(-8, 8, n // 2), rng.standard_normal(n // 4), rng.uniform(-1e3, 1e3, n // 4)])
+    x[:6] = [0.0, -0.0, np.pi / 2, 1e6, 2e6, np.inf]
+    y[:6] = [0.0, 1.0, 0.0, 3.0, 1.0, 1.0]
+    xd, yd = torch.as_tensor(x).cuda(), torch.as_tensor(y).cuda()
+    out = torch.empty((n, 5), dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().ccmp_detmath_probe(gpu_ctx.handle, xd.data_ptr(), yd.data_ptr(), out.data_ptr(), n, None),
+               "probe")
+    torch.cuda.synchronize()
+    import torch as _t
+    _lib.lib()  # keep loaded
+    got = out.cpu().numpy()
+    L = oracle_det.lib
+    exp = np.empty_like(got)
+    s, c = C.c_double(), C.c_double()
+    for i in range(n):
+        L.orc_sincos(x[i], C.byref(s), C.byref(c))
+        exp[i, 0], exp[i, 1] = s.value, c.value
+        exp[i, 2] = L.orc_atan2_nn(abs(x[i]), abs(y[i]))
+    exp[:, 3] = np.sqrt(np.abs(x))
+    with np.errstate(all="ignore"):
+        exp[:, 4] = x / y
+    same = (got.view(np.uint64) == exp.view(np.uint64)) | (np.isnan(got) & np.isnan(exp))
+    assert same.all(), "device/host arithmetic differs at %s" % np.argwhere(~same)[:5]
+
+
+@pytest.mark.parametrize("obj", OBJECTS)
+def test_function_bitwise_and_golden(gpu_ctx, oracle_det, obj):
+    import torch
+
+    c = _constraint(obj, gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, 0xF0, 0, 4096)
+    q[0] = np.array(load_cfg(obj)["start_joint"])
+    f_gpu = c.function_batch(torch.as_tensor(q).cuda()).cpu().numpy()
+    f_cpu = oracle_det.function_batch(P, q, NCPU)
+    assert np.array_equal(f_gpu.view(np.uint64), f_cpu.view(np.uint64))
+    if obj != "stefan":  # recorded planner outputs: geodesic rows sit just under (1e-3, 5e-3)
+        rows = load_path_rows(obj)
+        f = c.function_batch(torch.as_tensor(rows).cuda()).cpu().numpy()
+        on_manifold = f[:, 0] < 2e-3
+        assert on_manifold.sum() >= 6
+        assert (f[on_manifold, 0] <= 1e-3 + 2e-5).all() and (f[on_manifold, 1] <= 5e-3 + 5e-5).all()
+
+
+@pytest.mark.parametrize("obj,B,seed", [("Wine_Bottle", 4096, 0xC2), ("dumbbell", 1024, 0xC1), ("stefan", 1500, 0xC4)])
+def test_project_fd_bitwise(gpu_ctx, oracle_det, obj, B, seed):
+    """C2-sized Wine_Bottle batch (and the other two objects): q_out, ok and iters identical."""
+    import torch
+
+    c = _constraint(obj, gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, seed, 0, B)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+    qd = torch.as_tensor(q).cuda()
+    q_gpu, ok_gpu, it_gpu = c.project_batch(qd)
+    q_gpu, ok_gpu, it_gpu = q_gpu.cpu().numpy(), ok_gpu.cpu().numpy(), it_gpu.cpu().numpy()
+    d = np.abs(q_gpu - q_cpu).max(axis=1)
+    n_bad = int((d > TOL_RAD).sum())
+    print("%s B=%d: max|dq|=%.3e  >1e-6: %d  ok mismatches: %d  iter mismatches: %d  ok frac %.3f  mean iters %.1f"
+          % (obj, B, d.max(), n_bad, int((ok_gpu != ok_cpu).sum()), int((it_gpu != it_cpu).sum()), ok_cpu.mean(),
+             it_cpu.mean()))
+    assert n_bad == 0
+    assert np.array_equal(ok_gpu, ok_cpu)
+    assert np.array_equal(it_gpu.astype(np.int32), it_cpu)
+    assert np.array_equal(q_gpu.view(np.uint64), q_cpu.view(np.uint64)), "not bit-identical"
+
+
+def test_sample_project_bitwise(gpu_ctx, oracle_det):
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    B, seed, first = 1000, 0xABCDEF, 12345
+    q_gpu, ok_gpu, it_gpu, amb = c.sample_project_batch(seed, first, B, want_ambient=True)
+    q_cpu, ok_cpu, it_cpu = oracle_det.sample_project_batch(P, seed, first, B, NCPU)
+    amb_cpu = oracle_det.ambient_uniform_batch(P, seed, first, B)
+    assert np.array_equal(amb.cpu().numpy().view(np.uint64), amb_cpu.view(np.uint64))
+    assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+    assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)
+    assert np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
+    assert (np.abs(q_gpu.cpu().numpy()) <= np.pi).all()  # enforceBounds wrapped everything
+
+
+@pytest.mark.parametrize("B", [0, 1, 5, 10, 11, 61, 640, 641])
+def test_ragged_batches(gpu_ctx, oracle_det, B):
+    """empty / single / not a multiple of the 10-samples-per-wave grouping; in place."""
+    import torch
+
+    c = _constraint("dumbbell", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, 77, 0, B) if B else np.zeros((0, 14))
+    qd = torch.as_tensor(q).cuda()
+    out, ok, it = c.project_batch(qd, out=qd)  # in place, as the reference
+    torch.cuda.synchronize()
+    if B == 0:
+        return
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, 4)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+    assert np.array_equal(ok.cpu().numpy(), ok_cpu)
+
+
+def test_is_satisfied_and_joint_valid(gpu_ctx, oracle_det):
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, 5, 0, 512)
+    q_cpu, ok_cpu, _ = oracle_det.project_batch(P, q, NCPU)
+    both = np.concatenate([q, q_cpu])
+    d = torch.as_tensor(both).cuda()
+    sat = c.is_satisfied_batch(d).cpu().numpy()
+    jv = c.joint_valid_batch(d).cpu().numpy()
+    exp_sat = np.array([oracle_det.is_satisfied(P, x) for x in both], dtype=np.uint8)
+    exp_jv = np.array([oracle_det.joint_valid(P, x) for x in both], dtype=np.uint8)
+    assert np.array_equal(sat, exp_sat) and np.array_equal(jv, exp_jv)
+    assert sat[512:].all()  # every projected sample converged within 250 iterations here
+
+
+def test_single_state_surface(gpu_ctx, oracle_det):
+    """the reference-signature methods: project(x) in place -> bool, function, isSatisfied, jointValid"""
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    x0 = np.array(load_cfg("Wine_Bottle")["start_joint"])
+    assert c.isSatisfied(x0) and c.jointValid(x0)
+    x = x0.copy()
+    assert c.project(x) is True and np.array_equal(x, x0)  # already satisfied: zero iterations, untouched
+    x = oracle_det.ambient_uniform(P, 3, 3)
+    ok_cpu, x_cpu, _ = oracle_det.project(P, x)
+    ok = c.project(x)
+    assert ok == ok_cpu and np.array_equal(x.view(np.uint64), x_cpu.view(np.uint64))
+    assert np.array_equal(c.function(x_cpu), oracle_det.function(P, x_cpu))
+    with pytest.raises(ValueError):
+        c.setTolerance(0.0, 1e-3)
+
+
+def test_analytic_mode_statistics(gpu_ctx, oracle_det):
+    """the opt-in fast mode: same manifold, same acceptance statistics; not bit-comparable"""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx, mode=1)
+    P = _oracle_problem(oracle_det, c)
+    P.jacobian_mode = 0
+    B = 4096
+    q = oracle_det.ambient_uniform_batch(P, 0xC2, 0, B)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+    q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
+    f = c.function_batch(q_gpu).cpu().numpy()
+    conv = it_gpu.cpu().numpy() < 250
+    assert conv.mean() > 0.99
+    assert (f[conv, 0] <= 1e-3).all() and (f[conv, 1] <= 5e-3).all()
+    d = np.abs(q_gpu.cpu().numpy() - q_cpu).max(axis=1)
+    print("analytic vs FD oracle: median %.2e, frac>1e-6 %.3f, ok agreement %.4f, mean iters %.2f vs %.2f"
+          % (np.median(d), (d > 1e-6).mean(), (ok_gpu.cpu().numpy() == ok_cpu).mean(), it_gpu.float().mean().item(),
+             it_cpu.mean()))
+    assert np.median(d) < 1e-6
+    assert (ok_gpu.cpu().numpy() == ok_cpu).mean() > 0.97
+    assert abs(it_gpu.float().mean().item() - it_cpu.mean()) < 1.0
