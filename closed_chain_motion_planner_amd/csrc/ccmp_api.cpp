@@ -501,7 +501,7 @@ int ccmp_ctx_num_cus(const ccmp_ctx *ctx) { return ctx ? ctx->num_cus : 0; }
   { int rc_ = check_problem(p); if (rc_ != CCMP_OK) return rc_; } \
   DeviceGuard guard(ctx->device);                              \
   if (!guard.ok) return CCMP_ENODEV;                           \
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream; \
+  hipStream_t st = (hipStream_t)hip_stream; \
   ccmp_consts K;                                               \
   make_consts(*p, K)
 
@@ -578,7 +578,7 @@ int ccmp_enforce_bounds_batch(ccmp_ctx *ctx, double *q, size_t B, void *hip_stre
   if (!q) return CCMP_EINVAL;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  hipStream_t st = (hipStream_t)hip_stream;
   HIP_TRY(ccmp_launch_enforce_bounds(q, B, st));
   return CCMP_OK;
 }
@@ -589,7 +589,7 @@ int ccmp_compact_valid(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t
   if (!ctx || !count_dev) return CCMP_EINVAL;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  hipStream_t st = (hipStream_t)hip_stream;
   if (B == 0) {
     HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), st));
     return CCMP_OK;
@@ -613,7 +613,7 @@ int ccmp_detmath_probe(ccmp_ctx *ctx, const double *x_dev, const double *y_dev, 
   if (!ctx || !x_dev || !y_dev || !out_dev) return CCMP_EINVAL;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  hipStream_t st = (hipStream_t)hip_stream;
   if (n == 0) return CCMP_OK;
   HIP_TRY(ccmp_launch_detmath_probe(x_dev, y_dev, out_dev, n, st));
   return CCMP_OK;
