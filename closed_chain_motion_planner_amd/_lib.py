@@ -73,6 +73,15 @@ def lib():
         raise ImportError(
             "libccmp.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950). There is no CPU fallback." % LIBPATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 and must be the one that
+    # initialises the device if it is going to own the memory we launch on.  Loading libccmp.so first
+    # would pull /opt/rocm's copy in, and the device then fails to open for whichever comes second
+    # (seen on the GPU box: "no usable HIP device").  Importing torch first makes the loader resolve
+    # libccmp's libamdhip64.so.7 dependency to the already-loaded runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # C-only consumers link libccmp.so against the system ROCm directly
+        pass
     L = C.CDLL(LIBPATH)
     dp, u8p, u16p, vp = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.c_void_p
     pp = C.POINTER(CcmpProblem)
