@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (tools/profile.sh output) into profiles/<tag>_*.{csv,md,json}.
+
+HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in separate
+passes, both in KiB; on gfx950 FETCH_SIZE tallies 128-B requests of wide coalesced reads at 64 B,
+so the read side is reported both raw and doubled (upper bound); WRITE_SIZE is taken as is.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(d, kernel_sub):
+    out = collections.defaultdict(list)
+    meta = {}
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kernel_sub in r["Kernel_Name"]:
+                out[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
+                                          "Accum_VGPR_Count", "SGPR_Count")}
+    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}, meta
+
+
+def main():
+    tag = sys.argv[1]
+    kernel_sub = sys.argv[2] if len(sys.argv) > 2 else "project_fd_kernel"
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
+    krow = None
+    for r in csv.DictReader(open(stats)):
+        if kernel_sub in r["Name"]:
+            krow = r
+    allc, ns, meta = {}, {}, {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+        c, n, m = counters(os.path.join(src, sub), kernel_sub)
+        allc.update(c)
+        ns.update(n)
+        meta = m or meta
+    fetch_kib, write_kib = allc.get("FETCH_SIZE"), allc.get("WRITE_SIZE")
+    avg_ms = float(krow["AverageNs"]) / 1e6
+    algo = 225 * batch
+    traffic_lo = (fetch_kib + write_kib) * 1024 if fetch_kib is not None and write_kib is not None else None
+    traffic_hi = (2 * fetch_kib + write_kib) * 1024 if traffic_lo is not None else None
+    summary = {
+        "tag": tag, "kernel": kernel_sub, "batch": batch, "calls": int(krow["Calls"]), "avg_ms": avg_ms,
+        "min_ms": float(krow["MinNs"]) / 1e6, "max_ms": float(krow["MaxNs"]) / 1e6,
+        "projections_per_s_kernel": batch / (avg_ms * 1e-3),
+        "algorithmic_bytes_per_launch": algo, "achieved_GBps_algorithmic": algo / (avg_ms * 1e-3) / 1e9,
+        "counters_mean_per_launch": allc, "launch": meta,
+        "hbm_bytes_per_launch_raw": traffic_lo, "hbm_bytes_per_launch_fetch_doubled": traffic_hi,
+    }
+    json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
+    if traffic_hi is not None:
+        json.dump({"kernel": kernel_sub, "batch": batch, "hbm_bytes_per_launch": traffic_hi, "tag": tag,
+                   "note": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, gfx950 FETCH_SIZE x2 correction "
+                           "(upper bound for this kernel's 8-B-per-lane loads)"},
+                  open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+    with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
+        f.write("# rocprofv3 summary `%s` — kernel `%s`, batch %d\n\n" % (tag, kernel_sub, batch))
+        f.write("Command: `bash tools/profile.sh %s` (= `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 "
+                "--warmup 1 ...`, then separate `--pmc` passes).\n\n" % tag)
+        f.write("| quantity | value |\n|---|---|\n")
+        f.write("| calls / avg / min / max | %d / %.3f ms / %.3f ms / %.3f ms |\n" % (summary["calls"], avg_ms, summary["min_ms"], summary["max_ms"]))
+        f.write("| projections/s (kernel only) | %.3e |\n" % summary["projections_per_s_kernel"])
+        f.write("| algorithmic bytes per launch (225 B x %d) | %.1f MB -> %.3f GB/s = %.5f %% of 8 TB/s |\n"
+                % (batch, algo / 1e6, summary["achieved_GBps_algorithmic"], summary["achieved_GBps_algorithmic"] / 80.0))
+        if traffic_lo is not None:
+            f.write("| HBM traffic per launch (FETCH+WRITE raw / FETCH doubled) | %.1f MB / %.1f MB |\n" % (traffic_lo / 1e6, traffic_hi / 1e6))
+        for k in sorted(meta):
+            f.write("| %s | %s |\n" % (k, meta[k]))
+        f.write("\n| counter (mean per launch, %s) | value |\n|---|---|\n" % ", ".join("%s x%d" % kv for kv in list(ns.items())[:1]))
+        for k in sorted(allc):
+            f.write("| %s | %.4g |\n" % (k, allc[k]))
+        if "SQ_WAVE_CYCLES" in allc and "SQ_ACTIVE_INST_VALU" in allc:
+            f.write("\nDerived: VALU-active share of wave lifetime = %.3f; " % (allc["SQ_ACTIVE_INST_VALU"] / allc["SQ_WAVE_CYCLES"]))
+            if "SQ_WAIT_ANY" in allc:
+                f.write("wave parked (s_waitcnt) share = %.3f; " % (allc["SQ_WAIT_ANY"] / allc["SQ_WAVE_CYCLES"]))
+            if "SQ_WAIT_INST_ANY" in allc:
+                f.write("issue-stall share = %.3f; " % (allc["SQ_WAIT_INST_ANY"] / allc["SQ_WAVE_CYCLES"]))
+            if "GRBM_GUI_ACTIVE" in allc:
+                f.write("effective clock = %.2f GHz." % (allc["GRBM_GUI_ACTIVE"] / 8 / (avg_ms * 1e-3) / 1e9))
+            f.write("\n")
+    print(open(os.path.join(dst, tag + "_summary.md")).read())
+
+
+if __name__ == "__main__":
+    main()
