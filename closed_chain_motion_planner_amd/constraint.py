@@ -279,9 +279,11 @@ class KinematicChainConstraint:
 
     def jointValid(self, q):
         self._need_problem()
-        torch = _torch()
-        t = torch.as_tensor(np.ascontiguousarray(q, dtype=np.float64).reshape(1, 14)).to("cuda:%d" % self.ctx.device)
-        return bool(self.joint_valid_batch(t).cpu()[0])
+        x = np.ascontiguousarray(q, dtype=np.float64).reshape(14)
+        ok = np.zeros(1, dtype=np.uint8)
+        check(_lib.lib().ccmp_joint_valid_host(self.ctx.handle, C.byref(self.problem), _dptr(x),
+                                               ok.ctypes.data_as(C.POINTER(C.c_uint8)), 1), "ccmp_joint_valid_host")
+        return bool(ok[0])
 
     def project_host(self, q):
         """(B,14) numpy in -> (q_out, ok, iters) numpy out through the host-pointer entry point."""

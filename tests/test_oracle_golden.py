@@ -1,0 +1,237 @@
+"""The CPU oracle against everything that pins it: the reference's recorded planner outputs
+(tests/golden/paths, from debug/*_path.txt), the survey's cross-check constants, an independent
+50-digit mpmath formulation (tests/golden/mp_vectors.json) and the reference's documented quirks.
+No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, OBJECTS, load_cfg, load_path_rows
+
+# SURVEY.md Appendix A (computed at survey time by an independent numpy restatement)
+APPENDIX_A = {
+    "Wine_Bottle": dict(
+        init=[[-0.998943209742, -0.034359631195, 0.030526700683, -0.088290011624],
+              [-0.035138089435, 0.999061127784, -0.025341223765, -0.005935844107],
+              [-0.029627324909, -0.026387093345, -0.999212661511, 0.215053361662]],
+        tcp1=(0.455391283, 0.115767522, 1.398953451), tcp2=(0.450292705, -0.101468615, 1.316123660)),
+    "dumbbell": dict(
+        init=[[-0.998368700754, -0.054400280475, -0.017336286774, 0.593535975762],
+              [0.054650289716, -0.998403310082, -0.014289025522, -0.013928001854],
+              [-0.016531279103, -0.015213148940, 0.999747606604, 0.004071953333]],
+        tcp1=(0.353088529, 0.301572832, 1.380679233), tcp2=(0.946793469, 0.304356053, 1.382170216)),
+    "stefan": dict(
+        init=[[-0.974161128992, 0.225725015241, -0.007636246219, 0.292056451288],
+              [-0.225565471038, -0.974068662083, -0.017619870151, 0.381692128649],
+              [-0.011415473597, -0.015442119124, 0.999815596958, 0.007945445027]],
+        tcp1=(0.315231377, 0.223412581, 1.593750666), tcp2=(0.777877451, 0.100250166, 1.636629704)),
+}
+# rows of the recorded paths that are TRAC-IK vertices (off the manifold by ~1e-2)
+IK_ROWS = {"Wine_Bottle": {6, 7, 13, 14, 21, 22, 29}, "dumbbell": {4, 5, 8}}
+
+
+@pytest.fixture(scope="module", params=["det", "libm"])
+def orc(request, oracle_det, oracle_libm):
+    return oracle_det if request.param == "det" else oracle_libm
+
+
+@pytest.mark.parametrize("obj", OBJECTS)
+def test_init_chain_and_tcp_match_survey(orc, obj):
+    cfg = load_cfg(obj)
+    P = orc.problem(cfg)
+    A = np.array(APPENDIX_A[obj]["init"])
+    assert np.allclose(np.array(P.init_R).reshape(3, 3), A[:, :3], atol=2e-12)
+    assert np.allclose(np.array(P.init_p), A[:, 3], atol=2e-12)
+    _, p1 = orc.fk(P, 0, cfg["start_joint"][:7])
+    _, p2 = orc.fk(P, 1, cfg["start_joint"][7:])
+    assert np.allclose(p1, APPENDIX_A[obj]["tcp1"], atol=1e-9) and np.allclose(p2, APPENDIX_A[obj]["tcp2"], atol=1e-9)
+    f = orc.function(P, cfg["start_joint"])
+    assert f[0] < 1e-12 and f[1] < 1e-7  # the start state defines the manifold
+
+
+def test_wine_bottle_pose_comments(orc):
+    """config/Wine_Bottle.yaml:21-22 (MoveIt targets used to pick start_joint): ~5 mm agreement."""
+    cfg = load_cfg("Wine_Bottle")
+    P = orc.problem(cfg)
+    _, p1 = orc.fk(P, 0, cfg["start_joint"][:7])
+    _, p2 = orc.fk(P, 1, cfg["start_joint"][7:])
+    assert np.abs(p1 - [0.45, 0.11, 1.40]).max() < 7e-3 and np.abs(p2 - [0.45, -0.10, 1.32]).max() < 7e-3
+
+
+@pytest.mark.parametrize("obj", ["Wine_Bottle", "dumbbell"])
+def test_recorded_paths_sit_just_under_tolerance(orc, obj):
+    """Known-answer test for FK + residual + tolerances: every geodesic row of the reference's
+    recorded output has f0 in [7e-4, 1e-3], f1 <= 5e-3 — the signature of the 0.30-step Newton
+    stopping the first time both tolerances hold.  (Rows carry 6 significant digits: +-2e-5.)"""
+    P = orc.problem(load_cfg(obj))
+    rows = load_path_rows(obj)
+    f = np.array([orc.function(P, r) for r in rows])
+    assert f[0, 0] < 1e-5 and f[0, 1] < 1e-5  # row 1 = start_joint, rounding only
+    geo = [i for i in range(2, len(rows)) if i not in IK_ROWS[obj]]
+    assert len(geo) >= 4
+    assert (f[geo, 0] <= 1e-3 + 2e-5).all() and (f[geo, 0] >= 7e-4).all()
+    assert (f[geo, 1] <= 5e-3 + 5e-5).all()
+    ik = sorted(IK_ROWS[obj])
+    assert (f[ik, 0] > 5e-3).all()  # IK vertices are NOT on the manifold to tolerance
+    if obj == "Wine_Bottle":  # consecutive geodesic states are delta = 0.25 apart (ConstrainedPlanningCommon.cpp:118)
+        steps = [np.linalg.norm(rows[i + 1] - rows[i]) for i in (2, 3, 4)]
+        assert all(0.245 < s < 0.255 for s in steps)
+
+
+def test_against_mpmath_formulation(orc):
+    """Independent DH-matrix / trace-angle formulation at 50 digits (tests/golden/make_mp_vectors.py)."""
+    V = json.load(open(os.path.join(GOLDEN, "mp_vectors.json")))
+    for obj, d in V.items():
+        P = orc.problem(load_cfg(obj))
+        assert list(P.arm_index) == d["arm_index"]
+        assert np.abs(np.array(P.init_R) - d["init_R"]).max() < 5e-15
+        for c in d["cases"]:
+            R1, p1 = orc.fk(P, 0, c["x"][:7])
+            R2, p2 = orc.fk(P, 1, c["x"][7:])
+            assert np.abs(R1.ravel() - c["R1"]).max() < 5e-15 and np.abs(p1 - c["p1"]).max() < 5e-15
+            assert np.abs(R2.ravel() - c["R2"]).max() < 5e-15 and np.abs(p2 - c["p2"]).max() < 5e-15
+            assert np.abs(orc.function(P, c["x"]) - c["f"]).max() < 1e-13
+
+
+def test_arm_order_is_alphabetical(oracle_det):
+    """std::map iteration order (ConstrainedPlanningCommon.cpp:13-14,89-91): swapping arm1/arm2 in
+    the YAML must not change the problem."""
+    cfg = load_cfg("dumbbell")
+    P1 = oracle_det.problem(cfg)
+    swapped = dict(cfg, arm1=cfg["arm2"], arm2=cfg["arm1"])
+    P2 = oracle_det.problem(swapped)
+    assert bytes(P1) == bytes(P2) and list(P1.arm_index) == [0, 2]
+
+
+def test_fd_jacobian_matches_analytic(oracle_det):
+    P = oracle_det.problem(load_cfg("Wine_Bottle"))
+    worst = 0.0
+    for i in range(40):
+        x = oracle_det.ambient_uniform(P, 11, i)
+        Jf, Ja = oracle_det.jacobian(P, x), oracle_det.jacobian(P, x, analytic=True)
+        worst = max(worst, np.abs(Jf - Ja).max())
+    assert worst < 5e-7  # FD noise ~ eps/h
+
+
+def test_minnorm_solve_is_pseudoinverse(oracle_det):
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        J, f = rng.standard_normal((2, 14)), rng.standard_normal(2)
+        assert np.allclose(oracle_det.solve_minnorm(J, f), np.linalg.pinv(J) @ f, rtol=1e-11, atol=1e-13)
+    # rank deficient: parallel rows -> minimum-norm least squares, as Eigen's thresholded SVD solve
+    r = rng.standard_normal(14)
+    J = np.vstack([r, 2 * r])
+    f = np.array([1.0, 1.0])
+    assert np.allclose(oracle_det.solve_minnorm(J, f), np.linalg.pinv(J) @ f, rtol=1e-9, atol=1e-12)
+    assert np.array_equal(oracle_det.solve_minnorm(np.zeros((2, 14)), f), np.zeros(14))
+
+
+def test_project_semantics_and_quirks(oracle_det):
+    cfg = load_cfg("Wine_Bottle")
+    P = oracle_det.problem(cfg)
+    x0 = np.array(cfg["start_joint"])
+    ok, x, it = oracle_det.project(P, x0)
+    assert ok and it == 0 and np.array_equal(x, x0)  # already satisfied: zero iterations, untouched
+    stats = []
+    for i in range(64):
+        q = oracle_det.ambient_uniform(P, 0xC2, i)
+        ok, x, it = oracle_det.project(P, q)
+        f = oracle_det.function(P, x)
+        stats.append((ok, it))
+        assert it <= 250
+        if it < 250:  # exited through the residual test
+            assert f[0] <= P.tol_pos and f[1] <= P.tol_rot
+            assert ok == (oracle_det.joint_valid(P, x) and f[1] < P.tol_rot)  # strict < in the return (:75)
+        else:
+            assert not ok or (f[0] <= P.tol_pos and f[1] < P.tol_rot)
+        assert oracle_det.is_satisfied(P, x) == (f[0] <= P.tol_pos and f[1] <= P.tol_rot)
+    its = np.array([s[1] for s in stats])
+    assert 25 < its.mean() < 42  # mean ~33 for Wine_Bottle
+    # the iteration cap: with max_iter = 3 the iterate after exactly 3 updates is returned, ok false
+    P3 = oracle_det.problem(cfg)
+    P3.max_iter = 3
+    ok, x, it = oracle_det.project(P3, oracle_det.ambient_uniform(P, 0xC2, 0))
+    assert (not ok) and it == 3
+
+
+def test_joint_valid_margin(oracle_det):
+    P = oracle_det.problem(load_cfg("Wine_Bottle"))
+    mid = np.array([(P.lb[j % 7] + P.ub[j % 7]) / 2 for j in range(14)])
+    assert oracle_det.joint_valid(P, mid)
+    for j in (0, 3, 5, 7 + 6):
+        x = mid.copy(); x[j] = P.lb[j % 7] + 0.0009
+        assert not oracle_det.joint_valid(P, x)
+        x[j] = P.lb[j % 7] + 0.0011
+        assert oracle_det.joint_valid(P, x)
+        x[j] = P.ub[j % 7] - 0.0009
+        assert not oracle_det.joint_valid(P, x)
+
+
+def test_enforce_bounds_wraps_not_clamps(oracle_det):
+    x = np.zeros(14)
+    x[5] = 3.5          # inside joint 6's range (-0.0175, 3.7525) but > pi: wrapped to a negative angle
+    x[0] = -3.5
+    x[1] = np.pi        # v >= pi -> v - 2pi
+    x[2] = 7.0
+    y = oracle_det.enforce_bounds(x)
+    assert y[5] == 3.5 - 2 * np.pi and y[0] == -3.5 + 2 * np.pi and y[1] == np.pi - 2 * np.pi
+    assert y[2] == np.fmod(7.0, 2 * np.pi) and (np.abs(y) <= np.pi).all()
+
+
+def test_interpolate_and_distance(oracle_det):
+    a, b = np.zeros(14), np.zeros(14)
+    a[0], b[0] = 3.0, -3.0     # |diff| > pi: shortest arc through +-pi
+    a[1], b[1] = 0.5, 1.5
+    m = oracle_det.interpolate(a, b, 0.5)
+    assert m[1] == 1.0
+    assert abs(abs(m[0]) - np.pi) < 0.15 + 1e-12  # half-way along the short arc (length 2pi-6)
+    assert oracle_det.distance(a, b) == np.sqrt(36.0 + 1.0)  # plain Euclidean, not wrapped
+
+
+def test_discrete_geodesic_properties(oracle_det):
+    cfg = load_cfg("Wine_Bottle")
+    P = oracle_det.problem(cfg)
+    rows = load_path_rows("Wine_Bottle")
+    a, b = np.array(cfg["start_joint"]), rows[5]
+    ok, states, its = oracle_det.discrete_geodesic(P, a, b, interpolate=True)
+    assert np.array_equal(states[0], a)
+    for s in states[1:]:
+        assert oracle_det.is_satisfied(P, s)
+    steps = [oracle_det.distance(states[i], states[i + 1]) for i in range(len(states) - 1)]
+    assert all(s <= P.lambda_ * P.delta for s in steps)
+    d = [oracle_det.distance(s, b) for s in states]
+    assert all(d[i + 1] < d[i] for i in range(len(d) - 1))  # strictly closer each accepted step
+    if ok:
+        assert d[-1] <= P.delta
+    # from == to (or within delta): true immediately, only `from` in the list
+    ok2, st2, _ = oracle_det.discrete_geodesic(P, a, a + 0.01)
+    assert ok2 and len(st2) == 1
+
+
+def test_sampler_is_counter_based(oracle_det):
+    P = oracle_det.problem(load_cfg("stefan"))
+    a = oracle_det.ambient_uniform_batch(P, 9, 100, 8)
+    b = oracle_det.ambient_uniform_batch(P, 9, 104, 4)
+    assert np.array_equal(a[4:], b)  # sample i depends on (seed, i) only: shards reproduce the whole
+    lb, ub = np.array(P.lb[:]), np.array(P.ub[:])
+    assert (a[:, :7] >= lb).all() and (a[:, :7] <= ub).all() and (a[:, 7:] >= lb).all() and (a[:, 7:] <= ub).all()
+    assert oracle_det.lib.orc_splitmix64(0) == 0xE220A8397B1DCDAF  # published SplitMix64 first output for seed 0
+
+
+def test_libm_and_det_builds_agree_where_the_algorithm_is_well_conditioned(oracle_det, oracle_libm):
+    """Same algorithm, two rounding models: residuals agree to ~1e-15; the Newton iterates do NOT
+    stay within 1e-6 rad (the iteration amplifies ulp differences) — the reason GPU parity is
+    defined bitwise against the det build."""
+    cfg = load_cfg("Wine_Bottle")
+    Pd, Pl = oracle_det.problem(cfg), oracle_libm.problem(cfg)
+    q = oracle_det.ambient_uniform_batch(Pd, 0xC2, 0, 192)
+    fd, fl = oracle_det.function_batch(Pd, q, 4), oracle_libm.function_batch(Pl, q, 4)
+    assert np.abs(fd - fl).max() < 1e-13
+    qd, okd, itd = oracle_det.project_batch(Pd, q, 8)
+    ql, okl, itl = oracle_libm.project_batch(Pl, q, 8)
+    d = np.abs(qd - ql).max(axis=1)
+    assert np.median(d) < 1e-6          # most samples track each other...
+    assert (d > 1e-6).mean() > 0.03     # ...but a sizeable fraction does not, by construction of the reference
+    assert abs(okd.mean() - okl.mean()) < 0.05
