@@ -41,6 +41,10 @@ class Context:
     def set_waves_per_cu(self, w):
         check(_lib.lib().ccmp_ctx_set_waves_per_cu(self._h, int(w)), "ccmp_ctx_set_waves_per_cu")
 
+    def set_schedule(self, wave_kernel=1, small_batch=8192):
+        """0 = group kernel only, 1 = group kernel + wave-per-sample stragglers (default), 2 = wave-per-sample only"""
+        check(_lib.lib().ccmp_ctx_set_schedule(self._h, int(wave_kernel), int(small_batch)), "ccmp_ctx_set_schedule")
+
     def close(self):
         if self._h:
             _lib.lib().ccmp_ctx_destroy(self._h)

@@ -22,7 +22,8 @@
 extern "C" {
 hipError_t ccmp_launch_project_fd(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                   uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
-                                  unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
+                                  unsigned long long seed, unsigned long long first, int nblocks, double *pool,
+                                  int nblocks_wave, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                     unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
@@ -281,7 +282,11 @@ struct ccmp_ctx {
   int num_cus = 0;
   int waves_per_cu = 0;
   hipStream_t stream = nullptr;
-  unsigned long long *queue = nullptr; // work-queue head of the projector kernels
+  unsigned long long *queue = nullptr; // work-queue heads of the projector kernels (4 words)
+  double *pool = nullptr;              // straggler hand-over records (group kernel -> wave kernel)
+  size_t pool_cap = 0;                 // in records
+  int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
+  size_t small_batch = 8192;           // at or below: wave-per-sample kernel on everything
   unsigned int *scan = nullptr;        // compaction block counts
   size_t scan_cap = 0;
   // staging for the *_host conveniences
@@ -481,6 +486,7 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx)
   DeviceGuard guard(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->queue) (void)hipFree(ctx->queue);
+  if (ctx->pool) (void)hipFree(ctx->pool);
   if (ctx->scan) (void)hipFree(ctx->scan);
   if (ctx->stage) (void)hipFree(ctx->stage);
   (void)hipStreamDestroy(ctx->stream);
@@ -491,6 +497,13 @@ int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int w)
 {
   if (!ctx || w < 0 || w > 32) return CCMP_EINVAL;
   ctx->waves_per_cu = w;
+  return CCMP_OK;
+}
+int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch)
+{
+  if (!ctx || wave_kernel < 0 || wave_kernel > 2) return CCMP_EINVAL;
+  ctx->wave_kernel = wave_kernel;
+  ctx->small_batch = small_batch;
   return CCMP_OK;
 }
 int ccmp_ctx_device(const ccmp_ctx *ctx) { return ctx ? ctx->device : -1; }
@@ -522,8 +535,28 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (B == 0) return CCMP_OK;
   if (!q_out || !ok || (mode == 0 && !q_in)) return CCMP_EINVAL;
   if (p->jacobian_mode == CCMP_JAC_FD) {
-    const int nblocks = projector_blocks(ctx, B, 10, 6);
-    HIP_TRY(ccmp_launch_project_fd(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks, st));
+    // Large batches: the throughput (10 samples per wave) kernel until the queue drains, then the
+    // wave-per-sample kernel on the samples still in flight.  Small batches: wave-per-sample only.
+    const int wpc = ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12;
+    const int wave_blocks = ctx->num_cus * wpc;
+    int nblocks = projector_blocks(ctx, B, 10, 12);
+    int nwave = 0;
+    if (ctx->wave_kernel == 2 || (ctx->wave_kernel == 1 && B <= ctx->small_batch)) {
+      nblocks = 0;
+      nwave = (int)(B < (size_t)wave_blocks ? B : (size_t)wave_blocks);
+    } else if (ctx->wave_kernel == 1) {
+      const size_t need = (size_t)nblocks * 10;
+      if (ctx->pool_cap < need) { // grows outside any capture: first call at a size is never captured
+        if (ctx->pool) (void)hipFree(ctx->pool);
+        ctx->pool = nullptr;
+        ctx->pool_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->pool, need * 18 * sizeof(double)));
+        ctx->pool_cap = need;
+      }
+      nwave = (int)(need < (size_t)wave_blocks ? need : (size_t)wave_blocks);
+    }
+    HIP_TRY(ccmp_launch_project_fd(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
+                                   ctx->pool, nwave, st));
   } else {
     const int nblocks = projector_blocks(ctx, B, 64, 4);
     HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks, st));

@@ -30,13 +30,22 @@ namespace {
 
 constexpr int kGroup = 6;             // lanes per sample = stencil evaluations per column
 constexpr int kGroupsPerWave = 10;    // 60 of 64 lanes busy
-// LDS record layout (in doubles)
-constexpr int kX = 0;                 // x[14]           current iterate
-constexpr int kSC = 14;               // sc[14][2]       sin, cos of every joint of x
-constexpr int kPre = 42;              // pre[14][12]     chain frame in front of joint col: R(9), o(3) incl. offset_col
-constexpr int kEE = 210;              // ee[2][12]       world tool pose of each arm at x: R(9), p(3)
-constexpr int kJ = 234;               // J[2][14]
-constexpr int kRec = 265;             // 262 used; odd stride keeps groups on distinct LDS banks
+// LDS record of one group (in doubles).  The prefix frames are kept for ONE arm at a time (the
+// second arm's chain is re-run before its columns: +343 operations per iteration, -84 doubles of
+// LDS per sample), and the second arm's Jacobian columns overwrite prefix slots that have already
+// been consumed.  165 x 8 B x 10 groups = 13.2 KB per wave -> 12 waves per CU.
+constexpr int kX = 0;                 // x[14]        current iterate
+constexpr int kSC = 14;               // sc[14][2]    sin, cos of every joint of x
+constexpr int kPre = 42;              // pre[7][12]   chain frame in front of joint j of the current arm: R(9), o(3)
+                                      //              (slot j, doubles 0..1, is reused for J[:, 7+j] once consumed)
+constexpr int kEE = 126;              // ee[2][12]    world tool pose of each arm at x: R(9), p(3)
+constexpr int kJ0 = 150;              // J[:, 0..6]   interleaved (row0, row1) per column of arm 0
+constexpr int kRec = 165;             // 164 used; odd stride keeps the 10 groups on distinct LDS banks
+constexpr int kPoolEntry = 18;        // straggler hand-over record: x[14], idx, (iter,updates), norm1, norm2
+
+#ifndef CCMP_FD_WAVES_PER_SIMD
+#define CCMP_FD_WAVES_PER_SIMD 3
+#endif
 
 __device__ __forceinline__ double shfl_f64(double v, int src_lane)
 {
@@ -53,14 +62,87 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
   return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 
+// One arm's chain at x (sines/cosines from LDS).  With STORE the writer lane keeps the frame in
+// front of every joint (R before the joint's rotation, o including the joint's offset) in LDS.
+template <int ARM, bool STORE>
+__device__ __forceinline__ void chain_at_x(const ccmp_consts &K, double *rec, bool writer, double *T)
+{
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+  for (int i = 0; i < 7; i++) {
+    double Rj[9], Rn[9];
+    mulvec_acc(R, K.offset[ARM][i], o);
+    if (STORE && writer) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) rec[kPre + i * 12 + k] = R[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) rec[kPre + i * 12 + 9 + k] = o[k];
+    }
+    rot_sc(K.axis[ARM][i], K.aprod[ARM][i], rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], Rj);
+    mul33(R, Rj, Rn);
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = Rn[k];
+  }
+  tool_pose(K, ARM, R, o, &T[0], &T[9]);
+}
+
+// OMPL's default Constraint::jacobian for the 7 columns of one arm: each lane evaluates its stencil
+// point of column j from the cached prefix frame, the +/- lanes pair up through ds_bpermute.
+template <int ARM>
+__device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *rec, bool writer, bool plus, int nstep,
+                                                 int partner, int leader)
+{
+  double To[12]; // the other arm's (unperturbed) tool pose
+#pragma unroll
+  for (int k = 0; k < 12; k++) To[k] = rec[kEE + (1 - ARM) * 12 + k];
+  for (int j = 0; j < 7; j++) {
+    const double xj = rec[kX + ARM * 7 + j];
+    const double axj = ccmp_abs(xj);
+    const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1); // sqrt(eps)*max(1,|x_j|)
+    const double hh = plus ? h : -h;
+    double y = xj + hh;                 // y1[j] += h   /  y2[j] -= h
+    if (nstep >= 2) y = y + hh;
+    if (nstep >= 3) y = y + hh;
+    double R[9], o[3], s, c;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = rec[kPre + j * 12 + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) o[k] = rec[kPre + j * 12 + 9 + k];
+    ccmp_sincos(y, &s, &c);
+    {
+      double Rj[9], Rn[9];
+      rot_sc(K.axis[ARM][j], K.aprod[ARM][j], s, c, Rj);
+      mul33(R, Rj, Rn);
+#pragma unroll
+      for (int k = 0; k < 9; k++) R[k] = Rn[k];
+    }
+    for (int i = j + 1; i < 7; i++)
+      joint_step(K, ARM, i, rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], R, o);
+    double Tw[12], t[2];
+    tool_pose(K, ARM, R, o, &Tw[0], &Tw[9]);
+    if (ARM == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);
+    else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], t, nullptr, nullptr);
+    // m_s = (t1 - t2) / (y1[j] - y2[j]) with the stored perturbed values
+    const double tp0 = shfl_f64(t[0], partner), tp1 = shfl_f64(t[1], partner), yp = shfl_f64(y, partner);
+    const double den = plus ? (y - yp) : (yp - y);
+    const double m0 = (plus ? (t[0] - tp0) : (tp0 - t[0])) / den;
+    const double m1 = (plus ? (t[1] - tp1) : (tp1 - t[1])) / den;
+    const double m10 = shfl_f64(m0, leader), m20 = shfl_f64(m0, leader + 1), m30 = shfl_f64(m0, leader + 2);
+    const double m11 = shfl_f64(m1, leader), m21 = shfl_f64(m1, leader + 1), m31 = shfl_f64(m1, leader + 2);
+    if (writer) {
+      // out.col(j) = 1.5*m1 - 0.6*m2 + 0.1*m3; arm 1's columns go into the prefix slot just consumed
+      double *dst = (ARM == 0) ? (rec + kJ0 + 2 * j) : (rec + kPre + 12 * j);
+      dst[0] = CCMP_FMA(0.1, m30, CCMP_FMA(-0.6, m20, 1.5 * m10));
+      dst[1] = CCMP_FMA(0.1, m31, CCMP_FMA(-0.6, m21, 1.5 * m11));
+    }
+  }
+}
+
 // MODE 0: project q_in -> q_out.  MODE 1: sampleUniform = ambient sample -> project -> enforceBounds.
 template <int MODE>
-__global__ __launch_bounds__(64) void project_fd_kernel(const ccmp_consts K, const double *__restrict__ q_in,
-                                                        double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
-                                                        uint16_t *__restrict__ iters_out,
-                                                        double *__restrict__ q_ambient,
-                                                        unsigned long long B, unsigned long long *queue,
-                                                        unsigned long long seed, unsigned long long first_index)
+__global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
+    const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
+    uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
+    unsigned long long seed, unsigned long long first_index, double *__restrict__ pool, unsigned long long *pool_count)
 {
   __shared__ double lds[kGroupsPerWave * kRec];
   const int lane = threadIdx.x;
@@ -69,6 +151,7 @@ __global__ __launch_bounds__(64) void project_fd_kernel(const ccmp_consts K, con
   const bool live = g < kGroupsPerWave;
   const int leader = live ? kGroup * g : 0;
   double *rec = lds + (live ? g : 0) * kRec;  // idle lanes alias group 0 for reads, never write
+  const bool writer = live && r == 0;
   const bool plus = r < 3;                    // y1 side of the stencil; r>=3 is the y2 side
   const int nstep = (plus ? r : r - 3) + 1;   // how many h-steps this lane's point is away
   const int partner = live ? (plus ? lane + 3 : lane - 3) : lane;
@@ -102,8 +185,28 @@ __global__ __launch_bounds__(64) void project_fd_kernel(const ccmp_consts K, con
     }
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
     __syncthreads();
+    // ---- hand-over: once the queue is empty the samples still in flight go to the straggler pool
+    // (x, index, counters — everything else is recomputed from x) and the wave retires; the
+    // wave-per-sample kernel finishes them.  State is dumped at the loop top, where the next thing
+    // that happens to a sample is function(x) + the loop test — exactly where the other kernel starts.
+    if (pool != nullptr && __builtin_amdgcn_ballot_w64(drained) != 0ull) {
+      unsigned long long slot = 0;
+      if (active && r == 0) slot = atomicAdd(pool_count, 1ull);
+      slot = shfl_u64(slot, leader);
+      if (active) {
+        double *ent = pool + slot * kPoolEntry;
+        for (int e = r; e < 14; e += kGroup) ent[e] = rec[kX + e];
+        if (r == 0) {
+          ent[14] = __longlong_as_double((long long)idx);
+          ent[15] = __hiloint2double(updates, iter);
+          ent[16] = norm1;
+          ent[17] = norm2;
+        }
+      }
+      break;
+    }
 
-    // ---- phase 1: function(x) — sines/cosines, both chains (prefix frames kept), residual ----
+    // ---- phase 1: function(x) — sines/cosines, both chains, residual ---------------------------
     for (int e = r; e < 14; e += kGroup) {
       double s, c;
       ccmp_sincos(rec[kX + e], &s, &c);
@@ -112,33 +215,18 @@ __global__ __launch_bounds__(64) void project_fd_kernel(const ccmp_consts K, con
     __syncthreads();
     double f0, f1;
     {
-      double T[2][12];
+      double T0[12], T1[12], f[2];
+      chain_at_x<1, false>(K, rec, writer, T1);
+      if (writer) {
 #pragma unroll
-      for (int arm = 0; arm < 2; arm++) {
-        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
-        for (int i = 0; i < 7; i++) {
-          const int col = arm * 7 + i;
-          double Rj[9], Rn[9];
-          mulvec_acc(R, K.offset[arm][i], o);
-          if (live && r == 0) {
-#pragma unroll
-            for (int k = 0; k < 9; k++) rec[kPre + col * 12 + k] = R[k];
-#pragma unroll
-            for (int k = 0; k < 3; k++) rec[kPre + col * 12 + 9 + k] = o[k];
-          }
-          rot_sc(K.axis[arm][i], K.aprod[arm][i], rec[kSC + 2 * col], rec[kSC + 2 * col + 1], Rj);
-          mul33(R, Rj, Rn);
-#pragma unroll
-          for (int k = 0; k < 9; k++) R[k] = Rn[k];
-        }
-        tool_pose(K, arm, R, o, &T[arm][0], &T[arm][9]);
-        if (live && r == 0) {
-#pragma unroll
-          for (int k = 0; k < 12; k++) rec[kEE + arm * 12 + k] = T[arm][k];
-        }
+        for (int k = 0; k < 12; k++) rec[kEE + 12 + k] = T1[k];
       }
-      double f[2];
-      chain_residual(K, &T[0][0], &T[0][9], &T[1][0], &T[1][9], f, nullptr, nullptr);
+      chain_at_x<0, true>(K, rec, writer, T0); // arm 0's prefix frames stay in LDS for its columns
+      if (writer) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) rec[kEE + k] = T0[k];
+      }
+      chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
       f0 = f[0]; f1 = f[1];
     }
 
@@ -174,59 +262,29 @@ __global__ __launch_bounds__(64) void project_fd_kernel(const ccmp_consts K, con
       if (fin) active = false;
     }
     if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue; // nobody iterates: straight to refill
-    __syncthreads(); // prefix frames / tool poses written by r==0 are visible to the group
+    __syncthreads(); // prefix frames / tool poses written by the writer lane are visible to the group
 
     // ---- phase 2: OMPL's default Constraint::jacobian, one column per step --------------------
-    for (int col = 0; col < 14; col++) {
-      const int arm = col >= 7 ? 1 : 0;
-      const int j = col - 7 * arm;
-      const double xj = rec[kX + col];
-      const double axj = ccmp_abs(xj);
-      const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1); // sqrt(eps)*max(1,|x_j|)
-      const double hh = plus ? h : -h;
-      double y = xj + hh;                 // y1[j] += h   /  y2[j] -= h
-      if (nstep >= 2) y = y + hh;
-      if (nstep >= 3) y = y + hh;
-      double R[9], o[3], s, c;
-#pragma unroll
-      for (int k = 0; k < 9; k++) R[k] = rec[kPre + col * 12 + k];
-#pragma unroll
-      for (int k = 0; k < 3; k++) o[k] = rec[kPre + col * 12 + 9 + k];
-      ccmp_sincos(y, &s, &c);
-      {
-        double Rj[9], Rn[9];
-        rot_sc(K.axis[arm][j], K.aprod[arm][j], s, c, Rj);
-        mul33(R, Rj, Rn);
-#pragma unroll
-        for (int k = 0; k < 9; k++) R[k] = Rn[k];
-      }
-      for (int i = j + 1; i < 7; i++)
-        joint_step(K, arm, i, rec[kSC + 2 * (arm * 7 + i)], rec[kSC + 2 * (arm * 7 + i) + 1], R, o);
-      double Tw[12], To[12], t[2];
-      tool_pose(K, arm, R, o, &Tw[0], &Tw[9]);
-#pragma unroll
-      for (int k = 0; k < 12; k++) To[k] = rec[kEE + (1 - arm) * 12 + k];
-      if (arm == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);
-      else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], t, nullptr, nullptr);
-      // m_s = (t1 - t2) / (y1[j] - y2[j]) with the stored perturbed values
-      const double tp0 = shfl_f64(t[0], partner), tp1 = shfl_f64(t[1], partner), yp = shfl_f64(y, partner);
-      const double den = plus ? (y - yp) : (yp - y);
-      const double m0 = (plus ? (t[0] - tp0) : (tp0 - t[0])) / den;
-      const double m1 = (plus ? (t[1] - tp1) : (tp1 - t[1])) / den;
-      const double m10 = shfl_f64(m0, leader), m20 = shfl_f64(m0, leader + 1), m30 = shfl_f64(m0, leader + 2);
-      const double m11 = shfl_f64(m1, leader), m21 = shfl_f64(m1, leader + 1), m31 = shfl_f64(m1, leader + 2);
-      if (live && r == 0) {
-        rec[kJ + col] = CCMP_FMA(0.1, m30, CCMP_FMA(-0.6, m20, 1.5 * m10));
-        rec[kJ + 14 + col] = CCMP_FMA(0.1, m31, CCMP_FMA(-0.6, m21, 1.5 * m11));
-      }
+    jacobian_columns<0>(K, rec, writer, plus, nstep, partner, leader);
+    __syncthreads();
+    {
+      double T1[12];
+      chain_at_x<1, true>(K, rec, writer, T1); // re-run arm 1's chain to stage ITS prefix frames
     }
+    __syncthreads();
+    jacobian_columns<1>(K, rec, writer, plus, nstep, partner, leader);
     __syncthreads();
 
     // ---- Newton update: x -= 0.30 * J.jacobiSvd().solve(f) --------------------------------------
     {
       double Jr[28], dx[14];
 #pragma unroll
-      for (int k = 0; k < 28; k++) Jr[k] = rec[kJ + k];
+      for (int j = 0; j < 7; j++) {
+        Jr[j] = rec[kJ0 + 2 * j];
+        Jr[14 + j] = rec[kJ0 + 2 * j + 1];
+        Jr[7 + j] = rec[kPre + 12 * j];
+        Jr[21 + j] = rec[kPre + 12 * j + 1];
+      }
       solve_minnorm(Jr, f0, f1, dx);
       if (cont) {
 #pragma unroll
@@ -234,6 +292,218 @@ __global__ __launch_bounds__(64) void project_fd_kernel(const ccmp_consts K, con
           if (e % kGroup == r) rec[kX + e] = CCMP_FMA(-K.step, dx[e], rec[kX + e]);
         updates++;
       }
+    }
+    __syncthreads();
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// project_fd_wave_kernel — the same arithmetic, ONE WAVEFRONT PER SAMPLE (latency-oriented).
+// The 84 stencil evaluations of an iteration are spread over the 64 lanes (two rounds: 64 + 20, the
+// second round holds the evaluations with the shortest chain suffix), the two arms' chains at x run
+// on the two half-waves, 28 lanes combine the stencil into J.  Arm/joint indices differ per lane
+// here, so the kinematic constants are read from an LDS copy of ccmp_consts (same source functions,
+// same operation order, hence the same bits as the group kernel and the oracle).  ~2.5x the
+// wave-instructions per sample-iteration of the group kernel, but ~5x lower latency per sample:
+// used for the stragglers the group kernel hands over and for small batches.
+// SRC 0: q_in, SRC 1: ambient sampler, SRC 2: straggler pool.
+constexpr int wX = 0, wSC = 14, wPre = 42, wEE = 210, wJ = 234, wT = 262, wY = 430, wRec = 514;
+constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
+
+template <int SRC>
+__global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_wave_kernel(
+    const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
+    uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
+    unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
+    const unsigned long long *__restrict__ pool_count, int wrap_output)
+{
+  __shared__ double lds[wRec];
+  __shared__ double ktab[kConstsDoubles + 1];
+  const int lane = threadIdx.x;
+  {
+    const double *src = reinterpret_cast<const double *>(&K);
+    for (int k = lane; k < kConstsDoubles; k += 64) ktab[k] = src[k];
+  }
+  __syncthreads();
+  const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
+  double *rec = lds;
+  const unsigned long long total = (SRC == 2) ? *pool_count : B;
+
+  for (;;) {
+    // ---- next sample of this wave --------------------------------------------------------------
+    unsigned long long t = 0;
+    if (lane == 0) t = atomicAdd(queue, 1ull);
+    t = shfl_u64(t, 0);
+    if (t >= total) break;
+    unsigned long long idx;
+    int iter = 0, updates = 0;
+    double norm1 = 0.0, norm2 = 0.0;
+    if (SRC == 2) {
+      const double *ent = pool + t * kPoolEntry;
+      idx = (unsigned long long)__double_as_longlong(ent[14]);
+      iter = __double2hiint(ent[15]);
+      updates = __double2loint(ent[15]);
+      norm1 = ent[16];
+      norm2 = ent[17];
+      if (lane < 14) rec[wX + lane] = ent[lane];
+    } else {
+      idx = t;
+      if (lane < 14) {
+        double v;
+        if (SRC == 0) v = q_in[idx * 14 + lane];
+        else {
+          v = ambient_uniform(KL, seed, first_index + idx, lane);
+          if (q_ambient) q_ambient[idx * 14 + lane] = v;
+        }
+        rec[wX + lane] = v;
+      }
+    }
+    __syncthreads();
+
+    for (;;) { // Newton iterations of this sample
+      // ---- phase 1: function(x) -----------------------------------------------------------------
+      if (lane < 14) {
+        double s, c;
+        ccmp_sincos(rec[wX + lane], &s, &c);
+        rec[wSC + 2 * lane] = s;
+        rec[wSC + 2 * lane + 1] = c;
+      }
+      __syncthreads();
+      {
+        const int arm = lane >> 5; // half-wave per arm
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0}, T[12];
+        const bool wr = (lane & 31) == 0;
+        for (int i = 0; i < 7; i++) {
+          const int col = arm * 7 + i;
+          double Rj[9], Rn[9];
+          mulvec_acc(R, KL.offset[arm][i], o);
+          if (wr) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) rec[wPre + col * 12 + k] = R[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) rec[wPre + col * 12 + 9 + k] = o[k];
+          }
+          rot_sc(KL.axis[arm][i], KL.aprod[arm][i], rec[wSC + 2 * col], rec[wSC + 2 * col + 1], Rj);
+          mul33(R, Rj, Rn);
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = Rn[k];
+        }
+        tool_pose(KL, arm, R, o, &T[0], &T[9]);
+        if (wr) {
+#pragma unroll
+          for (int k = 0; k < 12; k++) rec[wEE + arm * 12 + k] = T[k];
+        }
+      }
+      __syncthreads();
+      double f0, f1;
+      {
+        double T0[12], T1[12], f[2];
+#pragma unroll
+        for (int k = 0; k < 12; k++) { T0[k] = rec[wEE + k]; T1[k] = rec[wEE + 12 + k]; }
+        chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
+        f0 = f[0]; f1 = f[1];
+      }
+      // ---- loop condition of ConstraintFunction.h:68 (wave-uniform here) -------------------------
+      bool cont = false;
+      {
+        const bool c1 = f0 > K.tol_pos;
+        norm1 = c1 ? 1.0 : 0.0;
+        bool resid = c1;
+        if (!c1) { norm2 = f1; resid = f1 > K.tol_rot; }
+        if (resid) { cont = iter < K.max_iter; iter++; }
+      }
+      if (!cont) {
+        bool bad = false;
+        if (lane < 14) {
+          const double v = rec[wX + lane];
+          const int jj = lane < 7 ? lane : lane - 7;
+          if (v < KL.lbe[jj]) bad = true;
+          if (v > KL.ube[jj]) bad = true;
+          q_out[idx * 14 + lane] = wrap_output ? wrap_pi(v) : v;
+        }
+        const bool gbad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+        if (lane == 0) {
+          ok_out[idx] = (uint8_t)((!gbad) && (norm1 < K.tol_pos) && (norm2 < K.tol_rot));
+          if (iters_out) iters_out[idx] = (uint16_t)updates;
+        }
+        break;
+      }
+
+      // ---- phase 2: the 84 stencil evaluations, two rounds -----------------------------------------
+      // evaluation e = 6*cs + point, columns sorted by chain-suffix length: cs -> (arm = cs&1, j = cs>>1)
+#pragma unroll
+      for (int round = 0; round < 2; round++) {
+        const int e = lane + 64 * round;
+        const bool valid = e < 84;
+        const int ec = valid ? e : 83;
+        const int cs = ec / 6, pt = ec - 6 * cs;
+        const int arm = cs & 1, j = cs >> 1, col = arm * 7 + j;
+        const bool plus = pt < 3;
+        const int nstep = (plus ? pt : pt - 3) + 1;
+        const double xj = rec[wX + col];
+        const double axj = ccmp_abs(xj);
+        const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
+        const double hh = plus ? h : -h;
+        double y = xj + hh;
+        if (nstep >= 2) y = y + hh;
+        if (nstep >= 3) y = y + hh;
+        double R[9], o[3], s, c;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = rec[wPre + col * 12 + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) o[k] = rec[wPre + col * 12 + 9 + k];
+        ccmp_sincos(y, &s, &c);
+        {
+          double Rj[9], Rn[9];
+          rot_sc(KL.axis[arm][j], KL.aprod[arm][j], s, c, Rj);
+          mul33(R, Rj, Rn);
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = Rn[k];
+        }
+        // suffix j+1..6; round 1 only holds j >= 5, so its loop is a single step
+        for (int i = (round == 0 ? 1 : 6); i < 7; i++) {
+          if (i > j) joint_step(KL, arm, i, rec[wSC + 2 * (arm * 7 + i)], rec[wSC + 2 * (arm * 7 + i) + 1], R, o);
+        }
+        double Tw[12], To[12], tt[2];
+        tool_pose(KL, arm, R, o, &Tw[0], &Tw[9]);
+#pragma unroll
+        for (int k = 0; k < 12; k++) To[k] = rec[wEE + (1 - arm) * 12 + k];
+        {
+          double A[12], Bq[12]; // (T1, T2) in role order: the perturbed arm's pose takes its own slot
+#pragma unroll
+          for (int k = 0; k < 12; k++) { A[k] = arm ? To[k] : Tw[k]; Bq[k] = arm ? Tw[k] : To[k]; }
+          chain_residual(K, &A[0], &A[9], &Bq[0], &Bq[9], tt, nullptr, nullptr);
+        }
+        if (valid) {
+          rec[wT + 2 * (6 * col + pt)] = tt[0];
+          rec[wT + 2 * (6 * col + pt) + 1] = tt[1];
+          rec[wY + 6 * col + pt] = y;
+        }
+      }
+      __syncthreads();
+      if (lane < 28) { // J[row][col] = 1.5 m1 - 0.6 m2 + 0.1 m3, m_s = (t1 - t2) / (y1[j] - y2[j])
+        const int row = lane >= 14 ? 1 : 0, col = lane - 14 * row;
+        double m[3];
+#pragma unroll
+        for (int sidx = 0; sidx < 3; sidx++) {
+          const int e1 = 6 * col + sidx, e2 = 6 * col + 3 + sidx;
+          m[sidx] = (rec[wT + 2 * e1 + row] - rec[wT + 2 * e2 + row]) / (rec[wY + e1] - rec[wY + e2]);
+        }
+        rec[wJ + lane] = CCMP_FMA(0.1, m[2], CCMP_FMA(-0.6, m[1], 1.5 * m[0]));
+      }
+      __syncthreads();
+      {
+        double Jr[28], dx[14];
+#pragma unroll
+        for (int k = 0; k < 28; k++) Jr[k] = rec[wJ + k];
+        solve_minnorm(Jr, f0, f1, dx);
+#pragma unroll
+        for (int e = 0; e < 14; e++)
+          if (e == lane) rec[wX + e] = CCMP_FMA(-K.step, dx[e], rec[wX + e]);
+        updates++;
+      }
+      __syncthreads();
     }
     __syncthreads();
   }
@@ -368,16 +638,31 @@ extern "C" {
 
 hipError_t ccmp_launch_project_fd(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                   uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
-                                  unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st)
+                                  unsigned long long seed, unsigned long long first, int nblocks, double *pool,
+                                  int nblocks_wave, hipStream_t st)
 {
-  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+  // queue[0]: sample queue of the group kernel; queue[1]: pool fill count; queue[2]: pool read head
+  hipError_t e = hipMemsetAsync(queue, 0, 4 * sizeof(unsigned long long), st);
   if (e != hipSuccess) return e;
-  if (mode == 0)
-    hipLaunchKernelGGL(project_fd_kernel<0>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue, seed, first);
-  else
-    hipLaunchKernelGGL(project_fd_kernel<1>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue, seed, first);
+  if (nblocks > 0) {
+    double *pl = nblocks_wave > 0 ? pool : nullptr;
+    if (mode == 0)
+      hipLaunchKernelGGL(project_fd_kernel<0>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, queue, seed, first, pl, queue + 1);
+    else
+      hipLaunchKernelGGL(project_fd_kernel<1>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, queue, seed, first, pl, queue + 1);
+    if (nblocks_wave > 0)
+      hipLaunchKernelGGL(project_fd_wave_kernel<2>, dim3(nblocks_wave), dim3(64), 0, st, *K, q_in, q_out, ok, iters,
+                         q_ambient, (unsigned long long)B, queue + 2, seed, first, pool, queue + 1, mode);
+  } else { // small batch: wave-per-sample kernel on everything
+    if (mode == 0)
+      hipLaunchKernelGGL(project_fd_wave_kernel<0>, dim3(nblocks_wave), dim3(64), 0, st, *K, q_in, q_out, ok, iters,
+                         q_ambient, (unsigned long long)B, queue + 2, seed, first, pool, queue + 1, 0);
+    else
+      hipLaunchKernelGGL(project_fd_wave_kernel<1>, dim3(nblocks_wave), dim3(64), 0, st, *K, q_in, q_out, ok, iters,
+                         q_ambient, (unsigned long long)B, queue + 2, seed, first, pool, queue + 1, 1);
+  }
   return hipGetLastError();
 }
 

@@ -96,6 +96,11 @@ int ccmp_ctx_create(int device, ccmp_ctx **out);
 void ccmp_ctx_destroy(ccmp_ctx *ctx);
 /* persistent waves per CU for the projector kernels (0 = built-in default) */
 int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
+/* projector scheduling: wave_kernel 0 = 10-samples-per-wave kernel only, 1 = that kernel until the sample queue
+ * drains, then the wave-per-sample kernel on the samples still in flight (default), 2 = wave-per-sample only;
+ * batches of at most small_batch samples always use the wave-per-sample kernel (default 8192).  Results are
+ * bit-identical under every setting. */
+int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch);
 int ccmp_ctx_device(const ccmp_ctx *ctx);
 int ccmp_ctx_num_cus(const ccmp_ctx *ctx);
 

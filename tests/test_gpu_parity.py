@@ -14,6 +14,7 @@ from conftest import NCPU, OBJECTS, config_path, load_cfg, load_path_rows
 
 pytestmark = pytest.mark.gpu
 
+_SCHED_CACHE = {}
 TOL_RAD = 1e-6  # north_star: "projected joints match the reference CPU projector ... to 1e-6 rad"
 
 
@@ -102,6 +103,31 @@ def test_project_fd_bitwise(gpu_ctx, oracle_det, obj, B, seed):
     assert np.array_equal(ok_gpu, ok_cpu)
     assert np.array_equal(it_gpu.astype(np.int32), it_cpu)
     assert np.array_equal(q_gpu.view(np.uint64), q_cpu.view(np.uint64)), "not bit-identical"
+
+
+@pytest.mark.parametrize("schedule,small", [(0, 0), (1, 0), (2, 0), (1, 8192)])
+def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small):
+    """group kernel only / group kernel + straggler hand-over to the wave-per-sample kernel /
+    wave-per-sample only / default policy: all bit-identical to the oracle."""
+    import torch
+
+    c = _constraint("stefan", gpu_ctx)  # longest iteration tails, some samples hit the 250 cap
+    P = _oracle_problem(oracle_det, c)
+    B = 3000
+    if "stefan" not in _SCHED_CACHE:
+        q = oracle_det.ambient_uniform_batch(P, 0x5C, 0, B)
+        _SCHED_CACHE["stefan"] = (q,) + oracle_det.project_batch(P, q, NCPU)
+    q, q_cpu, ok_cpu, it_cpu = _SCHED_CACHE["stefan"]
+    gpu_ctx.set_schedule(schedule, small)
+    try:
+        q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_schedule(1, 8192)
+    assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+    assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)
+    assert np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
+    assert it_cpu.max() == 250  # the cap was exercised
 
 
 def test_sample_project_bitwise(gpu_ctx, oracle_det):

@@ -32,7 +32,7 @@ def main():
         for B in (4096, 262144):
             q = c.ambient_uniform_batch(0xC3, 0, B)
             out = torch.empty_like(q)
-            for wpc in ((2, 4, 6, 7) if mode == 0 else (2, 4, 8)):
+            for wpc in ((6, 7, 8, 10, 12) if mode == 0 else (4, 8)):
                 ctx.set_waves_per_cu(wpc)
                 t0 = time.time()
                 ms = timed(lambda: c.project_batch(q, out=out), reps=2 if mode == 0 else 5)
