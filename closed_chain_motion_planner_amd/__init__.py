@@ -7,4 +7,6 @@ interface.  Importing the package needs neither a GPU nor the built library; usi
 from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem  # noqa: F401
 from .constraint import ArmModel, Context, KinematicChainConstraint, load_config  # noqa: F401
 
+from .space import format_path_matrix, jy_ProjectedStateSampler, jy_ProjectedStateSpace, parse_path_matrix  # noqa: F401
+
 __version__ = "0.1.0"

@@ -56,7 +56,8 @@ EXPORTS = [
     "ccmp_problem_from_yaml", "ccmp_problem_init", "ccmp_set_start", "ccmp_set_tolerance", "ccmp_set_calibration",
     "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_set_schedule", "ccmp_ctx_device", "ccmp_ctx_num_cus",
     "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
-    "ccmp_sample_project_batch", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid",
+    "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
+    "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid",
     "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_detmath_probe", "ccmp_strerror",
     "ccmp_last_hip_error", "ccmp_version", "ccmp_problem_sizeof",
 ]
@@ -102,6 +103,12 @@ def lib():
         "ccmp_is_satisfied_batch": ([vp, pp, vp, vp, C.c_size_t, vp], C.c_int),
         "ccmp_joint_valid_batch": ([vp, pp, vp, vp, C.c_size_t, vp], C.c_int),
         "ccmp_sample_project_batch": ([vp, pp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_sample_near_project_batch": ([vp, pp, C.c_uint64, C.c_uint64, vp, C.c_int, C.c_double, vp, vp, vp, vp,
+                                            C.c_size_t, vp], C.c_int),
+        "ccmp_sample_gaussian_project_batch": ([vp, pp, C.c_uint64, C.c_uint64, vp, C.c_int, C.c_double, vp, vp, vp, vp,
+                                                C.c_size_t, vp], C.c_int),
+        "ccmp_compute_t_wo_batch": ([vp, pp, vp, C.c_int, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_geodesic_batch": ([vp, pp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "ccmp_ambient_uniform_batch": ([vp, pp, C.c_uint64, C.c_uint64, vp, C.c_size_t, vp], C.c_int),
         "ccmp_enforce_bounds_batch": ([vp, vp, C.c_size_t, vp], C.c_int),
         "ccmp_compact_valid": ([vp, vp, vp, C.c_size_t, vp, vp, vp], C.c_int),

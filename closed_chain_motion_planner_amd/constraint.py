@@ -201,6 +201,64 @@ class KinematicChainConstraint:
                                                    _stream_handle(stream)), "ccmp_sample_project_batch")
         return out, ok, it, amb
 
+    def _sample_ref(self, fn_name, seed, first_index, ref, param, B, want_iters, want_ambient, stream):
+        self._need_problem()
+        torch = _torch()
+        dev = torch.device("cuda", self.ctx.device)
+        if not (isinstance(ref, torch.Tensor) and ref.is_cuda and ref.dtype == torch.float64 and ref.is_contiguous()
+                and ref.shape[-1] == 14 and ref.numel() in (14, 14 * B)):
+            raise ValueError("reference state(s): contiguous float64 CUDA tensor of shape (14,) or (B,14)")
+        stride = 0 if ref.numel() == 14 else 14
+        out = torch.empty((B, 14), dtype=torch.float64, device=dev)
+        ok = torch.empty(B, dtype=torch.uint8, device=dev)
+        it = torch.empty(B, dtype=torch.int16, device=dev) if want_iters else None
+        amb = torch.empty((B, 14), dtype=torch.float64, device=dev) if want_ambient else None
+        check(getattr(_lib.lib(), fn_name)(self.ctx.handle, C.byref(self.problem), int(seed), int(first_index), ref.data_ptr(),
+                                           stride, float(param), out.data_ptr(), ok.data_ptr(),
+                                           it.data_ptr() if it is not None else None,
+                                           amb.data_ptr() if amb is not None else None, B, _stream_handle(stream)), fn_name)
+        return out, ok, it, amb
+
+    def sample_near_project_batch(self, seed, first_index, near, distance, B, want_iters=True, want_ambient=False, stream=None):
+        """`jy_ProjectedStateSampler::sampleUniformNear` x B (jy_ProjectedStateSpace.cpp:17-22)."""
+        return self._sample_ref("ccmp_sample_near_project_batch", seed, first_index, near, distance, B, want_iters,
+                                want_ambient, stream)
+
+    def sample_gaussian_project_batch(self, seed, first_index, mean, std_dev, B, want_iters=True, want_ambient=False,
+                                      stream=None):
+        """`jy_ProjectedStateSampler::sampleGaussian` x B (jy_ProjectedStateSpace.cpp:24-29)."""
+        return self._sample_ref("ccmp_sample_gaussian_project_batch", seed, first_index, mean, std_dev, B, want_iters,
+                                want_ambient, stream)
+
+    def compute_t_wo_batch(self, q, stream=None):
+        """`IKTask::compute_t_wo` (ik_task.cpp:10-14) for the left arm's joints q[:, :7] -> (B,12): R row-major, p."""
+        self._need_problem()
+        torch = _torch()
+        if not (isinstance(q, torch.Tensor) and q.is_cuda and q.dtype == torch.float64 and q.dim() == 2 and q.is_contiguous()
+                and q.shape[1] >= 7):
+            raise ValueError("expected a contiguous (B,>=7) float64 CUDA tensor")
+        out = torch.empty((q.shape[0], 12), dtype=torch.float64, device=q.device)
+        check(_lib.lib().ccmp_compute_t_wo_batch(self.ctx.handle, C.byref(self.problem), q.data_ptr(), q.shape[1],
+                                                 out.data_ptr(), q.shape[0], _stream_handle(stream)), "ccmp_compute_t_wo_batch")
+        return out
+
+    def discrete_geodesic_batch(self, frm, to, max_states=64, stream=None):
+        """`jy_ProjectedStateSpace::discreteGeodesic` for E edges (jy_ProjectedStateSpace.cpp:32-96), run as with
+        interpolate == true.  Returns (states (E,max_states,14), n_states (E,), ok (E,), newton_iters (E,))."""
+        self._need_problem()
+        self._check_q(frm)
+        self._check_q(to)
+        torch = _torch()
+        E = frm.shape[0]
+        states = torch.empty((E, max_states, 14), dtype=torch.float64, device=frm.device)
+        n = torch.empty(E, dtype=torch.int32, device=frm.device)
+        ok = torch.empty(E, dtype=torch.uint8, device=frm.device)
+        its = torch.empty(E, dtype=torch.int32, device=frm.device)
+        check(_lib.lib().ccmp_geodesic_batch(self.ctx.handle, C.byref(self.problem), frm.data_ptr(), to.data_ptr(), E,
+                                             int(max_states), states.data_ptr(), n.data_ptr(), ok.data_ptr(), its.data_ptr(),
+                                             _stream_handle(stream)), "ccmp_geodesic_batch")
+        return states, n, ok, its
+
     def ambient_uniform_batch(self, seed, first_index, B, stream=None):
         self._need_problem()
         torch = _torch()

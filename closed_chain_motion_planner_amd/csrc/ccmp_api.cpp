@@ -33,6 +33,12 @@ hipError_t ccmp_launch_joint_valid(const ccmp_consts *K, const double *q, uint8_
 hipError_t ccmp_launch_ambient_uniform(const ccmp_consts *K, unsigned long long seed, unsigned long long first,
                                        double *q, size_t B, hipStream_t st);
 hipError_t ccmp_launch_enforce_bounds(double *q, size_t B, hipStream_t st);
+hipError_t ccmp_launch_ambient_ref(const ccmp_consts *K, int kind, unsigned long long seed, unsigned long long first,
+                                   const double *ref, int ref_stride, double param, double *q, size_t B, hipStream_t st);
+hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride, double *out, size_t B, hipStream_t st);
+hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
+                                size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
+                                unsigned long long *queue, int nblocks, hipStream_t st);
 hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st);
 hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, unsigned int *block_counts,
                                unsigned long long *total, hipStream_t st);
@@ -152,7 +158,16 @@ void make_consts(const ccmp_problem &P, ccmp_consts &K)
     K.lbe[i] = P.lb[i] + P.joint_eps;
     K.ube[i] = P.ub[i] - P.joint_eps;
     K.lb[i] = P.lb[i];
+    K.ub[i] = P.ub[i];
     K.span[i] = P.ub[i] - P.lb[i];
+  }
+  // t_o7.inverse() of arm 0 = (R^T, -(R^T p))
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) K.t_o7i_R[3 * i + j] = P.t_o7_R[0][3 * j + i];
+  {
+    double tmp[3];
+    ccmp::mulTvec(P.t_o7_R[0], P.t_o7_p[0], tmp);
+    for (int k = 0; k < 3; k++) K.t_o7i_p[k] = -tmp[k];
   }
   K.tol_pos = P.tol_pos;
   K.tol_rot = P.tol_rot;
@@ -574,6 +589,63 @@ int ccmp_sample_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t see
                               uint8_t *ok, uint16_t *iters, double *q_ambient, size_t B, void *hip_stream)
 {
   return project_common(ctx, p, 1, nullptr, q_out, ok, iters, q_ambient, B, seed, first_index, hip_stream);
+}
+
+static int sample_ref_common(ccmp_ctx *ctx, const ccmp_problem *p, int kind, uint64_t seed, uint64_t first_index,
+                             const double *ref, int ref_stride, double param, double *q_out, uint8_t *ok, uint16_t *iters,
+                             double *q_ambient, size_t B, void *hip_stream)
+{
+  if (!ctx || !p) return CCMP_EINVAL;
+  if (B == 0) return CCMP_OK;
+  if (!ref || !q_out || !ok || (ref_stride != 0 && ref_stride != 14) || !(param >= 0)) return CCMP_EINVAL;
+  {
+    CCMP_PROLOGUE();
+    HIP_TRY(ccmp_launch_ambient_ref(&K, kind, seed, first_index, ref, ref_stride, param, q_out, B, st));
+    if (q_ambient) HIP_TRY(hipMemcpyAsync(q_ambient, q_out, B * 14 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  int rc = ccmp_project_batch(ctx, p, q_out, q_out, ok, iters, B, hip_stream);
+  if (rc != CCMP_OK) return rc;
+  return ccmp_enforce_bounds_batch(ctx, q_out, B, hip_stream);
+}
+
+int ccmp_sample_near_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
+                                   const double *near, int near_stride, double distance, double *q_out, uint8_t *ok,
+                                   uint16_t *iters, double *q_ambient, size_t B, void *hip_stream)
+{
+  return sample_ref_common(ctx, p, 0, seed, first_index, near, near_stride, distance, q_out, ok, iters, q_ambient, B, hip_stream);
+}
+
+int ccmp_sample_gaussian_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
+                                       const double *mean, int mean_stride, double std_dev, double *q_out, uint8_t *ok,
+                                       uint16_t *iters, double *q_ambient, size_t B, void *hip_stream)
+{
+  return sample_ref_common(ctx, p, 1, seed, first_index, mean, mean_stride, std_dev, q_out, ok, iters, q_ambient, B, hip_stream);
+}
+
+int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, int q_stride, double *t_wo, size_t B,
+                            void *hip_stream)
+{
+  CCMP_PROLOGUE();
+  if (B == 0) return CCMP_OK;
+  if (!q || !t_wo || q_stride < 7) return CCMP_EINVAL;
+  HIP_TRY(ccmp_launch_t_wo(&K, q, q_stride, t_wo, B, st));
+  return CCMP_OK;
+}
+
+int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                        double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream)
+{
+  CCMP_PROLOGUE();
+  if (E == 0) return CCMP_OK;
+  if (!from || !to || !states || !n_states || !ok || max_states < 1) return CCMP_EINVAL;
+  if (!(p->delta > 0) || !(p->lambda > 0)) return CCMP_EINVAL;
+  if (p->jacobian_mode != CCMP_JAC_FD) return CCMP_EINVAL; // the extend step exists in reference arithmetic only
+  const int wpc = ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12;
+  size_t nb = (size_t)ctx->num_cus * (size_t)wpc;
+  if (nb > E) nb = E;
+  HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters,
+                               ctx->queue + 4, (int)nb, st));
+  return CCMP_OK;
 }
 
 int ccmp_is_satisfied_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B, void *hip_stream)

@@ -184,4 +184,38 @@ CCMP_HD double ccmp_atan2_nn(double y, double x)
   return ccmp_atan(y / x); /* x == 0 < y gives +inf -> pi/2 */
 }
 
+/* Natural logarithm for finite normal x > 0 (the only use: Box-Muller on u in (0,1]).  fdlibm scheme:
+ * x = 2^k (1+f), sqrt(2)/2 <= 1+f < sqrt(2), log(1+f) from s = f/(2+f) with a degree-14 minimax. */
+CCMP_HD double ccmp_log(double x)
+{
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  unsigned long long u;
+  __builtin_memcpy(&u, &x, 8);
+  int k = (int)((u >> 52) & 0x7ff) - 1023;
+  unsigned long long m = (u & 0x000fffffffffffffULL);
+  /* mantissa >= sqrt(2): use the next binade so that 1+f stays in [sqrt(2)/2, sqrt(2)) */
+  if (m >= 0x6a09e667f3bcdULL) { k += 1; m |= 0x3fe0000000000000ULL; }
+  else m |= 0x3ff0000000000000ULL;
+  double xm;
+  __builtin_memcpy(&xm, &m, 8);
+  const double f = xm - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  double t1 = CCMP_FMA(w, Lg6, Lg4);
+  t1 = CCMP_FMA(w, t1, Lg2);
+  t1 = w * t1;
+  double t2 = CCMP_FMA(w, Lg7, Lg5);
+  t2 = CCMP_FMA(w, t2, Lg3);
+  t2 = CCMP_FMA(w, t2, Lg1);
+  t2 = z * t2;
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  return CCMP_FMA(dk, ln2_hi, -((hfsq - CCMP_FMA(s, hfsq + R, dk * ln2_lo)) - f));
+}
+
 #endif /* CCMP_DETMATH_H */

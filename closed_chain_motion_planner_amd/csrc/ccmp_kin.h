@@ -32,7 +32,10 @@ struct ccmp_consts {
   double lbe[7];    /* lb + eps */
   double ube[7];    /* ub - eps */
   double lb[7];
+  double ub[7];
   double span[7];   /* ub - lb (sampler) */
+  double t_o7i_R[9]; /* inverse of arm 0's t_o7 (IKTask::compute_t_wo, src/base/constraints/ik_task.cpp:10-14) */
+  double t_o7i_p[3];
   double tol_pos, tol_rot, step;
   int32_t max_iter;
   int32_t pad;
@@ -233,6 +236,34 @@ CCMP_HD double ambient_uniform(const ccmp_consts &K, uint64_t seed, uint64_t ind
   uint64_t r = splitmix64(seed ^ (index * 14ULL + (uint64_t)j));
   double u = (double)(r >> 11) * 1.1102230246251565e-16; /* 2^-53 */
   return CCMP_FMA(K.span[j % 7], u, K.lb[j % 7]);
+}
+
+/* RealVectorStateSampler::sampleUniformNear: uniformReal(max(low, near-d), min(high, near+d)) */
+CCMP_HD double ambient_near(const ccmp_consts &K, uint64_t seed, uint64_t index, int j, double near, double d)
+{
+  const double low = K.lb[j % 7], high = K.ub[j % 7];
+  const double a = (near - d) > low ? (near - d) : low;
+  const double b = (near + d) < high ? (near + d) : high;
+  uint64_t r = splitmix64(seed ^ (index * 14ULL + (uint64_t)j));
+  double u = (double)(r >> 11) * 1.1102230246251565e-16;
+  return CCMP_FMA(b - a, u, a);
+}
+/* RealVectorStateSampler::sampleGaussian: mean + stdDev * N(0,1), clamped to the bounds.  OMPL's
+ * normal deviate is library-defined; here it is Box-Muller on two counter-based uniforms. */
+CCMP_HD double ambient_gaussian(const ccmp_consts &K, uint64_t seed, uint64_t index, int j, double mean, double stddev)
+{
+  const double low = K.lb[j % 7], high = K.ub[j % 7];
+  uint64_t r1 = splitmix64(seed ^ (index * 28ULL + 2ULL * (uint64_t)j));
+  uint64_t r2 = splitmix64(seed ^ (index * 28ULL + 2ULL * (uint64_t)j + 1ULL));
+  double u1 = (double)((r1 >> 11) + 1ULL) * 1.1102230246251565e-16; /* (0,1] */
+  double u2 = (double)(r2 >> 11) * 1.1102230246251565e-16;          /* [0,1) */
+  double s, c;
+  ccmp_sincos(6.283185307179586 * u2, &s, &c);
+  double z = ccmp_sqrt(-2.0 * ccmp_log(u1)) * c;
+  double v = CCMP_FMA(z, stddev, mean);
+  if (v < low) v = low;
+  else if (v > high) v = high;
+  return v;
 }
 
 } /* namespace ccmp */

@@ -126,6 +126,27 @@ int ccmp_joint_valid_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
 int ccmp_sample_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
                               double *q_out, uint8_t *ok, uint16_t *iters, double *q_ambient, size_t B,
                               void *hip_stream);
+/* jy_ProjectedStateSampler::sampleUniformNear (jy_ProjectedStateSpace.cpp:17-22): per dimension
+ * uniform in [max(low, near-d), min(high, near+d)], then project, then enforceBounds.  `near` holds one
+ * state per sample (near_stride 14) or one shared state (near_stride 0). */
+int ccmp_sample_near_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
+                                   const double *near, int near_stride, double distance, double *q_out, uint8_t *ok,
+                                   uint16_t *iters, double *q_ambient, size_t B, void *hip_stream);
+/* jy_ProjectedStateSampler::sampleGaussian (jy_ProjectedStateSpace.cpp:24-29): mean + stdDev*N(0,1) per
+ * dimension (Box-Muller on counter-based uniforms), clamped to the bounds, then project, then enforceBounds */
+int ccmp_sample_gaussian_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
+                                       const double *mean, int mean_stride, double std_dev, double *q_out, uint8_t *ok,
+                                       uint16_t *iters, double *q_ambient, size_t B, void *hip_stream);
+/* IKTask::compute_t_wo (src/base/constraints/ik_task.cpp:10-14): object pose t_wb*FK(q)*t_o7^-1 from the
+ * left arm's 7 joints (q + i*q_stride); t_wo[i] = rotation (9, row-major) then translation (3) */
+int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, int q_stride, double *t_wo, size_t B,
+                            void *hip_stream);
+/* jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96), E edges at once:
+ * states[e][0..n_states[e]) (capacity max_states each) = `from`, then every accepted state; ok[e] = the
+ * reference's return value.  Runs as the reference does with interpolate == true; for interpolate ==
+ * false the host truncates at the first state its StateValidityChecker rejects. */
+int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                        double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream);
 /* the ambient sampler alone (RealVectorStateSampler::sampleUniform over KinematicChain.h:75-100) */
 int ccmp_ambient_uniform_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
                                double *q_out, size_t B, void *hip_stream);

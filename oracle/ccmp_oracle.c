@@ -19,11 +19,13 @@
 #include "ccmp_detmath.h"
 #define ORC_SINCOS(x, s, c) ccmp_sincos((x), (s), (c))
 #define ORC_ATAN2_NN(y, x) ccmp_atan2_nn((y), (x))
+#define ORC_LOG(x) ccmp_log(x)
 #define FMA(a, b, c) CCMP_FMA(a, b, c)
 #else
 /* what a stock x86-64 build of the reference does: glibc sin/cos/atan2, no fused operations */
 #define ORC_SINCOS(x, s, c) do { *(s) = sin(x); *(c) = cos(x); } while (0)
 #define ORC_ATAN2_NN(y, x) atan2((y), (x))
+#define ORC_LOG(x) log(x)
 #define FMA(a, b, c) ((a) * (b) + (c))
 #endif
 /* a0*b0 + a1*b1 + a2*b2, accumulated left to right (optionally onto c) */
@@ -532,6 +534,45 @@ void orc_ambient_uniform(const orc_problem *P, uint64_t seed, uint64_t index, do
     uint64_t r = orc_splitmix64(seed ^ (index * 14ULL + (uint64_t)j));
     double u = (double)(r >> 11) * 1.1102230246251565e-16; /* 2^-53 */
     q[j] = FMA(P->ub[j % 7] - P->lb[j % 7], u, P->lb[j % 7]); /* RNG::uniformReal(low, high) */
+  }
+}
+
+double orc_log(double x) { return ORC_LOG(x); }
+
+/* RealVectorStateSampler::sampleUniformNear [3P OMPL]: per dimension
+ * uniformReal(max(low, near - distance), min(high, near + distance)) */
+void orc_ambient_near(const orc_problem *P, uint64_t seed, uint64_t index, const double near[14], double distance,
+                      double q[14])
+{
+  for (int j = 0; j < 14; j++) {
+    const double low = P->lb[j % 7], high = P->ub[j % 7];
+    const double a = (near[j] - distance) > low ? (near[j] - distance) : low;
+    const double b = (near[j] + distance) < high ? (near[j] + distance) : high;
+    uint64_t r = orc_splitmix64(seed ^ (index * 14ULL + (uint64_t)j));
+    double u = (double)(r >> 11) * 1.1102230246251565e-16;
+    q[j] = FMA(b - a, u, a);
+  }
+}
+
+/* RealVectorStateSampler::sampleGaussian [3P OMPL]: rng_.gaussian(mean, stdDev) clamped to the bounds.
+ * OMPL draws from std::normal_distribution (library-defined, unreproducible); the deviate here is
+ * Box-Muller on two counter-based uniforms — the same definition the kernel uses. */
+void orc_ambient_gaussian(const orc_problem *P, uint64_t seed, uint64_t index, const double mean[14], double stddev,
+                          double q[14])
+{
+  for (int j = 0; j < 14; j++) {
+    const double low = P->lb[j % 7], high = P->ub[j % 7];
+    uint64_t r1 = orc_splitmix64(seed ^ (index * 28ULL + 2ULL * (uint64_t)j));
+    uint64_t r2 = orc_splitmix64(seed ^ (index * 28ULL + 2ULL * (uint64_t)j + 1ULL));
+    double u1 = (double)((r1 >> 11) + 1ULL) * 1.1102230246251565e-16;
+    double u2 = (double)(r2 >> 11) * 1.1102230246251565e-16;
+    double s, c;
+    ORC_SINCOS(6.283185307179586 * u2, &s, &c);
+    double z = sqrt(-2.0 * ORC_LOG(u1)) * c;
+    double v = FMA(z, stddev, mean[j]);
+    if (v < low) v = low;
+    else if (v > high) v = high;
+    q[j] = v;
   }
 }
 

@@ -101,6 +101,11 @@ void orc_interpolate(const double from[14], const double to[14], double t, doubl
 double orc_distance(const double a[14], const double b[14]);
 uint64_t orc_splitmix64(uint64_t z);
 void orc_ambient_uniform(const orc_problem *P, uint64_t seed, uint64_t index, double q[14]);
+void orc_ambient_near(const orc_problem *P, uint64_t seed, uint64_t index, const double near[14], double distance,
+                      double q[14]);
+void orc_ambient_gaussian(const orc_problem *P, uint64_t seed, uint64_t index, const double mean[14], double stddev,
+                          double q[14]);
+double orc_log(double x);
 /* sampleUniform = ambient sample -> project (result ignored) -> enforceBounds */
 int orc_sample_uniform(const orc_problem *P, uint64_t seed, uint64_t index, double q[14], int32_t *iters);
 /* discreteGeodesic; valid(state, user) may be NULL (= always valid).  Returns the bool of the

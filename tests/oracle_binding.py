@@ -86,6 +86,10 @@ class Oracle:
         lib.orc_splitmix64.argtypes = [C.c_uint64]
         lib.orc_splitmix64.restype = C.c_uint64
         lib.orc_ambient_uniform.argtypes = [pp, C.c_uint64, C.c_uint64, dp]
+        lib.orc_ambient_near.argtypes = [pp, C.c_uint64, C.c_uint64, dp, C.c_double, dp]
+        lib.orc_ambient_gaussian.argtypes = [pp, C.c_uint64, C.c_uint64, dp, C.c_double, dp]
+        lib.orc_log.argtypes = [C.c_double]
+        lib.orc_log.restype = C.c_double
         lib.orc_discrete_geodesic.argtypes = [pp, dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, C.c_int,
                                               C.POINTER(C.c_int), C.POINTER(C.c_int64)]
         lib.orc_discrete_geodesic.restype = C.c_int
@@ -184,6 +188,16 @@ class Oracle:
         out = np.empty((B, 14))
         for i in range(B):
             self.lib.orc_ambient_uniform(C.byref(P), seed, first + i, _dptr(out[i]))
+        return out
+
+    def ambient_ref_batch(self, P, kind, seed, first, ref, param, B):
+        """kind 'near' / 'gaussian'; ref is (14,) shared or (B,14) per sample"""
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        out = np.empty((B, 14))
+        fn = self.lib.orc_ambient_near if kind == "near" else self.lib.orc_ambient_gaussian
+        for i in range(B):
+            r = ref if ref.ndim == 1 else np.ascontiguousarray(ref[i])
+            fn(C.byref(P), seed, first + i, _dptr(r), float(param), _dptr(out[i]))
         return out
 
     def discrete_geodesic(self, P, a, b, interpolate=False, max_states=256):

@@ -1,0 +1,141 @@
+"""The rows either side of the projector, GPU vs oracle, bit for bit: batched
+discreteGeodesic, Near/Gaussian samplers, compute_t_wo; plus the host mirrors built on them."""
+import numpy as np
+import pytest
+
+from conftest import NCPU, config_path, load_cfg, load_path_rows
+from test_gpu_parity import _constraint, _oracle_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _edges(oracle, P, n, seed):
+    """(from, to) pairs like growTree's: a state on the manifold and a target a few steps away"""
+    q = oracle.ambient_uniform_batch(P, seed, 0, 12 * n)
+    proj, ok, _ = oracle.project_batch(P, q, NCPU)
+    good = proj[ok == 1]
+    assert len(good) >= 2 * n
+    return good[:n].copy(), good[n: 2 * n].copy()
+
+
+def test_discrete_geodesic_batch_bitwise(gpu_ctx, oracle_det):
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    frm, to = _edges(oracle_det, P, 48, 0x6E0)
+    rows = load_path_rows("Wine_Bottle")
+    frm[0], to[0] = rows[0], rows[5]          # along the reference's recorded geodesic
+    frm[1], to[1] = rows[2], rows[2] + 0.01   # closer than delta: true immediately, only `from`
+    to[2] = frm[2] + 0.4 * (to[2] - frm[2]) / np.linalg.norm(to[2] - frm[2])  # short edge
+    maxs = 40
+    st, n, ok, its = c.discrete_geodesic_batch(torch.as_tensor(frm).cuda(), torch.as_tensor(to).cuda(), maxs)
+    st, n, ok, its = st.cpu().numpy(), n.cpu().numpy(), ok.cpu().numpy(), its.cpu().numpy()
+    n_ok = 0
+    for e in range(len(frm)):
+        ok_cpu, st_cpu, its_cpu = oracle_det.discrete_geodesic(P, frm[e], to[e], interpolate=True, max_states=maxs)
+        assert n[e] == len(st_cpu) and bool(ok[e]) == ok_cpu and its[e] == its_cpu, e
+        assert np.array_equal(st[e, : n[e]].view(np.uint64), st_cpu.view(np.uint64)), e
+        n_ok += ok_cpu
+    assert n[1] == 1 and ok[1] == 1
+    assert n.max() > 3  # some edge really traversed the manifold
+    print("geodesic: %d/%d edges reached their target, mean states %.1f, mean Newton iterations per edge %.1f"
+          % (n_ok, len(frm), n.mean(), its.mean()))
+
+
+def test_geodesic_host_mirror_with_validity(gpu_ctx, oracle_det):
+    """interpolate == False: the host validity checker cuts the list where the reference would break"""
+    from closed_chain_motion_planner_amd import jy_ProjectedStateSpace
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    rows = load_path_rows("Wine_Bottle")
+    frm, to = rows[0], rows[5]
+    full_ok, full, _ = oracle_det.discrete_geodesic(P, frm, to, interpolate=True)
+    assert len(full) >= 4
+    reject = full[3].copy()
+    space = jy_ProjectedStateSpace(c, isValid=lambda s: not np.array_equal(s, reject))
+    geo = []
+    ok = space.discreteGeodesic(frm, to, False, geo)
+    assert len(geo) == 3 and np.array_equal(np.array(geo), full[:3]) and ok is False
+    geo2 = []
+    assert space.discreteGeodesic(frm, to, True, geo2) == full_ok and len(geo2) == len(full)  # interpolate: checker unused
+
+
+@pytest.mark.parametrize("kind", ["near", "gaussian"])
+def test_near_and_gaussian_samplers_bitwise(gpu_ctx, oracle_det, kind):
+    import torch
+
+    c = _constraint("dumbbell", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    B, seed, first = 600, 0x77, 1000
+    ref_shared = np.array(load_cfg("dumbbell")["start_joint"])
+    ref_each = oracle_det.ambient_uniform_batch(P, 5, 0, B)
+    for ref, param in ((ref_shared, 0.3), (ref_each, 0.15)):
+        fn = c.sample_near_project_batch if kind == "near" else c.sample_gaussian_project_batch
+        q, ok, it, amb = fn(seed, first, torch.as_tensor(ref).cuda(), param, B, want_ambient=True)
+        amb_cpu = oracle_det.ambient_ref_batch(P, kind, seed, first, ref, param, B)
+        assert np.array_equal(amb.cpu().numpy().view(np.uint64), amb_cpu.view(np.uint64))
+        q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, amb_cpu, NCPU)
+        q_cpu = np.array([oracle_det.enforce_bounds(x) for x in q_cpu])
+        assert np.array_equal(q.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+        assert np.array_equal(ok.cpu().numpy(), ok_cpu)
+        lb, ub = np.array(P.lb[:]), np.array(P.ub[:])
+        a = amb.cpu().numpy()
+        assert (a[:, :7] >= lb).all() and (a[:, :7] <= ub).all() and (a[:, 7:] >= lb).all() and (a[:, 7:] <= ub).all()
+        if kind == "near":
+            r = ref if ref.ndim == 2 else ref[None, :]
+            assert (np.abs(a - r) <= param + 1e-15).all()
+
+
+def test_gaussian_deviate_statistics(gpu_ctx):
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    mean = torch.tensor([0.0, 0.0, 0.0, -1.5, 0.0, 1.8, 0.0] * 2, dtype=torch.float64).cuda()
+    _, _, _, amb = c.sample_gaussian_project_batch(1, 0, mean, 0.05, 20000, want_iters=False, want_ambient=True)
+    z = ((amb - mean) / 0.05).cpu().numpy()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and abs((z ** 4).mean() - 3.0) < 0.15
+
+
+def test_compute_t_wo_bitwise(gpu_ctx, oracle_det):
+    import torch
+
+    c = _constraint("stefan", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, 9, 0, 300)
+    q[0] = np.array(P.start_joint[:])
+    out = c.compute_t_wo_batch(torch.as_tensor(q).cuda()).cpu().numpy()
+    for i in range(len(q)):
+        R, p = oracle_det.compute_t_wo(P, q[i, :7])
+        assert np.array_equal(out[i, :9].view(np.uint64), R.ravel().view(np.uint64))
+        assert np.array_equal(out[i, 9:].view(np.uint64), p.view(np.uint64))
+    # at start_joint the object sits at t_wo_start — up to the 1.2e-4 by which config/stefan.yaml's quaternion
+    # is not unit (Eigen's toRotationMatrix does not normalise; Isometry::inverse assumes it did)
+    assert np.allclose(out[0, 9:], load_cfg("stefan")["t_wo_start_pos"], atol=5e-4)
+    cw = _constraint("Wine_Bottle", gpu_ctx)  # identity quaternion: exact
+    qs = np.array(load_cfg("Wine_Bottle")["start_joint"]).reshape(1, 14)
+    o = cw.compute_t_wo_batch(torch.as_tensor(qs).cuda()).cpu().numpy()[0]
+    assert np.allclose(o[9:], load_cfg("Wine_Bottle")["t_wo_start_pos"], atol=1e-14)
+    assert np.allclose(o[:9].reshape(3, 3), np.eye(3), atol=1e-14)
+
+
+def test_sampler_mirror_stream_is_batch_independent(gpu_ctx, oracle_det):
+    """sampleUniform(state) served from a GPU-filled buffer; the sample stream does not depend on the
+    refill size, and equals the oracle's sampleUniform"""
+    from closed_chain_motion_planner_amd import jy_ProjectedStateSampler
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    s1, s2 = jy_ProjectedStateSampler(c, seed=42, batch=8), jy_ProjectedStateSampler(c, seed=42, batch=5)
+    a, b = np.empty(14), np.empty(14)
+    exp, _, _ = oracle_det.sample_project_batch(P, 42, 0, 20, 4)
+    for i in range(20):
+        s1.sampleUniform(a)
+        s2.sampleUniform(b)
+        assert np.array_equal(a, b) and np.array_equal(a.view(np.uint64), exp[i].view(np.uint64))
+    near = np.array(load_cfg("Wine_Bottle")["start_joint"])
+    s1.sampleUniformNear(a, near, 0.1)
+    assert np.abs(a - near).max() < 0.5 and c.isSatisfied(a)
+    s1.sampleGaussian(a, near, 0.05)
+    assert c.isSatisfied(a)
