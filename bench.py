@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets several ranks share one GPU")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     return ap.parse_args()
 
 
@@ -88,8 +90,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.force_device >= 0:
+            local_rank = args.force_device
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world:
