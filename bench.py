@@ -168,15 +168,20 @@ def main():
         return
 
     value = world * B * args.steps / elapsed
-    kernel = "project_fd_kernel" if args.mode == "fd" else "project_fast_kernel"
+    kernel = "project_fd_kernel+project_fd_wave_kernel" if args.mode == "fd" else "project_fast_kernel"
     achieved_gbs = BYTES_PER_PROJECTION * B / (kms * 1e-3) / 1e9
-    traffic = None
+    traffic, valu = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath):  # PMC numbers come from separate rocprofv3 --pmc passes (tools/profile.sh), not from this run
         try:
             tj = json.load(open(tpath))
             if tj.get("kernel") == kernel and tj.get("batch") == B:
                 traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("valu_wave_insts_per_launch"):
+                    n = tj["valu_wave_insts_per_launch"]
+                    valu = {"executed_valu_wave_insts_per_launch": n, "cycles_per_inst": 4,
+                            "frac_of_fp64_issue_ceiling": n * 4.0 / (kms * 1e-3 * 2.4e9 * 1024),
+                            "source": "SQ_INSTS_VALU, profiles/%s" % tj.get("tag")}
         except Exception:
             traffic = None
     fp64_tflops = FLOP_PER_NEWTON_ITER * sum_iters / (kms * 1e-3) / 1e12
@@ -199,7 +204,7 @@ def main():
             "fp64": {"achieved": fp64_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fp64_tflops / FP64_VECTOR_PEAK_TFLOPS,
                      "algorithmic_flop": "2400 per Newton iteration x %.0f iterations per launch" % sum_iters},
-            "newton_iterations_per_s": sum_iters / (kms * 1e-3),
+            "newton_iterations_per_s": sum_iters / (kms * 1e-3), "valu_issue": valu,
         },
         "stats": {"ok_fraction": ok_frac, "mean_newton_iters": sum_iters / B, "valid_states_rank0": n_valid},
     }

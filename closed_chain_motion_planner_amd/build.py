@@ -16,7 +16,7 @@ LIBPATH = os.path.join(LIBDIR, "libccmp.so")
 ARCH = "gfx950"
 
 _UNITS = [
-    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
+    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"] + os.environ.get("CCMP_FD_EXTRA_FLAGS", "").split()),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=fast"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]

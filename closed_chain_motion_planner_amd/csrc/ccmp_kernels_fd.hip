@@ -46,6 +46,9 @@ constexpr int kPoolEntry = 18;        // straggler hand-over record: x[14], idx,
 #ifndef CCMP_FD_WAVES_PER_SIMD
 #define CCMP_FD_WAVES_PER_SIMD 3
 #endif
+#ifndef CCMP_WAVE_WAVES_PER_SIMD
+#define CCMP_WAVE_WAVES_PER_SIMD 2
+#endif
 
 __device__ __forceinline__ double shfl_f64(double v, int src_lane)
 {
@@ -91,9 +94,6 @@ template <int ARM>
 __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *rec, bool writer, bool plus, int nstep,
                                                  int partner, int leader)
 {
-  double To[12]; // the other arm's (unperturbed) tool pose
-#pragma unroll
-  for (int k = 0; k < 12; k++) To[k] = rec[kEE + (1 - ARM) * 12 + k];
   for (int j = 0; j < 7; j++) {
     const double xj = rec[kX + ARM * 7 + j];
     const double axj = ccmp_abs(xj);
@@ -117,8 +117,16 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
     }
     for (int i = j + 1; i < 7; i++)
       joint_step(K, ARM, i, rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], R, o);
-    double Tw[12], t[2];
+    double Tw[12], To[12], t[2];
     tool_pose(K, ARM, R, o, &Tw[0], &Tw[9]);
+    {
+      // the other arm's (unperturbed) tool pose, re-read from LDS every column: keeping it in
+      // registers across the column loop costs 24 VGPRs and pushes the kernel into scratch spills
+      const double *ee = rec + kEE + (1 - ARM) * 12;
+      asm volatile("" : "+v"(ee));
+#pragma unroll
+      for (int k = 0; k < 12; k++) To[k] = ee[k];
+    }
     if (ARM == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);
     else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], t, nullptr, nullptr);
     // m_s = (t1 - t2) / (y1[j] - y2[j]) with the stored perturbed values
@@ -171,14 +179,17 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
       if (want) {
         if (t < B) {
           idx = t; active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
-          for (int e = r; e < 14; e += kGroup) {
-            double v;
-            if (MODE == 0) v = q_in[idx * 14 + e];
-            else {
-              v = ambient_uniform(K, seed, first_index + idx, e);
-              if (q_ambient) q_ambient[idx * 14 + e] = v;
+#pragma unroll
+          for (int e = 0; e < 14; e++) {
+            if (e % kGroup == r) {
+              double v;
+              if (MODE == 0) v = q_in[idx * 14 + e];
+              else {
+                v = ambient_uniform(K, seed, first_index + idx, e);
+                if (q_ambient) q_ambient[idx * 14 + e] = v;
+              }
+              rec[kX + e] = v;
             }
-            rec[kX + e] = v;
           }
         } else drained = true;
       }
@@ -245,12 +256,14 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
       const bool fin = active && !cont;
       bool bad = false;
       if (fin) {
-        for (int e = r; e < 14; e += kGroup) {
-          const double v = rec[kX + e];
-          const int jj = e < 7 ? e : e - 7;
-          if (v < K.lbe[jj]) bad = true;
-          if (v > K.ube[jj]) bad = true;
-          q_out[idx * 14 + e] = (MODE == 1) ? wrap_pi(v) : v;
+#pragma unroll
+        for (int e = 0; e < 14; e++) {
+          if (e % kGroup == r) { // e is a compile-time constant here: limits come from SGPRs
+            const double v = rec[kX + e];
+            if (v < K.lbe[e % 7]) bad = true;
+            if (v > K.ube[e % 7]) bad = true;
+            q_out[idx * 14 + e] = (MODE == 1) ? wrap_pi(v) : v;
+          }
         }
       }
       const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);
@@ -482,7 +495,7 @@ __device__ __forceinline__ void stage_consts(const ccmp_consts &K, double *ktab,
 }
 
 template <int SRC>
-__global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_wave_kernel(
+__global__ __launch_bounds__(64, CCMP_WAVE_WAVES_PER_SIMD) void project_fd_wave_kernel(
     const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_wave_ke
 // the first invalid state, which is what the reference's break would have produced.
 constexpr int gPrev = wRec, gTo = wRec + 14, gRec = wRec + 28;
 
-__global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_wave_kernel(
+__global__ __launch_bounds__(64, CCMP_WAVE_WAVES_PER_SIMD) void geodesic_wave_kernel(
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, unsigned long long *queue)

@@ -16,21 +16,29 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def counters(d, kernel_sub):
-    out = collections.defaultdict(list)
+def counters(d, kernel_subs):
+    """mean per projector launch = sum over the launch's kernels (group kernel + straggler kernel)"""
+    per = {ks: collections.defaultdict(list) for ks in kernel_subs}
     meta = {}
     for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if kernel_sub in r["Kernel_Name"]:
-                out[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
-                                          "Accum_VGPR_Count", "SGPR_Count")}
-    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}, meta
+            for ks in kernel_subs:
+                if ks in r["Kernel_Name"]:
+                    per[ks][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    meta[ks] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
+                                                  "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+    out, n = collections.defaultdict(float), {}
+    for ks in kernel_subs:
+        for k, v in per[ks].items():
+            out[k] += sum(v) / len(v)
+            n[k] = len(v)
+    return dict(out), n, meta
 
 
 def main():
     tag = sys.argv[1]
-    kernel_sub = sys.argv[2] if len(sys.argv) > 2 else "project_fd_kernel"
+    kernel_subs = (sys.argv[2] if len(sys.argv) > 2 else "project_fd_kernel,project_fd_wave_kernel").split(",")
+    kernel_sub = "+".join(kernel_subs)
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
@@ -38,12 +46,18 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
     krow = None
+    parts = []
     for r in csv.DictReader(open(stats)):
-        if kernel_sub in r["Name"]:
-            krow = r
+        if any(ks in r["Name"] for ks in kernel_subs):
+            parts.append((r["Name"].split("(")[0], int(r["Calls"]), float(r["AverageNs"]) / 1e6))
+            if krow is None:
+                krow = dict(r)
+            else:  # one projector launch = one call of each kernel: durations add
+                for k in ("AverageNs", "MinNs", "MaxNs"):
+                    krow[k] = str(float(krow[k]) + float(r[k]))
     allc, ns, meta = {}, {}, {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-        c, n, m = counters(os.path.join(src, sub), kernel_sub)
+        c, n, m = counters(os.path.join(src, sub), kernel_subs)
         allc.update(c)
         ns.update(n)
         meta = m or meta
@@ -57,12 +71,13 @@ def main():
         "min_ms": float(krow["MinNs"]) / 1e6, "max_ms": float(krow["MaxNs"]) / 1e6,
         "projections_per_s_kernel": batch / (avg_ms * 1e-3),
         "algorithmic_bytes_per_launch": algo, "achieved_GBps_algorithmic": algo / (avg_ms * 1e-3) / 1e9,
-        "counters_mean_per_launch": allc, "launch": meta,
+        "counters_mean_per_launch": allc, "launch": meta, "kernels": parts,
         "hbm_bytes_per_launch_raw": traffic_lo, "hbm_bytes_per_launch_fetch_doubled": traffic_hi,
     }
     json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
     if traffic_hi is not None:
         json.dump({"kernel": kernel_sub, "batch": batch, "hbm_bytes_per_launch": traffic_hi, "tag": tag,
+                   "valu_wave_insts_per_launch": allc.get("SQ_INSTS_VALU"),
                    "note": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, gfx950 FETCH_SIZE x2 correction "
                            "(upper bound for this kernel's 8-B-per-lane loads)"},
                   open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
@@ -77,11 +92,21 @@ def main():
                 % (batch, algo / 1e6, summary["achieved_GBps_algorithmic"], summary["achieved_GBps_algorithmic"] / 80.0))
         if traffic_lo is not None:
             f.write("| HBM traffic per launch (FETCH+WRITE raw / FETCH doubled) | %.1f MB / %.1f MB |\n" % (traffic_lo / 1e6, traffic_hi / 1e6))
-        for k in sorted(meta):
-            f.write("| %s | %s |\n" % (k, meta[k]))
+        for name, calls, ms in parts:
+            f.write("| kernel `%s` | %d calls, avg %.3f ms |\n" % (name[-60:], calls, ms))
+        for ks in sorted(meta):
+            f.write("| launch config `%s` | %s |\n" % (ks, ", ".join("%s=%s" % kv for kv in sorted(meta[ks].items()))))
         f.write("\n| counter (mean per launch, %s) | value |\n|---|---|\n" % ", ".join("%s x%d" % kv for kv in list(ns.items())[:1]))
         for k in sorted(allc):
             f.write("| %s | %.4g |\n" % (k, allc[k]))
+        if "SQ_INSTS_VALU" in allc:
+            issue = allc["SQ_INSTS_VALU"] * 4.0  # FP64-dominated: 4 cycles per wave64 instruction on a SIMD-32 at 16 FP64 lanes/clk
+            avail = avg_ms * 1e-3 * 2.4e9 * 1024
+            f.write("\nVALU issue roofline: %.3e VALU wave-instructions per launch x 4 cycles = %.3e SIMD-cycles of %.3e available "
+                    "(1024 SIMDs x 2.4 GHz x %.2f ms) = **%.1f %%** of the FP64 issue ceiling.\n"
+                    % (allc["SQ_INSTS_VALU"], issue, avail, avg_ms, 100 * issue / avail))
+            summary["valu_issue_frac"] = issue / avail
+            json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
         if "SQ_WAVE_CYCLES" in allc and "SQ_ACTIVE_INST_VALU" in allc:
             f.write("\nDerived: VALU-active share of wave lifetime = %.3f; " % (allc["SQ_ACTIVE_INST_VALU"] / allc["SQ_WAVE_CYCLES"]))
             if "SQ_WAIT_ANY" in allc:

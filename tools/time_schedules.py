@@ -8,7 +8,7 @@ from tools.time_kernels import timed  # noqa: E402
 obj = sys.argv[1] if len(sys.argv) > 1 else "Wine_Bottle"
 ctx = Context(0)
 c = KinematicChainConstraint.from_yaml("tests/golden/config/%s.yaml" % obj, ctx=ctx)
-for B in (4096, 32768, 262144, 1048576):
+for B in (4096, 262144):
     q = c.ambient_uniform_batch(0xC3, 0, B)
     out = torch.empty_like(q)
     for sched, name in ((0, "group only"), (1, "group+wave"), (2, "wave only")):
