@@ -170,13 +170,18 @@ def main():
     value = world * B * args.steps / elapsed
     kernel = "project_fd_kernel+project_fd_wave_kernel" if args.mode == "fd" else "project_fast_kernel"
     achieved_gbs = BYTES_PER_PROJECTION * B / (kms * 1e-3) / 1e9
-    traffic, valu = None, None
+    traffic, valu, executed = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):  # PMC numbers come from separate rocprofv3 --pmc passes (tools/profile.sh), not from this run
         try:
             tj = json.load(open(tpath))
             if tj.get("kernel") == kernel and tj.get("batch") == B:
                 traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("executed_fp64_flop_per_launch"):
+                    ef = tj["executed_fp64_flop_per_launch"]
+                    executed = {"achieved": ef / (kms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ef / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                "source": "SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 per launch, profiles/%s" % tj.get("tag")}
                 if tj.get("valu_wave_insts_per_launch"):
                     n = tj["valu_wave_insts_per_launch"]
                     valu = {"executed_valu_wave_insts_per_launch": n, "cycles_per_inst": 4,
@@ -204,7 +209,7 @@ def main():
             "fp64": {"achieved": fp64_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fp64_tflops / FP64_VECTOR_PEAK_TFLOPS,
                      "algorithmic_flop": "2400 per Newton iteration x %.0f iterations per launch" % sum_iters},
-            "newton_iterations_per_s": sum_iters / (kms * 1e-3), "valu_issue": valu,
+            "newton_iterations_per_s": sum_iters / (kms * 1e-3), "valu_issue": valu, "fp64_executed": executed,
         },
         "stats": {"ok_fraction": ok_frac, "mean_newton_iters": sum_iters / B, "valid_states_rank0": n_valid},
     }

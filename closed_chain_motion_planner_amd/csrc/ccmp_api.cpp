@@ -23,7 +23,7 @@ extern "C" {
 hipError_t ccmp_launch_project_fd(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                   uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                   unsigned long long seed, unsigned long long first, int nblocks, double *pool,
-                                  int nblocks_wave, hipStream_t st);
+                                  int nblocks_wave, int dump_threshold, const unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                     unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
@@ -301,6 +301,8 @@ struct ccmp_ctx {
   double *pool = nullptr;              // straggler hand-over records (group kernel -> wave kernel)
   size_t pool_cap = 0;                 // in records
   int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
+  const unsigned int *order = nullptr; // experimental: externally supplied processing order
+  int dump_threshold = 10;             // hand a wave's samples over once the queue is dry and <= this many groups are busy
   size_t small_batch = 8192;           // at or below: wave-per-sample kernel on everything
   unsigned int *scan = nullptr;        // compaction block counts
   size_t scan_cap = 0;
@@ -516,9 +518,16 @@ int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int w)
 }
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch)
 {
-  if (!ctx || wave_kernel < 0 || wave_kernel > 2) return CCMP_EINVAL;
-  ctx->wave_kernel = wave_kernel;
+  if (!ctx || wave_kernel < 0 || (wave_kernel % 100) > 2 || wave_kernel / 100 > 10) return CCMP_EINVAL;
+  ctx->wave_kernel = wave_kernel % 100;
+  if (wave_kernel >= 100) ctx->dump_threshold = wave_kernel / 100; /* experimental: hundreds digit+ = hand-over threshold */
   ctx->small_batch = small_batch;
+  return CCMP_OK;
+}
+int ccmp_ctx_set_order_experimental(ccmp_ctx *ctx, const unsigned int *order_dev)
+{
+  if (!ctx) return CCMP_EINVAL;
+  ctx->order = order_dev;
   return CCMP_OK;
 }
 int ccmp_ctx_device(const ccmp_ctx *ctx) { return ctx ? ctx->device : -1; }
@@ -571,7 +580,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       nwave = (int)(need < (size_t)wave_blocks ? need : (size_t)wave_blocks);
     }
     HIP_TRY(ccmp_launch_project_fd(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
-                                   ctx->pool, nwave, st));
+                                   ctx->pool, nwave, ctx->dump_threshold, ctx->order, st));
   } else {
     const int nblocks = projector_blocks(ctx, B, 64, 4);
     HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks, st));

@@ -33,14 +33,15 @@ constexpr int kGroupsPerWave = 10;    // 60 of 64 lanes busy
 // LDS record of one group (in doubles).  The prefix frames are kept for ONE arm at a time (the
 // second arm's chain is re-run before its columns: +343 operations per iteration, -84 doubles of
 // LDS per sample), and the second arm's Jacobian columns overwrite prefix slots that have already
-// been consumed.  165 x 8 B x 10 groups = 13.2 KB per wave -> 12 waves per CU.
+// been consumed.  167 x 8 B x 10 groups = 13.4 KB per wave -> 12 waves per CU.
 constexpr int kX = 0;                 // x[14]        current iterate
 constexpr int kSC = 14;               // sc[14][2]    sin, cos of every joint of x
 constexpr int kPre = 42;              // pre[7][12]   chain frame in front of joint j of the current arm: R(9), o(3)
                                       //              (slot j, doubles 0..1, is reused for J[:, 7+j] once consumed)
 constexpr int kEE = 126;              // ee[2][12]    world tool pose of each arm at x: R(9), p(3)
 constexpr int kJ0 = 150;              // J[:, 0..6]   interleaved (row0, row1) per column of arm 0
-constexpr int kRec = 165;             // 164 used; odd stride keeps the 10 groups on distinct LDS banks
+constexpr int kF = 164;               // f[2]         residual at x (parked here across the Jacobian phase: VGPR relief)
+constexpr int kRec = 167;             // 166 used; odd stride keeps the 10 groups on distinct LDS banks
 constexpr int kPoolEntry = 18;        // straggler hand-over record: x[14], idx, (iter,updates), norm1, norm2
 
 #ifndef CCMP_FD_WAVES_PER_SIMD
@@ -150,7 +151,8 @@ template <int MODE>
 __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
-    unsigned long long seed, unsigned long long first_index, double *__restrict__ pool, unsigned long long *pool_count)
+    unsigned long long seed, unsigned long long first_index, double *__restrict__ pool, unsigned long long *pool_count,
+    int dump_threshold, const unsigned int *__restrict__ order)
 {
   __shared__ double lds[kGroupsPerWave * kRec];
   const int lane = threadIdx.x;
@@ -178,7 +180,8 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
       t = shfl_u64(t, leader);
       if (want) {
         if (t < B) {
-          idx = t; active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+          idx = order ? (unsigned long long)order[t] : t; // ticket -> sample: longest-predicted-first when scheduled
+          active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
 #pragma unroll
           for (int e = 0; e < 14; e++) {
             if (e % kGroup == r) {
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     // (x, index, counters — everything else is recomputed from x) and the wave retires; the
     // wave-per-sample kernel finishes them.  State is dumped at the loop top, where the next thing
     // that happens to a sample is function(x) + the loop test — exactly where the other kernel starts.
-    if (pool != nullptr && __builtin_amdgcn_ballot_w64(drained) != 0ull) {
+    if (pool != nullptr && __builtin_amdgcn_ballot_w64(drained) != 0ull &&
+        __builtin_popcountll(__builtin_amdgcn_ballot_w64(active && r == 0)) <= dump_threshold) {
       unsigned long long slot = 0;
       if (active && r == 0) slot = atomicAdd(pool_count, 1ull);
       slot = shfl_u64(slot, leader);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
       if (live) { rec[kSC + 2 * e] = s; rec[kSC + 2 * e + 1] = c; }
     }
     __syncthreads();
-    double f0, f1;
+    bool cont = false;
     {
       double T0[12], T1[12], f[2];
       chain_at_x<1, false>(K, rec, writer, T1);
@@ -238,18 +242,16 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
         for (int k = 0; k < 12; k++) rec[kEE + k] = T0[k];
       }
       chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
-      f0 = f[0]; f1 = f[1];
-    }
-
-    // ---- loop condition of ConstraintFunction.h:68, quirks included ---------------------------
-    // while (((norm1 = f[0] > tol1) || (norm2 = f[1]) > tol2) && iter++ < maxIterations)
-    bool cont = false;
-    if (active) {
-      const bool c1 = f0 > K.tol_pos;
-      norm1 = c1 ? 1.0 : 0.0;
-      bool resid = c1;
-      if (!c1) { norm2 = f1; resid = f1 > K.tol_rot; }
-      if (resid) { cont = iter < K.max_iter; iter++; }
+      if (writer) { rec[kF] = f[0]; rec[kF + 1] = f[1]; } // the solve reads them back after the Jacobian phase
+      // ---- loop condition of ConstraintFunction.h:68, quirks included -------------------------
+      // while (((norm1 = f[0] > tol1) || (norm2 = f[1]) > tol2) && iter++ < maxIterations)
+      if (active) {
+        const bool c1 = f[0] > K.tol_pos;
+        norm1 = c1 ? 1.0 : 0.0;
+        bool resid = c1;
+        if (!c1) { norm2 = f[1]; resid = f[1] > K.tol_rot; }
+        if (resid) { cont = iter < K.max_iter; iter++; }
+      }
     }
     // ---- finished groups: jointValid, write-back --------------------------------------------
     {
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
         Jr[7 + j] = rec[kPre + 12 * j];
         Jr[21 + j] = rec[kPre + 12 * j + 1];
       }
-      solve_minnorm(Jr, f0, f1, dx);
+      solve_minnorm(Jr, rec[kF], rec[kF + 1], dx);
       if (cont) {
 #pragma unroll
         for (int e = 0; e < 14; e++)
@@ -814,7 +816,7 @@ extern "C" {
 hipError_t ccmp_launch_project_fd(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                   uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                   unsigned long long seed, unsigned long long first, int nblocks, double *pool,
-                                  int nblocks_wave, hipStream_t st)
+                                  int nblocks_wave, int dump_threshold, const unsigned int *order, hipStream_t st)
 {
   // queue[0]: sample queue of the group kernel; queue[1]: pool fill count; queue[2]: pool read head
   hipError_t e = hipMemsetAsync(queue, 0, 4 * sizeof(unsigned long long), st);
@@ -823,10 +825,10 @@ hipError_t ccmp_launch_project_fd(const ccmp_consts *K, int mode, const double *
     double *pl = nblocks_wave > 0 ? pool : nullptr;
     if (mode == 0)
       hipLaunchKernelGGL(project_fd_kernel<0>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, queue, seed, first, pl, queue + 1);
+                         (unsigned long long)B, queue, seed, first, pl, queue + 1, dump_threshold, order);
     else
       hipLaunchKernelGGL(project_fd_kernel<1>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, queue, seed, first, pl, queue + 1);
+                         (unsigned long long)B, queue, seed, first, pl, queue + 1, dump_threshold, order);
     if (nblocks_wave > 0)
       hipLaunchKernelGGL(project_fd_wave_kernel<2>, dim3(nblocks_wave), dim3(64), 0, st, *K, q_in, q_out, ok, iters,
                          q_ambient, (unsigned long long)B, queue + 2, seed, first, pool, queue + 1, mode);

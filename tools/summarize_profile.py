@@ -56,7 +56,7 @@ def main():
                 for k in ("AverageNs", "MinNs", "MaxNs"):
                     krow[k] = str(float(krow[k]) + float(r[k]))
     allc, ns, meta = {}, {}, {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mix"):
         c, n, m = counters(os.path.join(src, sub), kernel_subs)
         allc.update(c)
         ns.update(n)
@@ -107,6 +107,18 @@ def main():
                     % (allc["SQ_INSTS_VALU"], issue, avail, avg_ms, 100 * issue / avail))
             summary["valu_issue_frac"] = issue / avail
             json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
+        if "SQ_INSTS_VALU_FMA_F64" in allc:
+            fl = (2 * allc["SQ_INSTS_VALU_FMA_F64"] + allc.get("SQ_INSTS_VALU_MUL_F64", 0) + allc.get("SQ_INSTS_VALU_ADD_F64", 0)) * 64
+            f.write("\nExecuted FP64: %.3e flop per launch (FMA x2 + MUL + ADD, x64 lanes) = **%.1f TFLOP/s = %.1f %% of the 78.6 TFLOP/s "
+                    "FP64 vector peak**; FP64 share of VALU instructions %.1f %%.\n"
+                    % (fl, fl / (avg_ms * 1e-3) / 1e12, 100 * fl / (avg_ms * 1e-3) / 78.6e12,
+                       100 * (allc["SQ_INSTS_VALU_FMA_F64"] + allc.get("SQ_INSTS_VALU_MUL_F64", 0) + allc.get("SQ_INSTS_VALU_ADD_F64", 0)
+                              + allc.get("SQ_INSTS_VALU_TRANS_F64", 0)) / allc["SQ_INSTS_VALU"]))
+            summary["executed_fp64_flop_per_launch"] = fl
+            json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
+            tj = json.load(open(os.path.join(dst, "traffic_latest.json")))
+            tj["executed_fp64_flop_per_launch"] = fl
+            json.dump(tj, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
         if "SQ_WAVE_CYCLES" in allc and "SQ_ACTIVE_INST_VALU" in allc:
             f.write("\nDerived: VALU-active share of wave lifetime = %.3f; " % (allc["SQ_ACTIVE_INST_VALU"] / allc["SQ_WAVE_CYCLES"]))
             if "SQ_WAIT_ANY" in allc:
