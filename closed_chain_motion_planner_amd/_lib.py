@@ -58,7 +58,7 @@ EXPORTS = [
     "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
     "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
     "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid",
-    "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_detmath_probe", "ccmp_strerror",
+    "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_sample_project_host", "ccmp_geodesic_host", "ccmp_detmath_probe", "ccmp_strerror",
     "ccmp_last_hip_error", "ccmp_version", "ccmp_problem_sizeof",
 ]
 
@@ -116,6 +116,8 @@ def lib():
         "ccmp_function_host": ([vp, pp, dp, dp, C.c_size_t], C.c_int),
         "ccmp_is_satisfied_host": ([vp, pp, dp, u8p, C.c_size_t], C.c_int),
         "ccmp_joint_valid_host": ([vp, pp, dp, u8p, C.c_size_t], C.c_int),
+        "ccmp_sample_project_host": ([vp, pp, C.c_uint64, C.c_uint64, dp, u8p, u16p, C.c_size_t], C.c_int),
+        "ccmp_geodesic_host": ([vp, pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32), u8p], C.c_int),
         "ccmp_detmath_probe": ([vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
         "ccmp_strerror": ([C.c_int], C.c_char_p),
         "ccmp_last_hip_error": ([], C.c_char_p),

@@ -821,4 +821,57 @@ int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q,
   return CCMP_OK;
 }
 
+int ccmp_sample_project_host(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index, double *q_out,
+                             uint8_t *ok, uint16_t *iters, size_t B)
+{
+  if (!ctx || !p) return CCMP_EINVAL;
+  if (B == 0) return CCMP_OK;
+  if (!q_out || !ok) return CCMP_EINVAL;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return CCMP_ENODEV;
+  const size_t qb = B * 14 * sizeof(double);
+  const size_t off_ok = (qb + 255) & ~(size_t)255;
+  const size_t off_it = (off_ok + B + 255) & ~(size_t)255;
+  int rc = ensure_stage(ctx, off_it + B * sizeof(uint16_t));
+  if (rc != CCMP_OK) return rc;
+  char *base = (char *)ctx->stage;
+  rc = ccmp_sample_project_batch(ctx, p, seed, first_index, (double *)base, (uint8_t *)(base + off_ok),
+                                 (uint16_t *)(base + off_it), nullptr, B, ctx->stream);
+  if (rc != CCMP_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(q_out, base, qb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ok, base + off_ok, B, hipMemcpyDeviceToHost, ctx->stream));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, base + off_it, B * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CCMP_OK;
+}
+
+int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                       double *states, int32_t *n_states, uint8_t *ok)
+{
+  if (!ctx || !p) return CCMP_EINVAL;
+  if (E == 0) return CCMP_OK;
+  if (!from || !to || !states || !n_states || !ok || max_states < 1) return CCMP_EINVAL;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return CCMP_ENODEV;
+  const size_t eb = E * 14 * sizeof(double);
+  const size_t sb = E * (size_t)max_states * 14 * sizeof(double);
+  const size_t off_to = (eb + 255) & ~(size_t)255;
+  const size_t off_st = (off_to + eb + 255) & ~(size_t)255;
+  const size_t off_n = (off_st + sb + 255) & ~(size_t)255;
+  const size_t off_ok = (off_n + E * sizeof(int32_t) + 255) & ~(size_t)255;
+  int rc = ensure_stage(ctx, off_ok + E);
+  if (rc != CCMP_OK) return rc;
+  char *base = (char *)ctx->stage;
+  HIP_TRY(hipMemcpyAsync(base, from, eb, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(base + off_to, to, eb, hipMemcpyHostToDevice, ctx->stream));
+  rc = ccmp_geodesic_batch(ctx, p, (const double *)base, (const double *)(base + off_to), E, max_states, (double *)(base + off_st),
+                           (int32_t *)(base + off_n), (uint8_t *)(base + off_ok), nullptr, ctx->stream);
+  if (rc != CCMP_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(states, base + off_st, sb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(n_states, base + off_n, E * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ok, base + off_ok, E, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CCMP_OK;
+}
+
 } // extern "C"

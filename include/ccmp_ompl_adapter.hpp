@@ -17,6 +17,7 @@
 #ifndef CCMP_OMPL_ADAPTER_HPP
 #define CCMP_OMPL_ADAPTER_HPP
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -101,6 +102,67 @@ private:
   ccmp_problem problem_;
 };
 
+// jy_ProjectedStateSampler::sampleUniform served from a buffer that ONE launch of `batch` fused
+// sample -> project -> enforceBounds refills when empty (src/base/jy_ProjectedStateSpace.cpp:10-15).
+// The stream of samples depends on (seed, running index) only, not on `batch`.
+class SampleBuffer {
+public:
+  SampleBuffer(const Projector &proj, uint64_t seed, size_t batch = 4096) : proj_(proj), seed_(seed), batch_(batch) {}
+  // writes 14 doubles; returns project()'s result for that sample (the reference ignores it)
+  bool next(double *state14)
+  {
+    if (pos_ >= buf_.size() / 14) refill();
+    std::memcpy(state14, &buf_[14 * pos_], 14 * sizeof(double));
+    return ok_[pos_++] != 0;
+  }
+
+private:
+  void refill()
+  {
+    buf_.resize(batch_ * 14);
+    ok_.resize(batch_);
+    check(ccmp_sample_project_host(proj_.ctx(), &proj_.problem(), seed_, next_index_, buf_.data(), ok_.data(), nullptr, batch_),
+          "ccmp_sample_project_host");
+    next_index_ += batch_;
+    pos_ = 0;
+  }
+  const Projector &proj_;
+  uint64_t seed_, next_index_ = 0;
+  size_t batch_, pos_ = 0;
+  std::vector<double> buf_;
+  std::vector<uint8_t> ok_;
+};
+
+// jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96) for one edge on raw
+// buffers.  `valid` (nullable) is the host StateValidityChecker; it is consulted only when !interpolate,
+// in order, and the list is cut at the first rejected state — where the reference's loop breaks.
+template <class ValidFn>
+inline bool discreteGeodesic(const Projector &proj, const double *from14, const double *to14, bool interpolate, ValidFn valid,
+                             std::vector<std::vector<double>> *geodesic, int max_states = 256)
+{
+  std::vector<double> states((size_t)max_states * 14);
+  int32_t n = 0;
+  uint8_t ok = 0;
+  check(ccmp_geodesic_host(proj.ctx(), &proj.problem(), from14, to14, 1, max_states, states.data(), &n, &ok), "ccmp_geodesic_host");
+  bool good = ok != 0;
+  int keep = n;
+  if (!interpolate) {
+    for (int k = 1; k < n; ++k)
+      if (!valid(&states[(size_t)k * 14])) {
+        keep = k;
+        double d = 0;
+        for (int i = 0; i < 14; ++i) { const double df = states[(size_t)(k - 1) * 14 + i] - to14[i]; d += df * df; }
+        good = std::sqrt(d) <= proj.problem().delta;
+        break;
+      }
+  }
+  if (geodesic) {
+    geodesic->clear();
+    for (int k = 0; k < keep; ++k) geodesic->emplace_back(&states[(size_t)k * 14], &states[(size_t)k * 14] + 14);
+  }
+  return good;
+}
+
 }  // namespace ccmp
 
 #ifdef CCMP_WITH_OMPL
@@ -166,6 +228,42 @@ private:
   std::shared_ptr<ccmp::Projector> impl_;
 };
 typedef std::shared_ptr<KinematicChainConstraint> ChainConstraintPtr;
+
+// jy_ProjectedStateSampler (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:18-29): same
+// name, same overrides; sampleUniform pops GPU-projected samples, Near/Gaussian keep the ambient draw of
+// the wrapped sampler and project through the constraint (one-state launches).
+class jy_ProjectedStateSampler : public ompl::base::WrapperStateSampler {
+public:
+  jy_ProjectedStateSampler(const ompl::base::ConstrainedStateSpace *space, ompl::base::StateSamplerPtr sampler, uint64_t seed = 0)
+    : ompl::base::WrapperStateSampler(space, std::move(sampler)),
+      constraint_(std::dynamic_pointer_cast<KinematicChainConstraint>(space->getConstraint())),
+      buffer_(constraint_->impl(), seed)
+  {
+  }
+  void sampleUniform(ompl::base::State *state) override
+  {
+    auto &&x = *state->as<ompl::base::ConstrainedStateSpace::StateType>();
+    double buf[14];
+    buffer_.next(buf);  // already projected and wrapped by enforceBounds on the GPU
+    for (int i = 0; i < 14; ++i) x[i] = buf[i];
+  }
+  void sampleUniformNear(ompl::base::State *state, const ompl::base::State *near, const double distance) override
+  {
+    ompl::base::WrapperStateSampler::sampleUniformNear(state, near, distance);
+    constraint_->project(state);
+    space_->enforceBounds(state);
+  }
+  void sampleGaussian(ompl::base::State *state, const ompl::base::State *mean, const double stdDev) override
+  {
+    ompl::base::WrapperStateSampler::sampleGaussian(state, mean, stdDev);
+    constraint_->project(state);
+    space_->enforceBounds(state);
+  }
+
+private:
+  std::shared_ptr<KinematicChainConstraint> constraint_;
+  ccmp::SampleBuffer buffer_;
+};
 #endif  // CCMP_WITH_OMPL
 
 #endif  // CCMP_OMPL_ADAPTER_HPP

@@ -48,6 +48,24 @@ int main(int argc, char **argv)
     std::vector<uint16_t> it(B);
     P.projectBatch(q.data(), out.data(), ok.data(), it.data(), B);
     for (size_t i = 0; i < B; i++) std::printf("batch %zu ok %d iters %u\n", i, ok[i], it[i]);
+    // sampler buffer: the stream must not depend on the refill size
+    ccmp::SampleBuffer s1(P, 42, 4), s2(P, 42, 3);
+    for (int i = 0; i < 7; i++) {
+      double a[14], b[14];
+      s1.next(a);
+      s2.next(b);
+      std::printf("sample %d same %d\n", i, std::memcmp(a, b, sizeof a) == 0 ? 1 : 0);
+      print_hex(a, 14);
+    }
+    // extend step from the first state towards the second, host validity rejecting nothing / everything
+    if (B >= 2) {
+      std::vector<std::vector<double>> geo;
+      bool g1 = ccmp::discreteGeodesic(P, &out[0], &out[14], true, [](const double *) { return true; }, &geo, 64);
+      std::printf("geodesic ok %d n %zu\n", g1 ? 1 : 0, geo.size());
+      for (auto &st : geo) print_hex(st.data(), 14);
+      bool g2 = ccmp::discreteGeodesic(P, &out[0], &out[14], false, [](const double *) { return false; }, &geo, 64);
+      std::printf("geodesic_rejected ok %d n %zu\n", g2 ? 1 : 0, geo.size());
+    }
   } catch (const std::exception &e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

@@ -52,7 +52,25 @@ def test_adapter_matches_oracle(ccmp_built, oracle_det, tmp_path):
         assert np.array_equal(f, oracle_det.function(P, x_cpu))
         assert int(hdr[9]) == int(oracle_det.joint_valid(P, x_cpu))
         assert int(hdr[7]) == int(oracle_det.is_satisfied(P, x_cpu))
+    proj = []
     for i in range(6):
-        ok_cpu, _, it_cpu = oracle_det.project(P, q[i])
+        ok_cpu, x_cpu, it_cpu = oracle_det.project(P, q[i])
+        proj.append(x_cpu)
         parts = out[k + i].split()
         assert int(parts[3]) == int(ok_cpu) and int(parts[5]) == it_cpu
+    k += 6
+    exp, _, _ = oracle_det.sample_project_batch(P, 42, 0, 7, 2)
+    for i in range(7):
+        assert out[k] == "sample %d same 1" % i
+        x = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in out[k + 1].split()])
+        assert np.array_equal(x.view(np.uint64), exp[i].view(np.uint64))
+        k += 2
+    ok_g, st_g, _ = oracle_det.discrete_geodesic(P, proj[0], proj[1], interpolate=True, max_states=64)
+    hdr = out[k].split()
+    assert int(hdr[2]) == int(ok_g) and int(hdr[4]) == len(st_g)
+    for j in range(len(st_g)):
+        x = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in out[k + 1 + j].split()])
+        assert np.array_equal(x.view(np.uint64), st_g[j].view(np.uint64))
+    k += 1 + len(st_g)
+    hdr = out[k].split()
+    assert int(hdr[4]) == min(1, len(st_g)) and (int(hdr[2]) == 0 or len(st_g) == 1)  # everything rejected: only `from` survives
