@@ -1,7 +1,8 @@
 """Builds libccmp.so (HIP kernels for gfx950 + the C-ABI host code) in-tree with hipcc.
 
-Three translation units with deliberately different floating-point flags:
-  ccmp_kernels_fd.hip    -ffp-contract=off -DCCMP_USE_FMA   canonical, bit-reproducible arithmetic
+Translation units with deliberately different flags:
+  ccmp_kernels_fd.hip    -ffp-contract=off -DCCMP_USE_FMA   canonical, bit-reproducible arithmetic (throughput kernel)
+  ccmp_kernels_wave.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one-wave-per-sample kernels
   ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   host set-up in the same rounding model
   ccmp_kernels_fast.hip  -ffp-contract=fast                 analytic fast mode, no bitwise claim
 """
@@ -16,11 +17,17 @@ LIBPATH = os.path.join(LIBDIR, "libccmp.so")
 ARCH = "gfx950"
 
 _UNITS = [
-    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"] + os.environ.get("CCMP_FD_EXTRA_FLAGS", "").split()),
+    # -disable-machine-licm: LLVM's machine LICM hoists ~35 FP64 polynomial/literal constants out of the Newton
+    # loop into VGPR pairs and then spills them to scratch (168 VGPRs + 30 spilled dwords); without it the
+    # throughput kernel needs 133 VGPRs and no scratch (measured +3.3 %, in-process A/B).  The wave kernels are
+    # 2.7 % slower with the option, hence their own unit.
+    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm"]
+     + os.environ.get("CCMP_FD_EXTRA_FLAGS", "").split()),
+    ("ccmp_kernels_wave.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=fast"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]
-_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", os.path.join("..", "..", "include", "ccmp.h")]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", os.path.join("..", "..", "include", "ccmp.h")]
 
 
 def hipcc_path():

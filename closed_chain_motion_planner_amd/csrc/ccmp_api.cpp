@@ -20,10 +20,14 @@
 #include "ccmp_kin.h"
 
 extern "C" {
-hipError_t ccmp_launch_project_fd(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
-                                  uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
-                                  unsigned long long seed, unsigned long long first, int nblocks, double *pool,
-                                  int nblocks_wave, int dump_threshold, const unsigned int *order, hipStream_t st);
+hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
+                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
+                                     unsigned long long seed, unsigned long long first, int nblocks, double *pool,
+                                     int dump_threshold, const unsigned int *order, hipStream_t st);
+hipError_t ccmp_launch_project_wave(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
+                                    uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
+                                    unsigned long long seed, unsigned long long first, const double *pool,
+                                    const unsigned long long *pool_count, int wrap_output, int nblocks, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                     unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
@@ -579,8 +583,18 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       }
       nwave = (int)(need < (size_t)wave_blocks ? need : (size_t)wave_blocks);
     }
-    HIP_TRY(ccmp_launch_project_fd(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
-                                   ctx->pool, nwave, ctx->dump_threshold, ctx->order, st));
+    // queue[0]: sample queue of the group kernel; queue[1]: pool fill count; queue[2]: read head of the wave kernel
+    HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
+    if (nblocks > 0) {
+      HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
+                                        nwave > 0 ? ctx->pool : nullptr, ctx->dump_threshold, ctx->order, st));
+      if (nwave > 0)
+        HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
+                                         ctx->queue + 1, mode, nwave, st));
+    } else {
+      HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
+                                       ctx->queue + 1, mode, nwave, st));
+    }
   } else {
     const int nblocks = projector_blocks(ctx, B, 64, 4);
     HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks, st));

@@ -24,7 +24,7 @@ def build(flags):
     objs = []
     for src, fl in b._UNITS:
         op = os.path.join(objdir, src + ".o")
-        extra = flags.split() if src == "ccmp_kernels_fd.hip" else []
+        extra = flags.split() if src == os.environ.get("AB_UNIT", "ccmp_kernels_fd.hip") else []
         subprocess.run([b.hipcc_path(), "--offload-arch=" + b.ARCH, "-fPIC", "-std=c++17"] + fl + extra +
                        ["-c", os.path.join(b.CSRC, src), "-o", op], check=True)
         objs.append(op)
