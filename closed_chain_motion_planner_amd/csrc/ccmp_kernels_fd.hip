@@ -76,6 +76,11 @@ template <int ARM>
 __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *rec, bool writer, bool plus, int nstep,
                                                  int partner, int leader)
 {
+#ifndef CCMP_RELOAD_TO
+  double To[12]; // the other arm's (unperturbed) tool pose: 24 VGPRs that save 12 LDS reads per column (-6.5 %, A/B)
+#pragma unroll
+  for (int k = 0; k < 12; k++) To[k] = rec[kEE + (1 - ARM) * 12 + k];
+#endif
   for (int j = 0; j < 7; j++) {
     const double xj = rec[kX + ARM * 7 + j];
     const double axj = ccmp_abs(xj);
@@ -99,8 +104,10 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
     }
     for (int i = j + 1; i < 7; i++)
       joint_step(K, ARM, i, rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], R, o);
-    double Tw[12], To[12], t[2];
+    double Tw[12], t[2];
     tool_pose(K, ARM, R, o, &Tw[0], &Tw[9]);
+#ifdef CCMP_RELOAD_TO
+    double To[12];
     {
       // the other arm's (unperturbed) tool pose, re-read from LDS every column: keeping it in
       // registers across the column loop costs 24 VGPRs and pushes the kernel into scratch spills
@@ -109,6 +116,7 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
 #pragma unroll
       for (int k = 0; k < 12; k++) To[k] = ee[k];
     }
+#endif
     if (ARM == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);
     else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], t, nullptr, nullptr);
     // m_s = (t1 - t2) / (y1[j] - y2[j]) with the stored perturbed values
