@@ -73,8 +73,7 @@ __device__ __forceinline__ void chain_at_x(const ccmp_consts &K, double *rec, bo
 // OMPL's default Constraint::jacobian for the 7 columns of one arm: each lane evaluates its stencil
 // point of column j from the cached prefix frame, the +/- lanes pair up through ds_bpermute.
 template <int ARM>
-__device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *rec, bool writer, bool plus, int nstep,
-                                                 int partner, int leader)
+__device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *rec, bool live, int r, bool plus, int nstep)
 {
 #ifndef CCMP_RELOAD_TO
   double To[12]; // the other arm's (unperturbed) tool pose: 24 VGPRs that save 12 LDS reads per column (-6.5 %, A/B)
@@ -109,8 +108,6 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
 #ifdef CCMP_RELOAD_TO
     double To[12];
     {
-      // the other arm's (unperturbed) tool pose, re-read from LDS every column: keeping it in
-      // registers across the column loop costs 24 VGPRs and pushes the kernel into scratch spills
       const double *ee = rec + kEE + (1 - ARM) * 12;
       asm volatile("" : "+v"(ee));
 #pragma unroll
@@ -119,18 +116,40 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
 #endif
     if (ARM == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);
     else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], t, nullptr, nullptr);
-    // m_s = (t1 - t2) / (y1[j] - y2[j]) with the stored perturbed values
-    const double tp0 = shfl_f64(t[0], partner), tp1 = shfl_f64(t[1], partner), yp = shfl_f64(y, partner);
-    const double den = plus ? (y - yp) : (yp - y);
-    const double m0 = (plus ? (t[0] - tp0) : (tp0 - t[0])) / den;
-    const double m1 = (plus ? (t[1] - tp1) : (tp1 - t[1])) / den;
-    const double m10 = shfl_f64(m0, leader), m20 = shfl_f64(m0, leader + 1), m30 = shfl_f64(m0, leader + 2);
-    const double m11 = shfl_f64(m1, leader), m21 = shfl_f64(m1, leader + 1), m31 = shfl_f64(m1, leader + 2);
-    if (writer) {
-      // out.col(j) = 1.5*m1 - 0.6*m2 + 0.1*m3; arm 1's columns go into the prefix slot just consumed
-      double *dst = (ARM == 0) ? (rec + kJ0 + 2 * j) : (rec + kPre + 12 * j);
-      dst[0] = CCMP_FMA(0.1, m30, CCMP_FMA(-0.6, m20, 1.5 * m10));
-      dst[1] = CCMP_FMA(0.1, m31, CCMP_FMA(-0.6, m21, 1.5 * m11));
+    // park this evaluation in the prefix slot the group has just consumed (12 doubles = 6 lanes x (f0, f1));
+    // the stencil is combined after the arm's 7 columns (stencil_combine) instead of through two dependent
+    // ds_bpermute rounds per column
+    if (live) {
+      rec[kPre + 12 * j + 2 * r] = t[0];
+      rec[kPre + 12 * j + 2 * r + 1] = t[1];
+    }
+  }
+}
+
+// out.col(j) = 1.5*m1 - 0.6*m2 + 0.1*m3 with m_s = (t1 - t2) / (y1[j] - y2[j]) for the 7 columns of one arm:
+// 14 entries spread over the group's 6 lanes; y1/y2 are rebuilt by the same sequential adds the evaluations
+// used.  Arm 0's entries go to kJ0, arm 1's into arm 0's (by now dead) sin/cos slots.
+template <int ARM>
+__device__ __forceinline__ void stencil_combine(double *rec, int r, bool live)
+{
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    const int e = r + kGroup * n; // entry: column e >> 1, row e & 1
+    if (e < 14 && live) {
+      const int c = e >> 1, row = e & 1;
+      const double xj = rec[kX + ARM * 7 + c];
+      const double axj = ccmp_abs(xj);
+      const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
+      double y1 = xj, y2 = xj, m[3];
+#pragma unroll
+      for (int sidx = 0; sidx < 3; sidx++) {
+        y1 = y1 + h;
+        y2 = y2 - h;
+        m[sidx] = (rec[kPre + 12 * c + 2 * sidx + row] - rec[kPre + 12 * c + 2 * (sidx + 3) + row]) / (y1 - y2);
+      }
+      const double Jv = CCMP_FMA(0.1, m[2], CCMP_FMA(-0.6, m[1], 1.5 * m[0]));
+      if (ARM == 0) rec[kJ0 + 2 * c + row] = Jv;
+      else rec[kSC + 2 * c + row] = Jv;
     }
   }
 }
@@ -153,7 +172,6 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
   const bool writer = live && r == 0;
   const bool plus = r < 3;                    // y1 side of the stencil; r>=3 is the y2 side
   const int nstep = (plus ? r : r - 3) + 1;   // how many h-steps this lane's point is away
-  const int partner = live ? (plus ? lane + 3 : lane - 3) : lane;
 
   unsigned long long idx = 0;
   int iter = 0, updates = 0;
@@ -278,14 +296,18 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     __syncthreads(); // prefix frames / tool poses written by the writer lane are visible to the group
 
     // ---- phase 2: OMPL's default Constraint::jacobian, one column per step --------------------
-    jacobian_columns<0>(K, rec, writer, plus, nstep, partner, leader);
+    jacobian_columns<0>(K, rec, live, r, plus, nstep);
+    __syncthreads();
+    stencil_combine<0>(rec, r, live);
     __syncthreads();
     {
       double T1[12];
       chain_at_x<1, true>(K, rec, writer, T1); // re-run arm 1's chain to stage ITS prefix frames
     }
     __syncthreads();
-    jacobian_columns<1>(K, rec, writer, plus, nstep, partner, leader);
+    jacobian_columns<1>(K, rec, live, r, plus, nstep);
+    __syncthreads();
+    stencil_combine<1>(rec, r, live);
     __syncthreads();
 
     // ---- Newton update: x -= 0.30 * J.jacobiSvd().solve(f) --------------------------------------
@@ -295,8 +317,8 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
       for (int j = 0; j < 7; j++) {
         Jr[j] = rec[kJ0 + 2 * j];
         Jr[14 + j] = rec[kJ0 + 2 * j + 1];
-        Jr[7 + j] = rec[kPre + 12 * j];
-        Jr[21 + j] = rec[kPre + 12 * j + 1];
+        Jr[7 + j] = rec[kSC + 2 * j];
+        Jr[21 + j] = rec[kSC + 2 * j + 1];
       }
       solve_minnorm(Jr, rec[kF], rec[kF + 1], dx);
       if (cont) {
