@@ -5,6 +5,7 @@ Translation units with deliberately different flags:
   ccmp_kernels_wave.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one-wave-per-sample kernels
   ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   host set-up in the same rounding model
   ccmp_kernels_fast.hip  -ffp-contract=fast                 analytic fast mode, no bitwise claim
+  ccmp_kernels_scout.hip -ffast-math                        FP32 iteration-count predictor + ordering (never touches results)
 """
 import os
 import shutil
@@ -25,6 +26,7 @@ _UNITS = [
      + os.environ.get("CCMP_FD_EXTRA_FLAGS", "").split()),
     ("ccmp_kernels_wave.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=fast"]),
+    ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]
 _HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", os.path.join("..", "..", "include", "ccmp.h")]

@@ -31,6 +31,9 @@ hipError_t ccmp_launch_project_wave(const ccmp_consts *K, int src, const double 
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                     unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
+hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
+                                   unsigned int *hist, unsigned int *order, unsigned long long *queue,
+                                   unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
 hipError_t ccmp_launch_function(const ccmp_consts *K, const double *q, double *f, size_t B, hipStream_t st);
 hipError_t ccmp_launch_is_satisfied(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, hipStream_t st);
 hipError_t ccmp_launch_joint_valid(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, hipStream_t st);
@@ -306,7 +309,11 @@ struct ccmp_ctx {
   size_t pool_cap = 0;                 // in records
   int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
   const unsigned int *order = nullptr; // experimental: externally supplied processing order
-  int dump_threshold = 10;             // hand a wave's samples over once the queue is dry and <= this many groups are busy
+  int lpt = 1;                         // 0: in-order; 1: FP32 scout + longest-predicted-first, hand-over kept; 2: same, no hand-over
+  size_t lpt_min_batch = 65536;        // below this the scout costs more than the tail it removes
+  void *lpt_buf = nullptr;             // pred (u16 x B) | hist (u32 x 1024) | order (u32 x B)
+  size_t lpt_cap = 0;                  // in samples
+  int dump_threshold = -1;             // hand a wave's samples over once the queue is dry and <= this many groups are busy; -1 = auto
   size_t small_batch = 8192;           // at or below: wave-per-sample kernel on everything
   unsigned int *scan = nullptr;        // compaction block counts
   size_t scan_cap = 0;
@@ -508,6 +515,7 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->queue) (void)hipFree(ctx->queue);
   if (ctx->pool) (void)hipFree(ctx->pool);
+  if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
   if (ctx->scan) (void)hipFree(ctx->scan);
   if (ctx->stage) (void)hipFree(ctx->stage);
   (void)hipStreamDestroy(ctx->stream);
@@ -526,6 +534,21 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch)
   ctx->wave_kernel = wave_kernel % 100;
   if (wave_kernel >= 100) ctx->dump_threshold = wave_kernel / 100; /* experimental: hundreds digit+ = hand-over threshold */
   ctx->small_batch = small_batch;
+  return CCMP_OK;
+}
+int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch)
+{
+  if (!ctx || mode < 0 || mode > 2) return CCMP_EINVAL;
+  ctx->lpt = mode;
+  ctx->lpt_min_batch = min_batch;
+  return CCMP_OK;
+}
+int ccmp_ctx_debug_lpt_pred(ccmp_ctx *ctx, uint16_t *host_out, size_t B)
+{
+  if (!ctx || !host_out || !ctx->lpt_buf || B > ctx->lpt_cap) return CCMP_EINVAL;
+  DeviceGuard guard(ctx->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_out, ctx->lpt_buf, B * sizeof(uint16_t), hipMemcpyDeviceToHost));
   return CCMP_OK;
 }
 int ccmp_ctx_set_order_experimental(ccmp_ctx *ctx, const unsigned int *order_dev)
@@ -585,9 +608,32 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     }
     // queue[0]: sample queue of the group kernel; queue[1]: pool fill count; queue[2]: read head of the wave kernel
     HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
+    const unsigned int *order = ctx->order;
+    if (nblocks > 0 && !order && ctx->lpt > 0 && B >= ctx->lpt_min_batch && B < 0xffffffffull) {
+      // FP32 scout pass -> predicted iteration counts -> descending counting sort -> processing order
+      if (ctx->lpt_cap < B) {
+        if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
+        ctx->lpt_buf = nullptr;
+        ctx->lpt_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->lpt_buf, ((B * 2 + 255) & ~(size_t)255) + 4096 + B * 4));
+        ctx->lpt_cap = B;
+      }
+      char *base = (char *)ctx->lpt_buf;
+      uint16_t *pred = (uint16_t *)base;
+      unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
+      unsigned int *ord = (unsigned int *)((char *)hist + 4096);
+      HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus * 1, st));
+      order = ord;
+      if (ctx->lpt == 2) nwave = 0;
+    }
+    // Hand-over threshold.  In index order the samples in flight when the queue runs dry include long ones:
+    // hand everything to the latency kernel at once (10).  Longest-first leaves only short samples at the end of
+    // large batches: let the throughput kernel finish them and hand over only nearly empty waves (3).
+    // (sweep: tools/time_lpt3.py)
+    const int dump_thr = ctx->dump_threshold >= 0 ? ctx->dump_threshold : ((order && B >= 100000) ? 3 : 10);
     if (nblocks > 0) {
       HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
-                                        nwave > 0 ? ctx->pool : nullptr, ctx->dump_threshold, ctx->order, st));
+                                        nwave > 0 ? ctx->pool : nullptr, dump_thr, order, st));
       if (nwave > 0)
         HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
                                          ctx->queue + 1, mode, nwave, st));

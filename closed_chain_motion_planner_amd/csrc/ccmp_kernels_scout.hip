@@ -1,0 +1,296 @@
+// ccmp_kernels_scout.hip — FP32 "scout" pass and longest-predicted-first ordering.
+//
+// The reference-arithmetic projector is fed from a work queue; Newton iteration counts spread from 15
+// to 250, so a batch ends with a tail in which a few long samples run on an otherwise idle chip.  An
+// oracle-perfect longest-first order removes that tail (tools/time_lpt.py).  This unit provides the
+// predictor: the SAME Newton iteration (same residual, stopping rule, step 0.30, cap) with the exact
+// (analytic) Jacobian, in single precision, one sample per lane — ~35x less arithmetic than the
+// finite-difference Jacobian and cheap FP32 sin/cos/div/sqrt — whose only output is the number of
+// updates each sample needed; then a 3-kernel counting sort (descending) produces the processing
+// order handed to project_fd_kernel.  NOTHING computed here reaches q_out/ok/iters: the order in
+// which samples are processed does not change a single bit of the results (the parity tests run with
+// and without it).  Built with contraction and fast-math; no rounding-model obligations.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ccmp_kin.h" // ccmp_consts, ambient_uniform (double, so that MODE 1 sees the same samples)
+
+namespace {
+
+struct consts_f {
+  float axis[2][7][3], offset[2][7][3], ee[2][3], R_tool[2][9], base_R[2][9], base_p[2][3];
+  float init_p[3], init_q[4];
+  float tol_pos, tol_rot, step;
+  int max_iter; // scout cap: min(problem cap, kScoutCap) — samples still unconverged there are all "long"
+};
+constexpr int kScoutCap = 96;
+
+__device__ __forceinline__ void mul33f(const float *A, const float *B, float *C)
+{
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+__device__ __forceinline__ void rotf(const float *a, float s, float c, float *R)
+{
+  const float t = 1.0f - c;
+  R[0] = a[0] * a[0] * t + c;        R[1] = a[0] * a[1] * t - a[2] * s; R[2] = a[0] * a[2] * t + a[1] * s;
+  R[3] = a[0] * a[1] * t + a[2] * s; R[4] = a[1] * a[1] * t + c;        R[5] = a[1] * a[2] * t - a[0] * s;
+  R[6] = a[0] * a[2] * t - a[1] * s; R[7] = a[1] * a[2] * t + a[0] * s; R[8] = a[2] * a[2] * t + c;
+}
+
+// quaternion (x,y,z,w) of a rotation matrix (Shepperd's branches, as Eigen)
+__device__ __forceinline__ void quatf(const float *m, float *q)
+{
+  const float tr = m[0] + m[4] + m[8];
+  if (tr > 0.0f) {
+    float t = sqrtf(tr + 1.0f);
+    q[3] = 0.5f * t; t = 0.5f / t;
+    q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+  } else if (m[0] >= m[4] && m[0] >= m[8]) {
+    float t = sqrtf(m[0] - m[4] - m[8] + 1.0f);
+    q[0] = 0.5f * t; t = 0.5f / t;
+    q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+  } else if (m[4] >= m[8]) {
+    float t = sqrtf(m[4] - m[8] - m[0] + 1.0f);
+    q[1] = 0.5f * t; t = 0.5f / t;
+    q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+  } else {
+    float t = sqrtf(m[8] - m[0] - m[4] + 1.0f);
+    q[2] = 0.5f * t; t = 0.5f / t;
+    q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+  }
+}
+
+// One arm's chain in float.  PASS 0: only the tool pose.  PASS 1: additionally the two Jacobian rows of the
+// arm's 7 joints from the probe vectors (al, bl, pl) expressed in the arm's base frame; sin/cos are simply
+// recomputed (FP32 sincos is two transcendental instructions) instead of keeping 84 floats of joint frames.
+template <int PASS>
+__device__ __forceinline__ void chain_f(const consts_f &K, const int arm, const float *q, float *Rw, float *pw,
+                                        const float *al, const float *bl, const float *pl, float sgn, float *J0, float *J1)
+{
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    float s, c;
+    __sincosf(q[i], &s, &c);
+    const float *off = K.offset[arm][i], *a = K.axis[arm][i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) o[k] += R[3 * k] * off[0] + R[3 * k + 1] * off[1] + R[3 * k + 2] * off[2];
+    if (PASS == 1) {
+      float z[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) z[k] = R[3 * k] * a[0] + R[3 * k + 1] * a[1] + R[3 * k + 2] * a[2];
+      const float r0 = pl[0] - o[0], r1 = pl[1] - o[1], r2 = pl[2] - o[2];
+      const float cx = z[1] * r2 - z[2] * r1, cy = z[2] * r0 - z[0] * r2, cz = z[0] * r1 - z[1] * r0;
+      J0[i] = sgn * (al[0] * cx + al[1] * cy + al[2] * cz);
+      J1[i] = sgn * (bl[0] * z[0] + bl[1] * z[1] + bl[2] * z[2]);
+    }
+    if (PASS == 0 || i < 6) {
+      float Rj[9], Rn[9];
+      rotf(a, s, c, Rj);
+      mul33f(R, Rj, Rn);
+#pragma unroll
+      for (int k = 0; k < 9; k++) R[k] = Rn[k];
+    }
+  }
+  if (PASS == 0) {
+    float pf[3], Rf[9];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pf[k] = o[k] + R[3 * k] * K.ee[arm][0] + R[3 * k + 1] * K.ee[arm][1] + R[3 * k + 2] * K.ee[arm][2];
+    mul33f(R, K.R_tool[arm], Rf);
+    mul33f(K.base_R[arm], Rf, Rw);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      pw[k] = K.base_p[arm][k] + K.base_R[arm][3 * k] * pf[0] + K.base_R[arm][3 * k + 1] * pf[1] + K.base_R[arm][3 * k + 2] * pf[2];
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void scout_kernel(const consts_f K, const ccmp_consts KD, const double *__restrict__ q_in,
+                                                    uint16_t *__restrict__ pred, unsigned long long B,
+                                                    unsigned long long *queue, unsigned long long seed,
+                                                    unsigned long long first_index)
+{
+  float x[14];
+  unsigned long long idx = 0;
+  int iter = 0;
+  bool active = false, drained = false;
+  for (;;) {
+    if (!active && !drained) {
+      const unsigned long long t = atomicAdd(queue, 1ull);
+      if (t < B) {
+        idx = t; active = true; iter = 0;
+#pragma unroll
+        for (int e = 0; e < 14; e++)
+          x[e] = (float)(MODE == 0 ? q_in[idx * 14 + e] : ccmp::ambient_uniform(KD, seed, first_index + idx, e));
+      } else drained = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+
+    float Rw0[9], pw0[3], Rw1[9], pw1[3];
+    chain_f<0>(K, 0, x, Rw0, pw0, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
+    chain_f<0>(K, 1, x + 7, Rw1, pw1, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
+    // chain = T2^-1 T1, residual against the initial chain
+    float Rc[9], pc[3], qc[4];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Rc[3 * i + j] = Rw1[i] * Rw0[j] + Rw1[3 + i] * Rw0[3 + j] + Rw1[6 + i] * Rw0[6 + j];
+    {
+      const float d0 = pw0[0] - pw1[0], d1 = pw0[1] - pw1[1], d2 = pw0[2] - pw1[2];
+#pragma unroll
+      for (int i = 0; i < 3; i++) pc[i] = Rw1[i] * d0 + Rw1[3 + i] * d1 + Rw1[6 + i] * d2;
+    }
+    quatf(Rc, qc);
+    const float bx = -K.init_q[0], by = -K.init_q[1], bz = -K.init_q[2], bw = K.init_q[3];
+    const float dw = qc[3] * bw - qc[0] * bx - qc[1] * by - qc[2] * bz;
+    const float dx = qc[3] * bx + qc[0] * bw + qc[1] * bz - qc[2] * by;
+    const float dy = qc[3] * by + qc[1] * bw + qc[2] * bx - qc[0] * bz;
+    const float dz = qc[3] * bz + qc[2] * bw + qc[0] * by - qc[1] * bx;
+    const float vn = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float f1 = 2.0f * atan2f(vn, fabsf(dw));
+    const float e0 = pc[0] - K.init_p[0], e1 = pc[1] - K.init_p[1], e2 = pc[2] - K.init_p[2];
+    const float f0 = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+
+    bool cont = false;
+    if (active) {
+      const bool resid = (f0 > K.tol_pos) || (f1 > K.tol_rot);
+      if (resid) cont = iter < K.max_iter;
+    }
+    if (active && !cont) {
+      pred[idx] = (uint16_t)iter;
+      active = false;
+    }
+    if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue;
+
+    // analytic 2x14 Jacobian and the minimum-norm step through the 2x2 Gram matrix
+    float u[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (f0 > 0.0f) { const float inv = 1.0f / f0; u[0] = e0 * inv; u[1] = e1 * inv; u[2] = e2 * inv; }
+    if (vn > 0.0f) { const float sg = (dw < 0.0f ? -1.0f : 1.0f) / vn; n[0] = dx * sg; n[1] = dy * sg; n[2] = dz * sg; }
+    float aw[3], bwv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      aw[k] = Rw1[3 * k] * u[0] + Rw1[3 * k + 1] * u[1] + Rw1[3 * k + 2] * u[2];
+      bwv[k] = Rw1[3 * k] * n[0] + Rw1[3 * k + 1] * n[1] + Rw1[3 * k + 2] * n[2];
+    }
+    float J0[14], J1[14];
+#pragma unroll
+    for (int arm = 0; arm < 2; arm++) {
+      float al[3], bl[3], pl[3];
+      const float *Bm = K.base_R[arm];
+      const float q0 = pw0[0] - K.base_p[arm][0], q1 = pw0[1] - K.base_p[arm][1], q2 = pw0[2] - K.base_p[arm][2];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        al[k] = Bm[k] * aw[0] + Bm[3 + k] * aw[1] + Bm[6 + k] * aw[2];
+        bl[k] = Bm[k] * bwv[0] + Bm[3 + k] * bwv[1] + Bm[6 + k] * bwv[2];
+        pl[k] = Bm[k] * q0 + Bm[3 + k] * q1 + Bm[6 + k] * q2;
+      }
+      chain_f<1>(K, arm, x + 7 * arm, nullptr, nullptr, al, bl, pl, arm == 0 ? 1.0f : -1.0f, J0 + 7 * arm, J1 + 7 * arm);
+    }
+    float ga = 0, gd = 0, gb = 0;
+#pragma unroll
+    for (int e = 0; e < 14; e++) { ga += J0[e] * J0[e]; gd += J1[e] * J1[e]; gb += J0[e] * J1[e]; }
+    const float det = ga * gd - gb * gb;
+    float y0 = 0.0f, y1 = 0.0f;
+    if (det > 1e-30f) { const float inv = 1.0f / det; y0 = (gd * f0 - gb * f1) * inv; y1 = (ga * f1 - gb * f0) * inv; }
+    if (cont) {
+#pragma unroll
+      for (int e = 0; e < 14; e++) x[e] -= K.step * (J0[e] * y0 + J1[e] * y1);
+      iter++;
+    }
+  }
+}
+
+constexpr int kBins = 1024;
+
+__global__ void hist_kernel(const uint16_t *__restrict__ pred, unsigned long long B, unsigned int *__restrict__ hist)
+{
+  __shared__ unsigned int h[kBins];
+  for (int k = threadIdx.x; k < kBins; k += blockDim.x) h[k] = 0;
+  __syncthreads();
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < B;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    unsigned int key = pred[i];
+    atomicAdd(&h[key < kBins ? key : kBins - 1], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kBins; k += blockDim.x)
+    if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+
+// exclusive scan in DESCENDING key order: base[k] = number of samples predicted longer than k
+__global__ void scan_desc_kernel(unsigned int *__restrict__ hist /* in: counts, out: running cursor = base */)
+{
+  if (threadIdx.x == 0) {
+    unsigned int run = 0;
+    for (int k = kBins - 1; k >= 0; k--) { const unsigned int c = hist[k]; hist[k] = run; run += c; }
+  }
+}
+
+// Counting-sort scatter with block-local ranking: LDS histogram of the block's keys, ONE global atomic per
+// (block, non-empty bin) to reserve a range, LDS atomics for the rank inside the range.
+constexpr int kScatterPerThread = 4;
+__global__ __launch_bounds__(256) void scatter_kernel(const uint16_t *__restrict__ pred, unsigned long long B,
+                                                      unsigned int *__restrict__ cursor, unsigned int *__restrict__ order)
+{
+  __shared__ unsigned int cnt[kBins], base[kBins];
+  for (int k = threadIdx.x; k < kBins; k += 256) cnt[k] = 0;
+  __syncthreads();
+  const unsigned long long i0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * kScatterPerThread;
+  unsigned int key[kScatterPerThread];
+#pragma unroll
+  for (int k = 0; k < kScatterPerThread; k++) {
+    const unsigned long long i = i0 + k;
+    key[k] = 0xffffffffu;
+    if (i < B) {
+      unsigned int v = pred[i];
+      key[k] = v < kBins ? v : kBins - 1;
+      atomicAdd(&cnt[key[k]], 1u);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kBins; k += 256) {
+    const unsigned int c = cnt[k];
+    base[k] = c ? atomicAdd(&cursor[k], c) : 0u;
+    cnt[k] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kScatterPerThread; k++)
+    if (key[k] != 0xffffffffu) order[base[key[k]] + atomicAdd(&cnt[key[k]], 1u)] = (unsigned int)(i0 + k);
+}
+
+} // namespace
+
+extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
+                                              unsigned int *hist, unsigned int *order, unsigned long long *queue,
+                                              unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st)
+{
+  consts_f F;
+  for (int a = 0; a < 2; a++) {
+    for (int i = 0; i < 7; i++)
+      for (int k = 0; k < 3; k++) { F.axis[a][i][k] = (float)K->axis[a][i][k]; F.offset[a][i][k] = (float)K->offset[a][i][k]; }
+    for (int k = 0; k < 3; k++) { F.ee[a][k] = (float)K->ee[a][k]; F.base_p[a][k] = (float)K->base_p[a][k]; }
+    for (int k = 0; k < 9; k++) { F.R_tool[a][k] = (float)K->R_tool[a][k]; F.base_R[a][k] = (float)K->base_R[a][k]; }
+  }
+  for (int k = 0; k < 3; k++) F.init_p[k] = (float)K->init_p[k];
+  for (int k = 0; k < 4; k++) F.init_q[k] = (float)K->init_q[k];
+  F.tol_pos = (float)K->tol_pos; F.tol_rot = (float)K->tol_rot; F.step = (float)K->step;
+  F.max_iter = K->max_iter < kScoutCap ? K->max_iter : kScoutCap;
+  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(hist, 0, kBins * sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  if (mode == 0)
+    hipLaunchKernelGGL(scout_kernel<0>, dim3(nblocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, queue, seed, first);
+  else
+    hipLaunchKernelGGL(scout_kernel<1>, dim3(nblocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, queue, seed, first);
+  hipLaunchKernelGGL(hist_kernel, dim3(256), dim3(256), 0, st, pred, (unsigned long long)B, hist);
+  hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist);
+  hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((B + 256 * kScatterPerThread - 1) / (256 * kScatterPerThread))), dim3(256), 0, st, pred,
+                     (unsigned long long)B, hist, order);
+  return hipGetLastError();
+}

@@ -101,6 +101,11 @@ int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
  * batches of at most small_batch samples always use the wave-per-sample kernel (default 8192).  Results are
  * bit-identical under every setting. */
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch);
+/* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
+ * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is
+ * processed longest first, straggler hand-over kept (default); 2 = the same without hand-over.  Used for
+ * batches of at least min_batch samples (default 65536).  Results are bit-identical under every setting. */
+int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch);
 int ccmp_ctx_device(const ccmp_ctx *ctx);
 int ccmp_ctx_num_cus(const ccmp_ctx *ctx);
 

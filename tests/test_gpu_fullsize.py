@@ -55,12 +55,17 @@ def test_full_batch_properties(gpu_ctx, oracle_det, obj, seed, tol, mean_lo, mea
     assert frac_conv > 0.99 and mean_lo < mean_it < mean_hi and int(it.max()) <= 250
     assert 0.18 < ok.float().mean().item() < 0.27
     # 5. scheduling never changes arithmetic: group kernel only == default policy, bit for bit
-    gpu_ctx.set_schedule(0, 0)
-    try:
-        out_g, ok_g, it_g = c.project_batch(q)
-    finally:
-        gpu_ctx.set_schedule(1, 8192)
-    assert torch.equal(out_g, out) and torch.equal(ok_g, ok) and torch.equal(it_g, it)
+    for sched, lpt in ((0, 0), (1, 0), (0, 2), (2, 0)):  # default above = hand-over + FP32-scout longest-first
+        if sched == 2 and obj != "Wine_Bottle":
+            continue  # wave-per-sample only: slow at this size, once is enough
+        gpu_ctx.set_schedule(sched, 0)
+        gpu_ctx.set_lpt(lpt, 0)
+        try:
+            out_g, ok_g, it_g = c.project_batch(q)
+        finally:
+            gpu_ctx.set_schedule(1, 8192)
+            gpu_ctx.set_lpt(1, 65536)
+        assert torch.equal(out_g, out) and torch.equal(ok_g, ok) and torch.equal(it_g, it), (sched, lpt)
     # 6. spot-check 192 random samples against the oracle, bit for bit
     rng = np.random.default_rng(1)
     idx = np.sort(rng.choice(B, 192, replace=False))

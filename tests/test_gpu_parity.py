@@ -105,8 +105,8 @@ def test_project_fd_bitwise(gpu_ctx, oracle_det, obj, B, seed):
     assert np.array_equal(q_gpu.view(np.uint64), q_cpu.view(np.uint64)), "not bit-identical"
 
 
-@pytest.mark.parametrize("schedule,small", [(0, 0), (1, 0), (2, 0), (1, 8192)])
-def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small):
+@pytest.mark.parametrize("schedule,small,lpt", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (1, 8192, 0), (1, 0, 1), (0, 0, 2)])
+def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, lpt):
     """group kernel only / group kernel + straggler hand-over to the wave-per-sample kernel /
     wave-per-sample only / default policy: all bit-identical to the oracle."""
     import torch
@@ -119,11 +119,13 @@ def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small):
         _SCHED_CACHE["stefan"] = (q,) + oracle_det.project_batch(P, q, NCPU)
     q, q_cpu, ok_cpu, it_cpu = _SCHED_CACHE["stefan"]
     gpu_ctx.set_schedule(schedule, small)
+    gpu_ctx.set_lpt(lpt, 0)  # lpt > 0 with min_batch 0: FP32 scout + longest-predicted-first even on this small batch
     try:
         q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
         torch.cuda.synchronize()
     finally:
         gpu_ctx.set_schedule(1, 8192)
+        gpu_ctx.set_lpt(1, 65536)
     assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)
     assert np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
