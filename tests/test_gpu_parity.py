@@ -220,3 +220,53 @@ def test_analytic_mode_statistics(gpu_ctx, oracle_det):
     assert np.median(d) < 1e-6
     assert (ok_gpu.cpu().numpy() == ok_cpu).mean() > 0.97
     assert abs(it_gpu.float().mean().item() - it_cpu.mean()) < 1.0
+
+
+def test_non_finite_and_out_of_range_inputs_terminate(gpu_ctx, oracle_det):
+    """NaN / inf / |q| beyond the sincos range: the projector must terminate at once with ok = 0 and zero
+    iterations (NaN residual fails both comparisons of the loop test), exactly as the oracle does; their
+    neighbours in the batch are unaffected."""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, 0xBAD, 0, 64)
+    q[3, 2] = np.nan
+    q[17, 9] = np.inf
+    q[29, 0] = -np.inf
+    q[40, 5] = 5e6      # finite, beyond CCMP_SINCOS_MAX: sincos returns NaN by definition
+    q[41, 5] = 1.6e6    # finite, inside the exact-reduction range: a legitimate (if absurd) angle
+    bad = [3, 17, 29, 40]
+    for sched in (0, 2):
+        gpu_ctx.set_schedule(sched, 0)
+        try:
+            out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
+            torch.cuda.synchronize()
+        finally:
+            gpu_ctx.set_schedule(1, 8192)
+        out, ok, it = out.cpu().numpy(), ok.cpu().numpy(), it.cpu().numpy()
+        q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, 4)
+        assert (ok[bad] == 0).all() and (it[bad] == 0).all() and (ok_cpu[bad] == 0).all() and (it_cpu[bad] == 0).all()
+        same = (out.view(np.uint64) == q_cpu.view(np.uint64)) | (np.isnan(out) & np.isnan(q_cpu))
+        assert same.all() and np.array_equal(ok, ok_cpu) and np.array_equal(it.astype(np.int32), it_cpu)
+    assert not c.isSatisfied(q[3]) and not c.isSatisfied(q[17])  # f.allFinite() is part of isSatisfied
+
+
+def test_iteration_cap_and_loose_tolerance(gpu_ctx, oracle_det):
+    import torch
+
+    c = _constraint("dumbbell", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, 0xCAB, 0, 200)
+    for max_iter, tol in ((0, (1e-3, 5e-3)), (3, (1e-3, 5e-3)), (250, (0.5, 1.0)), (250, (10.0, 10.0))):
+        c.problem.max_iter = max_iter
+        c.setTolerance(*tol)
+        P = _oracle_problem(oracle_det, c)
+        out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
+        q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, 4)
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64)), (max_iter, tol)
+        assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
+        assert int(it.max()) <= max_iter
+    # tolerance1 > 1: the reference's `norm1 = f[0] > tol1` stores a boolean, so "1.0 < 10.0" lets an unconverged
+    # sample through the return test only if the loop exited — which with tol 10 it does at once: all ok = jointValid
+    assert int(it.max()) == 0
