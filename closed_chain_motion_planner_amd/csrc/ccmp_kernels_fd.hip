@@ -32,15 +32,16 @@ constexpr int kGroupsPerWave = 10;    // 60 of 64 lanes busy
 // LDS record of one group (in doubles).  The prefix frames are kept for ONE arm at a time (the
 // second arm's chain is re-run before its columns: +343 operations per iteration, -84 doubles of
 // LDS per sample), and the second arm's Jacobian columns overwrite prefix slots that have already
-// been consumed.  167 x 8 B x 10 groups = 13.4 KB per wave -> 12 waves per CU.
+// been consumed.  165 x 8 B x 10 groups = 13.2 KB per wave -> 12 waves per CU.
 constexpr int kX = 0;                 // x[14]        current iterate
 constexpr int kSC = 14;               // sc[14][2]    sin, cos of every joint of x
 constexpr int kPre = 42;              // pre[7][12]   chain frame in front of joint j of the current arm: R(9), o(3)
                                       //              (slot j, doubles 0..1, is reused for J[:, 7+j] once consumed)
 constexpr int kEE = 126;              // ee[2][12]    world tool pose of each arm at x: R(9), p(3)
 constexpr int kJ0 = 150;              // J[:, 0..6]   interleaved (row0, row1) per column of arm 0
-constexpr int kF = 164;               // f[2]         residual at x (parked here across the Jacobian phase: VGPR relief)
-constexpr int kRec = 167;             // 166 used; odd stride keeps the 10 groups on distinct LDS banks
+constexpr int kRec = 165;             // 164 used; odd stride keeps the 10 groups on distinct LDS banks.  13200 B per wave:
+                                      // the allocation granule is 512 B, 12 x 13312 = 159744 <= 160 KiB (two more doubles
+                                      // per group would round to 13824 and cost a wave per CU)
 
 #ifndef CCMP_FD_WAVES_PER_SIMD
 #define CCMP_FD_WAVES_PER_SIMD 3
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     }
     __syncthreads();
     bool cont = false;
+    double f0, f1;
     {
       double T0[12], T1[12], f[2];
       chain_at_x<1, false>(K, rec, writer, T1);
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
         for (int k = 0; k < 12; k++) rec[kEE + k] = T0[k];
       }
       chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
-      if (writer) { rec[kF] = f[0]; rec[kF + 1] = f[1]; } // the solve reads them back after the Jacobian phase
+      f0 = f[0]; f1 = f[1];
       // ---- loop condition of ConstraintFunction.h:68, quirks included -------------------------
       // while (((norm1 = f[0] > tol1) || (norm2 = f[1]) > tol2) && iter++ < maxIterations)
       if (active) {
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
         Jr[7 + j] = rec[kSC + 2 * j];
         Jr[21 + j] = rec[kSC + 2 * j + 1];
       }
-      solve_minnorm(Jr, rec[kF], rec[kF + 1], dx);
+      solve_minnorm(Jr, f0, f1, dx);
       if (cont) {
 #pragma unroll
         for (int e = 0; e < 14; e++)
