@@ -139,3 +139,33 @@ def test_sampler_mirror_stream_is_batch_independent(gpu_ctx, oracle_det):
     assert np.abs(a - near).max() < 0.5 and c.isSatisfied(a)
     s1.sampleGaussian(a, near, 0.05)
     assert c.isSatisfied(a)
+
+
+def test_projector_is_graph_capturable(gpu_ctx, oracle_det):
+    """the whole launch sequence (queue memset, scout + sort, throughput kernel, hand-over kernel) is plain
+    stream work after the first call at a size: it can be captured into a HIP graph and replayed"""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    B = 20000
+    gpu_ctx.set_lpt(1, 0)
+    try:
+        q = c.ambient_uniform_batch(0x6A, 0, B)
+        out = torch.empty_like(q)
+        ref, ok_ref, it_ref = c.project_batch(q)          # un-captured first call: workspaces are allocated here
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            c.project_batch(q, out=out)                   # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(g, stream=side):
+            _, ok_g, it_g = c.project_batch(q, out=out)
+        for _ in range(3):
+            out.zero_()
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and torch.equal(ok_g, ok_ref) and torch.equal(it_g, it_ref)
+    finally:
+        gpu_ctx.set_lpt(1, 65536)
