@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--mode", choices=("fd", "analytic"), default="fd")
     ap.add_argument("--obj", default="Wine_Bottle")
     ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--tol", default="", help="tolerance1,tolerance2 (default: the reference's 1e-3,5e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets several ranks share one GPU")
@@ -114,6 +115,8 @@ def main():
         ctx.set_waves_per_cu(args.waves_per_cu)
     c = KinematicChainConstraint.from_yaml(os.path.join(ROOT, "tests", "golden", "config", args.obj + ".yaml"), ctx=ctx)
     c.setJacobianMode(CCMP_JAC_FD if args.mode == "fd" else CCMP_JAC_ANALYTIC)
+    if args.tol:
+        c.setTolerance(*[float(v) for v in args.tol.split(",")])
 
     B = args.batch
     seed = SEEDS.get(B, 0xC3) if world == 1 else 0xC5
@@ -197,7 +200,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": "config/%s.yaml, batch=%d uniform joint samples per GPU (BASELINE configs[2]; per-GPU shard of "
-                        "configs[4]), KinematicChainConstraint::project, tol (1e-3 m, 5e-3 rad), cap 250" % (args.obj, B),
+                        "configs[4]), KinematicChainConstraint::project, tol (%g m, %g rad), cap 250" % (args.obj, B, c.problem.tol_pos, c.problem.tol_rot),
             "jacobian_mode": "finite-difference (reference arithmetic, bit-identical to the CPU oracle)"
             if args.mode == "fd" else "analytic (fast mode, not bit-comparable)",
             "global_batch": world * B, "parallelism": "sample-sharded x%d, all-gather of valid states" % world,
