@@ -51,7 +51,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(obj, seed, ncores):
+def cpu_baseline(obj, seed, ncores, gpu_check=None):
     """CPU oracle (port of the reference algorithm, glibc sin/cos, FD Jacobian) on a bounded sample
     of the same workload: first `sample` samples of the bench batch, all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -72,7 +72,27 @@ def cpu_baseline(obj, seed, ncores):
     t0 = time.time()
     _, ok, it = O.project_batch(P, q, ncores)
     wall = time.time() - t0
+    # the same algorithm with the analytic Jacobian on the CPU (fair algorithmic comparison for the fast mode)
+    Pa = O.problem(cfg)
+    Pa.jacobian_mode = 1
+    t0 = time.time()
+    O.project_batch(Pa, q, ncores)
+    wall_a = time.time() - t0
+    # in-run parity evidence: the det build of the oracle vs the GPU on the first 2048 samples of the batch
+    parity = None
+    if gpu_check is not None:
+        import numpy as np
+        Od = Oracle("det")
+        Pd = Od.problem_from_bytes(gpu_check["problem_bytes"])
+        n = min(2048, sample)
+        qd, okd, itd = Od.project_batch(Pd, gpu_check["q_in"][:n], ncores)  # the very inputs the GPU projected
+        d = np.abs(qd - gpu_check["q_out"][:n]).max(axis=1)
+        parity = {"samples": n, "max_abs_dq": float(d.max()), "n_gt_1e-6": int((d > 1e-6).sum()),
+                  "bit_identical": bool(np.array_equal(qd.view(np.uint64), gpu_check["q_out"][:n].view(np.uint64))),
+                  "ok_mismatches": int((okd != gpu_check["ok"][:n]).sum()),
+                  "iteration_mismatches": int((itd != gpu_check["iters"][:n]).sum())}
     return {
+        "analytic_jacobian_value": sample / wall_a, "parity_gpu_vs_det_oracle": parity,
         "value": sample / wall, "unit": "projections/s", "cores": ncores, "kind": "port",
         "sample": "first %d samples of the bench batch, FD-faithful C oracle (glibc libm, -O2), %d threads; "
                   "single thread: %.1f projections/s" % (sample, ncores, per_core),
@@ -243,7 +263,11 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         try:
-            line["cpu_baseline"] = cpu_baseline(args.obj, seed, os.cpu_count() or 1)
+            gpu_check = None
+            if args.mode == "fd" and not args.tol:
+                gpu_check = {"problem_bytes": bytes(c.problem), "q_in": q_in[:2048].cpu().numpy(), "q_out": q_out[:2048].cpu().numpy(),
+                             "ok": ok[:2048].cpu().numpy(), "iters": it[:2048].cpu().numpy().astype("int32")}
+            line["cpu_baseline"] = cpu_baseline(args.obj, seed, os.cpu_count() or 1, gpu_check)
         except Exception as e:  # the oracle is a checker; its absence must not fail the GPU bench
             line["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(line), flush=True)
