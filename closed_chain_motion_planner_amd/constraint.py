@@ -351,6 +351,32 @@ class KinematicChainConstraint:
                                                ok.ctypes.data_as(C.POINTER(C.c_uint8)), 1), "ccmp_joint_valid_host")
         return bool(ok[0])
 
+    def project_sharded_host(self, q, contexts):
+        """(B,14) numpy -> (q_out, ok, iters) with the batch split over `contexts` (one process, several GPUs)."""
+        self._need_problem()
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B = q.shape[0]
+        out = np.empty_like(q)
+        ok = np.zeros(B, dtype=np.uint8)
+        it = np.zeros(B, dtype=np.uint16)
+        arr = (C.c_void_p * len(contexts))(*[cx.handle for cx in contexts])
+        check(_lib.lib().ccmp_project_sharded_host(arr, len(contexts), C.byref(self.problem), _dptr(q), _dptr(out),
+                                                   ok.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                   it.ctypes.data_as(C.POINTER(C.c_uint16)), B), "ccmp_project_sharded_host")
+        return out, ok, it
+
+    def sample_project_sharded_host(self, seed, first_index, B, contexts):
+        self._need_problem()
+        out = np.empty((B, 14))
+        ok = np.zeros(B, dtype=np.uint8)
+        it = np.zeros(B, dtype=np.uint16)
+        arr = (C.c_void_p * len(contexts))(*[cx.handle for cx in contexts])
+        check(_lib.lib().ccmp_sample_project_sharded_host(arr, len(contexts), C.byref(self.problem), int(seed), int(first_index),
+                                                          _dptr(out), ok.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                          it.ctypes.data_as(C.POINTER(C.c_uint16)), B),
+              "ccmp_sample_project_sharded_host")
+        return out, ok, it
+
     def project_host(self, q):
         """(B,14) numpy in -> (q_out, ok, iters) numpy out through the host-pointer entry point."""
         self._need_problem()

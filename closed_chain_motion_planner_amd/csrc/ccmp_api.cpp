@@ -934,4 +934,64 @@ int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from,
   return CCMP_OK;
 }
 
+static int sharded_common(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, int mode, const double *q_in, double *q_out,
+                          uint8_t *ok, uint16_t *iters, uint64_t seed, uint64_t first_index, size_t B)
+{
+  if (!ctxs || n < 1 || !p) return CCMP_EINVAL;
+  for (int g = 0; g < n; g++)
+    if (!ctxs[g]) return CCMP_EINVAL;
+  if (B == 0) return CCMP_OK;
+  if (!q_out || !ok || (mode == 0 && !q_in)) return CCMP_EINVAL;
+  struct Shard { size_t lo, hi, off_ok, off_it; };
+  std::vector<Shard> sh((size_t)n);
+  // phase 1: enqueue everything on every context's stream (no host wait in between)
+  for (int g = 0; g < n; g++) {
+    const size_t base = B / (size_t)n, rem = B % (size_t)n;
+    sh[g].lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem);
+    sh[g].hi = sh[g].lo + base + ((size_t)g < rem ? 1 : 0);
+    const size_t nb = sh[g].hi - sh[g].lo;
+    if (nb == 0) continue;
+    ccmp_ctx *ctx = ctxs[g];
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return CCMP_ENODEV;
+    const size_t qb = nb * 14 * sizeof(double);
+    sh[g].off_ok = (qb + 255) & ~(size_t)255;
+    sh[g].off_it = (sh[g].off_ok + nb + 255) & ~(size_t)255;
+    int rc = ensure_stage(ctx, sh[g].off_it + nb * sizeof(uint16_t));
+    if (rc != CCMP_OK) return rc;
+    char *stage = (char *)ctx->stage;
+    if (mode == 0) {
+      HIP_TRY(hipMemcpyAsync(stage, q_in + sh[g].lo * 14, qb, hipMemcpyHostToDevice, ctx->stream));
+      rc = ccmp_project_batch(ctx, p, (const double *)stage, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
+                              (uint16_t *)(stage + sh[g].off_it), nb, ctx->stream);
+    } else {
+      rc = ccmp_sample_project_batch(ctx, p, seed, first_index + sh[g].lo, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
+                                     (uint16_t *)(stage + sh[g].off_it), nullptr, nb, ctx->stream);
+    }
+    if (rc != CCMP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(q_out + sh[g].lo * 14, stage, qb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ok + sh[g].lo, stage + sh[g].off_ok, nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters + sh[g].lo, stage + sh[g].off_it, nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  // phase 2: wait for every shard
+  for (int g = 0; g < n; g++) {
+    if (sh[g].hi == sh[g].lo) continue;
+    DeviceGuard guard(ctxs[g]->device);
+    HIP_TRY(hipStreamSynchronize(ctxs[g]->stream));
+  }
+  return CCMP_OK;
+}
+
+int ccmp_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, const double *q_in, double *q_out,
+                              uint8_t *ok, uint16_t *iters, size_t B)
+{
+  return sharded_common(ctxs, n, p, 0, q_in, q_out, ok, iters, 0, 0, B);
+}
+
+int ccmp_sample_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
+                                     double *q_out, uint8_t *ok, uint16_t *iters, size_t B)
+{
+  return sharded_common(ctxs, n, p, 1, nullptr, q_out, ok, iters, seed, first_index, B);
+}
+
 } // extern "C"

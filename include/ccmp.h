@@ -174,11 +174,27 @@ int ccmp_sample_project_host(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed
 int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                        double *states, int32_t *n_states, uint8_t *ok);
 
+/* ---- one process, several GPUs (the reference's planner is a single process) ------------------------- */
+/* Contiguous shards of the batch go to the n contexts (one per device; the same device may appear twice),
+ * each shard is uploaded, projected and downloaded on its context's own stream, all concurrently; returns
+ * when every shard is back.  No collective is needed: every GPU returns its shard straight to the host
+ * tree.  Results are bit-identical to a single-GPU call.  (The one-process-per-GPU form with an RCCL
+ * all-gather of the valid states lives above the ABI: closed_chain_motion_planner_amd/distributed.py.) */
+int ccmp_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, const double *q_in, double *q_out,
+                              uint8_t *ok, uint16_t *iters, size_t B);
+/* sampleUniform x B across the contexts; sample i is a function of (seed, first_index + i) only */
+int ccmp_sample_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
+                                     double *q_out, uint8_t *ok, uint16_t *iters, size_t B);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------- */
 /* runs ccmp_detmath.h's sincos/atan2/sqrt/div on the device: out[i] = {sin,cos,atan2_nn(|x|,|y|),
  * sqrt(|x|), x/y} — used by tests to prove the device arithmetic is bit-identical to the host's */
 int ccmp_detmath_probe(ccmp_ctx *ctx, const double *x_dev, const double *y_dev, double *out_dev, size_t n,
                        void *hip_stream);
+/* experimental / diagnostic hooks used by tools/: an externally supplied processing order (device array of B
+ * sample indices, NULL = none) and a copy of the scout's predicted iteration counts of the last large call */
+int ccmp_ctx_set_order_experimental(ccmp_ctx *ctx, const unsigned int *order_dev);
+int ccmp_ctx_debug_lpt_pred(ccmp_ctx *ctx, uint16_t *host_out, size_t B);
 const char *ccmp_strerror(int code);
 const char *ccmp_last_hip_error(void);
 int ccmp_version(void);

@@ -169,3 +169,23 @@ def test_projector_is_graph_capturable(gpu_ctx, oracle_det):
         assert torch.equal(out, ref) and torch.equal(ok_g, ok_ref) and torch.equal(it_g, it_ref)
     finally:
         gpu_ctx.set_lpt(1, 65536)
+
+
+def test_single_process_sharding_over_contexts(gpu_ctx, oracle_det):
+    """ccmp_project_sharded_host: one process, n contexts (here two on the same device — the box has one GPU),
+    uneven shard sizes; bit-identical to the single-context call and to the oracle"""
+    from closed_chain_motion_planner_amd import Context
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    B = 1001
+    q = oracle_det.ambient_uniform_batch(P, 0x5A, 0, B)
+    ctxs = [gpu_ctx, Context(0), Context(0)]
+    out, ok, it = c.project_sharded_host(q, ctxs)
+    out1, ok1, it1 = c.project_host(q)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+    assert np.array_equal(out.view(np.uint64), out1.view(np.uint64)) and np.array_equal(ok, ok1) and np.array_equal(it, it1)
+    assert np.array_equal(out.view(np.uint64), q_cpu.view(np.uint64)) and np.array_equal(ok, ok_cpu)
+    s_out, s_ok, _ = c.sample_project_sharded_host(0x5A, 0, B, ctxs)
+    e_out, e_ok, _ = oracle_det.sample_project_batch(P, 0x5A, 0, B, NCPU)
+    assert np.array_equal(s_out.view(np.uint64), e_out.view(np.uint64)) and np.array_equal(s_ok, e_ok)
