@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
 
 
 // ---- simple per-lane kernels (one sample per lane; all bit-identical to the oracle) -------------
-__global__ void function_kernel(const ccmp_consts K, const double *__restrict__ q, double *__restrict__ f, size_t B)
+__global__ __launch_bounds__(64) void function_kernel(const ccmp_consts K, const double *__restrict__ q, double *__restrict__ f, size_t B)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -349,7 +349,7 @@ __global__ void function_kernel(const ccmp_consts K, const double *__restrict__ 
 }
 
 // KinematicChainConstraint::isSatisfied (ConstraintFunction.h:114-120)
-__global__ void is_satisfied_kernel(const ccmp_consts K, const double *__restrict__ q, uint8_t *__restrict__ ok, size_t B)
+__global__ __launch_bounds__(64) void is_satisfied_kernel(const ccmp_consts K, const double *__restrict__ q, uint8_t *__restrict__ ok, size_t B)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -408,7 +408,7 @@ __global__ void ambient_gaussian_kernel(const ccmp_consts K, unsigned long long 
 
 // IKTask::compute_t_wo (src/base/constraints/ik_task.cpp:10-14): object pose from the left arm's joints,
 // t_wb * FK(q) * t_o7.inverse(); out[i] = R (9, row-major) then p (3)
-__global__ void t_wo_kernel(const ccmp_consts K, const double *__restrict__ q, int q_stride, double *__restrict__ out, size_t B)
+__global__ __launch_bounds__(64) void t_wo_kernel(const ccmp_consts K, const double *__restrict__ q, int q_stride, double *__restrict__ out, size_t B)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;

@@ -129,7 +129,8 @@ CCMP_HD void tool_pose(const ccmp_consts &K, int arm, const double *R, const dou
 CCMP_HD void fk_arm(const ccmp_consts &K, int arm, const double *q, double *Rw, double *pw)
 {
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
-  for (int i = 0; i < 7; i++) {
+#pragma unroll
+  for (int i = 0; i < 7; i++) { /* unrolled: q[] then stays in registers in the per-lane kernels (no scratch) */
     double s, c;
     ccmp_sincos(q[i], &s, &c);
     joint_step(K, arm, i, s, c, R, o);
