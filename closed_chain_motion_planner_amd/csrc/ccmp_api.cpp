@@ -28,6 +28,10 @@ hipError_t ccmp_launch_project_wave(const ccmp_consts *K, int src, const double 
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, hipStream_t st);
+hipError_t ccmp_launch_project_pair(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
+                                    uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
+                                    unsigned long long seed, unsigned long long first, int wrap_output, int nblocks,
+                                    hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                     unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
@@ -309,6 +313,7 @@ struct ccmp_ctx {
   size_t pool_cap = 0;                 // in records
   int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
   const unsigned int *order = nullptr; // experimental: externally supplied processing order
+  int pair_kernel = 1;                 // batches of at most one sample per CU: one sample per PAIR of waves
   int lpt = 1;                         // 0: in-order; 1: FP32 scout + longest-predicted-first, hand-over kept; 2: same, no hand-over
   size_t lpt_min_batch = 65536;        // below this the scout costs more than the tail it removes
   void *lpt_buf = nullptr;             // pred (u16 x B) | hist (u32 x 1024) | order (u32 x B)
@@ -531,6 +536,7 @@ int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int w)
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch)
 {
   if (!ctx || wave_kernel < 0 || (wave_kernel % 100) > 2 || wave_kernel / 100 > 10) return CCMP_EINVAL;
+  ctx->pair_kernel = (wave_kernel % 100) != 2 || small_batch != 1; /* (2, small_batch = 1): single-wave kernel only, for A/B */
   ctx->wave_kernel = wave_kernel % 100;
   if (wave_kernel >= 100) ctx->dump_threshold = wave_kernel / 100; /* experimental: hundreds digit+ = hand-over threshold */
   ctx->small_batch = small_batch;
@@ -637,6 +643,10 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       if (nwave > 0)
         HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
                                          ctx->queue + 1, mode, nwave, st));
+    } else if (ctx->pair_kernel && B <= (size_t)ctx->num_cus) {
+      // a handful of samples (single-state calls of the reference signature): one sample per pair of waves is
+      // ~10 % quicker per sample; from a few hundred samples on the single-wave kernel wins (tools/time_small.py)
+      HIP_TRY(ccmp_launch_project_pair(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, mode, (int)B, st));
     } else {
       HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
                                        ctx->queue + 1, mode, nwave, st));

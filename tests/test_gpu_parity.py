@@ -105,10 +105,11 @@ def test_project_fd_bitwise(gpu_ctx, oracle_det, obj, B, seed):
     assert np.array_equal(q_gpu.view(np.uint64), q_cpu.view(np.uint64)), "not bit-identical"
 
 
-@pytest.mark.parametrize("schedule,small,lpt", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (1, 8192, 0), (1, 0, 1), (0, 0, 2)])
+@pytest.mark.parametrize("schedule,small,lpt", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 1, 0), (1, 8192, 0), (1, 0, 1), (0, 0, 2)])
 def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, lpt):
     """group kernel only / group kernel + straggler hand-over to the wave-per-sample kernel /
-    wave-per-sample only / default policy: all bit-identical to the oracle."""
+    latency kernels only (pair of waves per sample; single wave per sample) / default policy / FP32-scout
+    longest-first with and without hand-over: all bit-identical to the oracle."""
     import torch
 
     c = _constraint("stefan", gpu_ctx)  # longest iteration tails, some samples hit the 250 cap
@@ -146,7 +147,7 @@ def test_sample_project_bitwise(gpu_ctx, oracle_det):
     assert (np.abs(q_gpu.cpu().numpy()) <= np.pi).all()  # enforceBounds wrapped everything
 
 
-@pytest.mark.parametrize("B", [0, 1, 5, 10, 11, 61, 640, 641])
+@pytest.mark.parametrize("B", [0, 1, 5, 10, 11, 61, 256, 257, 640, 641])
 def test_ragged_batches(gpu_ctx, oracle_det, B):
     """empty / single / not a multiple of the 10-samples-per-wave grouping; in place."""
     import torch

@@ -1,0 +1,16 @@
+import sys
+import torch
+sys.path.insert(0, ".")
+from closed_chain_motion_planner_amd import Context, KinematicChainConstraint  # noqa: E402
+from tools.time_kernels import timed  # noqa: E402
+ctx = Context(0)
+c = KinematicChainConstraint.from_yaml("tests/golden/config/Wine_Bottle.yaml", ctx=ctx)
+for B in (1, 64, 1024, 2048, 4096, 8192):
+    q = c.ambient_uniform_batch(0xC2, 0, B)
+    out = torch.empty_like(q)
+    res = []
+    for name, sched, small in (("pair", 2, 0), ("single-wave", 2, 1), ("default", 1, 8192)):
+        ctx.set_schedule(sched, small)
+        ms = timed(lambda: c.project_batch(q, out=out), reps=5)
+        res.append("%s %7.3f ms (%.2e/s)" % (name, ms, B / ms * 1e3))
+    print("B=%-5d " % B + "   ".join(res), flush=True)
