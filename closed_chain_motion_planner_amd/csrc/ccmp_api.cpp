@@ -628,7 +628,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       uint16_t *pred = (uint16_t *)base;
       unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
       unsigned int *ord = (unsigned int *)((char *)hist + 4096);
-      HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus * 1, st));
+      HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus, st)); // one 256-thread block per CU, 4 samples per lane: more lanes only lengthen the per-wave maximum
       order = ord;
       if (ctx->lpt == 2) nwave = 0;
     }

@@ -9,8 +9,8 @@
 // point of the same manifold for ~20 % of uniform samples.  It is an opt-in fast mode; the default
 // mode is the FD-faithful kernel in ccmp_kernels_fd.hip.
 //
-// Decomposition: one sample per lane, everything in registers; lanes pull samples from a global
-// atomic queue so that early finishers refill (iteration counts spread 15..250).
+// Decomposition: one sample per lane, everything in registers; a lane that finishes a sample takes its next
+// one (static stride over the batch) while its neighbours keep iterating (iteration counts spread 15..250).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -55,14 +55,18 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K, c
                                                           unsigned long long first_index)
 {
   double x[14];
-  unsigned long long idx = 0;
+  unsigned long long idx = 0, next = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  (void)queue;
   int iter = 0, updates = 0;
   double norm1 = 0.0, norm2 = 0.0;
   bool active = false, drained = false;
 
   for (;;) {
     if (!active && !drained) {
-      const unsigned long long t = atomicAdd(queue, 1ull);
+      // static striding, not a shared queue head: one word saturates at ~88 single-lane dequeues per microsecond,
+      // which at 262144 samples would cost as much as the projections themselves
+      const unsigned long long t = next;
+      next += (unsigned long long)gridDim.x * blockDim.x;
       if (t < B) {
         idx = t; active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
 #pragma unroll

@@ -115,12 +115,20 @@ __global__ __launch_bounds__(256) void scout_kernel(const consts_f K, const ccmp
                                                     unsigned long long first_index)
 {
   float x[14];
-  unsigned long long idx = 0;
+  unsigned long long idx = 0, next = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   int iter = 0;
   bool active = false, drained = false;
+  (void)queue;
   for (;;) {
     if (!active && !drained) {
+#ifdef CCMP_SCOUT_ATOMIC_QUEUE
       const unsigned long long t = atomicAdd(queue, 1ull);
+#else
+      // static striding instead of a shared queue head: 262144 single-lane dequeues on one word cost more than
+      // the whole scout (one word saturates at ~88 dequeues/us); the imbalance of a few samples per lane is small
+      const unsigned long long t = next;
+      next += (unsigned long long)gridDim.x * blockDim.x;
+#endif
       if (t < B) {
         idx = t; active = true; iter = 0;
 #pragma unroll
