@@ -7,6 +7,7 @@ interface.  Importing the package needs neither a GPU nor the built library; usi
 from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem  # noqa: F401
 from .constraint import ArmModel, Context, KinematicChainConstraint, load_config  # noqa: F401
 
-from .space import format_path_matrix, jy_ProjectedStateSampler, jy_ProjectedStateSpace, parse_path_matrix  # noqa: F401
+from .space import (check_motion, format_path_matrix, geodesic_interpolate, jy_ProjectedStateSampler,  # noqa: F401
+                    jy_ProjectedStateSpace, parse_path_matrix)
 
 __version__ = "0.1.0"

@@ -5,7 +5,8 @@ discreteGeodesic` (:32-96) and the path-matrix format the reference dumps
 top of the batched GPU entry points of KinematicChainConstraint."""
 import numpy as np
 
-__all__ = ["jy_ProjectedStateSampler", "jy_ProjectedStateSpace", "format_path_matrix", "parse_path_matrix"]
+__all__ = ["jy_ProjectedStateSampler", "jy_ProjectedStateSpace", "check_motion", "geodesic_interpolate", "format_path_matrix",
+           "parse_path_matrix"]
 
 
 def _torch():
@@ -108,6 +109,32 @@ class jy_ProjectedStateSpace:
             del geodesic[:]
             geodesic.extend(st)
         return good
+
+
+def check_motion(space, s1, s2):
+    """OMPL `ConstrainedMotionValidator::checkMotion(s1, s2)` as the reference's planner calls it
+    (src/planner/stefanBiPRM.cpp:397-398,463-464): isSatisfied(s2) && discreteGeodesic(s1, s2)."""
+    return bool(space.constraint_.isSatisfied(s2)) and bool(space.discreteGeodesic(s1, s2, False, None))
+
+
+def geodesic_interpolate(states, t):
+    """OMPL `ConstrainedStateSpace::geodesicInterpolate`: the state at fraction t of the piecewise-linear
+    geodesic (used by `PathGeometric::interpolate`, src/base/constraints/ConstrainedPlanningCommon.cpp:217)."""
+    states = np.asarray(states, dtype=np.float64).reshape(-1, 14)
+    n = states.shape[0]
+    if n == 1:
+        return states[0].copy()
+    d = np.sqrt(((states[1:] - states[:-1]) ** 2).sum(axis=1))
+    total = d.sum()
+    if total == 0.0:
+        return states[0].copy()
+    target, acc = t * total, 0.0
+    for i in range(n - 1):
+        if acc + d[i] >= target or i == n - 2:
+            tt = 0.0 if d[i] == 0.0 else (target - acc) / d[i]
+            return states[i] + min(max(tt, 0.0), 1.0) * (states[i + 1] - states[i])
+        acc += d[i]
+    return states[-1].copy()
 
 
 def format_path_matrix(states):

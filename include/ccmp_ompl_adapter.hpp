@@ -12,6 +12,8 @@
 //       (replaces include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:21-137)
 //   class jy_ProjectedStateSampler : public ompl::base::WrapperStateSampler
 //       (replaces src/base/jy_ProjectedStateSpace.cpp:5-29)
+//   class jy_ProjectedStateSpace : public ompl::base::ProjectedStateSpace
+//       (replaces src/base/jy_ProjectedStateSpace.cpp:32-96)
 // Neither OMPL nor Eigen is installed in the build image of this repository, so part 2 is exercised
 // only by inspection; part 1 is compiled and run by tests/test_cpp_adapter.py.
 #ifndef CCMP_OMPL_ADAPTER_HPP
@@ -173,6 +175,7 @@ inline bool discreteGeodesic(const Projector &proj, const double *from14, const 
 #include <ompl/base/Constraint.h>
 #include <ompl/base/StateSampler.h>
 #include <ompl/base/spaces/constraint/ConstrainedStateSpace.h>
+#include <ompl/base/spaces/constraint/ProjectedStateSpace.h>
 #include <ompl/util/Exception.h>
 
 #include <closed_chain_motion_planner/kinematics/panda_model.h>  // ArmModelPtr {name, index, ...}
@@ -263,6 +266,63 @@ public:
 private:
   std::shared_ptr<KinematicChainConstraint> constraint_;
   ccmp::SampleBuffer buffer_;
+};
+
+// jy_ProjectedStateSpace (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:31-54): same name,
+// same overrides.  discreteGeodesic runs the traversal on the GPU and applies the space information's
+// StateValidityChecker on the host exactly where the reference consults it (src/base/jy_ProjectedStateSpace.cpp:
+// 65-68); checkMotion of OMPL's ConstrainedMotionValidator (isSatisfied(s2) && discreteGeodesic(s1, s2),
+// src/planner/stefanBiPRM.cpp:397-398,463-464) therefore needs no change.
+class jy_ProjectedStateSpace : public ompl::base::ProjectedStateSpace {
+public:
+  jy_ProjectedStateSpace(const ompl::base::StateSpacePtr &ambientSpace, const ompl::base::ConstraintPtr &constraint)
+    : ompl::base::ProjectedStateSpace(ambientSpace, constraint), chain_(std::dynamic_pointer_cast<KinematicChainConstraint>(constraint))
+  {
+    setName("jy_Projected" + space_->getName());
+  }
+  ompl::base::StateSamplerPtr allocDefaultStateSampler() const override
+  {
+    return std::make_shared<jy_ProjectedStateSampler>(this, space_->allocDefaultStateSampler());
+  }
+  ompl::base::StateSamplerPtr allocStateSampler() const override
+  {
+    return std::make_shared<jy_ProjectedStateSampler>(this, space_->allocStateSampler());
+  }
+  bool discreteGeodesic(const ompl::base::State *from, const ompl::base::State *to, bool interpolate,
+                        std::vector<ompl::base::State *> *geodesic) const override
+  {
+    double a[14], b[14];
+    const auto &fa = *from->as<StateType>();
+    const auto &tb = *to->as<StateType>();
+    for (int i = 0; i < 14; ++i) { a[i] = fa[i]; b[i] = tb[i]; }
+    ccmp::Projector &proj = chain_->impl();
+    proj.problem().delta = delta_;   // setDelta / setLambda of the base class stay the source of truth
+    proj.problem().lambda = lambda_;
+    auto &&svc = si_->getStateValidityChecker();
+    std::vector<std::vector<double>> states;
+    ompl::base::State *scratch = allocState();
+    const bool ok = ccmp::discreteGeodesic(proj, a, b, interpolate,
+                                           [&](const double *q) {
+                                             auto &x = *scratch->as<StateType>();
+                                             for (int i = 0; i < 14; ++i) x[i] = q[i];
+                                             return svc->isValid(scratch);
+                                           },
+                                           geodesic ? &states : nullptr);
+    freeState(scratch);
+    if (geodesic) {
+      geodesic->clear();
+      for (const auto &st : states) {
+        ompl::base::State *s = allocState();
+        auto &x = *s->as<StateType>();
+        for (int i = 0; i < 14; ++i) x[i] = st[i];
+        geodesic->push_back(s);
+      }
+    }
+    return ok;
+  }
+
+private:
+  std::shared_ptr<KinematicChainConstraint> chain_;
 };
 #endif  // CCMP_WITH_OMPL
 

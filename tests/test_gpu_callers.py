@@ -189,3 +189,24 @@ def test_single_process_sharding_over_contexts(gpu_ctx, oracle_det):
     s_out, s_ok, _ = c.sample_project_sharded_host(0x5A, 0, B, ctxs)
     e_out, e_ok, _ = oracle_det.sample_project_batch(P, 0x5A, 0, B, NCPU)
     assert np.array_equal(s_out.view(np.uint64), e_out.view(np.uint64)) and np.array_equal(s_ok, e_ok)
+
+
+def test_check_motion_and_geodesic_interpolate(gpu_ctx, oracle_det):
+    from closed_chain_motion_planner_amd import check_motion, geodesic_interpolate, jy_ProjectedStateSpace
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    rows = load_path_rows("Wine_Bottle")
+    space = jy_ProjectedStateSpace(c)
+    # rows 3..6 of the recorded path are consecutive geodesic states 0.25 apart: a motion between neighbours is valid
+    assert check_motion(space, rows[2], rows[3]) is True
+    off = rows[3] + 0.2  # not on the manifold: isSatisfied(s2) fails first
+    assert check_motion(space, rows[2], off) is False
+    ok, st, _ = oracle_det.discrete_geodesic(P, rows[0], rows[5], interpolate=True)
+    mid = geodesic_interpolate(st, 0.5)
+    d = np.sqrt(((st[1:] - st[:-1]) ** 2).sum(axis=1))
+    assert np.array_equal(geodesic_interpolate(st, 0.0), st[0]) and np.allclose(geodesic_interpolate(st, 1.0), st[-1])
+    # the midpoint lies on one of the segments, half of the total length from the start
+    acc = np.concatenate([[0], np.cumsum(d)])
+    i = int(np.searchsorted(acc, 0.5 * d.sum()) - 1)
+    assert abs(np.linalg.norm(mid - st[i]) + acc[i] - 0.5 * d.sum()) < 1e-12
