@@ -54,7 +54,7 @@ CCMP_JAC_ANALYTIC = 1
 # every symbol include/ccmp.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ccmp_problem_from_yaml", "ccmp_problem_init", "ccmp_set_start", "ccmp_set_tolerance", "ccmp_set_calibration",
-    "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_set_schedule", "ccmp_ctx_set_lpt", "ccmp_ctx_device", "ccmp_ctx_num_cus",
+    "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_set_schedule", "ccmp_ctx_set_option", "ccmp_ctx_set_lpt", "ccmp_ctx_device", "ccmp_ctx_num_cus",
     "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
     "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
     "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid",
@@ -97,6 +97,7 @@ def lib():
         "ccmp_ctx_destroy": ([vp], None),
         "ccmp_ctx_set_waves_per_cu": ([vp, C.c_int], C.c_int),
         "ccmp_ctx_set_schedule": ([vp, C.c_int, C.c_size_t], C.c_int),
+        "ccmp_ctx_set_option": ([vp, C.c_char_p, C.c_long], C.c_int),
         "ccmp_ctx_set_lpt": ([vp, C.c_int, C.c_size_t], C.c_int),
         "ccmp_ctx_device": ([vp], C.c_int),
         "ccmp_ctx_num_cus": ([vp], C.c_int),

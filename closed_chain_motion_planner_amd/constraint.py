@@ -45,6 +45,10 @@ class Context:
         """0 = group kernel only, 1 = group kernel + wave-per-sample stragglers (default), 2 = wave-per-sample only"""
         check(_lib.lib().ccmp_ctx_set_schedule(self._h, int(wave_kernel), int(small_batch)), "ccmp_ctx_set_schedule")
 
+    def set_option(self, name, value):
+        """tuning knobs: "handover_threshold" (-1 auto, 0..10), "pair_kernel" (0/1); results never change"""
+        check(_lib.lib().ccmp_ctx_set_option(self._h, name.encode(), int(value)), "ccmp_ctx_set_option(%s)" % name)
+
     def set_lpt(self, mode=1, min_batch=65536):
         """0 = index order, 1 = FP32 scout + longest-predicted-first (default), 2 = the same without hand-over"""
         check(_lib.lib().ccmp_ctx_set_lpt(self._h, int(mode), int(min_batch)), "ccmp_ctx_set_lpt")

@@ -535,11 +535,22 @@ int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int w)
 }
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch)
 {
-  if (!ctx || wave_kernel < 0 || (wave_kernel % 100) > 2 || wave_kernel / 100 > 10) return CCMP_EINVAL;
-  ctx->pair_kernel = (wave_kernel % 100) != 2 || small_batch != 1; /* (2, small_batch = 1): single-wave kernel only, for A/B */
-  ctx->wave_kernel = wave_kernel % 100;
-  if (wave_kernel >= 100) ctx->dump_threshold = wave_kernel / 100; /* experimental: hundreds digit+ = hand-over threshold */
+  if (!ctx || wave_kernel < 0 || wave_kernel > 2) return CCMP_EINVAL;
+  ctx->wave_kernel = wave_kernel;
   ctx->small_batch = small_batch;
+  return CCMP_OK;
+}
+int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
+{
+  if (!ctx || !name) return CCMP_EINVAL;
+  if (!strcmp(name, "handover_threshold")) { // -1 = automatic, 0..10 = hand a wave over once <= this many groups are busy
+    if (value < -1 || value > 10) return CCMP_EINVAL;
+    ctx->dump_threshold = (int)value;
+  } else if (!strcmp(name, "pair_kernel")) { // 0/1: one sample per pair of waves for batches of <= one sample per CU
+    ctx->pair_kernel = value != 0;
+  } else {
+    return CCMP_EINVAL;
+  }
   return CCMP_OK;
 }
 int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch)

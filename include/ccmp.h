@@ -101,6 +101,10 @@ int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
  * batches of at most small_batch samples always use the wave-per-sample kernel (default 8192).  Results are
  * bit-identical under every setting. */
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch);
+/* tuning knobs (results never change): "handover_threshold" (-1 = automatic, 0..10: hand a wave's samples to the
+ * latency kernel once the queue is dry and at most this many of its 10 groups are busy), "pair_kernel" (0/1: one
+ * sample per pair of waves for batches of at most one sample per CU).  CCMP_EINVAL for unknown names. */
+int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
 /* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
  * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is
  * processed longest first, straggler hand-over kept (default); 2 = the same without hand-over.  Used for

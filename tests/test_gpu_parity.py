@@ -105,8 +105,9 @@ def test_project_fd_bitwise(gpu_ctx, oracle_det, obj, B, seed):
     assert np.array_equal(q_gpu.view(np.uint64), q_cpu.view(np.uint64)), "not bit-identical"
 
 
-@pytest.mark.parametrize("schedule,small,lpt", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 1, 0), (1, 8192, 0), (1, 0, 1), (0, 0, 2)])
-def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, lpt):
+@pytest.mark.parametrize("schedule,small,lpt,thr", [(0, 0, 0, -1), (1, 0, 0, -1), (1, 0, 0, 2), (2, 0, 0, -1), (1, 8192, 0, -1),
+                                                    (1, 0, 1, -1), (1, 0, 1, 10), (0, 0, 2, -1)])
+def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, lpt, thr):
     """group kernel only / group kernel + straggler hand-over to the wave-per-sample kernel /
     latency kernels only (pair of waves per sample; single wave per sample) / default policy / FP32-scout
     longest-first with and without hand-over: all bit-identical to the oracle."""
@@ -121,12 +122,14 @@ def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, l
     q, q_cpu, ok_cpu, it_cpu = _SCHED_CACHE["stefan"]
     gpu_ctx.set_schedule(schedule, small)
     gpu_ctx.set_lpt(lpt, 0)  # lpt > 0 with min_batch 0: FP32 scout + longest-predicted-first even on this small batch
+    gpu_ctx.set_option("handover_threshold", thr)
     try:
         q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
         torch.cuda.synchronize()
     finally:
         gpu_ctx.set_schedule(1, 8192)
         gpu_ctx.set_lpt(1, 65536)
+        gpu_ctx.set_option("handover_threshold", -1)
     assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)
     assert np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
@@ -163,6 +166,23 @@ def test_ragged_batches(gpu_ctx, oracle_det, B):
     q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, 4)
     assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok.cpu().numpy(), ok_cpu)
+
+
+@pytest.mark.parametrize("pair", [0, 1])
+def test_tiny_batches_pair_and_single_wave_kernels(gpu_ctx, oracle_det, pair):
+    import torch
+
+    c = _constraint("stefan", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, 0x7A1, 0, 40)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, 4)
+    gpu_ctx.set_option("pair_kernel", pair)
+    try:
+        out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
+    finally:
+        gpu_ctx.set_option("pair_kernel", 1)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+    assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
 
 
 def test_is_satisfied_and_joint_valid(gpu_ctx, oracle_det):

@@ -9,6 +9,7 @@ for obj in ("Wine_Bottle", "stefan"):
     q = c.ambient_uniform_batch(0xC3, 0, 262144)
     out = torch.empty_like(q)
     for thr in (10, 8, 6, 4, 2):
-        ctx.set_schedule(1 + 100 * thr, 0)
+        ctx.set_schedule(1, 0)
+        ctx.set_option("handover_threshold", thr)
         ms = timed(lambda: c.project_batch(q, out=out), reps=3)
         print("%-12s dump_threshold=%-2d %9.3f ms  %.3e proj/s" % (obj, thr, ms, 262144 / ms * 1e3), flush=True)

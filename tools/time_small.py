@@ -9,8 +9,9 @@ for B in (1, 64, 1024, 2048, 4096, 8192):
     q = c.ambient_uniform_batch(0xC2, 0, B)
     out = torch.empty_like(q)
     res = []
-    for name, sched, small in (("pair", 2, 0), ("single-wave", 2, 1), ("default", 1, 8192)):
+    for name, sched, small, pair in (("pair", 2, 0, 1), ("single-wave", 2, 0, 0), ("default", 1, 8192, 1)):
         ctx.set_schedule(sched, small)
+        ctx.set_option("pair_kernel", pair)
         ms = timed(lambda: c.project_batch(q, out=out), reps=5)
         res.append("%s %7.3f ms (%.2e/s)" % (name, ms, B / ms * 1e3))
     print("B=%-5d " % B + "   ".join(res), flush=True)
