@@ -13,11 +13,13 @@
 // (+h,+2h,+3h,-h,-2h,-3h) of ONE Jacobian column; the wave walks the 14 columns in lock-step, so
 // arm/joint indices are wave-uniform and every kinematic constant is an SGPR operand.  A perturbed
 // evaluation reuses the unperturbed prefix of the chain (bit-identical to recomputing it) from LDS
-// and recomputes only the suffix.  Joint state, sines/cosines, prefix frames, tool poses and the
-// 2x14 Jacobian of each sample are staged in LDS (one 265-double record per group; odd stride =>
-// the 10 groups hit distinct banks, lanes of a group broadcast).  Groups pull samples from a
-// global atomic queue, so a group whose sample converges early refills while its neighbours keep
-// iterating (iteration counts spread 15..250).
+// and recomputes only the suffix.  Joint state, sines/cosines, prefix frames, tool poses, stencil
+// values and the 2x14 Jacobian of each sample are staged in LDS (one 165-double record per group; odd
+// stride => the 10 groups hit distinct banks, lanes of a group broadcast).  Groups pull samples from
+// a global atomic queue (optionally in longest-predicted-first order, ccmp_kernels_scout.hip), so a
+// group whose sample converges early refills while its neighbours keep iterating (iteration counts
+// spread 15..250); when the queue runs dry the samples still in flight are handed to the
+// wave-per-sample kernel (ccmp_kernels_wave.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -31,12 +33,13 @@ constexpr int kGroup = 6;             // lanes per sample = stencil evaluations 
 constexpr int kGroupsPerWave = 10;    // 60 of 64 lanes busy
 // LDS record of one group (in doubles).  The prefix frames are kept for ONE arm at a time (the
 // second arm's chain is re-run before its columns: +343 operations per iteration, -84 doubles of
-// LDS per sample), and the second arm's Jacobian columns overwrite prefix slots that have already
-// been consumed.  165 x 8 B x 10 groups = 13.2 KB per wave -> 12 waves per CU.
+// LDS per sample).  A consumed prefix slot (12 doubles) then holds the 6 lanes' residual pairs of
+// that column until the arm's stencil is combined; arm 0's Jacobian entries go to kJ0, arm 1's into
+// arm 0's (by then dead) sin/cos slots.  165 x 8 B x 10 groups = 13.2 KB per wave -> 12 waves per CU.
 constexpr int kX = 0;                 // x[14]        current iterate
 constexpr int kSC = 14;               // sc[14][2]    sin, cos of every joint of x
-constexpr int kPre = 42;              // pre[7][12]   chain frame in front of joint j of the current arm: R(9), o(3)
-                                      //              (slot j, doubles 0..1, is reused for J[:, 7+j] once consumed)
+constexpr int kPre = 42;              // pre[7][12]   chain frame in front of joint j of the current arm: R(9), o(3);
+                                      //              once consumed: (f0, f1) of the 6 stencil points of column j
 constexpr int kEE = 126;              // ee[2][12]    world tool pose of each arm at x: R(9), p(3)
 constexpr int kJ0 = 150;              // J[:, 0..6]   interleaved (row0, row1) per column of arm 0
 constexpr int kRec = 165;             // 164 used; odd stride keeps the 10 groups on distinct LDS banks.  13200 B per wave:
@@ -46,7 +49,6 @@ constexpr int kRec = 165;             // 164 used; odd stride keeps the 10 group
 #ifndef CCMP_FD_WAVES_PER_SIMD
 #define CCMP_FD_WAVES_PER_SIMD 3
 #endif
-
 
 // One arm's chain at x (sines/cosines from LDS).  With STORE the writer lane keeps the frame in
 // front of every joint (R before the joint's rotation, o including the joint's offset) in LDS.
@@ -71,12 +73,11 @@ __device__ __forceinline__ void chain_at_x(const ccmp_consts &K, double *rec, bo
   tool_pose(K, ARM, R, o, &T[0], &T[9]);
 }
 
-// OMPL's default Constraint::jacobian for the 7 columns of one arm: each lane evaluates its stencil
-// point of column j from the cached prefix frame, the +/- lanes pair up through ds_bpermute.
+// OMPL's default Constraint::jacobian, evaluation part, for the 7 columns of one arm: each lane evaluates
+// its stencil point of column j from the cached prefix frame and parks the residual pair in LDS.
 template <int ARM>
 __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *rec, bool live, int r, bool plus, int nstep)
 {
-#ifndef CCMP_RELOAD_TO
   double To[12]; // the other arm's (unperturbed) tool pose: 24 VGPRs that save 12 LDS reads per column (-6.5 %, A/B)
 #pragma unroll
   for (int k = 0; k < 12; k++) To[k] = rec[kEE + (1 - ARM) * 12 + k];
@@ -106,15 +107,6 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
       joint_step(K, ARM, i, rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], R, o);
     double Tw[12], t[2];
     tool_pose(K, ARM, R, o, &Tw[0], &Tw[9]);
-#ifdef CCMP_RELOAD_TO
-    double To[12];
-    {
-      const double *ee = rec + kEE + (1 - ARM) * 12;
-      asm volatile("" : "+v"(ee));
-#pragma unroll
-      for (int k = 0; k < 12; k++) To[k] = ee[k];
-    }
-#endif
     if (ARM == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);
     else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], t, nullptr, nullptr);
     // park this evaluation in the prefix slot the group has just consumed (12 doubles = 6 lanes x (f0, f1));
