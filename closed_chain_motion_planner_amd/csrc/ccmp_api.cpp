@@ -162,6 +162,9 @@ void make_consts(const ccmp_problem &P, ccmp_consts &K)
     }
     for (int k = 0; k < 3; k++) { K.ee[a][k] = P.ee[a][k]; K.base_p[a][k] = P.base_p[a][k]; }
     for (int k = 0; k < 9; k++) { K.R_tool[a][k] = P.R_tool[a][k]; K.base_R[a][k] = P.base_R[a][k]; }
+    bool diag = true; // t_wb.linear() exactly diag(+-1): tool_pose skips the products with exact zeros
+    for (int k = 0; k < 9; k++) diag = diag && (k % 4 == 0 ? (P.base_R[a][k] == 1.0 || P.base_R[a][k] == -1.0) : P.base_R[a][k] == 0.0);
+    if (diag) K.base_diag |= 1 << a;
   }
   for (int k = 0; k < 3; k++) K.init_p[k] = P.init_p[k];
   ccmp::quat_of(P.init_R, K.init_q);

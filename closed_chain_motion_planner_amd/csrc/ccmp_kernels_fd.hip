@@ -81,7 +81,6 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
   double To[12]; // the other arm's (unperturbed) tool pose: 24 VGPRs that save 12 LDS reads per column (-6.5 %, A/B)
 #pragma unroll
   for (int k = 0; k < 12; k++) To[k] = rec[kEE + (1 - ARM) * 12 + k];
-#endif
   for (int j = 0; j < 7; j++) {
     const double xj = rec[kX + ARM * 7 + j];
     const double axj = ccmp_abs(xj);
@@ -103,8 +102,24 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
 #pragma unroll
       for (int k = 0; k < 9; k++) R[k] = Rn[k];
     }
-    for (int i = j + 1; i < 7; i++)
-      joint_step(K, ARM, i, rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], R, o);
+    {
+      // suffix joints two at a time, R -> Rn -> R: no register copies of the frame between steps (61 instead of
+      // 76 instructions per joint; -0.6 % run time, A/B)
+      int i = j + 1;
+      if ((7 - i) & 1) {
+        joint_step(K, ARM, i, rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], R, o);
+        i++;
+      }
+      for (; i < 7; i += 2) {
+        double Rj[9], Rn[9];
+        mulvec_acc(R, K.offset[ARM][i], o);
+        rot_sc(K.axis[ARM][i], K.aprod[ARM][i], rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], Rj);
+        mul33(R, Rj, Rn);
+        mulvec_acc(Rn, K.offset[ARM][i + 1], o);
+        rot_sc(K.axis[ARM][i + 1], K.aprod[ARM][i + 1], rec[kSC + 2 * (ARM * 7 + i + 1)], rec[kSC + 2 * (ARM * 7 + i + 1) + 1], Rj);
+        mul33(Rn, Rj, R);
+      }
+    }
     double Tw[12], t[2];
     tool_pose(K, ARM, R, o, &Tw[0], &Tw[9]);
     if (ARM == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);

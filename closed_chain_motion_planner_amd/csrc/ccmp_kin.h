@@ -38,7 +38,7 @@ struct ccmp_consts {
   double t_o7i_p[3];
   double tol_pos, tol_rot, step;
   int32_t max_iter;
-  int32_t pad;
+  int32_t base_diag; /* bit a: base_R[a] is exactly diag(+-1, +-1, +-1) (every shipped t_wb, grasping_point.cpp:11-20) */
 };
 
 namespace ccmp {
@@ -120,6 +120,20 @@ CCMP_HD void tool_pose(const ccmp_consts &K, int arm, const double *R, const dou
   double pf[3] = {o[0], o[1], o[2]}, Rf[9];
   mulvec_acc(R, K.ee[arm], pf);
   mul33(R, K.R_tool[arm], Rf);
+#ifndef CCMP_NO_BASE_DIAG
+  if ((K.base_diag >> arm) & 1) {
+    /* t_wb.linear() = diag(+-1): the general product below adds exact zeros to d_r * Rf[r][c] and to
+     * fma(d_r, pf[r], base_p[r]) — the same bits for a third of the operations */
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double d = K.base_R[arm][4 * r];
+#pragma unroll
+      for (int c = 0; c < 3; c++) Rw[3 * r + c] = d * Rf[3 * r + c];
+      pw[r] = CCMP_FMA(d, pf[r], K.base_p[arm][r]);
+    }
+    return;
+  }
+#endif
   mul33(K.base_R[arm], Rf, Rw);
   pw[0] = K.base_p[arm][0]; pw[1] = K.base_p[arm][1]; pw[2] = K.base_p[arm][2];
   mulvec_acc(K.base_R[arm], pf, pw);

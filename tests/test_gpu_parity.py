@@ -291,3 +291,37 @@ def test_iteration_cap_and_loose_tolerance(gpu_ctx, oracle_det):
     # tolerance1 > 1: the reference's `norm1 = f[0] > tol1` stores a boolean, so "1.0 < 10.0" lets an unconverged
     # sample through the return test only if the loop exited — which with tol 10 it does at once: all ok = jointValid
     assert int(it.max()) == 0
+
+
+@pytest.mark.parametrize("schedule", [0, 2])
+def test_general_base_frames_take_the_full_product(gpu_ctx, oracle_det, schedule):
+    """Every shipped t_wb has linear part diag(+-1) and tool_pose skips the products with exact zeros there; a
+    tilted base (arm 2) and a 1-ulp-off identity (arm 1) must go through the general product, bit for bit."""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    a, b = 0.3, -0.7
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Rz = np.array([[np.cos(b), -np.sin(b), 0], [np.sin(b), np.cos(b), 0], [0, 0, 1]])
+    tilt = (Rz @ Rx).reshape(-1)
+    for k in range(9):
+        c.problem.base_R[9 + k] = float(tilt[k])
+    c.problem.base_R[0] = float(np.nextafter(1.0, 0.0))
+    c.setInitialPosition(np.array(c.problem.start_joint[:]))
+    P = _oracle_problem(oracle_det, c)
+    B = 600
+    q = oracle_det.ambient_uniform_batch(P, 0xBA5E, 0, B)
+    f_cpu = oracle_det.function_batch(P, q, NCPU)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+    gpu_ctx.set_schedule(schedule, 0)
+    try:
+        f_gpu = c.function_batch(torch.as_tensor(q).cuda())
+        q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_schedule(1, 8192)
+    assert np.array_equal(f_gpu.cpu().numpy().view(np.uint64), f_cpu.view(np.uint64))
+    assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+    assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)
+    assert np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
+    assert it_cpu.max() > 0

@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIBB = os.path.join(ROOT, "closed_chain_motion_planner_amd", "lib", "libccmp_B.so")
+LIBB = os.environ.get("AB_LIB", os.path.join(ROOT, "closed_chain_motion_planner_amd", "lib", "libccmp_B.so"))
 
 
 def build(flags):
