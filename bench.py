@@ -162,6 +162,10 @@ def main():
             kernel_ms.append((e0, e1))
         return ok, it, q_valid, cnt, gathered
 
+    if world > 1:
+        # communicator set-up (RCCL builds its rings on the first collective): not a step, so that --warmup 0 still
+        # times steps and not the rendezvous
+        gather_valid(torch.zeros((1, 14), dtype=torch.float64, device="cuda"), torch.ones(1, dtype=torch.int64, device="cuda"))
     for _ in range(args.warmup):
         step(False)
     if world > 1:

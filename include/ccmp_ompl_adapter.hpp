@@ -12,7 +12,7 @@
 //       (replaces include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:21-137)
 //   class jy_ProjectedStateSampler : public ompl::base::WrapperStateSampler
 //       (replaces src/base/jy_ProjectedStateSpace.cpp:5-29)
-//   class jy_ProjectedStateSpace : public ompl::base::ProjectedStateSpace
+//   class jy_ProjectedStateSpace : public ompl::base::ConstrainedStateSpace
 //       (replaces src/base/jy_ProjectedStateSpace.cpp:32-96)
 // Neither OMPL nor Eigen is installed in the build image of this repository, so part 2 is exercised
 // only by inspection; part 1 is compiled and run by tests/test_cpp_adapter.py.
@@ -175,7 +175,6 @@ inline bool discreteGeodesic(const Projector &proj, const double *from14, const 
 #include <ompl/base/Constraint.h>
 #include <ompl/base/StateSampler.h>
 #include <ompl/base/spaces/constraint/ConstrainedStateSpace.h>
-#include <ompl/base/spaces/constraint/ProjectedStateSpace.h>
 #include <ompl/util/Exception.h>
 
 #include <closed_chain_motion_planner/kinematics/panda_model.h>  // ArmModelPtr {name, index, ...}
@@ -183,6 +182,10 @@ inline bool discreteGeodesic(const Projector &proj, const double *from14, const 
 class KinematicChainConstraint : public ompl::base::Constraint {
 public:
   explicit KinematicChainConstraint(unsigned int links, int device = 0) : ompl::base::Constraint(links, 2), impl_(new ccmp::Projector(device)) {}
+  // the State* overloads of the base class stay visible next to the overrides below (the samplers and
+  // discreteGeodesic call project(State*) / isSatisfied(const State*), src/base/jy_ProjectedStateSpace.cpp:13,20,27,65)
+  using ompl::base::Constraint::project;
+  using ompl::base::Constraint::isSatisfied;
 
   void setArmModels(const ArmModelPtr &arm1, const ArmModelPtr &arm2) { impl_->setArmModels(arm1->name, arm1->index, arm2->name, arm2->index); }
   void setInitialPosition(const Eigen::Ref<const Eigen::VectorXd> init_joint)
@@ -235,14 +238,12 @@ typedef std::shared_ptr<KinematicChainConstraint> ChainConstraintPtr;
 // jy_ProjectedStateSampler (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:18-29): same
 // name, same overrides; sampleUniform pops GPU-projected samples, Near/Gaussian keep the ambient draw of
 // the wrapped sampler and project through the constraint (one-state launches).
+class jy_ProjectedStateSpace;
+typedef std::shared_ptr<jy_ProjectedStateSpace> jy_ProjectedStateSpacePtr;
+
 class jy_ProjectedStateSampler : public ompl::base::WrapperStateSampler {
 public:
-  jy_ProjectedStateSampler(const ompl::base::ConstrainedStateSpace *space, ompl::base::StateSamplerPtr sampler, uint64_t seed = 0)
-    : ompl::base::WrapperStateSampler(space, std::move(sampler)),
-      constraint_(std::dynamic_pointer_cast<KinematicChainConstraint>(space->getConstraint())),
-      buffer_(constraint_->impl(), seed)
-  {
-  }
+  jy_ProjectedStateSampler(const jy_ProjectedStateSpace *space, ompl::base::StateSamplerPtr sampler, uint64_t seed = 0);
   void sampleUniform(ompl::base::State *state) override
   {
     auto &&x = *state->as<ompl::base::ConstrainedStateSpace::StateType>();
@@ -263,8 +264,8 @@ public:
     space_->enforceBounds(state);
   }
 
-private:
-  std::shared_ptr<KinematicChainConstraint> constraint_;
+protected:
+  const std::shared_ptr<KinematicChainConstraint> constraint_;
   ccmp::SampleBuffer buffer_;
 };
 
@@ -273,13 +274,14 @@ private:
 // StateValidityChecker on the host exactly where the reference consults it (src/base/jy_ProjectedStateSpace.cpp:
 // 65-68); checkMotion of OMPL's ConstrainedMotionValidator (isSatisfied(s2) && discreteGeodesic(s1, s2),
 // src/planner/stefanBiPRM.cpp:397-398,463-464) therefore needs no change.
-class jy_ProjectedStateSpace : public ompl::base::ProjectedStateSpace {
+class jy_ProjectedStateSpace : public ompl::base::ConstrainedStateSpace {
 public:
   jy_ProjectedStateSpace(const ompl::base::StateSpacePtr &ambientSpace, const ompl::base::ConstraintPtr &constraint)
-    : ompl::base::ProjectedStateSpace(ambientSpace, constraint), chain_(std::dynamic_pointer_cast<KinematicChainConstraint>(constraint))
+    : ompl::base::ConstrainedStateSpace(ambientSpace, constraint), chain_(std::dynamic_pointer_cast<KinematicChainConstraint>(constraint))
   {
-    setName("jy_Projected" + space_->getName());
+    setName("Projected" + space_->getName());
   }
+  ~jy_ProjectedStateSpace() override = default;
   ompl::base::StateSamplerPtr allocDefaultStateSampler() const override
   {
     return std::make_shared<jy_ProjectedStateSampler>(this, space_->allocDefaultStateSampler());
@@ -288,8 +290,8 @@ public:
   {
     return std::make_shared<jy_ProjectedStateSampler>(this, space_->allocStateSampler());
   }
-  bool discreteGeodesic(const ompl::base::State *from, const ompl::base::State *to, bool interpolate,
-                        std::vector<ompl::base::State *> *geodesic) const override
+  bool discreteGeodesic(const ompl::base::State *from, const ompl::base::State *to, bool interpolate = false,
+                        std::vector<ompl::base::State *> *geodesic = nullptr) const override
   {
     double a[14], b[14];
     const auto &fa = *from->as<StateType>();
@@ -324,6 +326,13 @@ public:
 private:
   std::shared_ptr<KinematicChainConstraint> chain_;
 };
+
+inline jy_ProjectedStateSampler::jy_ProjectedStateSampler(const jy_ProjectedStateSpace *space, ompl::base::StateSamplerPtr sampler, uint64_t seed)
+  : ompl::base::WrapperStateSampler(space, std::move(sampler)),
+    constraint_(std::dynamic_pointer_cast<KinematicChainConstraint>(space->getConstraint())),
+    buffer_(constraint_->impl(), seed)
+{
+}
 #endif  // CCMP_WITH_OMPL
 
 #endif  // CCMP_OMPL_ADAPTER_HPP

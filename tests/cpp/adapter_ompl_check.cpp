@@ -1,0 +1,138 @@
+// Part 2 of include/ccmp_ompl_adapter.hpp (the classes with the reference's names) against the interface mock in
+// tests/cpp/mock_ompl (NOT OMPL): type-checks the overrides and runs their control flow on the GPU.
+// usage: adapter_ompl_check <start_joint 14 values...>
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define CCMP_WITH_OMPL
+#include "ccmp_ompl_adapter.hpp"
+
+namespace ob = ompl::base;
+
+static void print_hex(const char *tag, const double *v, int n)
+{
+  std::printf("%s", tag);
+  for (int i = 0; i < n; i++) {
+    uint64_t u;
+    std::memcpy(&u, &v[i], 8);
+    std::printf(" %016" PRIx64, u);
+  }
+  std::printf("\n");
+}
+
+// ambient space stand-in: KinematicChainSpace's enforceBounds (KinematicChain.h:118-130) and a fixed "sampler"
+class AmbientSampler : public ob::StateSampler {
+public:
+  using ob::StateSampler::StateSampler;
+  void sampleUniform(ob::State *s) override { fill(s, 0.1); }
+  void sampleUniformNear(ob::State *s, const ob::State *near, double d) override
+  {
+    auto &x = *s->as<ob::ConstrainedStateSpace::StateType>();
+    const auto &n = *near->as<ob::ConstrainedStateSpace::StateType>();
+    for (int i = 0; i < 14; i++) x[i] = n[i] + ((i & 1) ? d : -d) * 0.5;
+  }
+  void sampleGaussian(ob::State *s, const ob::State *mean, double sd) override { sampleUniformNear(s, mean, sd); }
+private:
+  static void fill(ob::State *s, double v)
+  {
+    auto &x = *s->as<ob::ConstrainedStateSpace::StateType>();
+    for (int i = 0; i < 14; i++) x[i] = v;
+  }
+};
+class AmbientSpace : public ob::StateSpace {
+public:
+  AmbientSpace() { setName("KinematicChainSpace"); }
+  ob::StateSamplerPtr allocDefaultStateSampler() const override { return std::make_shared<AmbientSampler>(this); }
+  void enforceBounds(ob::State *s) const override
+  {
+    auto &x = *s->as<ob::ConstrainedStateSpace::StateType>();
+    for (int i = 0; i < 14; i++) {
+      double v = std::fmod(x[i], 2.0 * M_PI);
+      if (v < -M_PI) v += 2.0 * M_PI;
+      else if (v >= M_PI) v -= 2.0 * M_PI;
+      x[i] = v;
+    }
+  }
+  ob::State *allocState() const override { return new ob::ConstrainedStateSpace::StateType(); }
+};
+class CountingChecker : public ob::StateValidityChecker {
+public:
+  explicit CountingChecker(int accept) : accept_(accept) {}
+  bool isValid(const ob::State *) const override { return calls_++ < accept_; }
+  mutable int calls_ = 0;
+  int accept_;
+};
+
+int main(int argc, char **argv)
+{
+  if (argc < 15) return 2;
+  try {
+    Eigen::VectorXd start(14);
+    for (int i = 0; i < 14; i++) start[i] = std::atof(argv[1 + i]);
+    // the set-up of ConstrainedProblem::setConstrainedOptions (ConstrainedPlanningCommon.cpp:116-132)
+    auto arm1 = std::make_shared<ArmModel>();
+    auto arm2 = std::make_shared<ArmModel>();
+    arm1->name = "panda_left"; arm1->index = 0;
+    arm2->name = "panda_right"; arm2->index = 1;
+    ChainConstraintPtr constraint = std::make_shared<KinematicChainConstraint>(14);
+    constraint->setArmModels(arm1, arm2);
+    constraint->setInitialPosition(start);
+    constraint->setTolerance(1e-3, 5e-3);
+    constraint->setMaxIterations(1000);
+    bool threw = false;
+    try { constraint->setTolerance(-1.0, 1.0); } catch (const ompl::Exception &) { threw = true; }
+    std::printf("throws %d codim %u\n", threw ? 1 : 0, constraint->getCoDimension());
+
+    auto ambient = std::make_shared<AmbientSpace>();
+    auto space = std::make_shared<jy_ProjectedStateSpace>(ambient, constraint);
+    ob::SpaceInformation si;
+    space->setSpaceInformation(&si);
+    space->setDelta(0.25);
+    space->setLambda(2.0);
+    std::printf("name %s\n", space->getName().c_str());
+
+    // Constraint::project(State*) -> the Eigen::Ref override -> GPU
+    ob::State *a = space->allocState(), *b = space->allocState();
+    auto &xa = *a->as<ob::ConstrainedStateSpace::StateType>();
+    auto &xb = *b->as<ob::ConstrainedStateSpace::StateType>();
+    for (int i = 0; i < 14; i++) xa[i] = start[i] + 0.05 * ((i % 3) - 1);
+    const bool oka = constraint->project(a);
+    std::printf("project %d satisfied %d\n", oka ? 1 : 0, constraint->isSatisfied(a) ? 1 : 0);
+    print_hex("xa", xa.values, 14);
+    Eigen::VectorXd f(2);
+    constraint->function(xa, f);
+    print_hex("fa", f.data(), 2);
+
+    // sampler: sampleUniform pops a GPU-projected, wrapped sample; Near projects the wrapped sampler's draw
+    ob::StateSamplerPtr sampler = space->allocDefaultStateSampler();
+    sampler->sampleUniform(b);
+    print_hex("uniform", xb.values, 14);
+    sampler->sampleUniformNear(b, a, 0.2);
+    std::printf("near_satisfied %d\n", constraint->isSatisfied(b) ? 1 : 0);
+    print_hex("near", xb.values, 14);
+
+    // extend step a -> b with a validity checker that accepts everything, then only the first two states
+    for (int accept : {1000000, 2}) {
+      auto svc = std::make_shared<CountingChecker>(accept);
+      si.setStateValidityChecker(svc);
+      std::vector<ob::State *> geo;
+      const bool g = space->discreteGeodesic(a, b, false, &geo);
+      std::printf("geodesic accept %d ok %d n %zu checker_calls %d\n", accept, g ? 1 : 0, geo.size(), svc->calls_);
+      for (ob::State *s : geo) {
+        print_hex("g", s->as<ob::ConstrainedStateSpace::StateType>()->values, 14);
+        space->freeState(s);
+      }
+    }
+    const bool gi = space->discreteGeodesic(a, b, true);
+    std::printf("geodesic_interpolate ok %d\n", gi ? 1 : 0);
+    space->freeState(a);
+    space->freeState(b);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -74,3 +74,66 @@ def test_adapter_matches_oracle(ccmp_built, oracle_det, tmp_path):
     k += 1 + len(st_g)
     hdr = out[k].split()
     assert int(hdr[4]) == min(1, len(st_g)) and (int(hdr[2]) == 0 or len(st_g) == 1)  # everything rejected: only `from` survives
+
+
+OMPL_EXE = os.path.join(ROOT, "tests", "cpp", "adapter_ompl_check")
+
+
+def _build_part2(ccmp_built):
+    libdir = os.path.dirname(ccmp_built)
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "mock_ompl"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "adapter_ompl_check.cpp"), "-L", libdir, "-lccmp", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath,/opt/rocm/lib", "-o", OMPL_EXE]
+    subprocess.run(cmd, check=True)
+    return OMPL_EXE
+
+
+def test_part2_type_checks_against_the_interface_mock(ccmp_built):
+    """Part 2 (the classes with the reference's names, deriving from OMPL's) compiled against tests/cpp/mock_ompl — an
+    interface mock, not OMPL: override signatures, the State* overloads kept visible, state access."""
+    assert os.path.exists(_build_part2(ccmp_built))
+
+
+def _hex_row(line, tag):
+    parts = line.split()
+    assert parts[0] == tag, line
+    return np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in parts[1:]])
+
+
+@pytest.mark.gpu
+def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
+    from closed_chain_motion_planner_amd import load_config
+
+    exe = _build_part2(ccmp_built)
+    P = oracle_det.problem_from_bytes(bytes(load_config(config_path("Wine_Bottle"))))
+    start = np.array(P.start_joint[:])
+    out = subprocess.run([exe] + ["%.17g" % v for v in start], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == "throws 1 codim 2"
+    assert out[1] == "name ProjectedKinematicChainSpace"
+    xa0 = start + 0.05 * ((np.arange(14) % 3) - 1)
+    ok_a, xa, _ = oracle_det.project(P, xa0)
+    assert out[2] == "project %d satisfied %d" % (int(ok_a), int(oracle_det.is_satisfied(P, xa)))
+    assert np.array_equal(_hex_row(out[3], "xa").view(np.uint64), xa.view(np.uint64))
+    assert np.array_equal(_hex_row(out[4], "fa"), oracle_det.function(P, xa))
+    exp, _, _ = oracle_det.sample_project_batch(P, 0, 0, 1, 1)  # sampleUniform: seed 0, running index 0
+    assert np.array_equal(_hex_row(out[5], "uniform").view(np.uint64), exp[0].view(np.uint64))
+    near0 = xa + np.where(np.arange(14) & 1, 0.2, -0.2) * 0.5
+    _, xn, _ = oracle_det.project(P, near0)
+    xn = oracle_det.enforce_bounds(xn)
+    assert out[6] == "near_satisfied %d" % int(oracle_det.is_satisfied(P, xn))
+    assert np.array_equal(_hex_row(out[7], "near").view(np.uint64), xn.view(np.uint64))
+    ok_g, st_g, _ = oracle_det.discrete_geodesic(P, xa, xn, interpolate=True, max_states=256)
+    k = 8
+    n_full = len(st_g)
+    assert out[k] == "geodesic accept 1000000 ok %d n %d checker_calls %d" % (int(ok_g), n_full, n_full - 1)
+    for j in range(n_full):
+        assert np.array_equal(_hex_row(out[k + 1 + j], "g").view(np.uint64), st_g[j].view(np.uint64))
+    k += 1 + n_full
+    hdr = out[k].split()
+    n_cut = min(n_full, 3)  # `from` + the two states the checker accepted
+    assert hdr[:3] == ["geodesic", "accept", "2"] and int(hdr[6]) == n_cut and int(hdr[8]) == min(n_full - 1, 3)
+    if n_full > 3:
+        d = float(np.sqrt(((st_g[2] - xn) ** 2).sum()))
+        assert int(hdr[4]) == int(d <= 0.25)
+    k += 1 + n_cut
+    assert out[k] == "geodesic_interpolate ok %d" % int(ok_g)
