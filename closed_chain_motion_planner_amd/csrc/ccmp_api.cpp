@@ -328,6 +328,8 @@ struct ccmp_ctx {
   // staging for the *_host conveniences
   void *stage = nullptr;
   size_t stage_cap = 0;
+  void *pin = nullptr;     // pinned, device-mapped host block for small *_host calls (single states of the reference signature)
+  void *pin_dev = nullptr; // the same block as the kernels see it
 };
 
 namespace {
@@ -356,6 +358,53 @@ int ensure_stage(ccmp_ctx *ctx, size_t bytes)
   ctx->stage_cap = bytes;
   return CCMP_OK;
 }
+
+// Host buffers of the *_host entry points.  Up to kPinBytes the kernels work directly on a pinned, device-mapped host
+// block (a single project(x) is then memcpy + launch + synchronize + memcpy: no staged pageable copies, ~3 driver
+// calls fewer); larger batches go through device staging with asynchronous copies.
+constexpr size_t kPinBytes = 64 * 1024;
+struct HostIO {
+  ccmp_ctx *ctx;
+  char *dev = nullptr;  // what the kernels get
+  char *host = nullptr; // pinned alias (small calls) or nullptr
+  struct Out { void *dst; size_t off, n; } outs[4];
+  int n_outs = 0;
+  explicit HostIO(ccmp_ctx *c) : ctx(c) {}
+  int begin(size_t bytes)
+  {
+    if (bytes <= kPinBytes) {
+      if (!ctx->pin) {
+        HIP_TRY(hipHostMalloc(&ctx->pin, kPinBytes, hipHostMallocMapped));
+        hipError_t e = hipHostGetDevicePointer(&ctx->pin_dev, ctx->pin, 0);
+        if (e != hipSuccess) { (void)hipHostFree(ctx->pin); ctx->pin = nullptr; return hip_fail(e, "hipHostGetDevicePointer"); }
+      }
+      host = (char *)ctx->pin;
+      dev = (char *)ctx->pin_dev;
+      return CCMP_OK;
+    }
+    int rc = ensure_stage(ctx, bytes);
+    dev = (char *)ctx->stage;
+    return rc;
+  }
+  int in(size_t off, const void *src, size_t n)
+  {
+    if (host) { memcpy(host + off, src, n); return CCMP_OK; }
+    HIP_TRY(hipMemcpyAsync(dev + off, src, n, hipMemcpyHostToDevice, ctx->stream));
+    return CCMP_OK;
+  }
+  int out(void *dst, size_t off, size_t n)
+  {
+    if (host) { outs[n_outs++] = Out{dst, off, n}; return CCMP_OK; }
+    HIP_TRY(hipMemcpyAsync(dst, dev + off, n, hipMemcpyDeviceToHost, ctx->stream));
+    return CCMP_OK;
+  }
+  int finish()
+  {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_outs; i++) memcpy(outs[i].dst, host + outs[i].off, outs[i].n);
+    return CCMP_OK;
+  }
+};
 
 int projector_blocks(const ccmp_ctx *ctx, size_t B, int samples_per_wave, int default_wpc)
 {
@@ -526,6 +575,7 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx)
   if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
   if (ctx->scan) (void)hipFree(ctx->scan);
   if (ctx->stage) (void)hipFree(ctx->stage);
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -829,20 +879,17 @@ int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, 
   const size_t qb = B * 14 * sizeof(double);
   const size_t off_ok = (qb + 255) & ~(size_t)255;
   const size_t off_it = (off_ok + B + 255) & ~(size_t)255;
-  int rc = ensure_stage(ctx, off_it + B * sizeof(uint16_t));
+  HostIO io(ctx);
+  int rc = io.begin(off_it + B * sizeof(uint16_t));
   if (rc != CCMP_OK) return rc;
-  char *base = (char *)ctx->stage;
-  double *dq = (double *)base;
-  uint8_t *dok = (uint8_t *)(base + off_ok);
-  uint16_t *dit = (uint16_t *)(base + off_it);
-  HIP_TRY(hipMemcpyAsync(dq, q_in, qb, hipMemcpyHostToDevice, ctx->stream));
-  rc = ccmp_project_batch(ctx, p, dq, dq, dok, dit, B, ctx->stream);
+  if ((rc = io.in(0, q_in, qb)) != CCMP_OK) return rc;
+  rc = ccmp_project_batch(ctx, p, (const double *)io.dev, (double *)io.dev, (uint8_t *)(io.dev + off_ok), (uint16_t *)(io.dev + off_it), B,
+                          ctx->stream);
   if (rc != CCMP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(q_out, dq, qb, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ok, dok, B, hipMemcpyDeviceToHost, ctx->stream));
-  if (iters) HIP_TRY(hipMemcpyAsync(iters, dit, B * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CCMP_OK;
+  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return rc;
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
+  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return rc;
+  return io.finish();
 }
 
 int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, double *f, size_t B)
@@ -854,15 +901,14 @@ int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, do
   if (!guard.ok) return CCMP_ENODEV;
   const size_t qb = B * 14 * sizeof(double);
   const size_t off_f = (qb + 255) & ~(size_t)255;
-  int rc = ensure_stage(ctx, off_f + B * 2 * sizeof(double));
+  HostIO io(ctx);
+  int rc = io.begin(off_f + B * 2 * sizeof(double));
   if (rc != CCMP_OK) return rc;
-  char *base = (char *)ctx->stage;
-  HIP_TRY(hipMemcpyAsync(base, q, qb, hipMemcpyHostToDevice, ctx->stream));
-  rc = ccmp_function_batch(ctx, p, (const double *)base, (double *)(base + off_f), B, ctx->stream);
+  if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
+  rc = ccmp_function_batch(ctx, p, (const double *)io.dev, (double *)(io.dev + off_f), B, ctx->stream);
   if (rc != CCMP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(f, base + off_f, B * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CCMP_OK;
+  if ((rc = io.out(f, off_f, B * 2 * sizeof(double))) != CCMP_OK) return rc;
+  return io.finish();
 }
 
 int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B)
@@ -874,15 +920,14 @@ int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
   if (!guard.ok) return CCMP_ENODEV;
   const size_t qb = B * 14 * sizeof(double);
   const size_t off_ok = (qb + 255) & ~(size_t)255;
-  int rc = ensure_stage(ctx, off_ok + B);
+  HostIO io(ctx);
+  int rc = io.begin(off_ok + B);
   if (rc != CCMP_OK) return rc;
-  char *base = (char *)ctx->stage;
-  HIP_TRY(hipMemcpyAsync(base, q, qb, hipMemcpyHostToDevice, ctx->stream));
-  rc = ccmp_is_satisfied_batch(ctx, p, (const double *)base, (uint8_t *)(base + off_ok), B, ctx->stream);
+  if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
+  rc = ccmp_is_satisfied_batch(ctx, p, (const double *)io.dev, (uint8_t *)(io.dev + off_ok), B, ctx->stream);
   if (rc != CCMP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(ok, base + off_ok, B, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CCMP_OK;
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
+  return io.finish();
 }
 
 int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B)
@@ -894,15 +939,14 @@ int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q,
   if (!guard.ok) return CCMP_ENODEV;
   const size_t qb = B * 14 * sizeof(double);
   const size_t off_ok = (qb + 255) & ~(size_t)255;
-  int rc = ensure_stage(ctx, off_ok + B);
+  HostIO io(ctx);
+  int rc = io.begin(off_ok + B);
   if (rc != CCMP_OK) return rc;
-  char *base = (char *)ctx->stage;
-  HIP_TRY(hipMemcpyAsync(base, q, qb, hipMemcpyHostToDevice, ctx->stream));
-  rc = ccmp_joint_valid_batch(ctx, p, (const double *)base, (uint8_t *)(base + off_ok), B, ctx->stream);
+  if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
+  rc = ccmp_joint_valid_batch(ctx, p, (const double *)io.dev, (uint8_t *)(io.dev + off_ok), B, ctx->stream);
   if (rc != CCMP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(ok, base + off_ok, B, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CCMP_OK;
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
+  return io.finish();
 }
 
 int ccmp_sample_project_host(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index, double *q_out,
@@ -916,17 +960,16 @@ int ccmp_sample_project_host(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed
   const size_t qb = B * 14 * sizeof(double);
   const size_t off_ok = (qb + 255) & ~(size_t)255;
   const size_t off_it = (off_ok + B + 255) & ~(size_t)255;
-  int rc = ensure_stage(ctx, off_it + B * sizeof(uint16_t));
+  HostIO io(ctx);
+  int rc = io.begin(off_it + B * sizeof(uint16_t));
   if (rc != CCMP_OK) return rc;
-  char *base = (char *)ctx->stage;
-  rc = ccmp_sample_project_batch(ctx, p, seed, first_index, (double *)base, (uint8_t *)(base + off_ok),
-                                 (uint16_t *)(base + off_it), nullptr, B, ctx->stream);
+  rc = ccmp_sample_project_batch(ctx, p, seed, first_index, (double *)io.dev, (uint8_t *)(io.dev + off_ok), (uint16_t *)(io.dev + off_it),
+                                 nullptr, B, ctx->stream);
   if (rc != CCMP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(q_out, base, qb, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ok, base + off_ok, B, hipMemcpyDeviceToHost, ctx->stream));
-  if (iters) HIP_TRY(hipMemcpyAsync(iters, base + off_it, B * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CCMP_OK;
+  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return rc;
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
+  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return rc;
+  return io.finish();
 }
 
 int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
@@ -943,19 +986,18 @@ int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from,
   const size_t off_st = (off_to + eb + 255) & ~(size_t)255;
   const size_t off_n = (off_st + sb + 255) & ~(size_t)255;
   const size_t off_ok = (off_n + E * sizeof(int32_t) + 255) & ~(size_t)255;
-  int rc = ensure_stage(ctx, off_ok + E);
+  HostIO io(ctx);
+  int rc = io.begin(off_ok + E);
   if (rc != CCMP_OK) return rc;
-  char *base = (char *)ctx->stage;
-  HIP_TRY(hipMemcpyAsync(base, from, eb, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(base + off_to, to, eb, hipMemcpyHostToDevice, ctx->stream));
-  rc = ccmp_geodesic_batch(ctx, p, (const double *)base, (const double *)(base + off_to), E, max_states, (double *)(base + off_st),
-                           (int32_t *)(base + off_n), (uint8_t *)(base + off_ok), nullptr, ctx->stream);
+  if ((rc = io.in(0, from, eb)) != CCMP_OK) return rc;
+  if ((rc = io.in(off_to, to, eb)) != CCMP_OK) return rc;
+  rc = ccmp_geodesic_batch(ctx, p, (const double *)io.dev, (const double *)(io.dev + off_to), E, max_states, (double *)(io.dev + off_st),
+                           (int32_t *)(io.dev + off_n), (uint8_t *)(io.dev + off_ok), nullptr, ctx->stream);
   if (rc != CCMP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(states, base + off_st, sb, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(n_states, base + off_n, E * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ok, base + off_ok, E, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CCMP_OK;
+  if ((rc = io.out(states, off_st, sb)) != CCMP_OK) return rc;
+  if ((rc = io.out(n_states, off_n, E * sizeof(int32_t))) != CCMP_OK) return rc;
+  if ((rc = io.out(ok, off_ok, E)) != CCMP_OK) return rc;
+  return io.finish();
 }
 
 static int sharded_common(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, int mode, const double *q_in, double *q_out,

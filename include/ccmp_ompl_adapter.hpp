@@ -327,6 +327,17 @@ private:
   std::shared_ptr<KinematicChainConstraint> chain_;
 };
 
+// jy_MotionValidator (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:57-69): unchanged logic,
+// isSatisfied(s2) is one single-state launch and the traversal runs in jy_ProjectedStateSpace::discreteGeodesic above.
+class jy_MotionValidator : public ompl::base::ConstrainedMotionValidator {
+public:
+  jy_MotionValidator(const ompl::base::SpaceInformationPtr &si) : ompl::base::ConstrainedMotionValidator(si) {}
+  bool checkMotion(const ompl::base::State *s1, const ompl::base::State *s2) const override
+  {
+    return ss_.getConstraint()->isSatisfied(s2) && ss_.discreteGeodesic(s1, s2, false);
+  }
+};
+
 inline jy_ProjectedStateSampler::jy_ProjectedStateSampler(const jy_ProjectedStateSpace *space, ompl::base::StateSamplerPtr sampler, uint64_t seed)
   : ompl::base::WrapperStateSampler(space, std::move(sampler)),
     constraint_(std::dynamic_pointer_cast<KinematicChainConstraint>(space->getConstraint())),

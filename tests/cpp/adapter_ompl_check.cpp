@@ -88,7 +88,9 @@ int main(int argc, char **argv)
 
     auto ambient = std::make_shared<AmbientSpace>();
     auto space = std::make_shared<jy_ProjectedStateSpace>(ambient, constraint);
-    ob::SpaceInformation si;
+    auto si_ptr = std::make_shared<ob::SpaceInformation>();
+    ob::SpaceInformation &si = *si_ptr;
+    si.setStateSpace(space);
     space->setSpaceInformation(&si);
     space->setDelta(0.25);
     space->setLambda(2.0);
@@ -126,6 +128,9 @@ int main(int argc, char **argv)
         space->freeState(s);
       }
     }
+    si.setStateValidityChecker(std::make_shared<CountingChecker>(1000000));
+    jy_MotionValidator mv(si_ptr);
+    std::printf("checkMotion %d %d\n", mv.checkMotion(a, b) ? 1 : 0, mv.checkMotion(b, a) ? 1 : 0);
     const bool gi = space->discreteGeodesic(a, b, true);
     std::printf("geodesic_interpolate ok %d\n", gi ? 1 : 0);
     space->freeState(a);

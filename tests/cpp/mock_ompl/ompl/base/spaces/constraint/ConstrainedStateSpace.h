@@ -16,16 +16,22 @@ public:
   virtual bool isValid(const State *state) const = 0;
 };
 typedef std::shared_ptr<StateValidityChecker> StateValidityCheckerPtr;
+class StateSpace;
 class SpaceInformation {
 public:
   const StateValidityCheckerPtr &getStateValidityChecker() const { return svc_; }
   void setStateValidityChecker(const StateValidityCheckerPtr &s) { svc_ = s; }
+  const std::shared_ptr<StateSpace> &getStateSpace() const { return space_; }
+  void setStateSpace(const std::shared_ptr<StateSpace> &s) { space_ = s; }
 private:
   StateValidityCheckerPtr svc_;
+  std::shared_ptr<StateSpace> space_;
 };
+typedef std::shared_ptr<SpaceInformation> SpaceInformationPtr;
 class StateSpace {
 public:
   virtual ~StateSpace() = default;
+  template <class T> const T *as() const { return static_cast<const T *>(this); }
   const std::string &getName() const { return name_; }
   void setName(const std::string &n) { name_ = n; }
   virtual StateSamplerPtr allocDefaultStateSampler() const = 0;
@@ -58,6 +64,21 @@ protected:
   const StateSpacePtr space_;
   const ConstraintPtr constraint_;
   double delta_, lambda_;
+};
+class MotionValidator {
+public:
+  explicit MotionValidator(const SpaceInformationPtr &si) : si_(si.get()) {}
+  virtual ~MotionValidator() = default;
+  virtual bool checkMotion(const State *s1, const State *s2) const = 0;
+protected:
+  SpaceInformation *si_;
+};
+class ConstrainedMotionValidator : public MotionValidator {
+public:
+  explicit ConstrainedMotionValidator(const SpaceInformationPtr &si) : MotionValidator(si), ss_(*si->getStateSpace()->as<ConstrainedStateSpace>()) {}
+  bool checkMotion(const State *s1, const State *s2) const override { return ss_.getConstraint()->isSatisfied(s2) && ss_.discreteGeodesic(s1, s2, false); }
+protected:
+  const ConstrainedStateSpace &ss_;
 };
 inline bool Constraint::project(State *state) const { return project(Eigen::Ref<Eigen::VectorXd>(*state->as<ConstrainedStateSpace::StateType>())); }
 inline bool Constraint::isSatisfied(const State *state) const { return isSatisfied(Eigen::Ref<const Eigen::VectorXd>(*state->as<ConstrainedStateSpace::StateType>())); }

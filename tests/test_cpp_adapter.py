@@ -136,4 +136,6 @@ def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
         d = float(np.sqrt(((st_g[2] - xn) ** 2).sum()))
         assert int(hdr[4]) == int(d <= 0.25)
     k += 1 + n_cut
-    assert out[k] == "geodesic_interpolate ok %d" % int(ok_g)
+    ok_back, _, _ = oracle_det.discrete_geodesic(P, xn, xa, interpolate=True, max_states=256)
+    assert out[k] == "checkMotion %d %d" % (int(oracle_det.is_satisfied(P, xn) and ok_g), int(oracle_det.is_satisfied(P, xa) and ok_back))
+    assert out[k + 1] == "geodesic_interpolate ok %d" % int(ok_g)
