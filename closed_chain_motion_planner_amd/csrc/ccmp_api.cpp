@@ -677,7 +677,8 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       nwave = (int)(need < (size_t)wave_blocks ? need : (size_t)wave_blocks);
     }
     // queue[0]: sample queue of the group kernel; queue[1]: pool fill count; queue[2]: read head of the wave kernel
-    HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
+    const bool pair_path = nblocks == 0 && ctx->pair_kernel && B <= (size_t)ctx->num_cus; // strides statically: no queue
+    if (!pair_path) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
     const unsigned int *order = ctx->order;
     if (nblocks > 0 && !order && ctx->lpt > 0 && B >= ctx->lpt_min_batch && B < 0xffffffffull) {
       // FP32 scout pass -> predicted iteration counts -> descending counting sort -> processing order
@@ -707,7 +708,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       if (nwave > 0)
         HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
                                          ctx->queue + 1, mode, nwave, st));
-    } else if (ctx->pair_kernel && B <= (size_t)ctx->num_cus) {
+    } else if (pair_path) {
       // a handful of samples (single-state calls of the reference signature): one sample per pair of waves is
       // ~10 % quicker per sample; from a few hundred samples on the single-wave kernel wins (tools/time_small.py)
       HIP_TRY(ccmp_launch_project_pair(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, mode, (int)B, st));

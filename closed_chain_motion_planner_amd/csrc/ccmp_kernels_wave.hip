@@ -268,8 +268,8 @@ __global__ __launch_bounds__(128) void project_fd_pair_kernel(
 {
   __shared__ double lds[wRec];
   __shared__ double ktab[kConstsDoubles + 1];
-  __shared__ unsigned long long ticket;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  (void)queue;
   {
     const double *src = reinterpret_cast<const double *>(&K);
     for (int k = tid; k < kConstsDoubles; k += 128) ktab[k] = src[k];
@@ -278,11 +278,8 @@ __global__ __launch_bounds__(128) void project_fd_pair_kernel(
   const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
   double *rec = lds;
 
-  for (;;) {
-    if (tid == 0) ticket = atomicAdd(queue, 1ull);
-    __syncthreads();
-    const unsigned long long idx = ticket;
-    if (idx >= B) break;
+  // launched with one block per sample (B <= number of CUs): static striding, no queue word to reset before the launch
+  for (unsigned long long idx = blockIdx.x; idx < B; idx += gridDim.x) {
     if (tid < 14) {
       double v;
       if (SRC == 0) v = q_in[idx * 14 + tid];
