@@ -28,6 +28,15 @@ def load_cfg(obj):
         return yaml.safe_load(f)
 
 
+def load_roadmap(obj):
+    """(nodes (N,14), directed edges) of the reference's recorded planner roadmap (tests/golden/make_fixtures.py)."""
+    import json
+
+    with open(os.path.join(GOLDEN, "roadmaps", obj + "_roadmap.json")) as f:
+        d = json.load(f)
+    return np.array(d["nodes"], dtype=np.float64), [tuple(e) for e in d["edges"]]
+
+
 def load_path_rows(obj):
     return np.loadtxt(os.path.join(GOLDEN, "paths", obj + "_path.txt"))
 

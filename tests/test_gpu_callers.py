@@ -43,6 +43,31 @@ def test_discrete_geodesic_batch_bitwise(gpu_ctx, oracle_det):
           % (n_ok, len(frm), n.mean(), its.mean()))
 
 
+@pytest.mark.parametrize("obj", ["Wine_Bottle", "dumbbell"])
+def test_recorded_roadmap_edges_bitwise(gpu_ctx, oracle_det, obj):
+    """Every directed edge of the reference's dumped roadmap through the GPU extend step: states, counts and flags
+    identical to the oracle (the endpoints are mostly IK milestones ~1e-2 off the manifold: first steps need real
+    Newton work, unlike edges between projected states)."""
+    import torch
+    from conftest import load_roadmap
+
+    c = _constraint(obj, gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    nodes, edges = load_roadmap(obj)
+    frm = np.array([nodes[a] for a, _ in edges])
+    to = np.array([nodes[b] for _, b in edges])
+    maxs = 64
+    st, n, ok, its = c.discrete_geodesic_batch(torch.as_tensor(frm).cuda(), torch.as_tensor(to).cuda(), maxs)
+    st, n, ok = st.cpu().numpy(), n.cpu().numpy(), ok.cpu().numpy()
+    reached = 0
+    for e in range(len(edges)):
+        ok_cpu, st_cpu, _ = oracle_det.discrete_geodesic(P, frm[e], to[e], interpolate=True, max_states=maxs)
+        assert int(ok[e]) == int(ok_cpu) and int(n[e]) == len(st_cpu), (edges[e], ok[e], ok_cpu, n[e], len(st_cpu))
+        assert np.array_equal(st[e, : n[e]].view(np.uint64), st_cpu.view(np.uint64))
+        reached += int(ok_cpu)
+    assert reached >= len(edges) - 1
+
+
 def test_geodesic_host_mirror_with_validity(gpu_ctx, oracle_det):
     """interpolate == False: the host validity checker cuts the list where the reference would break"""
     from closed_chain_motion_planner_amd import jy_ProjectedStateSpace

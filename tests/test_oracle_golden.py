@@ -210,6 +210,40 @@ def test_discrete_geodesic_properties(oracle_det):
     assert ok2 and len(st2) == 1
 
 
+@pytest.mark.parametrize("obj", ["Wine_Bottle", "dumbbell"])
+def test_recorded_roadmap_edges_are_traversable(oracle_det, obj):
+    """The reference's dumped roadmap (debug/<obj>_node_info.graphml): node 0 is start_joint; the other milestones are
+    IK vertices (off the manifold by ~1e-2, like the IK rows of the recorded paths) or projector outputs (just under
+    tolerance); every recorded connection was accepted by the reference's checkMotion (discreteGeodesic + collision),
+    so discreteGeodesic without the collision test must reach the target at least one way round."""
+    from conftest import load_roadmap
+
+    cfg = load_cfg(obj)
+    P = oracle_det.problem(cfg)
+    nodes, edges = load_roadmap(obj)
+    f = np.array([oracle_det.function(P, n) for n in nodes])
+    assert np.abs(nodes[0] - np.array(cfg["start_joint"])).max() < 1e-5 and f[0].max() < 1e-5
+    on = [i for i in range(1, len(nodes)) if oracle_det.is_satisfied(P, nodes[i])]
+    off = [i for i in range(1, len(nodes)) if i not in on]
+    for i in on:   # stopped by the Newton loop the first time both tolerances held
+        assert 7e-4 <= f[i, 0] <= 1e-3 + 2e-5 and f[i, 1] <= 5e-3 + 5e-5
+    for i in off:  # IK milestones
+        assert 5e-3 < f[i, 0] < 2.5e-2 and f[i, 1] < 8e-2
+    assert len(on) == (2 if obj == "Wine_Bottle" else 0)
+    pairs = sorted({(min(a, b), max(a, b)) for a, b in edges})
+    assert len(edges) == 2 * len(pairs)  # stored as two directed edges per connection
+    both = 0
+    for a, b in pairs:
+        ok_ab, st_ab, _ = oracle_det.discrete_geodesic(P, nodes[a], nodes[b], interpolate=True)
+        ok_ba, st_ba, _ = oracle_det.discrete_geodesic(P, nodes[b], nodes[a], interpolate=True)
+        assert ok_ab or ok_ba, (a, b)
+        both += int(ok_ab and ok_ba)
+        for st in (st_ab, st_ba):  # consecutive states at most lambda*delta apart, about dist/delta of them
+            assert all(oracle_det.distance(st[i], st[i + 1]) <= P.lambda_ * P.delta for i in range(len(st) - 1))
+    print("%s: %d connections, %d traversable both ways" % (obj, len(pairs), both))
+    assert both >= len(pairs) - 1
+
+
 def test_sampler_is_counter_based(oracle_det):
     P = oracle_det.problem(load_cfg("stefan"))
     a = oracle_det.ambient_uniform_batch(P, 9, 100, 8)
