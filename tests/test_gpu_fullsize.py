@@ -91,3 +91,24 @@ def test_shards_reproduce_the_whole(gpu_ctx):
     assert int(cnt.item()) == int(ok_w.sum().item())
     assert torch.equal(valid[: int(cnt.item())], whole[ok_w == 1])
     assert (whole.abs() <= np.pi).all()
+
+
+def test_c5_eight_shards_reproduce_the_two_million_batch(gpu_ctx):
+    """BASELINE configs[4] on one card: Wine_Bottle, 2 097 152 samples in one launch == the 8 rank shards of 262 144
+    (what bench.py --gpus 8 gives each rank), joints, flags and iteration counts; and the gathered valid states are
+    the whole batch's valid states in global order."""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    n, w = 2097152, 8
+    whole, ok_w, it_w, _ = c.sample_project_batch(0xC5, 0, n)
+    valid_parts = []
+    for r in range(w):
+        q, ok, it, _ = c.sample_project_batch(0xC5, r * (n // w), n // w)
+        sl = slice(r * (n // w), (r + 1) * (n // w))
+        assert torch.equal(q, whole[sl]) and torch.equal(ok, ok_w[sl]) and torch.equal(it, it_w[sl]), r
+        v, cnt = c.compact_valid(q, ok)
+        valid_parts.append(v[: int(cnt.item())].clone())
+    assert torch.equal(torch.cat(valid_parts), whole[ok_w == 1])
+    frac = float(ok_w.to(torch.float64).mean().item())
+    assert 0.15 < frac < 0.30 and 30.0 < float(it_w.to(torch.float64).mean().item()) < 36.0
