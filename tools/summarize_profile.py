@@ -49,7 +49,7 @@ def main():
     parts = []
     for r in csv.DictReader(open(stats)):
         if any(ks in r["Name"] for ks in kernel_subs):
-            parts.append((r["Name"].split("(")[0], int(r["Calls"]), float(r["AverageNs"]) / 1e6))
+            parts.append((next(ks for ks in kernel_subs if ks in r["Name"]), int(r["Calls"]), float(r["AverageNs"]) / 1e6))
             if krow is None:
                 krow = dict(r)
             else:  # one projector launch = one call of each kernel: durations add
