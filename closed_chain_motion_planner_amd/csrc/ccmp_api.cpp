@@ -516,9 +516,22 @@ int ccmp_problem_init(ccmp_problem *out, const char *arm1_name, int arm1_index, 
   return ccmp_set_start(out, start_joint);
 }
 
+static int problem_from_yaml_impl(const char *yaml_path, ccmp_problem *out);
+
 int ccmp_problem_from_yaml(const char *yaml_path, ccmp_problem *out)
 {
   if (!yaml_path || !out) return CCMP_EINVAL;
+  try { // the reader uses std::string / std::map: nothing may propagate through the C boundary
+    return problem_from_yaml_impl(yaml_path, out);
+  } catch (const std::bad_alloc &) {
+    return CCMP_ENOMEM;
+  } catch (...) {
+    return CCMP_EPARSE;
+  }
+}
+
+static int problem_from_yaml_impl(const char *yaml_path, ccmp_problem *out)
+{
   YamlDoc doc;
   int rc = parse_yaml(yaml_path, doc);
   if (rc != CCMP_OK) return rc;
@@ -1004,15 +1017,17 @@ int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from,
 static int sharded_common(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, int mode, const double *q_in, double *q_out,
                           uint8_t *ok, uint16_t *iters, uint64_t seed, uint64_t first_index, size_t B)
 {
-  if (!ctxs || n < 1 || !p) return CCMP_EINVAL;
+  if (!ctxs || n < 1 || n > 64 || !p) return CCMP_EINVAL;
   for (int g = 0; g < n; g++)
     if (!ctxs[g]) return CCMP_EINVAL;
   if (B == 0) return CCMP_OK;
   if (!q_out || !ok || (mode == 0 && !q_in)) return CCMP_EINVAL;
-  struct Shard { size_t lo, hi, off_ok, off_it; };
-  std::vector<Shard> sh((size_t)n);
-  // phase 1: enqueue everything on every context's stream (no host wait in between)
-  for (int g = 0; g < n; g++) {
+  struct Shard { size_t lo, hi, off_ok, off_it; bool busy; } sh[64];
+  for (int g = 0; g < n; g++) sh[g] = Shard{0, 0, 0, 0, false};
+  int rc = CCMP_OK;
+  // phase 1: upload and launch on every context's stream.  Copies from pageable host memory return once the data is
+  // staged, so the next GPU starts while this one computes.
+  for (int g = 0; g < n && rc == CCMP_OK; g++) {
     const size_t base = B / (size_t)n, rem = B % (size_t)n;
     sh[g].lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem);
     sh[g].hi = sh[g].lo + base + ((size_t)g < rem ? 1 : 0);
@@ -1020,33 +1035,44 @@ static int sharded_common(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, i
     if (nb == 0) continue;
     ccmp_ctx *ctx = ctxs[g];
     DeviceGuard guard(ctx->device);
-    if (!guard.ok) return CCMP_ENODEV;
+    if (!guard.ok) { rc = CCMP_ENODEV; break; }
     const size_t qb = nb * 14 * sizeof(double);
     sh[g].off_ok = (qb + 255) & ~(size_t)255;
     sh[g].off_it = (sh[g].off_ok + nb + 255) & ~(size_t)255;
-    int rc = ensure_stage(ctx, sh[g].off_it + nb * sizeof(uint16_t));
-    if (rc != CCMP_OK) return rc;
+    if ((rc = ensure_stage(ctx, sh[g].off_it + nb * sizeof(uint16_t))) != CCMP_OK) break;
     char *stage = (char *)ctx->stage;
+    sh[g].busy = true;
     if (mode == 0) {
-      HIP_TRY(hipMemcpyAsync(stage, q_in + sh[g].lo * 14, qb, hipMemcpyHostToDevice, ctx->stream));
+      hipError_t e = hipMemcpyAsync(stage, q_in + sh[g].lo * 14, qb, hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync(H2D shard)"); break; }
       rc = ccmp_project_batch(ctx, p, (const double *)stage, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
                               (uint16_t *)(stage + sh[g].off_it), nb, ctx->stream);
     } else {
       rc = ccmp_sample_project_batch(ctx, p, seed, first_index + sh[g].lo, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
                                      (uint16_t *)(stage + sh[g].off_it), nullptr, nb, ctx->stream);
     }
-    if (rc != CCMP_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(q_out + sh[g].lo * 14, stage, qb, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ok + sh[g].lo, stage + sh[g].off_ok, nb, hipMemcpyDeviceToHost, ctx->stream));
-    if (iters) HIP_TRY(hipMemcpyAsync(iters + sh[g].lo, stage + sh[g].off_it, nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
   }
-  // phase 2: wait for every shard
+  // phase 2: downloads (a copy into pageable memory waits for its shard's kernels; the other GPUs keep computing)
+  for (int g = 0; g < n && rc == CCMP_OK; g++) {
+    if (!sh[g].busy) continue;
+    ccmp_ctx *ctx = ctxs[g];
+    DeviceGuard guard(ctx->device);
+    const size_t nb = sh[g].hi - sh[g].lo;
+    const char *stage = (const char *)ctx->stage;
+    hipError_t e = hipMemcpyAsync(q_out + sh[g].lo * 14, stage, nb * 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ok + sh[g].lo, stage + sh[g].off_ok, nb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && iters)
+      e = hipMemcpyAsync(iters + sh[g].lo, stage + sh[g].off_it, nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H shard)");
+  }
+  // phase 3: wait for every stream that was given work, also on the error path (the caller's buffers must be quiet)
   for (int g = 0; g < n; g++) {
-    if (sh[g].hi == sh[g].lo) continue;
+    if (!sh[g].busy) continue;
     DeviceGuard guard(ctxs[g]->device);
-    HIP_TRY(hipStreamSynchronize(ctxs[g]->stream));
+    hipError_t e = hipStreamSynchronize(ctxs[g]->stream);
+    if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize(shard)");
   }
-  return CCMP_OK;
+  return rc;
 }
 
 int ccmp_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, const double *q_in, double *q_out,

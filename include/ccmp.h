@@ -91,6 +91,13 @@ int ccmp_set_tolerance(ccmp_problem *p, double tolerance1, double tolerance2);
 int ccmp_set_calibration(ccmp_problem *p, int arm_slot, const double dh_offsets[7][4]);
 
 /* ---- execution context -------------------------------------------------------------------------- */
+/* A context owns one device, one internal stream (used by the *_host entry points) and the work queues and
+ * workspaces of the projector kernels.  Launches made through ONE context must be ordered: issue them on one
+ * stream, or synchronise between streams — two projector launches of the same context running at once would
+ * share queue words.  Calls on one context from several threads must be serialised by the caller (the
+ * reference serialises its constraint calls with graphMutex_, src/planner/stefanBiPRM.cpp:280,383,449); use one
+ * context per thread or per stream for concurrency.  The problem description is passed by value into every
+ * launch: it may be changed between calls without synchronising. */
 typedef struct ccmp_ctx ccmp_ctx;
 int ccmp_ctx_create(int device, ccmp_ctx **out);
 void ccmp_ctx_destroy(ccmp_ctx *ctx);
@@ -179,7 +186,7 @@ int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from,
                        double *states, int32_t *n_states, uint8_t *ok);
 
 /* ---- one process, several GPUs (the reference's planner is a single process) ------------------------- */
-/* Contiguous shards of the batch go to the n contexts (one per device; the same device may appear twice),
+/* Contiguous shards of the batch go to the n contexts (1 <= n <= 64, one per device; the same device may appear twice),
  * each shard is uploaded, projected and downloaded on its context's own stream, all concurrently; returns
  * when every shard is back.  No collective is needed: every GPU returns its shard straight to the host
  * tree.  Results are bit-identical to a single-GPU call.  (The one-process-per-GPU form with an RCCL
