@@ -197,16 +197,26 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
         if (t < B) {
           idx = order ? (unsigned long long)order[t] : t; // ticket -> sample: longest-predicted-first when scheduled
           active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+          if (MODE == 0) {
+            // the 112-B row as seven 16-B pieces: lanes 0..5 of the group take 96 contiguous bytes in ONE
+            // instruction, lane 0 the last piece (14 single-lane 8-B loads before: same data, 7x the requests)
+            const double2 *row = reinterpret_cast<const double2 *>(q_in + idx * 14);
+            const double2 a = row[r];
+            rec[kX + 2 * r] = a.x;
+            rec[kX + 2 * r + 1] = a.y;
+            if (r == 0) {
+              const double2 b = row[6];
+              rec[kX + 12] = b.x;
+              rec[kX + 13] = b.y;
+            }
+          } else {
 #pragma unroll
-          for (int e = 0; e < 14; e++) {
-            if (e % kGroup == r) {
-              double v;
-              if (MODE == 0) v = q_in[idx * 14 + e];
-              else {
-                v = ambient_uniform(K, seed, first_index + idx, e);
+            for (int e = 0; e < 14; e++) {
+              if (e % kGroup == r) { // e is a compile-time constant here: bounds come from SGPRs
+                const double v = ambient_uniform(K, seed, first_index + idx, e);
                 if (q_ambient) q_ambient[idx * 14 + e] = v;
+                rec[kX + e] = v;
               }
-              rec[kX + e] = v;
             }
           }
         } else drained = true;
@@ -289,8 +299,21 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
             const double v = rec[kX + e];
             if (v < K.lbe[e % 7]) bad = true;
             if (v > K.ube[e % 7]) bad = true;
-            q_out[idx * 14 + e] = (MODE == 1) ? wrap_pi(v) : v;
           }
+        }
+        // row write-back in 16-B pieces: 96 contiguous bytes per group in one instruction + the last piece
+        double2 *row = reinterpret_cast<double2 *>(q_out + idx * 14);
+        double2 a;
+        a.x = rec[kX + 2 * r];
+        a.y = rec[kX + 2 * r + 1];
+        if (MODE == 1) { a.x = wrap_pi(a.x); a.y = wrap_pi(a.y); }
+        row[r] = a;
+        if (r == 0) {
+          double2 b;
+          b.x = rec[kX + 12];
+          b.y = rec[kX + 13];
+          if (MODE == 1) { b.x = wrap_pi(b.x); b.y = wrap_pi(b.y); }
+          row[6] = b;
         }
       }
       const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);
