@@ -128,7 +128,14 @@ def main():
     from closed_chain_motion_planner_amd.build import build_library
     from closed_chain_motion_planner_amd.distributed import gather_valid
 
-    build_library()  # no-op when the in-tree .so is current; raises if it cannot be built
+    # no-op when the in-tree .so is current; raises if it cannot be built.  One rank per node builds, the others wait:
+    # eight ranks compiling into the same build directory would race.
+    if world > 1:
+        if local_rank == 0:
+            build_library()
+        dist.barrier()
+    else:
+        build_library()
     dev = local_rank if world > 1 else 0
     ctx = Context(dev)
     if args.waves_per_cu:
