@@ -13,7 +13,7 @@ for obj in ("Wine_Bottle", "stefan"):
         for mode, thr in ((0, 10), (1, 10), (1, 5), (1, 3), (1, 1), (2, 10)):
             ctx.set_lpt(mode, 0)
             ctx.set_schedule(1, 0)
-        ctx.set_option("handover_threshold", thr)
+            ctx.set_option("handover_threshold", thr)
             ms = timed(lambda: c.project_batch(q, out=out), reps=4)
             res.append("lpt%d/thr%-2d %7.3f" % (mode, thr, ms))
         print("%-12s B=%-7d " % (obj, B) + "  ".join(res), flush=True)
