@@ -3,6 +3,7 @@
 Translation units with deliberately different flags:
   ccmp_kernels_fd.hip    -ffp-contract=off -DCCMP_USE_FMA   canonical, bit-reproducible arithmetic (throughput kernel)
   ccmp_kernels_wave.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one-wave-per-sample kernels
+  ccmp_kernels_flat.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one 128-thread block per sample (latency kernel)
   ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   host set-up in the same rounding model
   ccmp_kernels_fast.hip  -ffp-contract=fast                 analytic fast mode, no bitwise claim
   ccmp_kernels_scout.hip -ffast-math                        FP32 iteration-count predictor + ordering (never touches results)
@@ -25,6 +26,7 @@ _UNITS = [
     ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm"]
      + os.environ.get("CCMP_FD_EXTRA_FLAGS", "").split()),
     ("ccmp_kernels_wave.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
+    ("ccmp_kernels_flat.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm"]),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=fast"]),
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),

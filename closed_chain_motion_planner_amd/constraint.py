@@ -22,6 +22,9 @@ def _torch():
     return torch
 
 
+_SIZE_DEFAULT = C.c_size_t(-1).value  # CCMP_DEFAULT
+
+
 class Context:
     """ccmp_ctx: one per (process, device)."""
 
@@ -41,17 +44,21 @@ class Context:
     def set_waves_per_cu(self, w):
         check(_lib.lib().ccmp_ctx_set_waves_per_cu(self._h, int(w)), "ccmp_ctx_set_waves_per_cu")
 
-    def set_schedule(self, wave_kernel=1, small_batch=8192):
-        """0 = group kernel only, 1 = group kernel + wave-per-sample stragglers (default), 2 = wave-per-sample only"""
-        check(_lib.lib().ccmp_ctx_set_schedule(self._h, int(wave_kernel), int(small_batch)), "ccmp_ctx_set_schedule")
+    def set_schedule(self, wave_kernel=1, small_batch=None):
+        """0 = group kernel only, 1 = group kernel + latency kernel for stragglers (default), 2 = latency kernel only;
+        small_batch None = the library default"""
+        sb = _SIZE_DEFAULT if small_batch is None else int(small_batch)
+        check(_lib.lib().ccmp_ctx_set_schedule(self._h, int(wave_kernel), sb), "ccmp_ctx_set_schedule")
 
     def set_option(self, name, value):
-        """tuning knobs: "handover_threshold" (-1 auto, 0..10), "pair_kernel" (0/1); results never change"""
+        """tuning knobs: "handover_threshold" (-1 auto, 0..10), "flat_kernel" (0/1); results never change"""
         check(_lib.lib().ccmp_ctx_set_option(self._h, name.encode(), int(value)), "ccmp_ctx_set_option(%s)" % name)
 
-    def set_lpt(self, mode=1, min_batch=65536):
-        """0 = index order, 1 = FP32 scout + longest-predicted-first (default), 2 = the same without hand-over"""
-        check(_lib.lib().ccmp_ctx_set_lpt(self._h, int(mode), int(min_batch)), "ccmp_ctx_set_lpt")
+    def set_lpt(self, mode=1, min_batch=None):
+        """0 = index order, 1 = FP32 scout + longest-predicted-first (default), 2 = the same without hand-over;
+        min_batch None = the library default"""
+        mb = _SIZE_DEFAULT if min_batch is None else int(min_batch)
+        check(_lib.lib().ccmp_ctx_set_lpt(self._h, int(mode), mb), "ccmp_ctx_set_lpt")
 
     def close(self):
         if self._h:

@@ -28,10 +28,10 @@ hipError_t ccmp_launch_project_wave(const ccmp_consts *K, int src, const double 
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, hipStream_t st);
-hipError_t ccmp_launch_project_pair(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
+hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
-                                    unsigned long long seed, unsigned long long first, int wrap_output, int nblocks,
-                                    hipStream_t st);
+                                    unsigned long long seed, unsigned long long first, const double *pool,
+                                    const unsigned long long *pool_count, int wrap_output, int nblocks, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                     unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
@@ -49,7 +49,7 @@ hipError_t ccmp_launch_ambient_ref(const ccmp_consts *K, int kind, unsigned long
 hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride, double *out, size_t B, hipStream_t st);
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
-                                unsigned long long *queue, int nblocks, hipStream_t st);
+                                int nblocks, hipStream_t st);
 hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st);
 hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, unsigned int *block_counts,
                                unsigned long long *total, hipStream_t st);
@@ -306,6 +306,10 @@ int yaml_int(const YamlDoc &d, const char *key, int &out)
 
 } // namespace
 
+// scheduling defaults (sweeps: tools/time_small.py, tools/time_mid.py, tools/time_lpt3.py)
+constexpr size_t kDefaultSmallBatch = 8192;    // up to here the latency kernel alone is quickest
+constexpr size_t kDefaultLptMinBatch = 28672;  // from about one fill of the throughput kernel (30720 samples) on, ordering pays for the scout
+
 struct ccmp_ctx {
   int device = 0;
   int num_cus = 0;
@@ -316,13 +320,13 @@ struct ccmp_ctx {
   size_t pool_cap = 0;                 // in records
   int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
   const unsigned int *order = nullptr; // experimental: externally supplied processing order
-  int pair_kernel = 1;                 // batches of at most one sample per CU: one sample per PAIR of waves
+  int flat_kernel = 1;                 // latency work (small batches, hand-over): 1 = one-round 128-thread kernel, 0 = single-wave kernel
   int lpt = 1;                         // 0: in-order; 1: FP32 scout + longest-predicted-first, hand-over kept; 2: same, no hand-over
-  size_t lpt_min_batch = 65536;        // below this the scout costs more than the tail it removes
+  size_t lpt_min_batch = kDefaultLptMinBatch; // below this the scout costs more than the tail it removes
   void *lpt_buf = nullptr;             // pred (u16 x B) | hist (u32 x 1024) | order (u32 x B)
   size_t lpt_cap = 0;                  // in samples
   int dump_threshold = -1;             // hand a wave's samples over once the queue is dry and <= this many groups are busy; -1 = auto
-  size_t small_batch = 8192;           // at or below: wave-per-sample kernel on everything
+  size_t small_batch = kDefaultSmallBatch;    // at or below: latency kernel on everything
   unsigned int *scan = nullptr;        // compaction block counts
   size_t scan_cap = 0;
   // staging for the *_host conveniences
@@ -603,17 +607,18 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch)
 {
   if (!ctx || wave_kernel < 0 || wave_kernel > 2) return CCMP_EINVAL;
   ctx->wave_kernel = wave_kernel;
-  ctx->small_batch = small_batch;
+  ctx->small_batch = small_batch == CCMP_DEFAULT ? kDefaultSmallBatch : small_batch;
   return CCMP_OK;
 }
 int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
 {
   if (!ctx || !name) return CCMP_EINVAL;
-  if (!strcmp(name, "handover_threshold")) { // -1 = automatic, 0..10 = hand a wave over once <= this many groups are busy
+  if (!strcmp(name, "flat_kernel")) { // latency work: 1 = one-round 128-thread kernel (default), 0 = single-wave kernel
+    if (value != 0 && value != 1) return CCMP_EINVAL;
+    ctx->flat_kernel = (int)value;
+  } else if (!strcmp(name, "handover_threshold")) { // -1 = automatic, 0..10 = hand a wave over once <= this many groups are busy
     if (value < -1 || value > 10) return CCMP_EINVAL;
     ctx->dump_threshold = (int)value;
-  } else if (!strcmp(name, "pair_kernel")) { // 0/1: one sample per pair of waves for batches of <= one sample per CU
-    ctx->pair_kernel = value != 0;
   } else {
     return CCMP_EINVAL;
   }
@@ -623,7 +628,7 @@ int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch)
 {
   if (!ctx || mode < 0 || mode > 2) return CCMP_EINVAL;
   ctx->lpt = mode;
-  ctx->lpt_min_batch = min_batch;
+  ctx->lpt_min_batch = min_batch == CCMP_DEFAULT ? kDefaultLptMinBatch : min_batch;
   return CCMP_OK;
 }
 int ccmp_ctx_debug_lpt_pred(ccmp_ctx *ctx, uint16_t *host_out, size_t B)
@@ -690,8 +695,9 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       nwave = (int)(need < (size_t)wave_blocks ? need : (size_t)wave_blocks);
     }
     // queue[0]: sample queue of the group kernel; queue[1]: pool fill count; queue[2]: read head of the wave kernel
-    const bool pair_path = nblocks == 0 && ctx->pair_kernel && B <= (size_t)ctx->num_cus; // strides statically: no queue
-    if (!pair_path) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
+    const int flat_blocks = ctx->num_cus * 8; // 128-thread blocks of the one-round latency kernel: 16 waves per CU
+    const bool flat_static = ctx->flat_kernel && nblocks == 0 && B <= (size_t)flat_blocks; // one block per sample: no queue
+    if (!flat_static) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
     const unsigned int *order = ctx->order;
     if (nblocks > 0 && !order && ctx->lpt > 0 && B >= ctx->lpt_min_batch && B < 0xffffffffull) {
       // FP32 scout pass -> predicted iteration counts -> descending counting sort -> processing order
@@ -710,21 +716,26 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       order = ord;
       if (ctx->lpt == 2) nwave = 0;
     }
-    // Hand-over threshold.  In index order the samples in flight when the queue runs dry include long ones:
-    // hand everything to the latency kernel at once (10).  Longest-first leaves only short samples at the end of
-    // large batches: let the throughput kernel finish them and hand over only nearly empty waves (3).
-    // (sweep: tools/time_lpt3.py)
-    const int dump_thr = ctx->dump_threshold >= 0 ? ctx->dump_threshold : ((order && B >= 100000) ? 3 : 10);
+    // Hand-over threshold (sweeps: tools/time_mid.py, tools/time_lpt3.py).  Longest-first leaves only short samples
+    // at the end of large batches: let the throughput kernel finish them and hand over only nearly empty waves (4);
+    // mid-size ordered batches are in flight all at once, their long samples go over as soon as the queue is dry
+    // (10); in index order a wave is handed over once 6 or fewer of its 10 groups are still busy.
+    const int dump_thr = ctx->dump_threshold >= 0 ? ctx->dump_threshold : (order ? (B >= 100000 ? 4 : 10) : 6);
     if (nblocks > 0) {
       HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
                                         nwave > 0 ? ctx->pool : nullptr, dump_thr, order, st));
-      if (nwave > 0)
+      if (nwave > 0 && ctx->flat_kernel) {
+        const size_t need = (size_t)nblocks * 10;
+        HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
+                                         ctx->queue + 1, mode, (int)(need < (size_t)flat_blocks ? need : (size_t)flat_blocks), st));
+      } else if (nwave > 0) {
         HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
                                          ctx->queue + 1, mode, nwave, st));
-    } else if (pair_path) {
-      // a handful of samples (single-state calls of the reference signature): one sample per pair of waves is
-      // ~10 % quicker per sample; from a few hundred samples on the single-wave kernel wins (tools/time_small.py)
-      HIP_TRY(ccmp_launch_project_pair(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, mode, (int)B, st));
+      }
+    } else if (ctx->flat_kernel) {
+      // small batches and single states: one sample per 128-thread block, every evaluation of an iteration in one round
+      HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, flat_static ? nullptr : ctx->queue + 2, seed,
+                                       first, ctx->pool, ctx->queue + 1, mode, (int)(flat_static ? B : (size_t)flat_blocks), st));
     } else {
       HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
                                        ctx->queue + 1, mode, nwave, st));
@@ -797,11 +808,10 @@ int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from
   if (!from || !to || !states || !n_states || !ok || max_states < 1) return CCMP_EINVAL;
   if (!(p->delta > 0) || !(p->lambda > 0)) return CCMP_EINVAL;
   if (p->jacobian_mode != CCMP_JAC_FD) return CCMP_EINVAL; // the extend step exists in reference arithmetic only
-  const int wpc = ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12;
-  size_t nb = (size_t)ctx->num_cus * (size_t)wpc;
-  if (nb > E) nb = E;
-  HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters,
-                               ctx->queue + 4, (int)nb, st));
+  // one 128-thread block per edge; the hardware dispatcher balances edges of different length (the kernel strides
+  // over the edges if the grid is capped)
+  const size_t nb = E < ((size_t)1 << 20) ? E : ((size_t)1 << 20);
+  HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, (int)nb, st));
   return CCMP_OK;
 }
 

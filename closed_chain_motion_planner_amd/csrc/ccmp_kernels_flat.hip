@@ -1,0 +1,352 @@
+// ccmp_kernels_flat.hip — the latency kernel of the reference-arithmetic path: one sample per 128-thread block,
+// every residual evaluation of a Newton iteration in ONE round.  Canonical (bit-reproducible) rounding model:
+// built -ffp-contract=off -DCCMP_USE_FMA like ccmp_kernels_fd.hip, and like it with -mllvm -disable-machine-licm
+// (214 VGPRs and no scratch instead of 266: two blocks' waves per SIMD).
+#include "ccmp_fd_common.h"
+
+using namespace ccmp;
+
+namespace {
+
+constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
+
+// ------------------------------------------------------------------------------------------------
+// "Flat" Newton: one sample per 128-thread block, every evaluation of an iteration in ONE round.
+// Thread t < 84 owns stencil point (column t / 6, point t % 6) and runs the WHOLE 7-joint chain of its arm with its
+// joint perturbed — the same operations in the same order as re-entering at a cached prefix frame, so the same bits
+// — threads 84 and 85 run the two chains at x, threads 86..99 the 14 sines/cosines of x.  function(x) and the 84
+// evaluations of jacobian(x) are therefore computed side by side instead of one after the other (the Jacobian of
+// the final iterate is computed and dropped): ~1.5 k dependent instructions per Newton iteration instead of ~2.7 k
+// (pair kernel) / ~3.3 k (single-wave kernel).  Arm and joint differ per lane: constants come from the LDS copy.
+constexpr int fX = 0, fSC = 14, fEE = 42, fF = 66, fJ = 68, fT = 96, fY = 264, fV = 348, fRec = 350;
+
+__device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_consts &KL, double *rec, int tid, int &iter,
+                                            int &updates, double &norm1, double &norm2)
+{
+  const bool ev = tid < 84;                      // stencil evaluation
+  const bool at_x = tid == 84 || tid == 85;      // unperturbed chain of arm tid - 84
+  const bool sc_lane = tid >= 86 && tid < 100;   // sincos of x[tid - 86]
+  const int col = ev ? tid / 6 : 0, pt = ev ? tid - 6 * col : 0;
+  const int arm = ev ? (col >= 7 ? 1 : 0) : (tid == 85 ? 1 : 0);
+  const int j = ev ? col - 7 * arm : -1;
+  const bool plus = pt < 3;
+  const int nstep = (plus ? pt : pt - 3) + 1;
+  for (;;) {
+    // ---- A: angles.  y1[j] += h / y2[j] -= h by sequential adds as OMPL does; one sincos per lane -----------
+    double y = 0.0, s, c;
+    if (ev) {
+      const double xj = rec[fX + col];
+      const double axj = ccmp_abs(xj);
+      const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
+      const double hh = plus ? h : -h;
+      y = xj + hh;
+      if (nstep >= 2) y = y + hh;
+      if (nstep >= 3) y = y + hh;
+    } else if (sc_lane) {
+      y = rec[fX + tid - 86];
+    }
+    ccmp_sincos(y, &s, &c);
+    if (sc_lane) {
+      rec[fSC + 2 * (tid - 86)] = s;
+      rec[fSC + 2 * (tid - 86) + 1] = c;
+    }
+    __syncthreads();
+    // ---- B: the chain of this lane's arm, joint j at y, the others at x ------------------------------------
+    double Tw[12];
+    {
+      double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+      for (int i = 0; i < 7; i++) {
+        double Rj[9], Rn[9];
+        const double si = (i == j) ? s : rec[fSC + 2 * (arm * 7 + i)];
+        const double ci = (i == j) ? c : rec[fSC + 2 * (arm * 7 + i) + 1];
+        mulvec_acc(R, KL.offset[arm][i], o);
+        rot_sc(KL.axis[arm][i], KL.aprod[arm][i], si, ci, Rj);
+        mul33(R, Rj, Rn);
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = Rn[k];
+      }
+      tool_pose(KL, arm, R, o, &Tw[0], &Tw[9]);
+      if (at_x) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) rec[fEE + arm * 12 + k] = Tw[k];
+      }
+    }
+    __syncthreads();
+    // ---- C: residuals.  Evaluation lanes pair their pose with the partner arm's pose at x; lane 84 gives f(x) ----
+    {
+      double A[12], Bq[12], tt[2];
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        const double t0 = rec[fEE + k], t1 = rec[fEE + 12 + k];
+        A[k] = (ev && arm == 0) ? Tw[k] : t0;
+        Bq[k] = (ev && arm == 1) ? Tw[k] : t1;
+      }
+      chain_residual(K, &A[0], &A[9], &Bq[0], &Bq[9], tt, nullptr, nullptr);
+      if (ev) {
+        rec[fT + 2 * tid] = tt[0];
+        rec[fT + 2 * tid + 1] = tt[1];
+        rec[fY + tid] = y;
+      } else if (tid == 84) {
+        rec[fF] = tt[0];
+        rec[fF + 1] = tt[1];
+      }
+    }
+    __syncthreads();
+    const double f0 = rec[fF], f1 = rec[fF + 1];
+    // ---- loop condition of ConstraintFunction.h:68 (block-uniform) ------------------------------------------
+    bool cont = false;
+    {
+      const bool c1 = f0 > K.tol_pos;
+      norm1 = c1 ? 1.0 : 0.0;
+      bool resid = c1;
+      if (!c1) { norm2 = f1; resid = f1 > K.tol_rot; }
+      if (resid) { cont = iter < K.max_iter; iter++; }
+    }
+    if (!cont) return (norm1 < K.tol_pos) && (norm2 < K.tol_rot);
+    // ---- D: J[row][col] = 1.5 m1 - 0.6 m2 + 0.1 m3, m_s = (t1 - t2) / (y1[j] - y2[j]) ---------------------
+    if (tid < 28) {
+      const int row = tid >= 14 ? 1 : 0, cc = tid - 14 * row;
+      double m[3];
+#pragma unroll
+      for (int sidx = 0; sidx < 3; sidx++) {
+        const int e1 = 6 * cc + sidx, e2 = 6 * cc + 3 + sidx;
+        m[sidx] = (rec[fT + 2 * e1 + row] - rec[fT + 2 * e2 + row]) / (rec[fY + e1] - rec[fY + e2]);
+      }
+      rec[fJ + tid] = CCMP_FMA(0.1, m[2], CCMP_FMA(-0.6, m[1], 1.5 * m[0]));
+    }
+    __syncthreads();
+    // ---- E: minimum-norm step ----------------------------------------------------------------------------
+    {
+      double Jr[28], dx[14];
+#pragma unroll
+      for (int k = 0; k < 28; k++) Jr[k] = rec[fJ + k];
+      solve_minnorm(Jr, f0, f1, dx);
+#pragma unroll
+      for (int e = 0; e < 14; e++)
+        if (e == tid) rec[fX + e] = CCMP_FMA(-K.step, dx[e], rec[fX + e]);
+      updates++;
+    }
+    __syncthreads();
+  }
+}
+
+// jointValid(x) of the iterate in rec[fX..] (ConstraintFunction.h:43-55); every thread gets the result through LDS
+__device__ __forceinline__ bool flat_joint_valid(const ccmp_consts &KL, double *rec, int tid)
+{
+  bool bad = false;
+  if (tid < 14) {
+    const double v = rec[fX + tid];
+    const int jj = tid < 7 ? tid : tid - 7;
+    if (v < KL.lbe[jj]) bad = true;
+    if (v > KL.ube[jj]) bad = true;
+  }
+  const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0ull; // threads 0..13 sit in wave 0
+  if (tid == 0) rec[fV] = any_bad ? 1.0 : 0.0; // its own slot: a slower wave may still be reading f(x) from fF
+  __syncthreads();
+  const bool jv = rec[fV] == 0.0;
+  __syncthreads();
+  return jv;
+}
+
+// SRC 0: q_in, SRC 1: ambient sampler, SRC 2: straggler pool.  queue == nullptr: static striding (one block per
+// sample launches need no queue reset).
+template <int SRC>
+__global__ __launch_bounds__(128, 2) void project_fd_flat_kernel(
+    const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
+    uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
+    unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
+    const unsigned long long *__restrict__ pool_count, int wrap_output)
+{
+  __shared__ double lds[fRec];
+  __shared__ double ktab[kConstsDoubles + 1];
+  __shared__ unsigned long long ticket;
+  const int tid = threadIdx.x;
+  {
+    const double *src = reinterpret_cast<const double *>(&K);
+    for (int k = tid; k < kConstsDoubles; k += 128) ktab[k] = src[k];
+  }
+  __syncthreads();
+  const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
+  double *rec = lds;
+  const unsigned long long total = (SRC == 2) ? *pool_count : B;
+  unsigned long long t = blockIdx.x;
+
+  for (;;) {
+    if (queue) {
+      if (tid == 0) ticket = atomicAdd(queue, 1ull);
+      __syncthreads();
+      t = ticket;
+    }
+    if (t >= total) break;
+    unsigned long long idx;
+    int iter = 0, updates = 0;
+    double norm1 = 0.0, norm2 = 0.0;
+    if (SRC == 2) {
+      const double *ent = pool + t * kPoolEntry;
+      idx = (unsigned long long)__double_as_longlong(ent[14]);
+      iter = __double2hiint(ent[15]);
+      updates = __double2loint(ent[15]);
+      norm1 = ent[16];
+      norm2 = ent[17];
+      if (tid < 14) rec[fX + tid] = ent[tid];
+    } else {
+      idx = t;
+      if (tid < 14) {
+        double v;
+        if (SRC == 0) v = q_in[idx * 14 + tid];
+        else {
+          v = ambient_uniform(KL, seed, first_index + idx, tid);
+          if (q_ambient) q_ambient[idx * 14 + tid] = v;
+        }
+        rec[fX + tid] = v;
+      }
+    }
+    __syncthreads();
+    const bool conv = flat_newton(K, KL, rec, tid, iter, updates, norm1, norm2);
+    const bool jv = flat_joint_valid(KL, rec, tid);
+    if (tid < 14) {
+      const double v = rec[fX + tid];
+      q_out[idx * 14 + tid] = wrap_output ? wrap_pi(v) : v;
+    }
+    if (tid == 0) {
+      ok_out[idx] = (uint8_t)(jv && conv);
+      if (iters_out) iters_out[idx] = (uint16_t)updates;
+    }
+    __syncthreads();
+    if (!queue) t += gridDim.x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// geodesic_flat_kernel — jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96), one
+// 128-thread block per edge (from -> to): interpolate a step of delta towards `to` (KinematicChainSpace::interpolate,
+// KinematicChain.h:145-171), project it (flat_newton), apply the reference's four break tests, record the state.
+// The StateValidityChecker (MoveIt collision) stays on the host: the kernel runs as the reference does with
+// interpolate == true and the host truncates the list at the first invalid state, which is what the reference's
+// break would have produced.
+constexpr int gPrev = fRec, gTo = fRec + 14, gRec = fRec + 28;
+
+// RealVectorStateSpace::distance over the 14 joints (plain Euclidean, KinematicChainSpace does not override it),
+// summed serially in the canonical order; every thread computes it from LDS.
+__device__ __forceinline__ double lds_distance(const double *a, const double *b)
+{
+  double dist = 0.0;
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    const double diff = a[i] - b[i];
+    dist = CCMP_FMA(diff, diff, dist);
+  }
+  return ccmp_sqrt(dist);
+}
+
+__global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
+    const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
+    const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
+    int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters)
+{
+  __shared__ double lds[gRec];
+  __shared__ double ktab[kConstsDoubles + 1];
+  const int tid = threadIdx.x;
+  {
+    const double *src = reinterpret_cast<const double *>(&K);
+    for (int k = tid; k < kConstsDoubles; k += 128) ktab[k] = src[k];
+  }
+  __syncthreads();
+  const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
+  double *rec = lds;
+  const double pi = 3.14159265358979323846;
+
+  for (unsigned long long t = blockIdx.x; t < E; t += gridDim.x) {
+    double *out = states + t * (unsigned long long)max_states * 14ull;
+    if (tid < 14) {
+      const double a = from[t * 14 + tid];
+      rec[gPrev + tid] = a;
+      rec[gTo + tid] = to[t * 14 + tid];
+      if (max_states > 0) out[tid] = a; // geodesic->push_back(cloneState(from))
+    }
+    __syncthreads();
+    int n = max_states > 0 ? 1 : 0, its = 0;
+    double dist = lds_distance(rec + gPrev, rec + gTo), total = 0.0;
+    if (dist > delta) {
+      const double maxd = dist * lambda;
+      for (int guard = 0; guard < 1000000; guard++) { // the reference loop ends by itself; guard bounds a non-finite input
+        if (tid < 14) { // WrapperStateSpace::interpolate(previous, to, delta_ / dist, scratch)
+          const double tt = delta / dist;
+          const double fr = rec[gPrev + tid];
+          double diff = rec[gTo + tid] - fr, v;
+          if (ccmp_abs(diff) <= pi) v = CCMP_FMA(diff, tt, fr);
+          else {
+            if (diff > 0.0) diff = 2.0 * pi - diff;
+            else diff = -2.0 * pi - diff;
+            v = CCMP_FMA(-diff, tt, fr);
+            if (v > pi) v -= 2.0 * pi;
+            else if (v < -pi) v += 2.0 * pi;
+          }
+          rec[fX + tid] = v;
+        }
+        __syncthreads();
+        int iter = 0, updates = 0;
+        double norm1 = 0.0, norm2 = 0.0;
+        const bool conv = flat_newton(K, KL, rec, tid, iter, updates, norm1, norm2);
+        const bool jv = flat_joint_valid(KL, rec, tid);
+        its += updates;
+        if (!(conv && jv)) break;                        // not on manifold
+        const double step = lds_distance(rec + gPrev, rec + fX);
+        if (step > lambda * delta) break;                // deviated
+        total += step;
+        if (total > maxd) break;                         // wandered too far
+        const double newDist = lds_distance(rec + fX, rec + gTo);
+        if (newDist >= dist) break;                      // no closer than before
+        dist = newDist;
+        __syncthreads();
+        if (tid < 14) {
+          const double v = rec[fX + tid];
+          rec[gPrev + tid] = v;
+          if (n < max_states) out[(unsigned long long)n * 14ull + tid] = v;
+        }
+        if (n < max_states) n++;
+        __syncthreads();
+        if (!(dist >= delta)) break;
+      }
+    }
+    if (tid == 0) {
+      n_states[t] = n;
+      ok_out[t] = (uint8_t)(dist <= delta);
+      if (newton_iters) newton_iters[t] = its;
+    }
+    __syncthreads();
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+// one sample per 128-thread block, all evaluations of an iteration in one round; queue_head may be NULL (static striding)
+hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
+                                    uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
+                                    unsigned long long seed, unsigned long long first, const double *pool,
+                                    const unsigned long long *pool_count, int wrap_output, int nblocks, hipStream_t st)
+{
+  if (src == 0)
+    hipLaunchKernelGGL(project_fd_flat_kernel<0>, dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                       (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output);
+  else if (src == 1)
+    hipLaunchKernelGGL(project_fd_flat_kernel<1>, dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                       (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output);
+  else
+    hipLaunchKernelGGL(project_fd_flat_kernel<2>, dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                       (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output);
+  return hipGetLastError();
+}
+
+hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
+                                size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
+                                int nblocks, hipStream_t st)
+{
+  hipLaunchKernelGGL(geodesic_flat_kernel, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
+                     max_states, states, n_states, ok, newton_iters);
+  return hipGetLastError();
+}
+
+} // extern "C"

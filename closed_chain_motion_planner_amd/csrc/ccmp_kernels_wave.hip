@@ -255,269 +255,6 @@ __global__ __launch_bounds__(64, CCMP_WAVE_WAVES_PER_SIMD) void project_fd_wave_
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// project_fd_pair_kernel — one sample per PAIR of wavefronts (128-thread block), for small batches where the
-// longest sample's latency is the whole run time.  Wave w owns arm w: its chain at x in phase 1 (arm index
-// wave-uniform: kernarg constants), its 42 stencil evaluations in ONE round in phase 2 (the single-wave kernel
-// needs 64 + 20), and no role selects (the perturbed arm is wave-uniform).  Same arithmetic, same bits.
-template <int SRC>
-__global__ __launch_bounds__(128) void project_fd_pair_kernel(
-    const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
-    uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
-    unsigned long long seed, unsigned long long first_index, int wrap_output)
-{
-  __shared__ double lds[wRec];
-  __shared__ double ktab[kConstsDoubles + 1];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  (void)queue;
-  {
-    const double *src = reinterpret_cast<const double *>(&K);
-    for (int k = tid; k < kConstsDoubles; k += 128) ktab[k] = src[k];
-  }
-  __syncthreads();
-  const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
-  double *rec = lds;
-
-  // launched with one block per sample (B <= number of CUs): static striding, no queue word to reset before the launch
-  for (unsigned long long idx = blockIdx.x; idx < B; idx += gridDim.x) {
-    if (tid < 14) {
-      double v;
-      if (SRC == 0) v = q_in[idx * 14 + tid];
-      else {
-        v = ambient_uniform(KL, seed, first_index + idx, tid);
-        if (q_ambient) q_ambient[idx * 14 + tid] = v;
-      }
-      rec[wX + tid] = v;
-    }
-    __syncthreads();
-    int iter = 0, updates = 0;
-    double norm1 = 0.0, norm2 = 0.0;
-    bool conv = false;
-    for (;;) {
-      // ---- phase 1: function(x) ----------------------------------------------------------------
-      if (tid < 14) {
-        double s, c;
-        ccmp_sincos(rec[wX + tid], &s, &c);
-        rec[wSC + 2 * tid] = s;
-        rec[wSC + 2 * tid + 1] = c;
-      }
-      __syncthreads();
-      {
-        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0}, T[12];
-        for (int i = 0; i < 7; i++) {
-          const int col = w * 7 + i;
-          double Rj[9], Rn[9];
-          mulvec_acc(R, KL.offset[w][i], o);
-          if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 9; k++) rec[wPre + col * 12 + k] = R[k];
-#pragma unroll
-            for (int k = 0; k < 3; k++) rec[wPre + col * 12 + 9 + k] = o[k];
-          }
-          rot_sc(KL.axis[w][i], KL.aprod[w][i], rec[wSC + 2 * col], rec[wSC + 2 * col + 1], Rj);
-          mul33(R, Rj, Rn);
-#pragma unroll
-          for (int k = 0; k < 9; k++) R[k] = Rn[k];
-        }
-        tool_pose(KL, w, R, o, &T[0], &T[9]);
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 12; k++) rec[wEE + w * 12 + k] = T[k];
-        }
-      }
-      __syncthreads();
-      double f0, f1;
-      {
-        double T0[12], T1[12], f[2];
-#pragma unroll
-        for (int k = 0; k < 12; k++) { T0[k] = rec[wEE + k]; T1[k] = rec[wEE + 12 + k]; }
-        chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
-        f0 = f[0]; f1 = f[1];
-      }
-      bool cont = false;
-      {
-        const bool c1 = f0 > K.tol_pos;
-        norm1 = c1 ? 1.0 : 0.0;
-        bool resid = c1;
-        if (!c1) { norm2 = f1; resid = f1 > K.tol_rot; }
-        if (resid) { cont = iter < K.max_iter; iter++; }
-      }
-      if (!cont) { conv = (norm1 < K.tol_pos) && (norm2 < K.tol_rot); break; }
-
-      // ---- phase 2: wave w evaluates the 42 stencil points of arm w in one round ---------------------
-      {
-        const bool valid = lane < 42;
-        const int ec = valid ? lane : 41;
-        const int j = ec / 6, pt = ec - 6 * j, col = w * 7 + j;
-        const bool plus = pt < 3;
-        const int nstep = (plus ? pt : pt - 3) + 1;
-        const double xj = rec[wX + col];
-        const double axj = ccmp_abs(xj);
-        const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
-        const double hh = plus ? h : -h;
-        double y = xj + hh;
-        if (nstep >= 2) y = y + hh;
-        if (nstep >= 3) y = y + hh;
-        double R[9], o[3], s, c;
-#pragma unroll
-        for (int k = 0; k < 9; k++) R[k] = rec[wPre + col * 12 + k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) o[k] = rec[wPre + col * 12 + 9 + k];
-        ccmp_sincos(y, &s, &c);
-        {
-          double Rj[9], Rn[9];
-          rot_sc(KL.axis[w][j], KL.aprod[w][j], s, c, Rj);
-          mul33(R, Rj, Rn);
-#pragma unroll
-          for (int k = 0; k < 9; k++) R[k] = Rn[k];
-        }
-        for (int i = 1; i < 7; i++) {
-          if (i > j) joint_step(KL, w, i, rec[wSC + 2 * (w * 7 + i)], rec[wSC + 2 * (w * 7 + i) + 1], R, o);
-        }
-        double Tw[12], To[12], tt[2];
-        tool_pose(KL, w, R, o, &Tw[0], &Tw[9]);
-#pragma unroll
-        for (int k = 0; k < 12; k++) To[k] = rec[wEE + (1 - w) * 12 + k];
-        if (w == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], tt, nullptr, nullptr);
-        else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], tt, nullptr, nullptr);
-        if (valid) {
-          rec[wT + 2 * (6 * col + pt)] = tt[0];
-          rec[wT + 2 * (6 * col + pt) + 1] = tt[1];
-          rec[wY + 6 * col + pt] = y;
-        }
-      }
-      __syncthreads();
-      if (tid < 28) {
-        const int row = tid >= 14 ? 1 : 0, col = tid - 14 * row;
-        double m[3];
-#pragma unroll
-        for (int sidx = 0; sidx < 3; sidx++) {
-          const int e1 = 6 * col + sidx, e2 = 6 * col + 3 + sidx;
-          m[sidx] = (rec[wT + 2 * e1 + row] - rec[wT + 2 * e2 + row]) / (rec[wY + e1] - rec[wY + e2]);
-        }
-        rec[wJ + tid] = CCMP_FMA(0.1, m[2], CCMP_FMA(-0.6, m[1], 1.5 * m[0]));
-      }
-      __syncthreads();
-      {
-        double Jr[28], dx[14];
-#pragma unroll
-        for (int k = 0; k < 28; k++) Jr[k] = rec[wJ + k];
-        solve_minnorm(Jr, f0, f1, dx);
-        __syncthreads(); // every thread has read J and x before x moves
-#pragma unroll
-        for (int e = 0; e < 14; e++)
-          if (e == tid) rec[wX + e] = CCMP_FMA(-K.step, dx[e], rec[wX + e]);
-        updates++;
-      }
-      __syncthreads();
-    }
-    // ---- write-back ------------------------------------------------------------------------------
-    bool bad = false;
-    if (tid < 14) {
-      const double v = rec[wX + tid];
-      const int jj = tid < 7 ? tid : tid - 7;
-      if (v < KL.lbe[jj]) bad = true;
-      if (v > KL.ube[jj]) bad = true;
-      q_out[idx * 14 + tid] = wrap_output ? wrap_pi(v) : v;
-    }
-    const bool jv = __builtin_amdgcn_ballot_w64(bad) == 0ull; // lanes 0..13 all sit in wave 0
-    if (tid == 0) {
-      ok_out[idx] = (uint8_t)(jv && conv);
-      if (iters_out) iters_out[idx] = (uint16_t)updates;
-    }
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// geodesic_wave_kernel — jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:
-// 32-96), one wavefront per edge (from -> to): interpolate a step of delta towards `to`
-// (KinematicChainSpace::interpolate, KinematicChain.h:145-171), project it, apply the reference's
-// four break tests, record the state.  The StateValidityChecker (MoveIt collision) stays on the host:
-// the kernel runs as the reference does with interpolate == true and the host truncates the list at
-// the first invalid state, which is what the reference's break would have produced.
-constexpr int gPrev = wRec, gTo = wRec + 14, gRec = wRec + 28;
-
-__global__ __launch_bounds__(64, CCMP_WAVE_WAVES_PER_SIMD) void geodesic_wave_kernel(
-    const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
-    const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
-    int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, unsigned long long *queue)
-{
-  __shared__ double lds[gRec];
-  __shared__ double ktab[kConstsDoubles + 1];
-  const int lane = threadIdx.x;
-  stage_consts(K, ktab, lane);
-  __syncthreads();
-  const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
-  double *rec = lds;
-  const double pi = 3.14159265358979323846;
-
-  for (;;) {
-    unsigned long long t = 0;
-    if (lane == 0) t = atomicAdd(queue, 1ull);
-    t = shfl_u64(t, 0);
-    if (t >= E) break;
-    double *out = states + t * (unsigned long long)max_states * 14ull;
-    if (lane < 14) {
-      const double a = from[t * 14 + lane];
-      rec[gPrev + lane] = a;
-      rec[gTo + lane] = to[t * 14 + lane];
-      if (max_states > 0) out[lane] = a; // geodesic->push_back(cloneState(from))
-    }
-    __syncthreads();
-    int n = max_states > 0 ? 1 : 0, its = 0;
-    double dist = lds_distance(rec + gPrev, rec + gTo), total = 0.0;
-    if (dist > delta) {
-      const double maxd = dist * lambda;
-      for (int guard = 0; guard < 1000000; guard++) { // the reference loop ends by itself; guard bounds a non-finite input
-        if (lane < 14) { // WrapperStateSpace::interpolate(previous, to, delta_ / dist, scratch)
-          const double tt = delta / dist;
-          const double fr = rec[gPrev + lane];
-          double diff = rec[gTo + lane] - fr, v;
-          if (ccmp_abs(diff) <= pi) v = CCMP_FMA(diff, tt, fr);
-          else {
-            if (diff > 0.0) diff = 2.0 * pi - diff;
-            else diff = -2.0 * pi - diff;
-            v = CCMP_FMA(-diff, tt, fr);
-            if (v > pi) v -= 2.0 * pi;
-            else if (v < -pi) v += 2.0 * pi;
-          }
-          rec[wX + lane] = v;
-        }
-        __syncthreads();
-        int iter = 0, updates = 0;
-        double norm1 = 0.0, norm2 = 0.0;
-        const bool conv = wave_newton(K, KL, rec, lane, iter, updates, norm1, norm2);
-        const bool jv = wave_joint_valid(KL, rec, lane);
-        its += updates;
-        if (!(conv && jv)) break;                        // not on manifold
-        const double step = lds_distance(rec + gPrev, rec + wX);
-        if (step > lambda * delta) break;                // deviated
-        total += step;
-        if (total > maxd) break;                         // wandered too far
-        const double newDist = lds_distance(rec + wX, rec + gTo);
-        if (newDist >= dist) break;                      // no closer than before
-        dist = newDist;
-        __syncthreads();
-        if (lane < 14) {
-          const double v = rec[wX + lane];
-          rec[gPrev + lane] = v;
-          if (n < max_states) out[(unsigned long long)n * 14ull + lane] = v;
-        }
-        if (n < max_states) n++;
-        __syncthreads();
-        if (!(dist >= delta)) break;
-      }
-    }
-    if (lane == 0) {
-      n_states[t] = n;
-      ok_out[t] = (uint8_t)(dist <= delta);
-      if (newton_iters) newton_iters[t] = its;
-    }
-    __syncthreads();
-  }
-}
-
 } // namespace
 
 extern "C" {
@@ -537,32 +274,6 @@ hipError_t ccmp_launch_project_wave(const ccmp_consts *K, int src, const double 
   else
     hipLaunchKernelGGL(project_fd_wave_kernel<2>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
                        (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output);
-  return hipGetLastError();
-}
-
-// small batches: one sample per pair of wavefronts
-hipError_t ccmp_launch_project_pair(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
-                                    uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
-                                    unsigned long long seed, unsigned long long first, int wrap_output, int nblocks,
-                                    hipStream_t st)
-{
-  if (src == 0)
-    hipLaunchKernelGGL(project_fd_pair_kernel<0>, dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue_head, seed, first, wrap_output);
-  else
-    hipLaunchKernelGGL(project_fd_pair_kernel<1>, dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue_head, seed, first, wrap_output);
-  return hipGetLastError();
-}
-
-hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
-                                size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
-                                unsigned long long *queue, int nblocks, hipStream_t st)
-{
-  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(geodesic_wave_kernel, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to,
-                     (unsigned long long)E, max_states, states, n_states, ok, newton_iters, queue);
   return hipGetLastError();
 }
 

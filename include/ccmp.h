@@ -105,17 +105,20 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx);
 int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
 /* projector scheduling: wave_kernel 0 = 10-samples-per-wave kernel only, 1 = that kernel until the sample queue
  * drains, then the wave-per-sample kernel on the samples still in flight (default), 2 = wave-per-sample only;
- * batches of at most small_batch samples always use the wave-per-sample kernel (default 8192).  Results are
- * bit-identical under every setting. */
+ * batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = built-in default, 8192).
+ * Results are bit-identical under every setting. */
+#define CCMP_DEFAULT ((size_t)-1)
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch);
 /* tuning knobs (results never change): "handover_threshold" (-1 = automatic, 0..10: hand a wave's samples to the
- * latency kernel once the queue is dry and at most this many of its 10 groups are busy), "pair_kernel" (0/1: one
- * sample per pair of waves for batches of at most one sample per CU).  CCMP_EINVAL for unknown names. */
+ * latency kernel once the queue is dry and at most this many of its 10 groups are busy), "flat_kernel" (latency
+ * work — small batches, single states, handed-over samples: 1 = one sample per 128-thread block with every
+ * evaluation of an iteration in one round (default), 0 = one wavefront per sample).  CCMP_EINVAL for unknown names. */
 int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
 /* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
  * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is
  * processed longest first, straggler hand-over kept (default); 2 = the same without hand-over.  Used for
- * batches of at least min_batch samples (default 65536).  Results are bit-identical under every setting. */
+ * batches of at least min_batch samples (CCMP_DEFAULT = built-in default, 28672).  Results are bit-identical under
+ * every setting. */
 int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch);
 int ccmp_ctx_device(const ccmp_ctx *ctx);
 int ccmp_ctx_num_cus(const ccmp_ctx *ctx);

@@ -193,7 +193,7 @@ def test_projector_is_graph_capturable(gpu_ctx, oracle_det):
         torch.cuda.synchronize()
         assert torch.equal(out, ref) and torch.equal(ok_g, ok_ref) and torch.equal(it_g, it_ref)
     finally:
-        gpu_ctx.set_lpt(1, 65536)
+        gpu_ctx.set_lpt(1)
 
 
 def test_single_process_sharding_over_contexts(gpu_ctx, oracle_det):

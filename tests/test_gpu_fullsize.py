@@ -63,8 +63,8 @@ def test_full_batch_properties(gpu_ctx, oracle_det, obj, seed, tol, mean_lo, mea
         try:
             out_g, ok_g, it_g = c.project_batch(q)
         finally:
-            gpu_ctx.set_schedule(1, 8192)
-            gpu_ctx.set_lpt(1, 65536)
+            gpu_ctx.set_schedule(1)
+            gpu_ctx.set_lpt(1)
         assert torch.equal(out_g, out) and torch.equal(ok_g, ok) and torch.equal(it_g, it), (sched, lpt)
     # 6. spot-check 192 random samples against the oracle, bit for bit
     rng = np.random.default_rng(1)

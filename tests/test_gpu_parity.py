@@ -105,12 +105,15 @@ def test_project_fd_bitwise(gpu_ctx, oracle_det, obj, B, seed):
     assert np.array_equal(q_gpu.view(np.uint64), q_cpu.view(np.uint64)), "not bit-identical"
 
 
+@pytest.mark.parametrize("flat", [1, 0])
 @pytest.mark.parametrize("schedule,small,lpt,thr", [(0, 0, 0, -1), (1, 0, 0, -1), (1, 0, 0, 2), (2, 0, 0, -1), (1, 8192, 0, -1),
                                                     (1, 0, 1, -1), (1, 0, 1, 10), (0, 0, 2, -1)])
-def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, lpt, thr):
-    """group kernel only / group kernel + straggler hand-over to the wave-per-sample kernel /
-    latency kernels only (pair of waves per sample; single wave per sample) / default policy / FP32-scout
-    longest-first with and without hand-over: all bit-identical to the oracle."""
+def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, lpt, thr, flat):
+    """group kernel only / group kernel + straggler hand-over to the latency kernel / latency kernel only /
+    default policy / FP32-scout longest-first with and without hand-over, each with the one-round 128-thread
+    latency kernel (flat) and with the one-wavefront-per-sample kernel: all bit-identical to the oracle."""
+    if flat == 0 and schedule == 0:
+        pytest.skip("group kernel only: no latency kernel involved")
     import torch
 
     c = _constraint("stefan", gpu_ctx)  # longest iteration tails, some samples hit the 250 cap
@@ -123,13 +126,15 @@ def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, l
     gpu_ctx.set_schedule(schedule, small)
     gpu_ctx.set_lpt(lpt, 0)  # lpt > 0 with min_batch 0: FP32 scout + longest-predicted-first even on this small batch
     gpu_ctx.set_option("handover_threshold", thr)
+    gpu_ctx.set_option("flat_kernel", flat)
     try:
         q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
         torch.cuda.synchronize()
     finally:
-        gpu_ctx.set_schedule(1, 8192)
-        gpu_ctx.set_lpt(1, 65536)
+        gpu_ctx.set_schedule(1)
+        gpu_ctx.set_lpt(1)
         gpu_ctx.set_option("handover_threshold", -1)
+        gpu_ctx.set_option("flat_kernel", 1)
     assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)
     assert np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
@@ -168,19 +173,19 @@ def test_ragged_batches(gpu_ctx, oracle_det, B):
     assert np.array_equal(ok.cpu().numpy(), ok_cpu)
 
 
-@pytest.mark.parametrize("pair", [0, 1])
-def test_tiny_batches_pair_and_single_wave_kernels(gpu_ctx, oracle_det, pair):
+@pytest.mark.parametrize("flat", [1, 0])
+def test_tiny_batches_on_both_latency_kernels(gpu_ctx, oracle_det, flat):
     import torch
 
     c = _constraint("stefan", gpu_ctx)
     P = _oracle_problem(oracle_det, c)
     q = oracle_det.ambient_uniform_batch(P, 0x7A1, 0, 40)
     q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, 4)
-    gpu_ctx.set_option("pair_kernel", pair)
+    gpu_ctx.set_option("flat_kernel", flat)
     try:
         out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
     finally:
-        gpu_ctx.set_option("pair_kernel", 1)
+        gpu_ctx.set_option("flat_kernel", 1)
     assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
 
@@ -264,7 +269,7 @@ def test_non_finite_and_out_of_range_inputs_terminate(gpu_ctx, oracle_det):
             out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
             torch.cuda.synchronize()
         finally:
-            gpu_ctx.set_schedule(1, 8192)
+            gpu_ctx.set_schedule(1)
         out, ok, it = out.cpu().numpy(), ok.cpu().numpy(), it.cpu().numpy()
         q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, 4)
         assert (ok[bad] == 0).all() and (it[bad] == 0).all() and (ok_cpu[bad] == 0).all() and (it_cpu[bad] == 0).all()
@@ -319,7 +324,7 @@ def test_general_base_frames_take_the_full_product(gpu_ctx, oracle_det, schedule
         q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
         torch.cuda.synchronize()
     finally:
-        gpu_ctx.set_schedule(1, 8192)
+        gpu_ctx.set_schedule(1)
     assert np.array_equal(f_gpu.cpu().numpy().view(np.uint64), f_cpu.view(np.uint64))
     assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)

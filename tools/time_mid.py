@@ -21,7 +21,7 @@ for B in (8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072):
     res = []
     for name, v in variants:
         if v is None:
-            ctx.set_schedule(1, 8192); ctx.set_lpt(1, 65536); ctx.set_option("handover_threshold", -1); ctx.set_waves_per_cu(0)
+            ctx.set_schedule(1); ctx.set_lpt(1); ctx.set_option("handover_threshold", -1); ctx.set_waves_per_cu(0)
         else:
             ctx.set_schedule(*v["sched"]); ctx.set_lpt(*v["lpt"]); ctx.set_option("handover_threshold", v["thr"]); ctx.set_waves_per_cu(v["wpc"])
         ms = timed(lambda: c.project_batch(q, out=out), reps=3)
