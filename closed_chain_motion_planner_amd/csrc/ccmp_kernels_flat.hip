@@ -12,30 +12,104 @@ constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
 
 // ------------------------------------------------------------------------------------------------
 // "Flat" Newton: one sample per 128-thread block, every evaluation of an iteration in ONE round.
-// Thread t < 84 owns stencil point (column t / 6, point t % 6) and runs the WHOLE 7-joint chain of its arm with its
-// joint perturbed — the same operations in the same order as re-entering at a cached prefix frame, so the same bits
-// — threads 84 and 85 run the two chains at x, threads 86..99 the 14 sines/cosines of x.  function(x) and the 84
+// Wave w of the block owns arm w.  Its lanes 0..41 own the 42 stencil points of that arm's 7 Jacobian columns
+// (column lane / 6, point lane % 6) and each runs the WHOLE 7-joint chain of the arm with its joint perturbed — the
+// same operations in the same order as re-entering at a cached prefix frame, hence the same bits; lane 42 runs the
+// arm's chain at x; lanes 43..49 compute the sines/cosines of the arm's 7 joints.  function(x) and the 84
 // evaluations of jacobian(x) are therefore computed side by side instead of one after the other (the Jacobian of
-// the final iterate is computed and dropped): ~1.5 k dependent instructions per Newton iteration instead of ~2.7 k
-// (pair kernel) / ~3.3 k (single-wave kernel).  Arm and joint differ per lane: constants come from the LDS copy.
+// the final iterate is computed and dropped): ~1.5 k dependent instructions per Newton iteration instead of ~3.3 k
+// in the one-wavefront-per-sample kernel.  The arm is wave-uniform: kinematic constants are scalar operands from the
+// kernarg segment, as in the throughput kernel.
 constexpr int fX = 0, fSC = 14, fEE = 42, fF = 66, fJ = 68, fT = 96, fY = 264, fV = 348, fRec = 350;
 
-__device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_consts &KL, double *rec, int tid, int &iter,
-                                            int &updates, double &norm1, double &norm2)
+// Per-joint constants of both arms in chain order, 12 doubles per joint (offset 3, axis 3, axis products 6), so that a
+// joint's constants are six 16-byte LDS reads that can be issued one joint ahead of their use.
+constexpr int kStepDoubles = 12, kStepTab = 2 * 7 * kStepDoubles;
+
+__device__ __forceinline__ void stage_step_table(const ccmp_consts &K, double *tab, int tid)
 {
-  const bool ev = tid < 84;                      // stencil evaluation
-  const bool at_x = tid == 84 || tid == 85;      // unperturbed chain of arm tid - 84
-  const bool sc_lane = tid >= 86 && tid < 100;   // sincos of x[tid - 86]
-  const int col = ev ? tid / 6 : 0, pt = ev ? tid - 6 * col : 0;
-  const int arm = ev ? (col >= 7 ? 1 : 0) : (tid == 85 ? 1 : 0);
-  const int j = ev ? col - 7 * arm : -1;
+  for (int k = tid; k < kStepTab; k += 128) {
+    const int a = k / (7 * kStepDoubles), r = k - a * 7 * kStepDoubles, i = r / kStepDoubles, c = r - i * kStepDoubles;
+    tab[k] = c < 3 ? K.offset[a][i][c] : (c < 6 ? K.axis[a][i][c - 3] : K.aprod[a][i][c - 6]);
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab,
+                                                        double *rec, int lane, int j, double s, double c, double y)
+{
+  // ---- B: the chain of arm W, joint j at (s, c), the others at x --------------------------------------------------
+  double Tw[12];
+  {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+    const double2 *tab = reinterpret_cast<const double2 *>(steptab + W * 7 * kStepDoubles);
+    const double2 *sct = reinterpret_cast<const double2 *>(rec + fSC + 2 * W * 7);
+    double2 cur[6], nxt[6], sc_cur = sct[0], sc_nxt = sc_cur;
+#pragma unroll
+    for (int k = 0; k < 6; k++) cur[k] = tab[k];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      if (i < 6) { // next joint's constants and sin/cos: in flight while this joint is computed
+#pragma unroll
+        for (int k = 0; k < 6; k++) nxt[k] = tab[6 * (i + 1) + k];
+        sc_nxt = sct[i + 1];
+      }
+      double Rj[9], Rn[9];
+      const double si = (i == j) ? s : sc_cur.x;
+      const double ci = (i == j) ? c : sc_cur.y;
+      const double off[3] = {cur[0].x, cur[0].y, cur[1].x};
+      const double ax[3] = {cur[1].y, cur[2].x, cur[2].y};
+      const double ap[6] = {cur[3].x, cur[3].y, cur[4].x, cur[4].y, cur[5].x, cur[5].y};
+      mulvec_acc(R, off, o);
+      rot_sc(ax, ap, si, ci, Rj);
+      mul33(R, Rj, Rn);
+#pragma unroll
+      for (int k = 0; k < 9; k++) R[k] = Rn[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cur[k] = nxt[k];
+      sc_cur = sc_nxt;
+    }
+    tool_pose(KC, W, R, o, &Tw[0], &Tw[9]);
+    if (lane == 42) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) rec[fEE + W * 12 + k] = Tw[k];
+    }
+  }
+  __syncthreads();
+  // ---- C: residuals against the partner arm's pose at x; lane 42 of wave 0 yields f(x) --------------------------
+  {
+    double To[12], tt[2];
+#pragma unroll
+    for (int k = 0; k < 12; k++) To[k] = rec[fEE + (1 - W) * 12 + k];
+    if (W == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], tt, nullptr, nullptr);
+    else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], tt, nullptr, nullptr);
+    if (lane < 42) {
+      const int e = 6 * (W * 7 + j) + (lane - 6 * j);
+      rec[fT + 2 * e] = tt[0];
+      rec[fT + 2 * e + 1] = tt[1];
+      rec[fY + e] = y;
+    } else if (W == 0 && lane == 42) {
+      rec[fF] = tt[0];
+      rec[fF + 1] = tt[1];
+    }
+  }
+}
+
+__device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab, double *rec, int tid,
+                                            int &iter, int &updates, double &norm1, double &norm2)
+{
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform arm
+  const int lane = tid & 63;
+  const bool ev = lane < 42;                   // stencil evaluation
+  const bool sc_lane = lane >= 43 && lane < 50; // sincos of joint lane - 43 of arm w
+  const int j = ev ? lane / 6 : -1, pt = ev ? lane - 6 * j : 0;
   const bool plus = pt < 3;
   const int nstep = (plus ? pt : pt - 3) + 1;
   for (;;) {
     // ---- A: angles.  y1[j] += h / y2[j] -= h by sequential adds as OMPL does; one sincos per lane -----------
     double y = 0.0, s, c;
     if (ev) {
-      const double xj = rec[fX + col];
+      const double xj = rec[fX + w * 7 + j];
       const double axj = ccmp_abs(xj);
       const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
       const double hh = plus ? h : -h;
@@ -43,54 +117,16 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
       if (nstep >= 2) y = y + hh;
       if (nstep >= 3) y = y + hh;
     } else if (sc_lane) {
-      y = rec[fX + tid - 86];
+      y = rec[fX + w * 7 + lane - 43];
     }
     ccmp_sincos(y, &s, &c);
     if (sc_lane) {
-      rec[fSC + 2 * (tid - 86)] = s;
-      rec[fSC + 2 * (tid - 86) + 1] = c;
+      rec[fSC + 2 * (w * 7 + lane - 43)] = s;
+      rec[fSC + 2 * (w * 7 + lane - 43) + 1] = c;
     }
     __syncthreads();
-    // ---- B: the chain of this lane's arm, joint j at y, the others at x ------------------------------------
-    double Tw[12];
-    {
-      double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
-      for (int i = 0; i < 7; i++) {
-        double Rj[9], Rn[9];
-        const double si = (i == j) ? s : rec[fSC + 2 * (arm * 7 + i)];
-        const double ci = (i == j) ? c : rec[fSC + 2 * (arm * 7 + i) + 1];
-        mulvec_acc(R, KL.offset[arm][i], o);
-        rot_sc(KL.axis[arm][i], KL.aprod[arm][i], si, ci, Rj);
-        mul33(R, Rj, Rn);
-#pragma unroll
-        for (int k = 0; k < 9; k++) R[k] = Rn[k];
-      }
-      tool_pose(KL, arm, R, o, &Tw[0], &Tw[9]);
-      if (at_x) {
-#pragma unroll
-        for (int k = 0; k < 12; k++) rec[fEE + arm * 12 + k] = Tw[k];
-      }
-    }
-    __syncthreads();
-    // ---- C: residuals.  Evaluation lanes pair their pose with the partner arm's pose at x; lane 84 gives f(x) ----
-    {
-      double A[12], Bq[12], tt[2];
-#pragma unroll
-      for (int k = 0; k < 12; k++) {
-        const double t0 = rec[fEE + k], t1 = rec[fEE + 12 + k];
-        A[k] = (ev && arm == 0) ? Tw[k] : t0;
-        Bq[k] = (ev && arm == 1) ? Tw[k] : t1;
-      }
-      chain_residual(K, &A[0], &A[9], &Bq[0], &Bq[9], tt, nullptr, nullptr);
-      if (ev) {
-        rec[fT + 2 * tid] = tt[0];
-        rec[fT + 2 * tid + 1] = tt[1];
-        rec[fY + tid] = y;
-      } else if (tid == 84) {
-        rec[fF] = tt[0];
-        rec[fF + 1] = tt[1];
-      }
-    }
+    if (w == 0) flat_chain_and_residual<0>(K, KC, steptab, rec, lane, j, s, c, y);
+    else flat_chain_and_residual<1>(K, KC, steptab, rec, lane, j, s, c, y);
     __syncthreads();
     const double f0 = rec[fF], f1 = rec[fF + 1];
     // ---- loop condition of ConstraintFunction.h:68 (block-uniform) ------------------------------------------
@@ -157,14 +193,16 @@ __global__ __launch_bounds__(128, 2) void project_fd_flat_kernel(
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
     const unsigned long long *__restrict__ pool_count, int wrap_output)
 {
-  __shared__ double lds[fRec];
+  __shared__ __attribute__((aligned(16))) double lds[fRec];
   __shared__ double ktab[kConstsDoubles + 1];
+  __shared__ __attribute__((aligned(16))) double steptab[kStepTab];
   __shared__ unsigned long long ticket;
   const int tid = threadIdx.x;
   {
     const double *src = reinterpret_cast<const double *>(&K);
     for (int k = tid; k < kConstsDoubles; k += 128) ktab[k] = src[k];
   }
+  stage_step_table(K, steptab, tid);
   __syncthreads();
   const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
   double *rec = lds;
@@ -202,7 +240,7 @@ __global__ __launch_bounds__(128, 2) void project_fd_flat_kernel(
       }
     }
     __syncthreads();
-    const bool conv = flat_newton(K, KL, rec, tid, iter, updates, norm1, norm2);
+    const bool conv = flat_newton(K, KL, steptab, rec, tid, iter, updates, norm1, norm2);
     const bool jv = flat_joint_valid(KL, rec, tid);
     if (tid < 14) {
       const double v = rec[fX + tid];
@@ -244,13 +282,15 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters)
 {
-  __shared__ double lds[gRec];
+  __shared__ __attribute__((aligned(16))) double lds[gRec];
   __shared__ double ktab[kConstsDoubles + 1];
+  __shared__ __attribute__((aligned(16))) double steptab[kStepTab];
   const int tid = threadIdx.x;
   {
     const double *src = reinterpret_cast<const double *>(&K);
     for (int k = tid; k < kConstsDoubles; k += 128) ktab[k] = src[k];
   }
+  stage_step_table(K, steptab, tid);
   __syncthreads();
   const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
   double *rec = lds;
@@ -287,7 +327,7 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
         __syncthreads();
         int iter = 0, updates = 0;
         double norm1 = 0.0, norm2 = 0.0;
-        const bool conv = flat_newton(K, KL, rec, tid, iter, updates, norm1, norm2);
+        const bool conv = flat_newton(K, KL, steptab, rec, tid, iter, updates, norm1, norm2);
         const bool jv = flat_joint_valid(KL, rec, tid);
         its += updates;
         if (!(conv && jv)) break;                        // not on manifold
