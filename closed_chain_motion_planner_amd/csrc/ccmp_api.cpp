@@ -307,7 +307,7 @@ int yaml_int(const YamlDoc &d, const char *key, int &out)
 } // namespace
 
 // scheduling defaults (sweeps: tools/time_small.py, tools/time_mid.py, tools/time_lpt3.py)
-constexpr size_t kDefaultSmallBatch = 8192;    // up to here the latency kernel alone is quickest
+constexpr size_t kDefaultSmallBatch = 12288;   // up to here the latency kernel alone is quickest
 constexpr size_t kDefaultLptMinBatch = 28672;  // from about one fill of the throughput kernel (30720 samples) on, ordering pays for the scout
 
 struct ccmp_ctx {
