@@ -202,7 +202,7 @@ def main():
         return
 
     value = world * B * args.steps / elapsed
-    kernel = "project_fd_kernel+project_fd_wave_kernel+scout_kernel" if args.mode == "fd" else "project_fast_kernel"
+    kernel = "project_fd_kernel+project_fd_flat_kernel+scout_kernel" if args.mode == "fd" else "project_fast_kernel"
     achieved_gbs = BYTES_PER_PROJECTION * B / (kms * 1e-3) / 1e9
     traffic, valu, executed = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")

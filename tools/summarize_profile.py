@@ -37,7 +37,7 @@ def counters(d, kernel_subs):
 
 def main():
     tag = sys.argv[1]
-    kernel_subs = (sys.argv[2] if len(sys.argv) > 2 else "project_fd_kernel,project_fd_wave_kernel,scout_kernel").split(",")
+    kernel_subs = (sys.argv[2] if len(sys.argv) > 2 else "project_fd_kernel,project_fd_flat_kernel,scout_kernel").split(",")
     kernel_sub = "+".join(kernel_subs)
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
