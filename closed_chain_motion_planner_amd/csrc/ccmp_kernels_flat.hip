@@ -20,6 +20,22 @@ constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
 // the final iterate is computed and dropped): ~1.5 k dependent instructions per Newton iteration instead of ~3.3 k
 // in the one-wavefront-per-sample kernel.  The arm is wave-uniform: kinematic constants are scalar operands from the
 // kernarg segment, as in the throughput kernel.
+#ifdef CCMP_FLAT_TIMING
+// phase timing of thread 0 of block 0 (tools/time_phases.py; never defined in the product build)
+__device__ unsigned long long g_flat_timing[8];
+__device__ __forceinline__ void flat_tick(int k, unsigned long long &prev)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    g_flat_timing[k] += now - prev;
+    prev = now;
+  }
+}
+#define FLAT_TICK(k) flat_tick(k, tprev)
+#else
+#define FLAT_TICK(k) do { } while (0)
+#endif
+
 constexpr int fX = 0, fSC = 14, fEE = 42, fF = 66, fJ = 68, fT = 96, fY = 264, fV = 348, fRec = 350;
 
 // Per-joint constants of both arms in chain order, 12 doubles per joint (offset 3, axis 3, axis products 6), so that a
@@ -36,7 +52,8 @@ __device__ __forceinline__ void stage_step_table(const ccmp_consts &K, double *t
 
 template <int W>
 __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab,
-                                                        double *rec, int lane, int j, double s, double c, double y)
+                                                        double *rec, int lane, int j, double s, double c, double y,
+                                                        unsigned long long &tprev)
 {
   // ---- B: the chain of arm W, joint j at (s, c), the others at x --------------------------------------------------
   double Tw[12];
@@ -76,6 +93,7 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
     }
   }
   __syncthreads();
+  FLAT_TICK(1);
   // ---- C: residuals against the partner arm's pose at x; lane 42 of wave 0 yields f(x) --------------------------
   {
     double To[12], tt[2];
@@ -105,6 +123,7 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
   const int j = ev ? lane / 6 : -1, pt = ev ? lane - 6 * j : 0;
   const bool plus = pt < 3;
   const int nstep = (plus ? pt : pt - 3) + 1;
+  unsigned long long tprev = __builtin_readcyclecounter();
   for (;;) {
     // ---- A: angles.  y1[j] += h / y2[j] -= h by sequential adds as OMPL does; one sincos per lane -----------
     double y = 0.0, s, c;
@@ -125,9 +144,11 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
       rec[fSC + 2 * (w * 7 + lane - 43) + 1] = c;
     }
     __syncthreads();
-    if (w == 0) flat_chain_and_residual<0>(K, KC, steptab, rec, lane, j, s, c, y);
-    else flat_chain_and_residual<1>(K, KC, steptab, rec, lane, j, s, c, y);
+    FLAT_TICK(0);
+    if (w == 0) flat_chain_and_residual<0>(K, KC, steptab, rec, lane, j, s, c, y, tprev);
+    else flat_chain_and_residual<1>(K, KC, steptab, rec, lane, j, s, c, y, tprev);
     __syncthreads();
+    FLAT_TICK(2);
     const double f0 = rec[fF], f1 = rec[fF + 1];
     // ---- loop condition of ConstraintFunction.h:68 (block-uniform) ------------------------------------------
     bool cont = false;
@@ -151,18 +172,23 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
       rec[fJ + tid] = CCMP_FMA(0.1, m[2], CCMP_FMA(-0.6, m[1], 1.5 * m[0]));
     }
     __syncthreads();
+    FLAT_TICK(3);
     // ---- E: minimum-norm step ----------------------------------------------------------------------------
     {
       double Jr[28], dx[14];
 #pragma unroll
       for (int k = 0; k < 28; k++) Jr[k] = rec[fJ + k];
       solve_minnorm(Jr, f0, f1, dx);
+      // thread e < 14 moves x[e]: its dx is picked by a select chain in registers and x is touched once (fourteen
+      // predicated LDS read-modify-writes in a row cost ~1400 cycles of LDS round trips)
+      double mine = dx[0];
 #pragma unroll
-      for (int e = 0; e < 14; e++)
-        if (e == tid) rec[fX + e] = CCMP_FMA(-K.step, dx[e], rec[fX + e]);
+      for (int e = 1; e < 14; e++) mine = (tid == e) ? dx[e] : mine;
+      if (tid < 14) rec[fX + tid] = CCMP_FMA(-K.step, mine, rec[fX + tid]);
       updates++;
     }
     __syncthreads();
+    FLAT_TICK(4);
   }
 }
 
@@ -388,5 +414,17 @@ hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambd
                      max_states, states, n_states, ok, newton_iters);
   return hipGetLastError();
 }
+
+#ifdef CCMP_FLAT_TIMING
+hipError_t ccmp_debug_flat_timing(unsigned long long *out8, int reset)
+{
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_flat_timing), 8 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_flat_timing), z, sizeof z);
+  }
+  return e;
+}
+#endif
 
 } // extern "C"
