@@ -112,3 +112,28 @@ def test_c5_eight_shards_reproduce_the_two_million_batch(gpu_ctx):
     assert torch.equal(torch.cat(valid_parts), whole[ok_w == 1])
     frac = float(ok_w.to(torch.float64).mean().item())
     assert 0.15 < frac < 0.30 and 30.0 < float(it_w.to(torch.float64).mean().item()) < 36.0
+
+
+@pytest.mark.parametrize("obj,seed", [("Wine_Bottle", 0x51), ("stefan", 0x52)])
+def test_latency_kernels_agree_and_repeat(gpu_ctx, obj, seed):
+    """65536 samples through the latency kernels alone: the one-round 128-thread kernel, run five times (its phases are
+    separated by barriers and share LDS slots — a missing barrier shows up as run-to-run differences), equals the
+    one-wavefront-per-sample kernel and the default policy, bit for bit."""
+    import torch
+
+    c = _constraint(obj, gpu_ctx)
+    n = 65536
+    q = c.ambient_uniform_batch(seed, 0, n)
+    ref = c.project_batch(q)  # default policy (scout + throughput kernel + hand-over)
+    try:
+        gpu_ctx.set_schedule(2, 0)
+        gpu_ctx.set_option("flat_kernel", 0)
+        wave = c.project_batch(q)
+        gpu_ctx.set_option("flat_kernel", 1)
+        for rep in range(5):
+            flat = c.project_batch(q)
+            for a, b, w in zip(flat, ref, wave):
+                assert torch.equal(a, b) and torch.equal(a, w), (obj, rep)
+    finally:
+        gpu_ctx.set_schedule(1)
+        gpu_ctx.set_option("flat_kernel", 1)
