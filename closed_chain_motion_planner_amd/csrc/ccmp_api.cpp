@@ -307,7 +307,7 @@ int yaml_int(const YamlDoc &d, const char *key, int &out)
 } // namespace
 
 // scheduling defaults (sweeps: tools/time_small.py, tools/time_mid.py, tools/time_lpt3.py)
-constexpr size_t kDefaultSmallBatch = 12288;   // up to here the latency kernel alone is quickest
+constexpr size_t kDefaultSmallBatch = 24576;   // up to here the latency kernel alone is quickest
 constexpr size_t kDefaultLptMinBatch = 28672;  // from about one fill of the throughput kernel (30720 samples) on, ordering pays for the scout
 
 struct ccmp_ctx {
@@ -716,11 +716,11 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       order = ord;
       if (ctx->lpt == 2) nwave = 0;
     }
-    // Hand-over threshold (sweeps: tools/time_mid.py, tools/time_lpt3.py).  Longest-first leaves only short samples
-    // at the end of large batches: let the throughput kernel finish them and hand over only nearly empty waves (4);
-    // mid-size ordered batches are in flight all at once, their long samples go over as soon as the queue is dry
-    // (10); in index order a wave is handed over once 6 or fewer of its 10 groups are still busy.
-    const int dump_thr = ctx->dump_threshold >= 0 ? ctx->dump_threshold : (order ? (B >= 100000 ? 4 : 10) : 6);
+    // Hand-over threshold (sweeps: tools/time_mid.py, tools/time_lpt3.py).  Once the queue is dry the samples still in
+    // flight go to the latency kernel at once (10: it iterates ~15x faster than a fully occupied throughput wave);
+    // only very large longest-first batches end on short samples that the throughput kernel finishes itself, handing
+    // over nearly empty waves only (4).
+    const int dump_thr = ctx->dump_threshold >= 0 ? ctx->dump_threshold : ((order && B >= 200000) ? 4 : 10);
     if (nblocks > 0) {
       HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
                                         nwave > 0 ? ctx->pool : nullptr, dump_thr, order, st));

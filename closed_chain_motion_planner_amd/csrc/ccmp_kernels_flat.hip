@@ -160,33 +160,38 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
       if (resid) { cont = iter < K.max_iter; iter++; }
     }
     if (!cont) return (norm1 < K.tol_pos) && (norm2 < K.tol_rot);
-    // ---- D: J[row][col] = 1.5 m1 - 0.6 m2 + 0.1 m3, m_s = (t1 - t2) / (y1[j] - y2[j]) ---------------------
-    if (tid < 28) {
-      const int row = tid >= 14 ? 1 : 0, cc = tid - 14 * row;
-      double m[3];
+    // ---- D + E on wave 0 alone: the stencil combination needs 28 lanes, the min-norm solve is a serial computation
+    // that every lane replicates — a second wave repeating it would only take issue slots from other blocks.  Wave 1
+    // waits at the barrier below.  Inside one wave LDS operations execute in order: a fence orders the combination's
+    // writes before the solve's reads, no s_barrier (wave 1 would never arrive at it).
+    if (w == 0) {
+      // J[row][col] = 1.5 m1 - 0.6 m2 + 0.1 m3, m_s = (t1 - t2) / (y1[j] - y2[j])
+      if (lane < 28) {
+        const int row = lane >= 14 ? 1 : 0, cc = lane - 14 * row;
+        double m[3];
 #pragma unroll
-      for (int sidx = 0; sidx < 3; sidx++) {
-        const int e1 = 6 * cc + sidx, e2 = 6 * cc + 3 + sidx;
-        m[sidx] = (rec[fT + 2 * e1 + row] - rec[fT + 2 * e2 + row]) / (rec[fY + e1] - rec[fY + e2]);
+        for (int sidx = 0; sidx < 3; sidx++) {
+          const int e1 = 6 * cc + sidx, e2 = 6 * cc + 3 + sidx;
+          m[sidx] = (rec[fT + 2 * e1 + row] - rec[fT + 2 * e2 + row]) / (rec[fY + e1] - rec[fY + e2]);
+        }
+        rec[fJ + lane] = CCMP_FMA(0.1, m[2], CCMP_FMA(-0.6, m[1], 1.5 * m[0]));
       }
-      rec[fJ + tid] = CCMP_FMA(0.1, m[2], CCMP_FMA(-0.6, m[1], 1.5 * m[0]));
-    }
-    __syncthreads();
-    FLAT_TICK(3);
-    // ---- E: minimum-norm step ----------------------------------------------------------------------------
-    {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      FLAT_TICK(3);
+      // minimum-norm step
       double Jr[28], dx[14];
 #pragma unroll
       for (int k = 0; k < 28; k++) Jr[k] = rec[fJ + k];
       solve_minnorm(Jr, f0, f1, dx);
-      // thread e < 14 moves x[e]: its dx is picked by a select chain in registers and x is touched once (fourteen
+      // lane e < 14 moves x[e]: its dx is picked by a select chain in registers and x is touched once (fourteen
       // predicated LDS read-modify-writes in a row cost ~1400 cycles of LDS round trips)
       double mine = dx[0];
 #pragma unroll
-      for (int e = 1; e < 14; e++) mine = (tid == e) ? dx[e] : mine;
-      if (tid < 14) rec[fX + tid] = CCMP_FMA(-K.step, mine, rec[fX + tid]);
-      updates++;
+      for (int e = 1; e < 14; e++) mine = (lane == e) ? dx[e] : mine;
+      if (lane < 14) rec[fX + lane] = CCMP_FMA(-K.step, mine, rec[fX + lane]);
     }
+    updates++;
     __syncthreads();
     FLAT_TICK(4);
   }

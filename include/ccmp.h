@@ -105,7 +105,7 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx);
 int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
 /* projector scheduling: wave_kernel 0 = 10-samples-per-wave kernel only, 1 = that kernel until the sample queue
  * drains, then the wave-per-sample kernel on the samples still in flight (default), 2 = wave-per-sample only;
- * batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = built-in default, 12288).
+ * batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = built-in default, 24576).
  * Results are bit-identical under every setting. */
 #define CCMP_DEFAULT ((size_t)-1)
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch);
