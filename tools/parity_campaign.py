@@ -1,0 +1,61 @@
+"""Large-sample parity campaign on the GPU box: the HIP path (default policy, through the C ABI) against the det-build
+CPU oracle on all host threads, bit for bit.  Writes profiles/parity_campaign.json.
+
+    python tools/parity_campaign.py [samples_per_case]        (default 200000; ~30 s of oracle time per case on 256 threads)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from closed_chain_motion_planner_amd import Context, KinematicChainConstraint  # noqa: E402
+from oracle_binding import Oracle, build_oracle  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+NCPU = os.cpu_count() or 8
+build_oracle()
+orc = Oracle("det")
+ctx = Context(0)
+cases = [("Wine_Bottle", None, 0xA1), ("stefan", None, 0xA2), ("dumbbell", None, 0xA3), ("stefan", (5e-4, 2.5e-3), 0xA4)]
+report = {"samples_per_case": N, "host_threads": NCPU, "cases": []}
+for obj, tol, seed in cases:
+    c = KinematicChainConstraint.from_yaml(os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml"), ctx=ctx)
+    if tol:
+        c.setTolerance(*tol)
+    P = orc.problem_from_bytes(bytes(c.problem))
+    # projector on resident inputs
+    q = c.ambient_uniform_batch(seed, 0, N)
+    out, ok, it = c.project_batch(q)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    q_cpu, ok_cpu, it_cpu = orc.project_batch(P, q.cpu().numpy(), NCPU)
+    t_cpu = time.time() - t0
+    out_h, ok_h, it_h = out.cpu().numpy(), ok.cpu().numpy(), it.cpu().numpy().astype(np.int32)
+    same_q = int((out_h.view(np.uint64) == q_cpu.view(np.uint64)).all(axis=1).sum())
+    entry = {
+        "object": obj, "tolerance": list(tol) if tol else [1e-3, 5e-3], "seed": seed, "samples": N,
+        "rows_bit_identical": same_q, "ok_mismatches": int((ok_h != ok_cpu).sum()), "iteration_mismatches": int((it_h != it_cpu).sum()),
+        "max_abs_dq": float(np.nanmax(np.abs(out_h - q_cpu))), "ok_fraction": float(ok_cpu.mean()), "mean_iterations": float(it_cpu.mean()),
+        "max_iterations": int(it_cpu.max()), "oracle_seconds": round(t_cpu, 1), "oracle_threads": NCPU,
+    }
+    # fused sampler path: sampleUniform = ambient sample -> project -> enforceBounds
+    n2 = N // 4
+    sq, sok, sit, _ = c.sample_project_batch(seed + 0x100, 12345, n2)
+    sq_cpu, sok_cpu, sit_cpu = orc.sample_project_batch(P, seed + 0x100, 12345, n2, NCPU)
+    entry["sampler_rows_bit_identical"] = int((sq.cpu().numpy().view(np.uint64) == sq_cpu.view(np.uint64)).all(axis=1).sum())
+    entry["sampler_samples"] = n2
+    entry["sampler_ok_mismatches"] = int((sok.cpu().numpy() != sok_cpu).sum())
+    report["cases"].append(entry)
+    print(json.dumps(entry), flush=True)
+    assert same_q == N and entry["ok_mismatches"] == 0 and entry["iteration_mismatches"] == 0
+    assert entry["sampler_rows_bit_identical"] == n2 and entry["sampler_ok_mismatches"] == 0
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+with open(os.path.join(ROOT, "profiles", "parity_campaign.json"), "w") as f:
+    json.dump(report, f, indent=1)
+print("all cases bit-identical")
