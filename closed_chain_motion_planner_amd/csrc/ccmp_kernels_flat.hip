@@ -1,7 +1,7 @@
 // ccmp_kernels_flat.hip — the latency kernel of the reference-arithmetic path: one sample per 128-thread block,
 // every residual evaluation of a Newton iteration in ONE round.  Canonical (bit-reproducible) rounding model:
 // built -ffp-contract=off -DCCMP_USE_FMA like ccmp_kernels_fd.hip, and like it with -mllvm -disable-machine-licm
-// (214 VGPRs and no scratch instead of 266: two blocks' waves per SIMD).
+// (124 VGPRs and no scratch: four waves per SIMD, eight blocks per CU).
 #include "ccmp_fd_common.h"
 
 using namespace ccmp;
@@ -18,8 +18,10 @@ constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
 // arm's chain at x; lanes 43..49 compute the sines/cosines of the arm's 7 joints.  function(x) and the 84
 // evaluations of jacobian(x) are therefore computed side by side instead of one after the other (the Jacobian of
 // the final iterate is computed and dropped): ~1.5 k dependent instructions per Newton iteration instead of ~3.3 k
-// in the one-wavefront-per-sample kernel.  The arm is wave-uniform: kinematic constants are scalar operands from the
-// kernarg segment, as in the throughput kernel.
+// in the one-wavefront-per-sample kernel.  The arm is wave-uniform (no role selects); the per-joint constants come from
+// an LDS step table read one joint ahead (scalar loads from the kernarg segment were 15 % slower here: one or two
+// waves per SIMD cannot hide the scalar-cache round trips).  The stencil combination and the solve run on wave 0
+// only; wave 1 waits at the barrier and leaves its issue slots to other blocks.
 #ifdef CCMP_FLAT_TIMING
 // phase timing of thread 0 of block 0 (tools/time_phases.py; never defined in the product build)
 __device__ unsigned long long g_flat_timing[8];
