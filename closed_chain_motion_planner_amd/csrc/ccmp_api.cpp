@@ -673,6 +673,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   CCMP_PROLOGUE();
   if (B == 0) return CCMP_OK;
   if (!q_out || !ok || (mode == 0 && !q_in)) return CCMP_EINVAL;
+  if ((((uintptr_t)q_in) | ((uintptr_t)q_out)) & 15u) return CCMP_EINVAL; // rows are moved in 16-byte pieces
   if (p->jacobian_mode == CCMP_JAC_FD) {
     // Large batches: the throughput (10 samples per wave) kernel until the queue drains, then the
     // wave-per-sample kernel on the samples still in flight.  Small batches: wave-per-sample only.

@@ -129,7 +129,8 @@ int ccmp_function_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, d
                         void *hip_stream);
 /* KinematicChainConstraint::project (ConstraintFunction.h:57-82): q_out[i] = final iterate whether
  * or not ok[i]; ok[i] = the reference's return value; iters[i] (nullable) = Newton updates done.
- * q_in == q_out is allowed (in place, as the reference). */
+ * q_in == q_out is allowed (in place, as the reference).  q_in and q_out must be 16-byte aligned (any row of a
+ * hipMalloc'ed [B][14] array is): CCMP_EINVAL otherwise. */
 int ccmp_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, double *q_out,
                        uint8_t *ok, uint16_t *iters, size_t B, void *hip_stream);
 /* KinematicChainConstraint::isSatisfied (ConstraintFunction.h:114-120) */

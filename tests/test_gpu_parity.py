@@ -330,3 +330,17 @@ def test_general_base_frames_take_the_full_product(gpu_ctx, oracle_det, schedule
     assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)
     assert np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
     assert it_cpu.max() > 0
+
+
+def test_misaligned_rows_are_rejected(gpu_ctx):
+    """rows travel in 16-byte pieces: an 8-byte-aligned (but not 16-byte-aligned) joint buffer is an argument error"""
+    import torch
+    from closed_chain_motion_planner_amd import _lib
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    flat = torch.zeros(14 * 4 + 1, dtype=torch.float64, device="cuda")
+    mis = flat[1:]  # data_ptr() + 8
+    assert mis.data_ptr() % 16 == 8
+    ok = torch.zeros(4, dtype=torch.uint8, device="cuda")
+    rc = _lib.lib().ccmp_project_batch(gpu_ctx.handle, C.byref(c.problem), mis.data_ptr(), mis.data_ptr(), ok.data_ptr(), None, 4, None)
+    assert rc == -1  # CCMP_EINVAL
