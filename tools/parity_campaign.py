@@ -18,6 +18,7 @@ from closed_chain_motion_planner_amd import Context, KinematicChainConstraint  #
 from oracle_binding import Oracle, build_oracle  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+NE = int(sys.argv[2]) if len(sys.argv) > 2 else 10000  # geodesic edges per case
 NCPU = os.cpu_count() or 8
 build_oracle()
 orc = Oracle("det")
@@ -51,8 +52,31 @@ for obj, tol, seed in cases:
     entry["sampler_rows_bit_identical"] = int((sq.cpu().numpy().view(np.uint64) == sq_cpu.view(np.uint64)).all(axis=1).sum())
     entry["sampler_samples"] = n2
     entry["sampler_ok_mismatches"] = int((sok.cpu().numpy() != sok_cpu).sum())
+    # extend step: edges between valid projected states, GPU batch vs one oracle call per edge on a thread pool
+    # (ctypes releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    good = out[ok == 1]
+    ne = min(NE, good.shape[0] // 2)
+    frm, to = good[:ne].contiguous(), good[ne:2 * ne].contiguous()
+    d = to - frm
+    to = (frm + d / d.norm(dim=1, keepdim=True)).contiguous()  # targets 1 rad away: a handful of delta steps each
+    maxs = 16
+    st, nst, gok, _ = c.discrete_geodesic_batch(frm, to, maxs)
+    st, nst, gok = st.cpu().numpy(), nst.cpu().numpy(), gok.cpu().numpy()
+    frm_h, to_h = frm.cpu().numpy(), to.cpu().numpy()
+
+    def one(e):
+        ok_c, st_c, _ = orc.discrete_geodesic(P, frm_h[e], to_h[e], interpolate=True, max_states=maxs)
+        return bool(ok_c) == bool(gok[e]) and len(st_c) == int(nst[e]) and np.array_equal(st[e, : nst[e]].view(np.uint64), st_c.view(np.uint64))
+
+    with ThreadPoolExecutor(max_workers=min(64, NCPU)) as ex:
+        same_edges = sum(ex.map(one, range(ne)))
+    entry["geodesic_edges"] = ne
+    entry["geodesic_edges_bit_identical"] = int(same_edges)
+    entry["geodesic_mean_states"] = float(nst.mean())
     report["cases"].append(entry)
     print(json.dumps(entry), flush=True)
+    assert same_edges == ne
     assert same_q == N and entry["ok_mismatches"] == 0 and entry["iteration_mismatches"] == 0
     assert entry["sampler_rows_bit_identical"] == n2 and entry["sampler_ok_mismatches"] == 0
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
