@@ -148,6 +148,24 @@ void quat_to_R(const double *q, double *R)
   R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
 }
 
+// Do both arms carry the structure of the uncalibrated Panda that the STOCK kernels assume (ccmp_kin.h: kStockZ,
+// kStockOff, kStockEe)?  Exact comparisons: a component the kernels skip must be exactly zero, a z joint's axis exactly
+// (0, 0, 1).  Calibration offsets (ccmp_set_calibration) fail the test and get the general kernels.
+bool is_stock_structure(const ccmp_problem &P)
+{
+  for (int a = 0; a < 2; a++) {
+    for (int i = 0; i < 7; i++) {
+      const double *ax = P.axis[a][i];
+      if (ccmp::kStockZ[i] && !(ax[0] == 0.0 && ax[1] == 0.0 && ax[2] == 1.0)) return false;
+      for (int k = 0; k < 3; k++)
+        if (!((ccmp::kStockOff[i] >> k) & 1) && !(P.offset[a][i][k] == 0.0)) return false;
+    }
+    for (int k = 0; k < 3; k++)
+      if (!((ccmp::kStockEe >> k) & 1) && !(P.ee[a][k] == 0.0)) return false;
+  }
+  return true;
+}
+
 // Kernel constants from the problem.  Pure re-packing plus products of constants (each a single
 // IEEE multiply/add, hence identical wherever it is evaluated).
 void make_consts(const ccmp_problem &P, ccmp_consts &K)
@@ -166,6 +184,7 @@ void make_consts(const ccmp_problem &P, ccmp_consts &K)
     for (int k = 0; k < 9; k++) diag = diag && (k % 4 == 0 ? (P.base_R[a][k] == 1.0 || P.base_R[a][k] == -1.0) : P.base_R[a][k] == 0.0);
     if (diag) K.base_diag |= 1 << a;
   }
+  K.stock = is_stock_structure(P) ? 1 : 0;
   for (int k = 0; k < 3; k++) K.init_p[k] = P.init_p[k];
   ccmp::quat_of(P.init_R, K.init_q);
   for (int i = 0; i < 7; i++) {
@@ -321,6 +340,7 @@ struct ccmp_ctx {
   int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
   const unsigned int *order = nullptr; // experimental: externally supplied processing order
   int flat_kernel = 1;                 // latency work (small batches, hand-over): 1 = one-round 128-thread kernel, 0 = single-wave kernel
+  int stock_kernels = 1;               // 0: always the general kernels, also for the stock Panda structure (tests, A/B)
   int lpt = 1;                         // 0: in-order; 1: FP32 scout + longest-predicted-first, hand-over kept; 2: same, no hand-over
   size_t lpt_min_batch = kDefaultLptMinBatch; // below this the scout costs more than the tail it removes
   void *lpt_buf = nullptr;             // pred (u16 x B) | hist (u32 x 1024) | order (u32 x B)
@@ -616,6 +636,9 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   if (!strcmp(name, "flat_kernel")) { // latency work: 1 = one-round 128-thread kernel (default), 0 = single-wave kernel
     if (value != 0 && value != 1) return CCMP_EINVAL;
     ctx->flat_kernel = (int)value;
+  } else if (!strcmp(name, "stock_kernels")) { // 1 = kernels specialised for the stock Panda structure when it applies (default)
+    if (value != 0 && value != 1) return CCMP_EINVAL;
+    ctx->stock_kernels = (int)value;
   } else if (!strcmp(name, "handover_threshold")) { // -1 = automatic, 0..10 = hand a wave over once <= this many groups are busy
     if (value < -1 || value > 10) return CCMP_EINVAL;
     ctx->dump_threshold = (int)value;
@@ -655,7 +678,8 @@ int ccmp_ctx_num_cus(const ccmp_ctx *ctx) { return ctx ? ctx->num_cus : 0; }
   if (!guard.ok) return CCMP_ENODEV;                           \
   hipStream_t st = (hipStream_t)hip_stream; \
   ccmp_consts K;                                               \
-  make_consts(*p, K)
+  make_consts(*p, K);                                          \
+  if (!ctx->stock_kernels) K.stock = 0
 
 int ccmp_function_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, double *f, size_t B, void *hip_stream)
 {

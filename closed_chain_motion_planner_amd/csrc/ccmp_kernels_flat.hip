@@ -52,7 +52,33 @@ __device__ __forceinline__ void stage_step_table(const ccmp_consts &K, double *t
   }
 }
 
-template <int W>
+// joints I..6 of the chain of arm W with compile-time joint indices (STOCK: the exact-zero structure of the uncalibrated
+// Panda is known to the compiler, ccmp_kin.h); the constants of joint I+1 are read while joint I is computed
+template <int W, bool STOCK, int I>
+__device__ __forceinline__ void flat_chain_from(const double2 *tab, const double2 *sct, int j, double s, double c, const double2 *cur,
+                                                double2 sc_cur, double *R, double *o)
+{
+  if constexpr (I < 7) {
+    double2 nxt[6], sc_nxt = sc_cur;
+    if constexpr (I < 6) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) nxt[k] = tab[6 * (I + 1) + k];
+      sc_nxt = sct[I + 1];
+    }
+    double Rn[9];
+    const double si = (I == j) ? s : sc_cur.x;
+    const double ci = (I == j) ? c : sc_cur.y;
+    const double off[3] = {cur[0].x, cur[0].y, cur[1].x};
+    const double ax[3] = {cur[1].y, cur[2].x, cur[2].y};
+    const double ap[6] = {cur[3].x, cur[3].y, cur[4].x, cur[4].y, cur[5].x, cur[5].y};
+    chain_step<I, STOCK>(off, ax, ap, si, ci, R, Rn, o);
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = Rn[k];
+    flat_chain_from<W, STOCK, I + 1>(tab, sct, j, s, c, nxt, sc_nxt, R, o);
+  }
+}
+
+template <int W, bool STOCK>
 __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab,
                                                         double *rec, int lane, int j, double s, double c, double y,
                                                         unsigned long long &tprev)
@@ -63,32 +89,11 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
     const double2 *tab = reinterpret_cast<const double2 *>(steptab + W * 7 * kStepDoubles);
     const double2 *sct = reinterpret_cast<const double2 *>(rec + fSC + 2 * W * 7);
-    double2 cur[6], nxt[6], sc_cur = sct[0], sc_nxt = sc_cur;
+    double2 cur[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) cur[k] = tab[k];
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-      if (i < 6) { // next joint's constants and sin/cos: in flight while this joint is computed
-#pragma unroll
-        for (int k = 0; k < 6; k++) nxt[k] = tab[6 * (i + 1) + k];
-        sc_nxt = sct[i + 1];
-      }
-      double Rj[9], Rn[9];
-      const double si = (i == j) ? s : sc_cur.x;
-      const double ci = (i == j) ? c : sc_cur.y;
-      const double off[3] = {cur[0].x, cur[0].y, cur[1].x};
-      const double ax[3] = {cur[1].y, cur[2].x, cur[2].y};
-      const double ap[6] = {cur[3].x, cur[3].y, cur[4].x, cur[4].y, cur[5].x, cur[5].y};
-      mulvec_acc(R, off, o);
-      rot_sc(ax, ap, si, ci, Rj);
-      mul33(R, Rj, Rn);
-#pragma unroll
-      for (int k = 0; k < 9; k++) R[k] = Rn[k];
-#pragma unroll
-      for (int k = 0; k < 6; k++) cur[k] = nxt[k];
-      sc_cur = sc_nxt;
-    }
-    tool_pose(KC, W, R, o, &Tw[0], &Tw[9]);
+    flat_chain_from<W, STOCK, 0>(tab, sct, j, s, c, cur, sct[0], R, o);
+    tool_pose_t<STOCK>(KC, W, R, o, &Tw[0], &Tw[9]);
     if (lane == 42) {
 #pragma unroll
       for (int k = 0; k < 12; k++) rec[fEE + W * 12 + k] = Tw[k];
@@ -115,6 +120,7 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
   }
 }
 
+template <bool STOCK>
 __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab, double *rec, int tid,
                                             int &iter, int &updates, double &norm1, double &norm2)
 {
@@ -147,8 +153,8 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
     }
     __syncthreads();
     FLAT_TICK(0);
-    if (w == 0) flat_chain_and_residual<0>(K, KC, steptab, rec, lane, j, s, c, y, tprev);
-    else flat_chain_and_residual<1>(K, KC, steptab, rec, lane, j, s, c, y, tprev);
+    if (w == 0) flat_chain_and_residual<0, STOCK>(K, KC, steptab, rec, lane, j, s, c, y, tprev);
+    else flat_chain_and_residual<1, STOCK>(K, KC, steptab, rec, lane, j, s, c, y, tprev);
     __syncthreads();
     FLAT_TICK(2);
     const double f0 = rec[fF], f1 = rec[fF + 1];
@@ -219,7 +225,7 @@ __device__ __forceinline__ bool flat_joint_valid(const ccmp_consts &KL, double *
 
 // SRC 0: q_in, SRC 1: ambient sampler, SRC 2: straggler pool.  queue == nullptr: static striding (one block per
 // sample launches need no queue reset).
-template <int SRC>
+template <int SRC, bool STOCK>
 __global__ __launch_bounds__(128, 2) void project_fd_flat_kernel(
     const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(128, 2) void project_fd_flat_kernel(
       }
     }
     __syncthreads();
-    const bool conv = flat_newton(K, KL, steptab, rec, tid, iter, updates, norm1, norm2);
+    const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2);
     const bool jv = flat_joint_valid(KL, rec, tid);
     if (tid < 14) {
       const double v = rec[fX + tid];
@@ -310,6 +316,7 @@ __device__ __forceinline__ double lds_distance(const double *a, const double *b)
   return ccmp_sqrt(dist);
 }
 
+template <bool STOCK>
 __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
         __syncthreads();
         int iter = 0, updates = 0;
         double norm1 = 0.0, norm2 = 0.0;
-        const bool conv = flat_newton(K, KL, steptab, rec, tid, iter, updates, norm1, norm2);
+        const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2);
         const bool jv = flat_joint_valid(KL, rec, tid);
         its += updates;
         if (!(conv && jv)) break;                        // not on manifold
@@ -401,15 +408,20 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, hipStream_t st)
 {
-  if (src == 0)
-    hipLaunchKernelGGL(project_fd_flat_kernel<0>, dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output);
-  else if (src == 1)
-    hipLaunchKernelGGL(project_fd_flat_kernel<1>, dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output);
-  else
-    hipLaunchKernelGGL(project_fd_flat_kernel<2>, dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output);
+#define CCMP_LAUNCH_FLAT(SRC, STOCK)                                                                                             \
+  hipLaunchKernelGGL((project_fd_flat_kernel<SRC, STOCK>), dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
+                     (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output)
+  if (src == 0) {
+    if (K->stock) CCMP_LAUNCH_FLAT(0, true);
+    else CCMP_LAUNCH_FLAT(0, false);
+  } else if (src == 1) {
+    if (K->stock) CCMP_LAUNCH_FLAT(1, true);
+    else CCMP_LAUNCH_FLAT(1, false);
+  } else {
+    if (K->stock) CCMP_LAUNCH_FLAT(2, true);
+    else CCMP_LAUNCH_FLAT(2, false);
+  }
+#undef CCMP_LAUNCH_FLAT
   return hipGetLastError();
 }
 
@@ -417,8 +429,12 @@ hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambd
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int nblocks, hipStream_t st)
 {
-  hipLaunchKernelGGL(geodesic_flat_kernel, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                     max_states, states, n_states, ok, newton_iters);
+  if (K->stock)
+    hipLaunchKernelGGL(geodesic_flat_kernel<true>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
+                       max_states, states, n_states, ok, newton_iters);
+  else
+    hipLaunchKernelGGL(geodesic_flat_kernel<false>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
+                       max_states, states, n_states, ok, newton_iters);
   return hipGetLastError();
 }
 

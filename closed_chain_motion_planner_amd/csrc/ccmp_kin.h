@@ -39,6 +39,8 @@ struct ccmp_consts {
   double tol_pos, tol_rot, step;
   int32_t max_iter;
   int32_t base_diag; /* bit a: base_R[a] is exactly diag(+-1, +-1, +-1) (every shipped t_wb, grasping_point.cpp:11-20) */
+  int32_t stock;     /* both arms carry the stock Panda structure (see kStockZ below): launchers pick the STOCK kernels */
+  int32_t pad;
 };
 
 namespace ccmp {
@@ -102,6 +104,70 @@ CCMP_HD void rot_sc(const double *a, const double *ap, double s, double c, doubl
   R[8] = CCMP_FMA(ap[5], t, c);
 }
 
+/* ---- structure of the stock Panda constants -------------------------------------------------------------------
+ * With zero calibration offsets (the shipped configuration: PandaModel::initModel(dh) is commented out at
+ * ConstrainedPlanningCommon.cpp:97) the constants of panda_rbdl.cpp:97-147 contain exact zeros and ones: joints 1, 3
+ * and 5 rotate about exactly (0, 0, 1); of the 21 joint-offset components only six are non-zero; the hand offset has
+ * no x component.  A product with an exact zero is an exact zero, and adding it changes no bit (beyond the sign of a
+ * sum that is itself exactly zero), so kernels instantiated with STOCK = true skip those operations and still
+ * reproduce the general formulas bit for bit.  The host selects STOCK only after comparing the constants exactly
+ * (ccmp_api.cpp: is_stock_structure); anything else — calibrated arms — runs the general code. */
+constexpr int kStockZ[7] = {1, 0, 1, 0, 1, 0, 0};   /* axis == (0, 0, 1) exactly */
+constexpr int kStockOff[7] = {4, 0, 4, 1, 5, 0, 1}; /* bit k: offset component k may be non-zero */
+constexpr int kStockEe = 6;                         /* ee = (0, y, z) */
+
+/* r += A v where the components of v not flagged in NZ are exactly zero: the skipped terms of mulvec_acc are exact
+ * zeros added to the running sum, the others keep their order. */
+template <int NZ>
+CCMP_HD void mulvec_acc_nz(const double *A, const double *v, double *r)
+{
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double a = r[i];
+    if (NZ & 1) a = CCMP_FMA(A[3 * i], v[0], a);
+    if (NZ & 2) a = CCMP_FMA(A[3 * i + 1], v[1], a);
+    if (NZ & 4) a = CCMP_FMA(A[3 * i + 2], v[2], a);
+    r[i] = a;
+  }
+}
+
+/* Rn = R * Rot((0, 0, 1), angle): rot_sc gives [[c, -s, 0], [s, c, 0], [0, 0, (1 - c) + c]] (the last entry is NOT 1:
+ * it is rounded twice, as in the general formula) and mul33's remaining terms are products with those exact zeros. */
+CCMP_HD void mul_zrot(const double *R, double s, double c, double *Rn)
+{
+  const double t = 1.0 - c;
+  const double w = t + c;
+  const double ns = -s;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    Rn[3 * r] = CCMP_FMA(R[3 * r + 1], s, R[3 * r] * c);
+    Rn[3 * r + 1] = CCMP_FMA(R[3 * r + 1], c, R[3 * r] * ns);
+    Rn[3 * r + 2] = R[3 * r + 2] * w;
+  }
+}
+
+/* Rn = R * Rot(axis_I, q_I) with the joint index known at compile time; ax / ap are the joint's axis and axis
+ * products (not read for a stock z joint) */
+template <int I, bool STOCK>
+CCMP_HD void chain_rot(const double *ax, const double *ap, double s, double c, const double *R, double *Rn)
+{
+  if (STOCK && kStockZ[I]) {
+    mul_zrot(R, s, c, Rn);
+  } else {
+    double Rj[9];
+    rot_sc(ax, ap, s, c, Rj);
+    mul33(R, Rj, Rn);
+  }
+}
+/* joint I of the chain: o += R*offset_I, then Rn = R*Rot(axis_I, q_I) */
+template <int I, bool STOCK>
+CCMP_HD void chain_step(const double *off, const double *ax, const double *ap, double s, double c, const double *R, double *Rn,
+                        double *o)
+{
+  mulvec_acc_nz<STOCK ? kStockOff[I] : 7>(R, off, o);
+  chain_rot<I, STOCK>(ax, ap, s, c, R, Rn);
+}
+
 /* One joint of the chain: o += R*offset_i (joint origin), then R = R*Rot(axis_i, q_i). */
 CCMP_HD void joint_step(const ccmp_consts &K, int arm, int i, double s, double c, double *R, double *o)
 {
@@ -115,10 +181,11 @@ CCMP_HD void joint_step(const ccmp_consts &K, int arm, int i, double s, double c
 
 /* Body-7 frame (R,o) -> world pose of the hand frame: getTranslation/getRotation
  * (panda_rbdl.cpp:24-33) then t_wb * (ConstraintFunction.h:89-90). */
-CCMP_HD void tool_pose(const ccmp_consts &K, int arm, const double *R, const double *o, double *Rw, double *pw)
+template <bool STOCK>
+CCMP_HD void tool_pose_t(const ccmp_consts &K, int arm, const double *R, const double *o, double *Rw, double *pw)
 {
   double pf[3] = {o[0], o[1], o[2]}, Rf[9];
-  mulvec_acc(R, K.ee[arm], pf);
+  mulvec_acc_nz<STOCK ? kStockEe : 7>(R, K.ee[arm], pf);
   mul33(R, K.R_tool[arm], Rf);
 #ifndef CCMP_NO_BASE_DIAG
   if ((K.base_diag >> arm) & 1) {
@@ -137,6 +204,11 @@ CCMP_HD void tool_pose(const ccmp_consts &K, int arm, const double *R, const dou
   mul33(K.base_R[arm], Rf, Rw);
   pw[0] = K.base_p[arm][0]; pw[1] = K.base_p[arm][1]; pw[2] = K.base_p[arm][2];
   mulvec_acc(K.base_R[arm], pf, pw);
+}
+
+CCMP_HD void tool_pose(const ccmp_consts &K, int arm, const double *R, const double *o, double *Rw, double *pw)
+{
+  tool_pose_t<false>(K, arm, R, o, Rw, pw);
 }
 
 /* Full FK of one arm (world pose of its hand frame). */

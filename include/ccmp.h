@@ -112,7 +112,9 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch);
 /* tuning knobs (results never change): "handover_threshold" (-1 = automatic, 0..10: hand a wave's samples to the
  * latency kernel once the queue is dry and at most this many of its 10 groups are busy), "flat_kernel" (latency
  * work — small batches, single states, handed-over samples: 1 = one sample per 128-thread block with every
- * evaluation of an iteration in one round (default), 0 = one wavefront per sample).  CCMP_EINVAL for unknown names. */
+ * evaluation of an iteration in one round (default), 0 = one wavefront per sample), "stock_kernels" (1 = when both arms
+ * carry the exact-zero structure of the uncalibrated Panda, run kernels that skip the products with those zeros —
+ * same bits, fewer operations (default); 0 = always the general kernels).  CCMP_EINVAL for unknown names. */
 int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
 /* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
  * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is

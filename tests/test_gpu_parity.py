@@ -344,3 +344,32 @@ def test_misaligned_rows_are_rejected(gpu_ctx):
     ok = torch.zeros(4, dtype=torch.uint8, device="cuda")
     rc = _lib.lib().ccmp_project_batch(gpu_ctx.handle, C.byref(c.problem), mis.data_ptr(), mis.data_ptr(), ok.data_ptr(), None, 4, None)
     assert rc == -1  # CCMP_EINVAL
+
+
+@pytest.mark.parametrize("calibrated", [False, True])
+def test_stock_structure_kernels_and_general_kernels(gpu_ctx, oracle_det, calibrated):
+    """The latency kernel has an instantiation for the exact-zero structure of the uncalibrated Panda (products with
+    exact zeros skipped).  Stock problem: specialised == general == oracle.  With calibration offsets (ccmp_set_calibration:
+    axes tilt, offsets fill in) the structure test fails on the host and the general kernel must be the one that runs."""
+    import torch
+    from closed_chain_motion_planner_amd import _lib
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    if calibrated:
+        dh = (C.c_double * 28)(*[1e-3 * ((7 * i) % 5 - 2) for i in range(28)])
+        assert _lib.lib().ccmp_set_calibration(C.byref(c.problem), 0, dh) == 0
+        assert _lib.lib().ccmp_set_calibration(C.byref(c.problem), 1, dh) == 0
+    P = _oracle_problem(oracle_det, c)
+    q = oracle_det.ambient_uniform_batch(P, 0x57C, 0, 700)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+    f_cpu = oracle_det.function_batch(P, q, NCPU)
+    for stock in (1, 0):
+        gpu_ctx.set_option("stock_kernels", stock)
+        try:
+            out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
+            f = c.function_batch(torch.as_tensor(q).cuda())
+        finally:
+            gpu_ctx.set_option("stock_kernels", 1)
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64)), (calibrated, stock)
+        assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
+        assert np.array_equal(f.cpu().numpy().view(np.uint64), f_cpu.view(np.uint64))
