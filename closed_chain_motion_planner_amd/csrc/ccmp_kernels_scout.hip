@@ -108,7 +108,78 @@ __device__ __forceinline__ void chain_f(const consts_f &K, const int arm, const 
   }
 }
 
-template <int MODE>
+// The same chain for the stock Panda structure, where every joint axis is a coordinate axis (to FP32: the 6e-17
+// leftovers of cos(pi/2) in the reference's constants are far below single precision): joint rotations are planar,
+// most offset components vanish, the tool rotation is block-diagonal.  A prediction needs no more than that; the
+// launcher falls back to chain_f when the constants do not look like this (calibrated arms).
+//                                joint:  1   2   3   4   5   6   7
+constexpr int kAxIdx[7] = {2, 1, 2, 1, 2, 1, 2};          // rotation axis: 1 = y, 2 = z
+constexpr float kAxSgn[7] = {1.f, 1.f, 1.f, -1.f, 1.f, -1.f, -1.f};
+constexpr int kOffNz[7] = {4, 0, 4, 1, 5, 0, 1};          // non-zero offset components (bit k)
+
+template <int PASS>
+__device__ __forceinline__ void chain_stock_f(const consts_f &K, const int arm, const float *q, float *Rw, float *pw,
+                                              const float *al, const float *bl, const float *pl, float sgn, float *J0, float *J1)
+{
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    float s, c;
+    __sincosf(q[i], &s, &c);
+    s *= kAxSgn[i];
+    const float *off = K.offset[arm][i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (kOffNz[i] & 1) o[k] += R[3 * k] * off[0];
+      if (kOffNz[i] & 4) o[k] += R[3 * k + 2] * off[2];
+    }
+    if (PASS == 1) {
+      float z[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) z[k] = kAxSgn[i] * R[3 * k + kAxIdx[i]];
+      const float r0 = pl[0] - o[0], r1 = pl[1] - o[1], r2 = pl[2] - o[2];
+      const float cx = z[1] * r2 - z[2] * r1, cy = z[2] * r0 - z[0] * r2, cz = z[0] * r1 - z[1] * r0;
+      J0[i] = sgn * (al[0] * cx + al[1] * cy + al[2] * cz);
+      J1[i] = sgn * (bl[0] * z[0] + bl[1] * z[1] + bl[2] * z[2]);
+    }
+    if (PASS == 0 || i < 6) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (kAxIdx[i] == 2) { // about z: columns 0 and 1 turn
+          const float a = R[3 * k], b = R[3 * k + 1];
+          R[3 * k] = a * c + b * s;
+          R[3 * k + 1] = b * c - a * s;
+        } else {              // about y: columns 0 and 2 turn
+          const float a = R[3 * k], b = R[3 * k + 2];
+          R[3 * k] = a * c - b * s;
+          R[3 * k + 2] = a * s + b * c;
+        }
+      }
+    }
+  }
+  if (PASS == 0) {
+    // hand offset along the flange's z only; tool rotation = [[t00, t01, 0], [t10, t11, 0], [0, 0, t22]]; base = diag
+    const float *T = K.R_tool[arm], *Bm = K.base_R[arm];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float pf = o[k] + R[3 * k + 2] * K.ee[arm][2];
+      pw[k] = K.base_p[arm][k] + Bm[4 * k] * pf;
+      Rw[3 * k] = Bm[4 * k] * (R[3 * k] * T[0] + R[3 * k + 1] * T[3]);
+      Rw[3 * k + 1] = Bm[4 * k] * (R[3 * k] * T[1] + R[3 * k + 1] * T[4]);
+      Rw[3 * k + 2] = Bm[4 * k] * (R[3 * k + 2] * T[8]);
+    }
+  }
+}
+
+template <int PASS, bool STOCK>
+__device__ __forceinline__ void chain_sel(const consts_f &K, const int arm, const float *q, float *Rw, float *pw, const float *al,
+                                          const float *bl, const float *pl, float sgn, float *J0, float *J1)
+{
+  if (STOCK) chain_stock_f<PASS>(K, arm, q, Rw, pw, al, bl, pl, sgn, J0, J1);
+  else chain_f<PASS>(K, arm, q, Rw, pw, al, bl, pl, sgn, J0, J1);
+}
+
+template <int MODE, bool STOCK>
 __global__ __launch_bounds__(256) void scout_kernel(const consts_f K, const ccmp_consts KD, const double *__restrict__ q_in,
                                                     uint16_t *__restrict__ pred, unsigned long long B,
                                                     unsigned long long *queue, unsigned long long seed,
@@ -139,8 +210,8 @@ __global__ __launch_bounds__(256) void scout_kernel(const consts_f K, const ccmp
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
 
     float Rw0[9], pw0[3], Rw1[9], pw1[3];
-    chain_f<0>(K, 0, x, Rw0, pw0, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
-    chain_f<0>(K, 1, x + 7, Rw1, pw1, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
+    chain_sel<0, STOCK>(K, 0, x, Rw0, pw0, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
+    chain_sel<0, STOCK>(K, 1, x + 7, Rw1, pw1, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
     // chain = T2^-1 T1, residual against the initial chain
     float Rc[9], pc[3], qc[4];
 #pragma unroll
@@ -196,7 +267,7 @@ __global__ __launch_bounds__(256) void scout_kernel(const consts_f K, const ccmp
         bl[k] = Bm[k] * bwv[0] + Bm[3 + k] * bwv[1] + Bm[6 + k] * bwv[2];
         pl[k] = Bm[k] * q0 + Bm[3 + k] * q1 + Bm[6 + k] * q2;
       }
-      chain_f<1>(K, arm, x + 7 * arm, nullptr, nullptr, al, bl, pl, arm == 0 ? 1.0f : -1.0f, J0 + 7 * arm, J1 + 7 * arm);
+      chain_sel<1, STOCK>(K, arm, x + 7 * arm, nullptr, nullptr, al, bl, pl, arm == 0 ? 1.0f : -1.0f, J0 + 7 * arm, J1 + 7 * arm);
     }
     float ga = 0, gd = 0, gb = 0;
 #pragma unroll
@@ -292,10 +363,35 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(hist, 0, kBins * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
-  if (mode == 0)
-    hipLaunchKernelGGL(scout_kernel<0>, dim3(nblocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, queue, seed, first);
-  else
-    hipLaunchKernelGGL(scout_kernel<1>, dim3(nblocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, queue, seed, first);
+  // does the model look like the stock Panda to single precision?  (axes on coordinate axes, the expected zero offsets,
+  // block-diagonal tool rotation, diagonal base rotation)  Only the prediction depends on it.
+  bool stock = true;
+  const float tol = 1e-6f;
+  for (int a = 0; a < 2 && stock; a++) {
+    for (int i = 0; i < 7; i++) {
+      for (int k = 0; k < 3; k++) {
+        const float want = k == kAxIdx[i] ? kAxSgn[i] : 0.0f;
+        if (!(fabsf(F.axis[a][i][k] - want) < tol)) stock = false;
+        if (!((kOffNz[i] >> k) & 1) && !(fabsf(F.offset[a][i][k]) < tol)) stock = false;
+      }
+    }
+    if (!(fabsf(F.ee[a][0]) < tol && fabsf(F.ee[a][1]) < tol)) stock = false;
+    const int zero_t[4] = {2, 5, 6, 7};
+    for (int k = 0; k < 4; k++)
+      if (!(fabsf(F.R_tool[a][zero_t[k]]) < tol)) stock = false;
+    for (int k = 0; k < 9; k++)
+      if (k % 4 != 0 && !(fabsf(F.base_R[a][k]) < tol)) stock = false;
+  }
+#define CCMP_LAUNCH_SCOUT(MODE, STOCK) \
+  hipLaunchKernelGGL((scout_kernel<MODE, STOCK>), dim3(nblocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, queue, seed, first)
+  if (mode == 0) {
+    if (stock) CCMP_LAUNCH_SCOUT(0, true);
+    else CCMP_LAUNCH_SCOUT(0, false);
+  } else {
+    if (stock) CCMP_LAUNCH_SCOUT(1, true);
+    else CCMP_LAUNCH_SCOUT(1, false);
+  }
+#undef CCMP_LAUNCH_SCOUT
   hipLaunchKernelGGL(hist_kernel, dim3(256), dim3(256), 0, st, pred, (unsigned long long)B, hist);
   hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist);
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((B + 256 * kScatterPerThread - 1) / (256 * kScatterPerThread))), dim3(256), 0, st, pred,
