@@ -21,32 +21,39 @@ using namespace ccmp;
 
 namespace {
 
-// Forward chain of one arm in its own base frame, keeping every joint's axis z_i and origin o_i.
+// Forward chain of one arm in its own base frame, keeping every joint's axis z_i and origin o_i; joint indices are
+// compile-time so that the STOCK instantiation can skip the products with the stock Panda's exact zeros (ccmp_kin.h).
+template <bool STOCK, int I>
+__device__ __forceinline__ void chain_frames_from(const ccmp_consts &K, const int arm, const double *q, double (*z)[3], double (*oj)[3],
+                                                  double *R, double *o)
+{
+  if constexpr (I < 7) {
+    double s, c;
+    ccmp_sincos(q[I], &s, &c);
+    mulvec_acc_nz<STOCK ? kStockOff[I] : 7>(R, K.offset[arm][I], o);
+    const double *a = K.axis[arm][I];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      z[I][k] = (STOCK && kStockZ[I]) ? R[3 * k + 2] : dot3(R[3 * k], a[0], R[3 * k + 1], a[1], R[3 * k + 2], a[2]);
+      oj[I][k] = o[k];
+    }
+    double Rn[9];
+    chain_rot<I, STOCK>(a, K.aprod[arm][I], s, c, R, Rn);
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = Rn[k];
+    chain_frames_from<STOCK, I + 1>(K, arm, q, z, oj, R, o);
+  }
+}
+template <bool STOCK>
 __device__ __forceinline__ void chain_frames(const ccmp_consts &K, const int arm, const double *q, double (*z)[3],
                                              double (*oj)[3], double *R, double *o)
 {
   R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
   o[0] = 0; o[1] = 0; o[2] = 0;
-#pragma unroll
-  for (int i = 0; i < 7; i++) {
-    double s, c;
-    ccmp_sincos(q[i], &s, &c);
-    mulvec_acc(R, K.offset[arm][i], o);
-    const double *a = K.axis[arm][i];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      z[i][k] = dot3(R[3 * k], a[0], R[3 * k + 1], a[1], R[3 * k + 2], a[2]);
-      oj[i][k] = o[k];
-    }
-    double Rj[9], Rn[9];
-    rot_sc(a, K.aprod[arm][i], s, c, Rj);
-    mul33(R, Rj, Rn);
-#pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = Rn[k];
-  }
+  chain_frames_from<STOCK, 0>(K, arm, q, z, oj, R, o);
 }
 
-template <int MODE>
+template <int MODE, bool STOCK>
 __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K, const double *__restrict__ q_in,
                                                           double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
                                                           uint16_t *__restrict__ iters_out,
@@ -86,8 +93,8 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K, c
 #pragma unroll
     for (int arm = 0; arm < 2; arm++) {
       double R[9], o[3];
-      chain_frames(K, arm, x + 7 * arm, z[arm], oj[arm], R, o);
-      tool_pose(K, arm, R, o, Rw[arm], pw[arm]);
+      chain_frames<STOCK>(K, arm, x + 7 * arm, z[arm], oj[arm], R, o);
+      tool_pose_t<STOCK>(K, arm, R, o, Rw[arm], pw[arm]);
     }
     double f[2], dq[4], pc[3];
     chain_residual(K, Rw[0], pw[0], Rw[1], pw[1], f, dq, pc);
@@ -176,11 +183,16 @@ extern "C" hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, c
 {
   hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
   if (e != hipSuccess) return e;
-  if (mode == 0)
-    hipLaunchKernelGGL(project_fast_kernel<0>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue, seed, first);
-  else
-    hipLaunchKernelGGL(project_fast_kernel<1>, dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                       (unsigned long long)B, queue, seed, first);
+#define CCMP_LAUNCH_FAST(MODE, STOCK)                                                                                              \
+  hipLaunchKernelGGL((project_fast_kernel<MODE, STOCK>), dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
+                     (unsigned long long)B, queue, seed, first)
+  if (mode == 0) {
+    if (K->stock) CCMP_LAUNCH_FAST(0, true);
+    else CCMP_LAUNCH_FAST(0, false);
+  } else {
+    if (K->stock) CCMP_LAUNCH_FAST(1, true);
+    else CCMP_LAUNCH_FAST(1, false);
+  }
+#undef CCMP_LAUNCH_FAST
   return hipGetLastError();
 }
