@@ -373,3 +373,17 @@ def test_stock_structure_kernels_and_general_kernels(gpu_ctx, oracle_det, calibr
         assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64)), (calibrated, stock)
         assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
         assert np.array_equal(f.cpu().numpy().view(np.uint64), f_cpu.view(np.uint64))
+    # the extend step runs on the same Newton routine: both instantiations, bit for bit against the oracle
+    good = q_cpu[ok_cpu == 1]
+    frm, to = good[:24].copy(), good[24:48].copy()
+    for stock in (1, 0):
+        gpu_ctx.set_option("stock_kernels", stock)
+        try:
+            st, n, gok, _ = c.discrete_geodesic_batch(torch.as_tensor(frm).cuda(), torch.as_tensor(to).cuda(), 32)
+        finally:
+            gpu_ctx.set_option("stock_kernels", 1)
+        st, n, gok = st.cpu().numpy(), n.cpu().numpy(), gok.cpu().numpy()
+        for e in range(len(frm)):
+            ok_c, st_c, _ = oracle_det.discrete_geodesic(P, frm[e], to[e], interpolate=True, max_states=32)
+            assert int(gok[e]) == int(ok_c) and int(n[e]) == len(st_c), (calibrated, stock, e)
+            assert np.array_equal(st[e, : n[e]].view(np.uint64), st_c.view(np.uint64))
