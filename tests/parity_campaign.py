@@ -1,7 +1,7 @@
-"""Large-sample parity campaign on the GPU box: the HIP path (default policy, through the C ABI) against the det-build
+"""Test infrastructure (run by hand, not collected by pytest).  Large-sample parity campaign on the GPU box: the HIP path (default policy, through the C ABI) against the det-build
 CPU oracle on all host threads, bit for bit.  Writes profiles/parity_campaign.json.
 
-    python tools/parity_campaign.py [samples_per_case]        (default 200000; ~30 s of oracle time per case on 256 threads)
+    python tests/parity_campaign.py [samples_per_case] [edges_per_case]        (default 200000; ~30 s of oracle time per case on 256 threads)
 """
 import json
 import os
@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # oracle_binding lives next to this file
 import torch  # noqa: E402
 from closed_chain_motion_planner_amd import Context, KinematicChainConstraint  # noqa: E402
 from oracle_binding import Oracle, build_oracle  # noqa: E402
