@@ -83,6 +83,7 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
                                                         double *rec, int lane, int j, double s, double c, double y,
                                                         unsigned long long &tprev)
 {
+  (void)tprev; // only the -DCCMP_FLAT_TIMING build ticks it
   // ---- B: the chain of arm W, joint j at (s, c), the others at x --------------------------------------------------
   double Tw[12];
   {

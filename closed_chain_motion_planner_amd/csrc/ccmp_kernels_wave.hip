@@ -1,6 +1,6 @@
-// ccmp_kernels_wave.hip — one-wavefront-per-sample kernels in the canonical (bit-reproducible) rounding model:
-// the latency-oriented projector (stragglers handed over by the throughput kernel, small batches) and the
-// batched discreteGeodesic.  Built -ffp-contract=off -DCCMP_USE_FMA like ccmp_kernels_fd.hip; kept in its own
+// ccmp_kernels_wave.hip — the one-wavefront-per-sample projector in the canonical (bit-reproducible) rounding model:
+// the north star's literal layout, selectable with the context option "flat_kernel" = 0 (the default latency kernel is
+// ccmp_kernels_flat.hip).  Built -ffp-contract=off -DCCMP_USE_FMA like ccmp_kernels_fd.hip; kept in its own
 // translation unit because the two benefit from different code-generation options (build.py).
 #include "ccmp_fd_common.h"
 
@@ -174,19 +174,6 @@ __device__ __forceinline__ bool wave_joint_valid(const ccmp_consts &KL, const do
     if (v > KL.ube[jj]) bad = true;
   }
   return __builtin_amdgcn_ballot_w64(bad) == 0ull;
-}
-
-// RealVectorStateSpace::distance over the 14 joints (plain Euclidean, KinematicChainSpace does not
-// override it), summed serially in the canonical order; every lane computes it from LDS.
-__device__ __forceinline__ double lds_distance(const double *a, const double *b)
-{
-  double dist = 0.0;
-#pragma unroll
-  for (int i = 0; i < 14; i++) {
-    const double diff = a[i] - b[i];
-    dist = CCMP_FMA(diff, diff, dist);
-  }
-  return ccmp_sqrt(dist);
 }
 
 __device__ __forceinline__ void stage_consts(const ccmp_consts &K, double *ktab, int lane)
