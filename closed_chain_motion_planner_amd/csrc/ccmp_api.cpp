@@ -739,13 +739,15 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       unsigned int *ord = (unsigned int *)((char *)hist + 4096);
       HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus, st)); // one 256-thread block per CU, 4 samples per lane: more lanes only lengthen the per-wave maximum
       order = ord;
-      if (ctx->lpt == 2) nwave = 0;
+      // Large ordered batches end on their shortest samples, and the scout is accurate there (tools/scout_tail.py: in the
+      // last fill of a 262144-sample batch it predicts <= 21 iterations and the truth is <= 23): nothing worth
+      // handing over is left, and without hand-over the waves need not poll the queue head every iteration
+      // (-3 % at 262144 Wine_Bottle, tools/time_lpt3.py).
+      if (ctx->lpt == 2 || (ctx->dump_threshold < 0 && B >= 120000)) nwave = 0;
     }
-    // Hand-over threshold (sweeps: tools/time_mid.py, tools/time_lpt3.py).  Once the queue is dry the samples still in
-    // flight go to the latency kernel at once (10: it iterates ~15x faster than a fully occupied throughput wave);
-    // only very large longest-first batches end on short samples that the throughput kernel finishes itself, handing
-    // over nearly empty waves only (4).
-    const int dump_thr = ctx->dump_threshold >= 0 ? ctx->dump_threshold : ((order && B >= 200000) ? 4 : 10);
+    // Hand-over threshold (sweeps: tools/time_mid.py, tools/time_lpt3.py): once the queue is dry the samples still in
+    // flight go to the latency kernel at once (it iterates ~20x faster than a fully occupied throughput wave).
+    const int dump_thr = ctx->dump_threshold >= 0 ? ctx->dump_threshold : 10;
     if (nblocks > 0) {
       HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
                                         nwave > 0 ? ctx->pool : nullptr, dump_thr, order, st));

@@ -118,7 +118,8 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int wave_kernel, size_t small_batch);
 int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
 /* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
  * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is
- * processed longest first, straggler hand-over kept (default); 2 = the same without hand-over.  Used for
+ * processed longest first, straggler hand-over kept up to 120000 samples and dropped above (default); 2 = the same
+ * without hand-over at any size.  Used for
  * batches of at least min_batch samples (CCMP_DEFAULT = built-in default, 28672).  Results are bit-identical under
  * every setting. */
 int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch);
