@@ -741,8 +741,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       order = ord;
       // Large ordered batches end on their shortest samples, and the scout is accurate there (tools/scout_tail.py: in the
       // last fill of a 262144-sample batch it predicts <= 21 iterations and the truth is <= 23): nothing worth
-      // handing over is left, and without hand-over the waves need not poll the queue head every iteration
-      // (-3 % at 262144 Wine_Bottle, tools/time_lpt3.py).
+      // handing over is left (-3 % at 262144 Wine_Bottle without it, tools/time_lpt3.py).
       if (ctx->lpt == 2 || (ctx->dump_threshold < 0 && B >= 120000)) nwave = 0;
     }
     // Hand-over threshold (sweeps: tools/time_mid.py, tools/time_lpt3.py): once the queue is dry the samples still in
