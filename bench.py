@@ -266,8 +266,23 @@ def main():
 
         main_mode = CCMP_JAC_FD if args.mode == "fd" else CCMP_JAC_ANALYTIC
         other = CCMP_JAC_ANALYTIC if args.mode == "fd" else CCMP_JAC_FD
+        def single_latency_us(reps=40):
+            # the reference-signature call: one state through the host entry point (copy in, launch, synchronise, copy out)
+            import numpy as np
+            c.setJacobianMode(main_mode)
+            qs = c.ambient_uniform_batch(0xC1, 0, reps).cpu().numpy()
+            ts = []
+            for i in range(reps):
+                x = qs[i].copy()
+                t0 = time.perf_counter()
+                c.project(x)
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts[4:]) * 1e6)
+
         line["secondary"] = {
             "batch4096_projections_per_s": quick(main_mode, 4096, 10),
+            "batch32768_projections_per_s": quick(main_mode, 32768, 10),
+            "single_project_call_median_us": single_latency_us(),
             ("analytic" if args.mode == "fd" else "fd") + "_mode_projections_per_s": quick(other, B, 5),
         }
         c.setJacobianMode(main_mode)
