@@ -23,10 +23,11 @@ _UNITS = [
     # loop into VGPR pairs and then spills them to scratch (168 VGPRs + 30 spilled dwords); without it the
     # throughput kernel needs 133 VGPRs and no scratch (measured +3.3 %, in-process A/B).  The wave kernels are
     # 2.7 % slower with the option, hence their own unit.
-    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm"]
+    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
      + os.environ.get("CCMP_FD_EXTRA_FLAGS", "").split()),
     ("ccmp_kernels_wave.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
-    ("ccmp_kernels_flat.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm"]),
+    # max-ilp scheduling: -0.6 % (throughput kernel) ... -1.5 % (latency kernel, single state), in-process A/B
+    ("ccmp_kernels_flat.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=fast"]),
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
