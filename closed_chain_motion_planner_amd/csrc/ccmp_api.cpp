@@ -690,6 +690,72 @@ int ccmp_function_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, d
   return CCMP_OK;
 }
 
+// ---- scheduling of a reference-arithmetic batch ---------------------------------------------------------------------
+// Which kernels a batch of B samples runs on.  Pure function of the context's settings and B; never changes a result.
+//   latency kernel alone            B <= small_batch (or schedule 2): one sample per block, lowest latency per sample
+//   throughput kernel (+ hand-over) otherwise: 10 samples per wavefront from a queue; when the queue runs dry the samples
+//                                   still in flight go to the latency kernel
+//   scout + longest-first order     from lpt_min_batch on; from 120000 samples on without hand-over (see below)
+struct FdPlan {
+  int group_blocks = 0;    // persistent wavefronts of the throughput kernel; 0 = latency kernel alone
+  bool handover = false;   // throughput kernel dumps its last samples to the pool, the latency kernel finishes them
+  bool scout = false;      // FP32 scout pass + descending counting sort -> processing order
+  int dump_threshold = 10; // a wave hands over once the queue is dry and at most this many of its 10 groups are busy
+  int latency_blocks = 0;  // grid of the latency kernel (direct launch or hand-over)
+  bool latency_static = false; // one block per sample, static striding: no queue word to reset
+};
+
+static FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order)
+{
+  FdPlan pl;
+  const int wpc = ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12;
+  // latency kernels: the flat kernel runs 8 blocks of 128 threads per CU (16 waves), the one-wave kernel wpc waves
+  const size_t lat_cap = ctx->flat_kernel ? (size_t)ctx->num_cus * 8 : (size_t)ctx->num_cus * (size_t)wpc;
+  const bool latency_only = ctx->wave_kernel == 2 || (ctx->wave_kernel == 1 && B <= ctx->small_batch);
+  if (latency_only) {
+    pl.latency_blocks = (int)(B < lat_cap ? B : lat_cap);
+    pl.latency_static = ctx->flat_kernel && B <= lat_cap;
+    return pl;
+  }
+  pl.group_blocks = projector_blocks(ctx, B, 10, 12);
+  pl.handover = ctx->wave_kernel == 1;
+  pl.scout = !external_order && ctx->lpt > 0 && B >= ctx->lpt_min_batch && B < 0xffffffffull;
+  // Large ordered batches end on their shortest samples, and the scout is accurate there (tools/scout_tail.py: in the
+  // last fill of a 262144-sample batch it predicts <= 21 iterations and the truth is <= 23): nothing worth handing
+  // over is left (-3 % at 262144 Wine_Bottle without it, tools/time_lpt3.py).  An explicit threshold keeps hand-over.
+  if (pl.scout && (ctx->lpt == 2 || (ctx->dump_threshold < 0 && B >= 120000))) pl.handover = false;
+  // Once the queue is dry the samples still in flight go to the latency kernel at once (it iterates ~20x faster than
+  // a fully occupied throughput wave); sweeps: tools/time_mid.py, tools/time_lpt3.py.
+  pl.dump_threshold = ctx->dump_threshold >= 0 ? ctx->dump_threshold : 10;
+  if (pl.handover) {
+    const size_t in_flight = (size_t)pl.group_blocks * 10;
+    pl.latency_blocks = (int)(in_flight < lat_cap ? in_flight : lat_cap);
+  }
+  return pl;
+}
+
+// workspaces owned by the context; they grow outside any stream capture (the first call at a size is never captured)
+static int ensure_pool(ccmp_ctx *ctx, size_t records)
+{
+  if (ctx->pool_cap >= records) return CCMP_OK;
+  if (ctx->pool) (void)hipFree(ctx->pool);
+  ctx->pool = nullptr;
+  ctx->pool_cap = 0;
+  HIP_TRY(hipMalloc((void **)&ctx->pool, records * 18 * sizeof(double)));
+  ctx->pool_cap = records;
+  return CCMP_OK;
+}
+static int ensure_lpt_buffers(ccmp_ctx *ctx, size_t B)
+{
+  if (ctx->lpt_cap >= B) return CCMP_OK;
+  if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
+  ctx->lpt_buf = nullptr;
+  ctx->lpt_cap = 0;
+  HIP_TRY(hipMalloc(&ctx->lpt_buf, ((B * 2 + 255) & ~(size_t)255) + 4096 + B * 4)); // pred u16 | hist 1024 x u32 | order u32
+  ctx->lpt_cap = B;
+  return CCMP_OK;
+}
+
 static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const double *q_in, double *q_out,
                           uint8_t *ok, uint16_t *iters, double *q_ambient, size_t B, uint64_t seed, uint64_t first,
                           void *hip_stream)
@@ -698,77 +764,51 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (B == 0) return CCMP_OK;
   if (!q_out || !ok || (mode == 0 && !q_in)) return CCMP_EINVAL;
   if ((((uintptr_t)q_in) | ((uintptr_t)q_out)) & 15u) return CCMP_EINVAL; // rows are moved in 16-byte pieces
-  if (p->jacobian_mode == CCMP_JAC_FD) {
-    // Large batches: the throughput (10 samples per wave) kernel until the queue drains, then the
-    // wave-per-sample kernel on the samples still in flight.  Small batches: wave-per-sample only.
-    const int wpc = ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12;
-    const int wave_blocks = ctx->num_cus * wpc;
-    int nblocks = projector_blocks(ctx, B, 10, 12);
-    int nwave = 0;
-    if (ctx->wave_kernel == 2 || (ctx->wave_kernel == 1 && B <= ctx->small_batch)) {
-      nblocks = 0;
-      nwave = (int)(B < (size_t)wave_blocks ? B : (size_t)wave_blocks);
-    } else if (ctx->wave_kernel == 1) {
-      const size_t need = (size_t)nblocks * 10;
-      if (ctx->pool_cap < need) { // grows outside any capture: first call at a size is never captured
-        if (ctx->pool) (void)hipFree(ctx->pool);
-        ctx->pool = nullptr;
-        ctx->pool_cap = 0;
-        HIP_TRY(hipMalloc((void **)&ctx->pool, need * 18 * sizeof(double)));
-        ctx->pool_cap = need;
-      }
-      nwave = (int)(need < (size_t)wave_blocks ? need : (size_t)wave_blocks);
-    }
-    // queue[0]: sample queue of the group kernel; queue[1]: pool fill count; queue[2]: read head of the wave kernel
-    const int flat_blocks = ctx->num_cus * 8; // 128-thread blocks of the one-round latency kernel: 16 waves per CU
-    const bool flat_static = ctx->flat_kernel && nblocks == 0 && B <= (size_t)flat_blocks; // one block per sample: no queue
-    if (!flat_static) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
-    const unsigned int *order = ctx->order;
-    if (nblocks > 0 && !order && ctx->lpt > 0 && B >= ctx->lpt_min_batch && B < 0xffffffffull) {
-      // FP32 scout pass -> predicted iteration counts -> descending counting sort -> processing order
-      if (ctx->lpt_cap < B) {
-        if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
-        ctx->lpt_buf = nullptr;
-        ctx->lpt_cap = 0;
-        HIP_TRY(hipMalloc(&ctx->lpt_buf, ((B * 2 + 255) & ~(size_t)255) + 4096 + B * 4));
-        ctx->lpt_cap = B;
-      }
-      char *base = (char *)ctx->lpt_buf;
-      uint16_t *pred = (uint16_t *)base;
-      unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
-      unsigned int *ord = (unsigned int *)((char *)hist + 4096);
-      HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus, st)); // one 256-thread block per CU, 4 samples per lane: more lanes only lengthen the per-wave maximum
-      order = ord;
-      // Large ordered batches end on their shortest samples, and the scout is accurate there (tools/scout_tail.py: in the
-      // last fill of a 262144-sample batch it predicts <= 21 iterations and the truth is <= 23): nothing worth
-      // handing over is left (-3 % at 262144 Wine_Bottle without it, tools/time_lpt3.py).
-      if (ctx->lpt == 2 || (ctx->dump_threshold < 0 && B >= 120000)) nwave = 0;
-    }
-    // Hand-over threshold (sweeps: tools/time_mid.py, tools/time_lpt3.py): once the queue is dry the samples still in
-    // flight go to the latency kernel at once (it iterates ~20x faster than a fully occupied throughput wave).
-    const int dump_thr = ctx->dump_threshold >= 0 ? ctx->dump_threshold : 10;
-    if (nblocks > 0) {
-      HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks,
-                                        nwave > 0 ? ctx->pool : nullptr, dump_thr, order, st));
-      if (nwave > 0 && ctx->flat_kernel) {
-        const size_t need = (size_t)nblocks * 10;
-        HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
-                                         ctx->queue + 1, mode, (int)(need < (size_t)flat_blocks ? need : (size_t)flat_blocks), st));
-      } else if (nwave > 0) {
-        HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
-                                         ctx->queue + 1, mode, nwave, st));
-      }
-    } else if (ctx->flat_kernel) {
-      // small batches and single states: one sample per 128-thread block, every evaluation of an iteration in one round
-      HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, flat_static ? nullptr : ctx->queue + 2, seed,
-                                       first, ctx->pool, ctx->queue + 1, mode, (int)(flat_static ? B : (size_t)flat_blocks), st));
-    } else {
-      HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 2, seed, first, ctx->pool,
-                                       ctx->queue + 1, mode, nwave, st));
-    }
-  } else {
+  if (p->jacobian_mode != CCMP_JAC_FD) {
     const int nblocks = projector_blocks(ctx, B, 64, 4);
     HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks, st));
+    return CCMP_OK;
+  }
+  const FdPlan pl = plan_fd_batch(ctx, B, ctx->order != nullptr);
+  // queue[0]: sample queue of the throughput kernel; queue[1]: pool fill count; queue[2]: read head of the latency kernel
+  unsigned long long *const q_group = ctx->queue, *const q_pool_count = ctx->queue + 1, *const q_latency = ctx->queue + 2;
+  if (!pl.latency_static) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
+
+  if (pl.group_blocks == 0) { // small batches and single states
+    if (ctx->flat_kernel)
+      HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
+                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, st));
+    else
+      HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count,
+                                       mode, pl.latency_blocks, st));
+    return CCMP_OK;
+  }
+
+  const unsigned int *order = ctx->order;
+  if (pl.scout) { // FP32 scout pass -> predicted iteration counts -> descending counting sort -> processing order
+    int rc = ensure_lpt_buffers(ctx, B);
+    if (rc != CCMP_OK) return rc;
+    char *base = (char *)ctx->lpt_buf;
+    uint16_t *pred = (uint16_t *)base;
+    unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
+    unsigned int *ord = (unsigned int *)((char *)hist + 4096);
+    // one 256-thread block per CU, 4 samples per lane at 262144: more lanes only lengthen the per-wave maximum
+    HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus, st));
+    order = ord;
+  }
+  if (pl.handover) {
+    int rc = ensure_pool(ctx, (size_t)pl.group_blocks * 10);
+    if (rc != CCMP_OK) return rc;
+  }
+  HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_group, seed, first, pl.group_blocks,
+                                    pl.handover ? ctx->pool : nullptr, pl.dump_threshold, order, st));
+  if (pl.handover) { // the pool's fill count is read on the device: the latency kernel's surplus blocks exit at once
+    if (ctx->flat_kernel)
+      HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
+                                       pl.latency_blocks, st));
+    else
+      HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
+                                       pl.latency_blocks, st));
   }
   return CCMP_OK;
 }
