@@ -4,7 +4,8 @@ Translation units with deliberately different flags:
   ccmp_kernels_fd.hip    -ffp-contract=off -DCCMP_USE_FMA   canonical, bit-reproducible arithmetic (throughput kernel)
   ccmp_kernels_wave.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one-wave-per-sample kernels
   ccmp_kernels_flat.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one 128-thread block per sample (latency kernel)
-  ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   host set-up in the same rounding model
+  ccmp_problem.cpp       -ffp-contract=off -DCCMP_USE_FMA   host set-up (problem, constants) in the same rounding model
+  ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   context, scheduling, launches
   ccmp_kernels_fast.hip  -ffp-contract=fast                 analytic fast mode, no bitwise claim
   ccmp_kernels_scout.hip -ffast-math                        FP32 iteration-count predictor + ordering (never touches results)
 """
@@ -30,9 +31,10 @@ _UNITS = [
     ("ccmp_kernels_flat.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=fast"]),
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
+    ("ccmp_problem.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]
-_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", os.path.join("..", "..", "include", "ccmp.h")]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_host.h", os.path.join("..", "..", "include", "ccmp.h")]
 
 
 def hipcc_path():

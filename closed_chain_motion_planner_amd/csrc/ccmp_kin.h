@@ -16,7 +16,7 @@
 
 #include "ccmp_detmath.h"
 
-/* Kernel-side constants derived from ccmp_problem (ccmp_api.cpp: make_consts).  Passed by value
+/* Kernel-side constants derived from ccmp_problem (ccmp_problem.cpp: make_consts).  Passed by value
  * as a kernel argument: every lane reads the same entry at the same time, so the compiler keeps
  * them in SGPRs (scalar loads from the kernarg segment), never in VGPRs. */
 struct ccmp_consts {
@@ -111,7 +111,7 @@ CCMP_HD void rot_sc(const double *a, const double *ap, double s, double c, doubl
  * no x component.  A product with an exact zero is an exact zero, and adding it changes no bit (beyond the sign of a
  * sum that is itself exactly zero), so kernels instantiated with STOCK = true skip those operations and still
  * reproduce the general formulas bit for bit.  The host selects STOCK only after comparing the constants exactly
- * (ccmp_api.cpp: is_stock_structure); anything else — calibrated arms — runs the general code. */
+ * (ccmp_problem.cpp: is_stock_structure); anything else — calibrated arms — runs the general code. */
 constexpr int kStockZ[7] = {1, 0, 1, 0, 1, 0, 0};   /* axis == (0, 0, 1) exactly */
 constexpr int kStockOff[7] = {4, 0, 4, 1, 5, 0, 1}; /* bit k: offset component k may be non-zero */
 constexpr int kStockEe = 6;                         /* ee = (0, y, z) */
