@@ -7,7 +7,8 @@ interface.  Importing the package needs neither a GPU nor the built library; usi
 from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem  # noqa: F401
 from .constraint import ArmModel, Context, KinematicChainConstraint, load_config  # noqa: F401
 
-from .space import (check_motion, format_path_matrix, geodesic_interpolate, jy_ProjectedStateSampler,  # noqa: F401
-                    jy_ProjectedStateSpace, parse_path_matrix)
+from .space import (check_motion, format_graphml, format_graphviz, format_path_matrix, geodesic_interpolate,  # noqa: F401
+                    jy_ProjectedStateSampler, jy_ProjectedStateSpace, next_sampler_seed, parse_graphml, parse_path_matrix,
+                    splitmix64)
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -53,12 +53,12 @@ CCMP_JAC_ANALYTIC = 1
 
 # every symbol include/ccmp.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "ccmp_problem_from_yaml", "ccmp_problem_init", "ccmp_set_start", "ccmp_set_tolerance", "ccmp_set_calibration",
+    "ccmp_problem_from_yaml", "ccmp_problem_init", "ccmp_set_arms", "ccmp_set_start", "ccmp_set_tolerance", "ccmp_set_calibration",
     "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_set_schedule", "ccmp_ctx_set_option", "ccmp_ctx_set_lpt", "ccmp_ctx_device", "ccmp_ctx_num_cus",
     "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
     "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
     "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid",
-    "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_sample_project_host", "ccmp_geodesic_host", "ccmp_project_sharded_host", "ccmp_sample_project_sharded_host", "ccmp_ctx_set_order_experimental",
+    "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_sample_project_host", "ccmp_sample_ref_project_host", "ccmp_geodesic_host", "ccmp_project_sharded_host", "ccmp_sample_project_sharded_host", "ccmp_ctx_set_order_experimental",
     "ccmp_ctx_debug_lpt_pred", "ccmp_detmath_probe", "ccmp_strerror",
     "ccmp_last_hip_error", "ccmp_version", "ccmp_problem_sizeof",
 ]
@@ -90,6 +90,7 @@ def lib():
     sig = {
         "ccmp_problem_from_yaml": ([C.c_char_p, pp], C.c_int),
         "ccmp_problem_init": ([pp, C.c_char_p, C.c_int, C.c_char_p, C.c_int, dp, dp, dp, dp, dp], C.c_int),
+        "ccmp_set_arms": ([pp, C.c_char_p, C.c_int, C.c_char_p, C.c_int], C.c_int),
         "ccmp_set_start": ([pp, dp], C.c_int),
         "ccmp_set_tolerance": ([pp, C.c_double, C.c_double], C.c_int),
         "ccmp_set_calibration": ([pp, C.c_int, dp], C.c_int),
@@ -120,6 +121,7 @@ def lib():
         "ccmp_is_satisfied_host": ([vp, pp, dp, u8p, C.c_size_t], C.c_int),
         "ccmp_joint_valid_host": ([vp, pp, dp, u8p, C.c_size_t], C.c_int),
         "ccmp_sample_project_host": ([vp, pp, C.c_uint64, C.c_uint64, dp, u8p, u16p, C.c_size_t], C.c_int),
+        "ccmp_sample_ref_project_host": ([vp, pp, C.c_int, C.c_uint64, C.c_uint64, dp, C.c_double, dp, u8p, u16p, C.c_size_t], C.c_int),
         "ccmp_geodesic_host": ([vp, pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32), u8p], C.c_int),
         "ccmp_project_sharded_host": ([C.POINTER(vp), C.c_int, pp, dp, dp, u8p, u16p, C.c_size_t], C.c_int),
         "ccmp_sample_project_sharded_host": ([C.POINTER(vp), C.c_int, pp, C.c_uint64, C.c_uint64, dp, u8p, u16p, C.c_size_t], C.c_int),

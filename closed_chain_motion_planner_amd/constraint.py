@@ -134,15 +134,17 @@ class KinematicChainConstraint:
         """ConstraintFunction.h:122-126.  Callers pass arms in std::map (alphabetical) order, as
         ConstrainedPlanningCommon.cpp:126 does."""
         self._arms = [arm1, arm2]
-        q0 = np.zeros(14)
-        if self.problem is not None:
-            q0 = np.array(self.problem.start_joint[:], dtype=np.float64)
-        P = CcmpProblem()
-        check(_lib.lib().ccmp_problem_init(C.byref(P), arm1.name.encode(), arm1.index, arm2.name.encode(), arm2.index,
-                                           _dptr(q0), None, None, None, None), "ccmp_problem_init")
-        if self.problem is not None:  # keep tolerances / mode chosen earlier
-            P.tol_pos, P.tol_rot, P.jacobian_mode = self.problem.tol_pos, self.problem.tol_rot, self.problem.jacobian_mode
-        self.problem = P
+        if self.problem is None:
+            P = CcmpProblem()
+            check(_lib.lib().ccmp_problem_init(C.byref(P), arm1.name.encode(), arm1.index, arm2.name.encode(), arm2.index,
+                                               _dptr(np.zeros(14)), None, None, None, None), "ccmp_problem_init")
+            self.problem = P
+        else:
+            # the reference calls this AFTER loadConfig (ConstrainedPlanningCommon.cpp:126): only the arm / base-frame
+            # fields change; object poses, start state, tolerances, delta / lambda, calibration and mode are kept and
+            # init_chain_ / t_o7 are recomputed for the new arms
+            check(_lib.lib().ccmp_set_arms(C.byref(self.problem), arm1.name.encode(), arm1.index, arm2.name.encode(),
+                                           arm2.index), "ccmp_set_arms")
 
     def setInitialPosition(self, init_joint):
         """ConstraintFunction.h:31-40."""
@@ -198,7 +200,14 @@ class KinematicChainConstraint:
         check(_lib.lib().ccmp_project_batch(self.ctx.handle, C.byref(self.problem), q.data_ptr(), out.data_ptr(),
                                             ok.data_ptr(), it.data_ptr() if it is not None else None, B,
                                             _stream_handle(stream)), "ccmp_project_batch")
-        return out, ok, it
+        return out, ok, self._iters(it)
+
+    def _iters(self, it):
+        """the C side writes uint16 counts into an int16 tensor (torch's uint16 has few kernels): identical up to the
+        reference's cap of 250; widen when a caller raised max_iter past 32767"""
+        if it is not None and self.problem.max_iter > 32767:
+            return it.to(_torch().int32) & 0xFFFF
+        return it
 
     def sample_project_batch(self, seed, first_index, B, want_iters=True, want_ambient=False, stream=None):
         """`jy_ProjectedStateSampler::sampleUniform` x B (jy_ProjectedStateSpace.cpp:10-15)."""
@@ -214,7 +223,7 @@ class KinematicChainConstraint:
                                                    it.data_ptr() if it is not None else None,
                                                    amb.data_ptr() if amb is not None else None, B,
                                                    _stream_handle(stream)), "ccmp_sample_project_batch")
-        return out, ok, it, amb
+        return out, ok, self._iters(it), amb
 
     def _sample_ref(self, fn_name, seed, first_index, ref, param, B, want_iters, want_ambient, stream):
         self._need_problem()
@@ -232,7 +241,7 @@ class KinematicChainConstraint:
                                            stride, float(param), out.data_ptr(), ok.data_ptr(),
                                            it.data_ptr() if it is not None else None,
                                            amb.data_ptr() if amb is not None else None, B, _stream_handle(stream)), fn_name)
-        return out, ok, it, amb
+        return out, ok, self._iters(it), amb
 
     def sample_near_project_batch(self, seed, first_index, near, distance, B, want_iters=True, want_ambient=False, stream=None):
         """`jy_ProjectedStateSampler::sampleUniformNear` x B (jy_ProjectedStateSpace.cpp:17-22)."""

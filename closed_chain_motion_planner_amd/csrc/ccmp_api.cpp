@@ -701,6 +701,31 @@ int ccmp_sample_project_host(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed
   return io.finish();
 }
 
+int ccmp_sample_ref_project_host(ccmp_ctx *ctx, const ccmp_problem *p, int kind, uint64_t seed, uint64_t first_index,
+                                 const double ref[14], double param, double *q_out, uint8_t *ok, uint16_t *iters, size_t B)
+{
+  if (!ctx || !p) return CCMP_EINVAL;
+  if (B == 0) return CCMP_OK;
+  if (!ref || !q_out || !ok || (kind != 0 && kind != 1)) return CCMP_EINVAL;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return CCMP_ENODEV;
+  const size_t qb = B * 14 * sizeof(double);
+  const size_t off_ok = (qb + 255) & ~(size_t)255;
+  const size_t off_it = (off_ok + B + 255) & ~(size_t)255;
+  const size_t off_ref = (off_it + B * sizeof(uint16_t) + 255) & ~(size_t)255;
+  HostIO io(ctx);
+  int rc = io.begin(off_ref + 14 * sizeof(double));
+  if (rc != CCMP_OK) return rc;
+  if ((rc = io.in(off_ref, ref, 14 * sizeof(double))) != CCMP_OK) return rc;
+  rc = sample_ref_common(ctx, p, kind, seed, first_index, (const double *)(io.dev + off_ref), 0, param, (double *)io.dev,
+                         (uint8_t *)(io.dev + off_ok), (uint16_t *)(io.dev + off_it), nullptr, B, ctx->stream);
+  if (rc != CCMP_OK) return rc;
+  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return rc;
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
+  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return rc;
+  return io.finish();
+}
+
 int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                        double *states, int32_t *n_states, uint8_t *ok)
 {

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
       if (max_states > 0) out[tid] = a; // geodesic->push_back(cloneState(from))
     }
     __syncthreads();
-    int n = max_states > 0 ? 1 : 0, its = 0;
+    int n = 1, its = 0; // counts every state, stored or not: n_states > max_states reports a list that did not fit
     double dist = lds_distance(rec + gPrev, rec + gTo), total = 0.0;
     if (dist > delta) {
       const double maxd = dist * lambda;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
           rec[gPrev + tid] = v;
           if (n < max_states) out[(unsigned long long)n * 14ull + tid] = v;
         }
-        if (n < max_states) n++;
+        n++;
         __syncthreads();
         if (!(dist >= delta)) break;
       }

@@ -346,6 +346,22 @@ int ccmp_problem_init(ccmp_problem *out, const char *arm1_name, int arm1_index, 
   return ccmp_set_start(out, start_joint);
 }
 
+// KinematicChainConstraint::setArmModels on a problem that is already set up (the reference calls it after loadConfig,
+// ConstrainedPlanningCommon.cpp:126): only the arm selection and the base frames change; init_chain_ and t_o7 follow
+int ccmp_set_arms(ccmp_problem *p, const char *arm1_name, int arm1_index, const char *arm2_name, int arm2_index)
+{
+  if (!p || !arm1_name || !arm2_name) return CCMP_EINVAL;
+  if (arm1_index < 0 || arm1_index > 2 || arm2_index < 0 || arm2_index > 2) return CCMP_EINVAL;
+  int idx[2];
+  if (strcmp(arm1_name, arm2_name) <= 0) { idx[0] = arm1_index; idx[1] = arm2_index; }
+  else { idx[0] = arm2_index; idx[1] = arm1_index; }
+  for (int a = 0; a < 2; a++) {
+    p->arm_index[a] = idx[a];
+    base_frame(idx[a], p->base_R[a], p->base_p[a]);
+  }
+  return ccmp_set_start(p, p->start_joint);
+}
+
 static int problem_from_yaml_impl(const char *yaml_path, ccmp_problem *out);
 
 int ccmp_problem_from_yaml(const char *yaml_path, ccmp_problem *out)

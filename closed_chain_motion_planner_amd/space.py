@@ -3,10 +3,14 @@
 discreteGeodesic` (:32-96) and the path-matrix format the reference dumps
 (PathGeometric::printAsMatrix, src/base/constraints/ConstrainedPlanningCommon.cpp:219-222), all on
 top of the batched GPU entry points of KinematicChainConstraint."""
+import itertools
+import os
+import threading
+
 import numpy as np
 
 __all__ = ["jy_ProjectedStateSampler", "jy_ProjectedStateSpace", "check_motion", "geodesic_interpolate", "format_path_matrix",
-           "parse_path_matrix"]
+           "parse_path_matrix", "format_graphml", "parse_graphml", "format_graphviz", "splitmix64", "next_sampler_seed"]
 
 
 def _torch():
@@ -15,20 +19,50 @@ def _torch():
     return torch
 
 
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(z):
+    """one SplitMix64 output (the generator of the kernels' counter-based sampler, csrc/ccmp_fd_common.h)"""
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+# Every sampler owns an independently seeded stream, as every OMPL StateSampler owns its own ompl::RNG (seeded from a
+# process-wide seed generator; src/base/jy_ProjectedStateSpace.cpp:5-8 wraps such a sampler).  Samplers created without
+# an explicit seed draw one from this process-wide sequence; set CCMP_SEED for reproducible runs (ompl::RNG::setSeed).
+_seed_lock = threading.Lock()
+_seed_counter = itertools.count()
+_process_seed = None
+
+
+def next_sampler_seed():
+    global _process_seed
+    with _seed_lock:
+        if _process_seed is None:
+            env = os.environ.get("CCMP_SEED")
+            _process_seed = int(env, 0) & _M64 if env else int.from_bytes(os.urandom(8), "little")
+        return splitmix64((_process_seed + next(_seed_counter)) & _M64)
+
+
 class jy_ProjectedStateSampler:
     """`sampleUniform(state)` / `sampleUniformNear` / `sampleGaussian` with the reference's signatures
     (state = numpy (14,), written in place).  sampleUniform is served from a buffer that ONE GPU launch
     of `batch` fused sample->project->enforceBounds fills whenever it runs empty, invisible to the
     planner; the reference ignores project()'s result here, and so does this class."""
 
-    def __init__(self, constraint, seed=0, batch=4096):
+    def __init__(self, constraint, seed=None, batch=4096):
         self.constraint_ = constraint
-        self.seed = int(seed)
+        self.seed = next_sampler_seed() if seed is None else int(seed) & _M64  # None: its own stream, like an ompl::RNG
         self.batch = int(batch)
         self._next_index = 0  # global sample counter: the stream of samples does not depend on `batch`
         self._buf = None
         self._pos = 0
-        self._near_index = 0
+        self.lookahead = 32   # Near / Gaussian samples drawn per launch around one reference state
+        self._ref_buf = {}
+        self._ref_index = 0
 
     def _refill(self):
         q, ok, _, _ = self.constraint_.sample_project_batch(self.seed, self._next_index, self.batch, want_iters=False)
@@ -43,21 +77,32 @@ class jy_ProjectedStateSampler:
         state[:] = self._buf[self._pos]
         self._pos += 1
 
-    def sampleUniformNear(self, state, near, distance):
+    # sampleUniformNear / sampleGaussian: `near` may change from call to call, so nothing can be drawn before the call;
+    # but a launch of `lookahead` samples around the same state costs what a launch of one does (one 128-thread block
+    # per sample on an otherwise idle GPU), so a call that sees a new (state, parameter) draws `lookahead` samples and
+    # the following calls with the same arguments are served from that buffer.  Every refill takes fresh indices of
+    # the sampler's counter-based stream: no sample is ever handed out twice, whatever the call pattern.
+    def _sample_ref(self, kind, state, ref, param):
         torch = _torch()
-        ref = torch.as_tensor(np.ascontiguousarray(near, dtype=np.float64)).to("cuda:%d" % self.constraint_.ctx.device)
-        q, _, _, _ = self.constraint_.sample_near_project_batch(self.seed ^ 0x4E454152, self._near_index, ref, distance, 1,
-                                                               want_iters=False)
-        self._near_index += 1
-        state[:] = q.cpu().numpy()[0]
+        ref = np.ascontiguousarray(ref, dtype=np.float64).reshape(14)
+        key = (ref.tobytes(), float(param))
+        buf = self._ref_buf.get(kind)
+        if buf is None or buf[0] != key or buf[2] >= buf[1].shape[0]:
+            dev_ref = torch.as_tensor(ref).to("cuda:%d" % self.constraint_.ctx.device)
+            fn = self.constraint_.sample_near_project_batch if kind == "near" else self.constraint_.sample_gaussian_project_batch
+            seed = self.seed ^ (0x4E454152 if kind == "near" else 0x47415553)
+            q, _, _, _ = fn(seed, self._ref_index, dev_ref, float(param), self.lookahead, want_iters=False)
+            self._ref_index += self.lookahead
+            buf = [key, q.cpu().numpy(), 0]
+            self._ref_buf[kind] = buf
+        state[:] = buf[1][buf[2]]
+        buf[2] += 1
+
+    def sampleUniformNear(self, state, near, distance):
+        self._sample_ref("near", state, near, distance)
 
     def sampleGaussian(self, state, mean, stdDev):
-        torch = _torch()
-        ref = torch.as_tensor(np.ascontiguousarray(mean, dtype=np.float64)).to("cuda:%d" % self.constraint_.ctx.device)
-        q, _, _, _ = self.constraint_.sample_gaussian_project_batch(self.seed ^ 0x47415553, self._near_index, ref, stdDev, 1,
-                                                                   want_iters=False)
-        self._near_index += 1
-        state[:] = q.cpu().numpy()[0]
+        self._sample_ref("gaussian", state, mean, stdDev)
 
 
 class jy_ProjectedStateSpace:
@@ -67,10 +112,21 @@ class jy_ProjectedStateSpace:
     list at the first rejected state — exactly where the reference's loop would have stopped
     (jy_ProjectedStateSpace.cpp:65-68)."""
 
-    def __init__(self, constraint, isValid=None, max_states=256):
+    def __init__(self, constraint, isValid=None, max_states=256, seed=None):
         self.constraint_ = constraint
         self.isValid = isValid
         self.max_states = int(max_states)
+        self._seed = next_sampler_seed() if seed is None else int(seed) & _M64
+        self._n_samplers = itertools.count()
+
+    def allocStateSampler(self, batch=4096):
+        """`allocStateSampler` / `allocDefaultStateSampler` (jy_ProjectedStateSpace.h:41-49): every sampler of a space
+        gets its own stream — seed = splitmix64(space seed + running sampler number) — so the planner's sampler, the
+        valid-state sampler and a re-plan never repeat each other's samples."""
+        return jy_ProjectedStateSampler(self.constraint_, seed=splitmix64((self._seed + next(self._n_samplers)) & _M64),
+                                        batch=batch)
+
+    allocDefaultStateSampler = allocStateSampler
 
     def setDelta(self, delta):
         self.constraint_.problem.delta = float(delta)
@@ -88,11 +144,23 @@ class jy_ProjectedStateSpace:
         f = torch.as_tensor(np.ascontiguousarray(frm, dtype=np.float64)).to(dev)
         t = torch.as_tensor(np.ascontiguousarray(to, dtype=np.float64)).to(dev)
         states, n, ok, _ = self.constraint_.discrete_geodesic_batch(f, t, self.max_states)
-        states, n, ok = states.cpu().numpy(), n.cpu().numpy(), ok.cpu().numpy()
+        n, ok = n.cpu().numpy(), ok.cpu().numpy()
+        rows = [None] * len(n)
+        long = np.nonzero(n > self.max_states)[0]
+        if len(long):
+            # n_states is the true length: these lists were cut at max_states.  Run them again with room for the
+            # longest — a cut list must never reach the validity test or the caller as if it were complete.
+            idx = torch.as_tensor(long, device=f.device)
+            s2, n2, _, _ = self.constraint_.discrete_geodesic_batch(f[idx].contiguous(), t[idx].contiguous(), int(n[long].max()))
+            s2, n2 = s2.cpu().numpy(), n2.cpu().numpy()
+            for k, e in enumerate(long):
+                assert n2[k] == n[e]
+                rows[e] = s2[k, : n2[k]]
+        states = states.cpu().numpy()
         delta = self.constraint_.problem.delta
         out = []
         for e in range(states.shape[0]):
-            st = states[e, : n[e]]
+            st = rows[e] if rows[e] is not None else states[e, : n[e]]
             good = bool(ok[e])
             if not interpolate and self.isValid is not None:
                 for k in range(1, st.shape[0]):
@@ -139,14 +207,58 @@ def geodesic_interpolate(states, t):
 
 def format_path_matrix(states):
     """`PathGeometric::printAsMatrix`: one state per line, values in C++ default stream format (%g, 6
-    significant digits), each followed by a space — what scripts/execute_path.py and visualize_path.py
-    of the reference parse."""
+    significant digits), each followed by a space, and one empty line after the last state — what
+    scripts/execute_path.py and visualize_path.py of the reference parse."""
     lines = []
     for s in np.asarray(states, dtype=np.float64).reshape(-1, 14):
         lines.append("".join("%g " % v for v in s))
-    return "\n".join(lines) + "\n"
+    return "\n".join(lines) + "\n\n"
 
 
 def parse_path_matrix(text):
     rows = [[float(v) for v in ln.split()] for ln in text.splitlines() if ln.strip()]
     return np.array(rows, dtype=np.float64).reshape(-1, 14)
+
+
+# ---- planner-graph dumps (ConstrainedProblem::dumpGraph, ConstrainedPlanningCommon.h:73-87) ---------------------------
+_GRAPHML_HEAD = (
+    '<?xml version="1.0" encoding="UTF-8"?>\n'
+    '<graphml xmlns="http://graphml.graphdrawing.org/xmlns" xmlns:xsi="http://www.w3.org/2001/XMLSchema-instance" '
+    'xsi:schemaLocation="http://graphml.graphdrawing.org/xmlns http://graphml.graphdrawing.org/xmlns/1.0/graphml.xsd">\n'
+    '  <key id="key0" for="node" attr.name="coords" attr.type="string" />\n'
+    '  <key id="key1" for="edge" attr.name="weight" attr.type="double" />\n'
+    '  <graph id="G" edgedefault="directed" parse.nodeids="free" parse.edgeids="canonical" parse.order="nodesfirst">\n')
+
+
+def format_graphml(nodes, edges, weights=None):
+    """`PlannerData::printGraphML` as `dumpGraph` writes `<obj>_node_info.graphml`: node data = the state's reals in
+    default stream format joined by commas, directed edges in insertion order, edge data = the edge weight."""
+    out = [_GRAPHML_HEAD]
+    for i, q in enumerate(np.asarray(nodes, dtype=np.float64).reshape(-1, 14)):
+        out.append('    <node id="n%d">\n      <data key="key0">%s</data>\n    </node>\n' % (i, ",".join("%g" % v for v in q)))
+    for k, (a, b) in enumerate(edges):
+        w = 1.0 if weights is None else float(weights[k])
+        out.append('    <edge id="e%d" source="n%d" target="n%d">\n      <data key="key1">%g</data>\n    </edge>\n' % (k, a, b, w))
+    out.append("  </graph>\n</graphml>\n")
+    return "".join(out)
+
+
+def parse_graphml(text):
+    """(nodes (N,14), directed edges, weights) of a `printGraphML` dump"""
+    import xml.etree.ElementTree as ET
+
+    ns = "{http://graphml.graphdrawing.org/xmlns}"
+    root = ET.fromstring(text)
+    ids, nodes, edges, weights = {}, [], [], []
+    for n in root.iter(ns + "node"):
+        ids[n.get("id")] = len(nodes)
+        nodes.append([float(v) for v in n.find(ns + "data").text.split(",")])
+    for e in root.iter(ns + "edge"):
+        edges.append((ids[e.get("source")], ids[e.get("target")]))
+        weights.append(float(e.find(ns + "data").text))
+    return np.array(nodes, dtype=np.float64).reshape(-1, 14), edges, weights
+
+
+def format_graphviz(n_nodes, edges):
+    """`PlannerData::printGraphviz` as `dumpGraph` writes `<obj>_graph_info.dot`"""
+    return "digraph G {\n" + "".join("%d;\n" % i for i in range(int(n_nodes))) + "".join("%d->%d ;\n" % (a, b) for a, b in edges) + "}\n"

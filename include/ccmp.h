@@ -81,6 +81,11 @@ int ccmp_problem_init(ccmp_problem *out, const char *arm1_name, int arm1_index, 
                       int arm2_index, const double start_joint[14], const double obj_start_pos[3],
                       const double obj_start_quat_xyzw[4], const double obj_goal_pos[3],
                       const double obj_goal_quat_xyzw[4]);
+/* KinematicChainConstraint::setArmModels (ConstraintFunction.h:122-126) on a problem that is already set up — the
+ * reference calls it after loadConfig (ConstrainedPlanningCommon.cpp:126): arm selection and base frames change
+ * (arms are ordered by name, as the reference's std::map does), init_chain_ and t_o7 are recomputed from the stored
+ * start_joint and object pose; tolerances, delta/lambda, calibration (kept per slot), mode and object poses stay */
+int ccmp_set_arms(ccmp_problem *p, const char *arm1_name, int arm1_index, const char *arm2_name, int arm2_index);
 /* KinematicChainConstraint::setInitialPosition (ConstraintFunction.h:31-40) and the t_o7 of
  * ConstrainedPlanningCommon.cpp:110-111 */
 int ccmp_set_start(ccmp_problem *p, const double q0[14]);
@@ -164,8 +169,10 @@ int ccmp_sample_gaussian_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uin
 int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, int q_stride, double *t_wo, size_t B,
                             void *hip_stream);
 /* jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96), E edges at once:
- * states[e][0..n_states[e]) (capacity max_states each) = `from`, then every accepted state; ok[e] = the
- * reference's return value.  Runs as the reference does with interpolate == true; for interpolate ==
+ * states[e][0..min(n_states[e], max_states)) (capacity max_states each) = `from`, then every accepted state;
+ * n_states[e] = the TRUE length of the geodesic, also when it exceeds max_states: n_states[e] > max_states means
+ * the list was cut and the call must be repeated with a larger buffer before anything is concluded from it (the
+ * adapter and the Python mirror do that); ok[e] = the reference's return value.  Runs as the reference does with interpolate == true; for interpolate ==
  * false the host truncates at the first state its StateValidityChecker rejects. */
 int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                         double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream);
@@ -187,6 +194,10 @@ int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
 int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B);
 int ccmp_sample_project_host(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index, double *q_out,
                              uint8_t *ok, uint16_t *iters, size_t B);
+/* sampleUniformNear (kind 0, param = distance) / sampleGaussian (kind 1, param = stdDev) x B around ONE host reference
+ * state (jy_ProjectedStateSpace.cpp:17-29): ambient draw, project, enforceBounds */
+int ccmp_sample_ref_project_host(ccmp_ctx *ctx, const ccmp_problem *p, int kind, uint64_t seed, uint64_t first_index,
+                                 const double ref[14], double param, double *q_out, uint8_t *ok, uint16_t *iters, size_t B);
 /* states: [E][max_states][14], n_states: [E], ok: [E] (host buffers) */
 int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                        double *states, int32_t *n_states, uint8_t *ok);

@@ -1,8 +1,10 @@
 // ccmp_ompl_adapter.hpp — header-only C++ host side above the C ABI (include/ccmp.h).
 //
 // Part 1 (always available, no third-party headers): ccmp::Projector, an RAII owner of a
-// ccmp_ctx + ccmp_problem with the reference's method names on raw double[14] buffers, and
-// ccmp::SampleBuffer, a refill-on-empty batch of GPU-projected uniform samples.
+// ccmp_ctx + ccmp_problem with the reference's method names on raw double[14] buffers;
+// ccmp::SampleBuffer / ccmp::RefSampleBuffer, refill-on-empty batches of GPU-projected samples;
+// ccmp::discreteGeodesic; and the dump formats of the reference's planner run (ccmp::printAsMatrix,
+// ccmp::printGraphML, ccmp::printGraphviz).
 //
 // Part 2 (compiled only with -DCCMP_WITH_OMPL, i.e. inside the reference's catkin workspace where
 // OMPL and Eigen exist): drop-in replacements that keep the reference's class names and virtual
@@ -19,12 +21,18 @@
 #ifndef CCMP_OMPL_ADAPTER_HPP
 #define CCMP_OMPL_ADAPTER_HPP
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <ostream>
+#include <random>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ccmp.h"
@@ -40,10 +48,32 @@ inline void check(int rc, const char *what)
   if (rc != CCMP_OK) throw Error(rc, what);
 }
 
-// Owner of one execution context and one problem description.  All const methods are re-entrant
-// with respect to the problem (it is passed by value into every launch); calls on one Projector
-// from several threads must be serialised by the caller, exactly as the reference's graphMutex_
-// serialises them today (src/planner/stefanBiPRM.cpp:280,383,449).
+// SplitMix64 (the generator behind the kernels' counter-based samplers) and a process-wide source of sampler seeds:
+// every sampler owns its own stream, as every OMPL StateSampler owns its own ompl::RNG.  CCMP_SEED in the
+// environment makes runs reproducible (the counterpart of ompl::RNG::setSeed).
+inline uint64_t splitmix64(uint64_t z)
+{
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+inline uint64_t next_sampler_seed()
+{
+  static const uint64_t process_seed = [] {
+    if (const char *env = std::getenv("CCMP_SEED")) return (uint64_t)std::strtoull(env, nullptr, 0);
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+  }();
+  static std::atomic<uint64_t> counter{0};
+  return splitmix64(process_seed + counter.fetch_add(1, std::memory_order_relaxed));
+}
+
+// Owner of one execution context and one problem description.  The drop-in KinematicChainConstraint is touched from
+// more than one thread in the reference (the jy_GoalLazySamples sampling thread; checkForSolution beside
+// constructRoadmap, src/planner/stefanBiPRM.cpp:848) and one ccmp_ctx holds per-call state (pinned I/O block, queue
+// words, stream): every call that uses the context takes the Projector's mutex for its duration — negligible next to
+// a ~100 us launch.  The problem is passed by value into every launch and may be changed between calls.
 class Projector {
 public:
   explicit Projector(int device = 0) { check(ccmp_ctx_create(device, &ctx_), "ccmp_ctx_create"); std::memset(&problem_, 0, sizeof problem_); }
@@ -54,14 +84,23 @@ public:
 
   // grasping_point::loadConfig + ConstrainedProblem set-up (src/kinematics/grasping_point.cpp:34-65,
   // src/base/constraints/ConstrainedPlanningCommon.cpp:85-132)
-  void loadConfig(const std::string &yaml_path) { check(ccmp_problem_from_yaml(yaml_path.c_str(), &problem_), "ccmp_problem_from_yaml"); }
+  void loadConfig(const std::string &yaml_path)
+  {
+    check(ccmp_problem_from_yaml(yaml_path.c_str(), &problem_), "ccmp_problem_from_yaml");
+    configured_ = true;
+  }
+  // KinematicChainConstraint::setArmModels (ConstraintFunction.h:122-126).  On a configured problem (the reference calls
+  // it after loadConfig, ConstrainedPlanningCommon.cpp:126) only the arm / base-frame fields change: object poses,
+  // tolerances, delta / lambda, calibration and mode are kept, init_chain_ and t_o7 are recomputed.
   void setArmModels(const std::string &name1, int index1, const std::string &name2, int index2)
   {
-    double q0[14];
-    std::memcpy(q0, problem_.start_joint, sizeof q0);
-    const double t1 = problem_.tol_pos, t2 = problem_.tol_rot;
-    check(ccmp_problem_init(&problem_, name1.c_str(), index1, name2.c_str(), index2, q0, nullptr, nullptr, nullptr, nullptr), "ccmp_problem_init");
-    if (t1 > 0 && t2 > 0) { problem_.tol_pos = t1; problem_.tol_rot = t2; }
+    if (configured_) {
+      check(ccmp_set_arms(&problem_, name1.c_str(), index1, name2.c_str(), index2), "ccmp_set_arms");
+    } else {
+      const double q0[14] = {0};
+      check(ccmp_problem_init(&problem_, name1.c_str(), index1, name2.c_str(), index2, q0, nullptr, nullptr, nullptr, nullptr), "ccmp_problem_init");
+      configured_ = true;
+    }
   }
   void setInitialPosition(const double *init_joint14) { check(ccmp_set_start(&problem_, init_joint14), "ccmp_set_start"); }
   // throws where the reference throws ompl::Exception (ConstraintFunction.h:106-108)
@@ -72,25 +111,33 @@ public:
   bool project(double *x14) const
   {
     uint8_t ok = 0;
+    std::lock_guard<std::mutex> hold(mu_);
     check(ccmp_project_host(ctx_, &problem_, x14, x14, &ok, nullptr, 1), "ccmp_project_host");
     return ok != 0;
   }
-  void function(const double *x14, double *out2) const { check(ccmp_function_host(ctx_, &problem_, x14, out2, 1), "ccmp_function_host"); }
+  void function(const double *x14, double *out2) const
+  {
+    std::lock_guard<std::mutex> hold(mu_);
+    check(ccmp_function_host(ctx_, &problem_, x14, out2, 1), "ccmp_function_host");
+  }
   bool isSatisfied(const double *x14) const
   {
     uint8_t ok = 0;
+    std::lock_guard<std::mutex> hold(mu_);
     check(ccmp_is_satisfied_host(ctx_, &problem_, x14, &ok, 1), "ccmp_is_satisfied_host");
     return ok != 0;
   }
   bool jointValid(const double *x14) const
   {
     uint8_t ok = 0;
+    std::lock_guard<std::mutex> hold(mu_);
     check(ccmp_joint_valid_host(ctx_, &problem_, x14, &ok, 1), "ccmp_joint_valid_host");
     return ok != 0;
   }
   // batches on host buffers (q row-major [B][14])
   void projectBatch(const double *q_in, double *q_out, uint8_t *ok, uint16_t *iters, size_t B) const
   {
+    std::lock_guard<std::mutex> hold(mu_);
     check(ccmp_project_host(ctx_, &problem_, q_in, q_out, ok, iters, B), "ccmp_project_host");
   }
   unsigned getCoDimension() const { return 2; }
@@ -98,10 +145,14 @@ public:
   const ccmp_problem &problem() const { return problem_; }
   ccmp_problem &problem() { return problem_; }
   ccmp_ctx *ctx() const { return ctx_; }
+  // for callers that use ctx() directly (the buffers and discreteGeodesic below): hold this across the call
+  std::mutex &mutex() const { return mu_; }
 
 private:
+  mutable std::mutex mu_;
   ccmp_ctx *ctx_ = nullptr;
   ccmp_problem problem_;
+  bool configured_ = false;
 };
 
 // jy_ProjectedStateSampler::sampleUniform served from a buffer that ONE launch of `batch` fused
@@ -123,6 +174,7 @@ private:
   {
     buf_.resize(batch_ * 14);
     ok_.resize(batch_);
+    std::lock_guard<std::mutex> hold(proj_.mutex());
     check(ccmp_sample_project_host(proj_.ctx(), &proj_.problem(), seed_, next_index_, buf_.data(), ok_.data(), nullptr, batch_),
           "ccmp_sample_project_host");
     next_index_ += batch_;
@@ -135,6 +187,52 @@ private:
   std::vector<uint8_t> ok_;
 };
 
+// jy_ProjectedStateSampler::sampleUniformNear / sampleGaussian (src/base/jy_ProjectedStateSpace.cpp:17-29) through the
+// batched counter-based kernels.  The reference state may change from call to call, so nothing can be drawn ahead of
+// the call; but `lookahead` samples around one state cost what one does (a 128-thread block per sample on an
+// otherwise idle GPU), so a call with a new (state, parameter) draws `lookahead` samples in one launch and the
+// following calls with the same arguments pop from that buffer.  Every refill takes fresh indices of the sampler's
+// stream: no sample is handed out twice, whatever the call pattern.
+class RefSampleBuffer {
+public:
+  enum Kind { Near = 0, Gaussian = 1 };
+  RefSampleBuffer(const Projector &proj, uint64_t seed, Kind kind, size_t lookahead = 32)
+    : proj_(proj), seed_(seed ^ (kind == Near ? 0x4E454152ull : 0x47415553ull)), kind_(kind), lookahead_(lookahead)
+  {
+  }
+  // writes 14 doubles: a sample around ref14 (Near: within `param` per dimension; Gaussian: std dev `param`),
+  // projected and wrapped by enforceBounds; returns project()'s result
+  bool next(double *state14, const double *ref14, double param)
+  {
+    if (pos_ >= filled_ || param != param_ || std::memcmp(ref_, ref14, sizeof ref_) != 0) refill(ref14, param);
+    std::memcpy(state14, &buf_[14 * pos_], 14 * sizeof(double));
+    return ok_[pos_++] != 0;
+  }
+
+private:
+  void refill(const double *ref14, double param)
+  {
+    std::memcpy(ref_, ref14, sizeof ref_);
+    param_ = param;
+    buf_.resize(lookahead_ * 14);
+    ok_.resize(lookahead_);
+    std::lock_guard<std::mutex> hold(proj_.mutex());
+    check(ccmp_sample_ref_project_host(proj_.ctx(), &proj_.problem(), (int)kind_, seed_, next_index_, ref_, param_, buf_.data(), ok_.data(),
+                                       nullptr, lookahead_),
+          "ccmp_sample_ref_project_host");
+    next_index_ += lookahead_;
+    filled_ = lookahead_;
+    pos_ = 0;
+  }
+  const Projector &proj_;
+  uint64_t seed_, next_index_ = 0;
+  Kind kind_;
+  size_t lookahead_, pos_ = 0, filled_ = 0;
+  double ref_[14] = {0}, param_ = 0;
+  std::vector<double> buf_;
+  std::vector<uint8_t> ok_;
+};
+
 // jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96) for one edge on raw
 // buffers.  `valid` (nullable) is the host StateValidityChecker; it is consulted only when !interpolate,
 // in order, and the list is cut at the first rejected state — where the reference's loop breaks.
@@ -142,10 +240,20 @@ template <class ValidFn>
 inline bool discreteGeodesic(const Projector &proj, const double *from14, const double *to14, bool interpolate, ValidFn valid,
                              std::vector<std::vector<double>> *geodesic, int max_states = 256)
 {
-  std::vector<double> states((size_t)max_states * 14);
+  std::vector<double> states;
   int32_t n = 0;
   uint8_t ok = 0;
-  check(ccmp_geodesic_host(proj.ctx(), &proj.problem(), from14, to14, 1, max_states, states.data(), &n, &ok), "ccmp_geodesic_host");
+  for (;;) {
+    states.resize((size_t)max_states * 14);
+    {
+      std::lock_guard<std::mutex> hold(proj.mutex());
+      check(ccmp_geodesic_host(proj.ctx(), &proj.problem(), from14, to14, 1, max_states, states.data(), &n, &ok), "ccmp_geodesic_host");
+    }
+    if (n <= max_states) break;
+    // n is the true length: the list did not fit (small delta, long edge).  A cut list must never reach the
+    // validity test or the caller as if it were complete — run the edge again with room for all of it.
+    max_states = n;
+  }
   bool good = ok != 0;
   int keep = n;
   if (!interpolate) {
@@ -163,6 +271,55 @@ inline bool discreteGeodesic(const Projector &proj, const double *from14, const 
     for (int k = 0; k < keep; ++k) geodesic->emplace_back(&states[(size_t)k * 14], &states[(size_t)k * 14] + 14);
   }
   return good;
+}
+
+// ---- dump formats of the reference's planner run ----------------------------------------------------------------------
+// PathGeometric::printAsMatrix as ConstrainedProblem::solveOnce writes `<obj>_path.txt`
+// (src/base/constraints/ConstrainedPlanningCommon.cpp:219-222) and scripts/execute_path.py:65-87 / visualize_path.py
+// parse it: the reals of one state per line in default stream format, each followed by a space, and one empty line
+// after the last state.
+inline void printAsMatrix(std::ostream &out, const double *states, size_t n_states, size_t dim = 14)
+{
+  for (size_t i = 0; i < n_states; ++i) {
+    for (size_t j = 0; j < dim; ++j) out << states[i * dim + j] << ' ';
+    out << '\n';
+  }
+  out << '\n';
+  out.flush();
+}
+
+// PlannerData::printGraphML as ConstrainedProblem::dumpGraph writes `<obj>_node_info.graphml`
+// (include/closed_chain_motion_planner/base/constraints/ConstrainedPlanningCommon.h:73-87): node data = the reals of
+// the milestone joined by commas, directed edges in insertion order with their weight (nullptr = 1 each).
+inline void printGraphML(std::ostream &out, const double *nodes, size_t n_nodes, const std::pair<unsigned, unsigned> *edges,
+                         size_t n_edges, const double *weights = nullptr, size_t dim = 14)
+{
+  out << "<?xml version=\"1.0\" encoding=\"UTF-8\"?>\n"
+         "<graphml xmlns=\"http://graphml.graphdrawing.org/xmlns\" xmlns:xsi=\"http://www.w3.org/2001/XMLSchema-instance\" "
+         "xsi:schemaLocation=\"http://graphml.graphdrawing.org/xmlns http://graphml.graphdrawing.org/xmlns/1.0/graphml.xsd\">\n"
+         "  <key id=\"key0\" for=\"node\" attr.name=\"coords\" attr.type=\"string\" />\n"
+         "  <key id=\"key1\" for=\"edge\" attr.name=\"weight\" attr.type=\"double\" />\n"
+         "  <graph id=\"G\" edgedefault=\"directed\" parse.nodeids=\"free\" parse.edgeids=\"canonical\" parse.order=\"nodesfirst\">\n";
+  for (size_t i = 0; i < n_nodes; ++i) {
+    out << "    <node id=\"n" << i << "\">\n      <data key=\"key0\">";
+    for (size_t j = 0; j < dim; ++j) out << (j ? "," : "") << nodes[i * dim + j];
+    out << "</data>\n    </node>\n";
+  }
+  for (size_t k = 0; k < n_edges; ++k)
+    out << "    <edge id=\"e" << k << "\" source=\"n" << edges[k].first << "\" target=\"n" << edges[k].second
+        << "\">\n      <data key=\"key1\">" << (weights ? weights[k] : 1.0) << "</data>\n    </edge>\n";
+  out << "  </graph>\n</graphml>\n";
+  out.flush();
+}
+
+// PlannerData::printGraphviz as dumpGraph writes `<obj>_graph_info.dot`
+inline void printGraphviz(std::ostream &out, size_t n_nodes, const std::pair<unsigned, unsigned> *edges, size_t n_edges)
+{
+  out << "digraph G {\n";
+  for (size_t i = 0; i < n_nodes; ++i) out << i << ";\n";
+  for (size_t k = 0; k < n_edges; ++k) out << edges[k].first << "->" << edges[k].second << " ;\n";
+  out << "}\n";
+  out.flush();
 }
 
 }  // namespace ccmp
@@ -236,14 +393,17 @@ private:
 typedef std::shared_ptr<KinematicChainConstraint> ChainConstraintPtr;
 
 // jy_ProjectedStateSampler (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:18-29): same
-// name, same overrides; sampleUniform pops GPU-projected samples, Near/Gaussian keep the ambient draw of
-// the wrapped sampler and project through the constraint (one-state launches).
+// name, same overrides; all three draw from the GPU's counter-based samplers through refill-on-empty buffers
+// (sampleUniform: `batch` samples per launch; Near / Gaussian: a look-ahead around the current reference state).
+// Every sampler has its own stream: the space hands out seed = splitmix64(space seed + running sampler number),
+// as every OMPL sampler owns an independently seeded ompl::RNG.
 class jy_ProjectedStateSpace;
 typedef std::shared_ptr<jy_ProjectedStateSpace> jy_ProjectedStateSpacePtr;
 
 class jy_ProjectedStateSampler : public ompl::base::WrapperStateSampler {
 public:
-  jy_ProjectedStateSampler(const jy_ProjectedStateSpace *space, ompl::base::StateSamplerPtr sampler, uint64_t seed = 0);
+  jy_ProjectedStateSampler(const jy_ProjectedStateSpace *space, ompl::base::StateSamplerPtr sampler);
+  jy_ProjectedStateSampler(const jy_ProjectedStateSpace *space, ompl::base::StateSamplerPtr sampler, uint64_t seed);
   void sampleUniform(ompl::base::State *state) override
   {
     auto &&x = *state->as<ompl::base::ConstrainedStateSpace::StateType>();
@@ -253,20 +413,26 @@ public:
   }
   void sampleUniformNear(ompl::base::State *state, const ompl::base::State *near, const double distance) override
   {
-    ompl::base::WrapperStateSampler::sampleUniformNear(state, near, distance);
-    constraint_->project(state);
-    space_->enforceBounds(state);
+    sampleAround(near_, state, near, distance);
   }
   void sampleGaussian(ompl::base::State *state, const ompl::base::State *mean, const double stdDev) override
   {
-    ompl::base::WrapperStateSampler::sampleGaussian(state, mean, stdDev);
-    constraint_->project(state);
-    space_->enforceBounds(state);
+    sampleAround(gauss_, state, mean, stdDev);
   }
 
 protected:
+  void sampleAround(ccmp::RefSampleBuffer &buf, ompl::base::State *state, const ompl::base::State *ref, double param)
+  {
+    const auto &r = *ref->as<ompl::base::ConstrainedStateSpace::StateType>();
+    auto &&x = *state->as<ompl::base::ConstrainedStateSpace::StateType>();
+    double rb[14], out[14];
+    for (int i = 0; i < 14; ++i) rb[i] = r[i];
+    buf.next(out, rb, param);  // ambient draw, project (result ignored, as the reference does) and enforceBounds on the GPU
+    for (int i = 0; i < 14; ++i) x[i] = out[i];
+  }
   const std::shared_ptr<KinematicChainConstraint> constraint_;
   ccmp::SampleBuffer buffer_;
+  ccmp::RefSampleBuffer near_, gauss_;
 };
 
 // jy_ProjectedStateSpace (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:31-54): same name,
@@ -277,18 +443,21 @@ protected:
 class jy_ProjectedStateSpace : public ompl::base::ConstrainedStateSpace {
 public:
   jy_ProjectedStateSpace(const ompl::base::StateSpacePtr &ambientSpace, const ompl::base::ConstraintPtr &constraint)
-    : ompl::base::ConstrainedStateSpace(ambientSpace, constraint), chain_(std::dynamic_pointer_cast<KinematicChainConstraint>(constraint))
+    : ompl::base::ConstrainedStateSpace(ambientSpace, constraint), chain_(std::dynamic_pointer_cast<KinematicChainConstraint>(constraint)),
+      seed_(ccmp::next_sampler_seed())
   {
     setName("Projected" + space_->getName());
   }
+  // the seed of the next sampler of this space: splitmix64(space seed + n++)
+  uint64_t nextSamplerSeed() const { return ccmp::splitmix64(seed_ + samplers_.fetch_add(1, std::memory_order_relaxed)); }
   ~jy_ProjectedStateSpace() override = default;
   ompl::base::StateSamplerPtr allocDefaultStateSampler() const override
   {
-    return std::make_shared<jy_ProjectedStateSampler>(this, space_->allocDefaultStateSampler());
+    return std::make_shared<jy_ProjectedStateSampler>(this, space_->allocDefaultStateSampler(), nextSamplerSeed());
   }
   ompl::base::StateSamplerPtr allocStateSampler() const override
   {
-    return std::make_shared<jy_ProjectedStateSampler>(this, space_->allocStateSampler());
+    return std::make_shared<jy_ProjectedStateSampler>(this, space_->allocStateSampler(), nextSamplerSeed());
   }
   bool discreteGeodesic(const ompl::base::State *from, const ompl::base::State *to, bool interpolate = false,
                         std::vector<ompl::base::State *> *geodesic = nullptr) const override
@@ -325,6 +494,8 @@ public:
 
 private:
   std::shared_ptr<KinematicChainConstraint> chain_;
+  uint64_t seed_;
+  mutable std::atomic<uint64_t> samplers_{0};
 };
 
 // jy_MotionValidator (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:57-69): unchanged logic,
@@ -341,7 +512,14 @@ public:
 inline jy_ProjectedStateSampler::jy_ProjectedStateSampler(const jy_ProjectedStateSpace *space, ompl::base::StateSamplerPtr sampler, uint64_t seed)
   : ompl::base::WrapperStateSampler(space, std::move(sampler)),
     constraint_(std::dynamic_pointer_cast<KinematicChainConstraint>(space->getConstraint())),
-    buffer_(constraint_->impl(), seed)
+    buffer_(constraint_->impl(), seed),
+    near_(constraint_->impl(), seed, ccmp::RefSampleBuffer::Near),
+    gauss_(constraint_->impl(), seed, ccmp::RefSampleBuffer::Gaussian)
+{
+}
+// the reference's two-argument constructor (jy_ProjectedStateSpace.h:21): its own stream, like every other sampler
+inline jy_ProjectedStateSampler::jy_ProjectedStateSampler(const jy_ProjectedStateSpace *space, ompl::base::StateSamplerPtr sampler)
+  : jy_ProjectedStateSampler(space, std::move(sampler), space->nextSamplerSeed())
 {
 }
 #endif  // CCMP_WITH_OMPL

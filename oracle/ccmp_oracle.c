@@ -589,9 +589,11 @@ int orc_discrete_geodesic(const orc_problem *P, const double from[14], const dou
                           int interpolate, orc_valid_fn valid, void *user, double *out,
                           int max_states, int *n_states, int64_t *newton_iters)
 {
-  int n = 0;
+  /* n counts every state of the geodesic (`from` included) whether or not it fits: n_states > max_states tells the
+   * caller that the list was cut at max_states and must be re-run with a larger buffer */
+  int n = 1;
   int64_t its = 0;
-  if (out && max_states > 0) { memcpy(out, from, 14 * sizeof(double)); n = 1; }
+  if (out && max_states > 0) memcpy(out, from, 14 * sizeof(double));
   const double tolerance = P->delta;
   double dist, step = 0, total = 0;
   if ((dist = orc_distance(from, to)) <= tolerance) {
@@ -616,7 +618,8 @@ int orc_discrete_geodesic(const orc_problem *P, const double from[14], const dou
     if (newDist >= dist) break;
     dist = newDist;
     memcpy(previous, scratch, sizeof previous);
-    if (out && n < max_states) { memcpy(out + 14 * n, scratch, 14 * sizeof(double)); n++; }
+    if (out && n < max_states) memcpy(out + 14 * n, scratch, 14 * sizeof(double));
+    n++;
   } while (dist >= tolerance);
   if (n_states) *n_states = n;
   if (newton_iters) *newton_iters = its;
@@ -641,52 +644,70 @@ void orc_compute_t_wo(const orc_problem *P, const double q_left[7], double R[9],
 }
 
 /* ---- batch drivers ---------------------------------------------------------------------------- */
+/* Threads take samples in small dynamic chunks from a shared counter: iteration counts spread 15..250 per
+ * sample, so a static B/n partition leaves most threads idle while the unluckiest one finishes. */
 typedef struct {
   const orc_problem *P;
-  const double *q_in;
+  const double *q_in, *q_to;
   double *q_out;
   double *f;
   uint8_t *ok;
-  int32_t *iters;
+  int32_t *iters, *n_states;
   uint64_t seed, first;
-  size_t lo, hi;
-  int kind; /* 0 project, 1 function, 2 sample+project */
+  size_t B, chunk;
+  size_t *next; /* shared ticket counter */
+  int max_states;
+  int kind; /* 0 project, 1 function, 2 sample+project, 3 discreteGeodesic (interpolate == true) */
 } orc_job;
+
+static void orc_do(const orc_job *j, size_t i)
+{
+  if (j->kind == 1) { orc_function(j->P, j->q_in + 14 * i, j->f + 2 * i); return; }
+  if (j->kind == 3) {
+    int n = 0;
+    int64_t its = 0;
+    int ok = orc_discrete_geodesic(j->P, j->q_in + 14 * i, j->q_to + 14 * i, 1, NULL, NULL,
+                                   j->q_out + 14 * (size_t)j->max_states * i, j->max_states, &n, &its);
+    j->ok[i] = (uint8_t)ok;
+    j->n_states[i] = n;
+    if (j->iters) j->iters[i] = (int32_t)its;
+    return;
+  }
+  double x[14];
+  int32_t it = 0;
+  int ok;
+  if (j->kind == 0) { memcpy(x, j->q_in + 14 * i, sizeof x); ok = orc_project(j->P, x, &it); }
+  else ok = orc_sample_uniform(j->P, j->seed, j->first + i, x, &it);
+  memcpy(j->q_out + 14 * i, x, sizeof x);
+  if (j->ok) j->ok[i] = (uint8_t)ok;
+  if (j->iters) j->iters[i] = it;
+}
 
 static void *orc_worker(void *arg)
 {
-  orc_job *j = (orc_job *)arg;
-  for (size_t i = j->lo; i < j->hi; i++) {
-    if (j->kind == 1) { orc_function(j->P, j->q_in + 14 * i, j->f + 2 * i); continue; }
-    double x[14];
-    int32_t it = 0;
-    int ok;
-    if (j->kind == 0) { memcpy(x, j->q_in + 14 * i, sizeof x); ok = orc_project(j->P, x, &it); }
-    else ok = orc_sample_uniform(j->P, j->seed, j->first + i, x, &it);
-    memcpy(j->q_out + 14 * i, x, sizeof x);
-    if (j->ok) j->ok[i] = (uint8_t)ok;
-    if (j->iters) j->iters[i] = it;
+  const orc_job *j = (const orc_job *)arg;
+  for (;;) {
+    const size_t lo = __atomic_fetch_add(j->next, j->chunk, __ATOMIC_RELAXED);
+    if (lo >= j->B) break;
+    const size_t hi = lo + j->chunk < j->B ? lo + j->chunk : j->B;
+    for (size_t i = lo; i < hi; i++) orc_do(j, i);
   }
   return NULL;
 }
 
-static void orc_run(orc_job proto, size_t B, int nthreads)
+static void orc_run(orc_job job, size_t B, int nthreads)
 {
   if (nthreads < 1) nthreads = 1;
   if ((size_t)nthreads > B) nthreads = B ? (int)B : 1;
+  size_t next = 0;
+  job.B = B;
+  job.next = &next;
+  job.chunk = job.kind == 1 ? 256 : (job.kind == 3 ? 1 : 4);
+  if (nthreads == 1) { orc_worker(&job); return; }
   pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
-  orc_job *jobs = (orc_job *)malloc(sizeof(orc_job) * nthreads);
-  for (int t = 0; t < nthreads; t++) {
-    jobs[t] = proto;
-    jobs[t].lo = B * (size_t)t / (size_t)nthreads;
-    jobs[t].hi = B * (size_t)(t + 1) / (size_t)nthreads;
-    if (nthreads == 1) { orc_worker(&jobs[t]); }
-    else pthread_create(&th[t], NULL, orc_worker, &jobs[t]);
-  }
-  if (nthreads > 1)
-    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, orc_worker, &job);
+  for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
   free(th);
-  free(jobs);
 }
 
 void orc_function_batch(const orc_problem *P, const double *q, double *f, size_t B, int nthreads)
@@ -710,4 +731,15 @@ void orc_sample_project_batch(const orc_problem *P, uint64_t seed, uint64_t firs
   orc_job j; memset(&j, 0, sizeof j);
   j.P = P; j.q_out = q_out; j.ok = ok; j.iters = iters; j.seed = seed; j.first = first_index; j.kind = 2;
   orc_run(j, B, nthreads);
+}
+
+/* E edges through orc_discrete_geodesic (interpolate == true, no validity callback): states [E][max_states][14],
+ * n_states[e] the true length (may exceed max_states), newton_iters[e] (nullable) the Newton updates spent */
+void orc_discrete_geodesic_batch(const orc_problem *P, const double *from, const double *to, size_t E, int max_states,
+                                 double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, int nthreads)
+{
+  orc_job j; memset(&j, 0, sizeof j);
+  j.P = P; j.q_in = from; j.q_to = to; j.q_out = states; j.n_states = n_states; j.ok = ok; j.iters = newton_iters;
+  j.max_states = max_states; j.kind = 3;
+  orc_run(j, E, nthreads);
 }

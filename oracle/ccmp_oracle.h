@@ -109,19 +109,22 @@ double orc_log(double x);
 /* sampleUniform = ambient sample -> project (result ignored) -> enforceBounds */
 int orc_sample_uniform(const orc_problem *P, uint64_t seed, uint64_t index, double q[14], int32_t *iters);
 /* discreteGeodesic; valid(state, user) may be NULL (= always valid).  Returns the bool of the
- * reference; *n_states counts states written to out (first one is `from`), capped at max_states. */
+ * reference; *n_states counts the states of the geodesic (first one is `from`); only the first max_states are written to out. */
 typedef int (*orc_valid_fn)(const double q[14], void *user);
 int orc_discrete_geodesic(const orc_problem *P, const double from[14], const double to[14],
                           int interpolate, orc_valid_fn valid, void *user, double *out,
                           int max_states, int *n_states, int64_t *newton_iters);
 void orc_compute_t_wo(const orc_problem *P, const double q_left[7], double R[9], double p[3]);
 
-/* --- batch drivers (pthreads; for parity runs and the CPU baseline timing) ------------------ */
+/* --- batch drivers (pthreads, dynamic chunks from a shared counter; for parity runs and the CPU baseline timing) --- */
 void orc_function_batch(const orc_problem *P, const double *q, double *f, size_t B, int nthreads);
 void orc_project_batch(const orc_problem *P, const double *q_in, double *q_out, uint8_t *ok,
                        int32_t *iters, size_t B, int nthreads);
 void orc_sample_project_batch(const orc_problem *P, uint64_t seed, uint64_t first_index,
                               double *q_out, uint8_t *ok, int32_t *iters, size_t B, int nthreads);
+/* E edges of discreteGeodesic (interpolate == true); n_states[e] is the true length, also beyond max_states */
+void orc_discrete_geodesic_batch(const orc_problem *P, const double *from, const double *to, size_t E, int max_states,
+                                 double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, int nthreads);
 /* elementary functions of this build (libm or detmath) exposed for tests */
 void orc_sincos(double x, double *s, double *c);
 double orc_atan2_nn(double y, double x);

@@ -65,6 +65,21 @@ int main(int argc, char **argv)
       for (auto &st : geo) print_hex(st.data(), 14);
       bool g2 = ccmp::discreteGeodesic(P, &out[0], &out[14], false, [](const double *) { return false; }, &geo, 64);
       std::printf("geodesic_rejected ok %d n %zu\n", g2 ? 1 : 0, geo.size());
+      // a buffer that is too small must not cut the list: the adapter re-runs the edge with room for all of it
+      bool g3 = ccmp::discreteGeodesic(P, &out[0], &out[14], true, [](const double *) { return true; }, &geo, 1);
+      std::printf("geodesic_small_buffer ok %d n %zu\n", g3 ? 1 : 0, geo.size());
+      // sampleUniformNear / sampleGaussian around the first projected state through the look-ahead buffers
+      ccmp::RefSampleBuffer nb(P, 42, ccmp::RefSampleBuffer::Near, 4), gb(P, 42, ccmp::RefSampleBuffer::Gaussian, 4);
+      for (int i = 0; i < 6; i++) {  // 6 > look-ahead: the second refill continues the stream
+        double a[14];
+        nb.next(a, &out[0], 0.2);
+        std::printf("near %d\n", i);
+        print_hex(a, 14);
+      }
+      double g[14];
+      gb.next(g, &out[0], 0.05);
+      std::printf("gauss 0\n");
+      print_hex(g, 14);
     }
   } catch (const std::exception &e) {
     std::fprintf(stderr, "error: %s\n", e.what());

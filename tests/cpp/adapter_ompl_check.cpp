@@ -108,11 +108,19 @@ int main(int argc, char **argv)
     constraint->function(xa, f);
     print_hex("fa", f.data(), 2);
 
-    // sampler: sampleUniform pops a GPU-projected, wrapped sample; Near projects the wrapped sampler's draw
+    // samplers: every sampler of the space has its own counter-based stream (seed = splitmix64(space seed + n));
+    // sampleUniform / Near / Gaussian pop GPU-projected, wrapped samples
     ob::StateSamplerPtr sampler = space->allocDefaultStateSampler();
+    ob::StateSamplerPtr sampler2 = space->allocStateSampler();
     sampler->sampleUniform(b);
     print_hex("uniform", xb.values, 14);
+    sampler2->sampleUniform(b);
+    print_hex("uniform2", xb.values, 14);
+    sampler->sampleGaussian(b, a, 0.05);
+    print_hex("gauss", xb.values, 14);
     sampler->sampleUniformNear(b, a, 0.2);
+    print_hex("near0", xb.values, 14);
+    sampler->sampleUniformNear(b, a, 0.2);  // same reference state: served from the look-ahead buffer
     std::printf("near_satisfied %d\n", constraint->isSatisfied(b) ? 1 : 0);
     print_hex("near", xb.values, 14);
 

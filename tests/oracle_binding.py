@@ -98,6 +98,8 @@ class Oracle:
         lib.orc_project_batch.argtypes = [pp, dp, dp, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_size_t, C.c_int]
         lib.orc_sample_project_batch.argtypes = [pp, C.c_uint64, C.c_uint64, dp, C.POINTER(C.c_uint8),
                                                  C.POINTER(C.c_int32), C.c_size_t, C.c_int]
+        lib.orc_discrete_geodesic_batch.argtypes = [pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32),
+                                                    C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_int]
         lib.orc_sincos.argtypes = [C.c_double, dp, dp]
         lib.orc_atan2_nn.argtypes = [C.c_double, C.c_double]
         lib.orc_atan2_nn.restype = C.c_double
@@ -206,6 +208,8 @@ class Oracle:
         n = C.c_int(0); its = C.c_int64(0)
         ok = self.lib.orc_discrete_geodesic(C.byref(P), _dptr(a), _dptr(b), int(interpolate), None, None,
                                             _dptr(out), max_states, C.byref(n), C.byref(its))
+        if n.value > max_states:  # the list did not fit: n_states reports the true length
+            return self.discrete_geodesic(P, a, b, interpolate, max_states=n.value)
         return bool(ok), out[: n.value].copy(), its.value
 
     def compute_t_wo(self, P, q7):
@@ -240,6 +244,17 @@ class Oracle:
                                           ok.ctypes.data_as(C.POINTER(C.c_uint8)),
                                           it.ctypes.data_as(C.POINTER(C.c_int32)), B, nthreads)
         return out, ok, it
+
+    def discrete_geodesic_batch(self, P, frm, to, max_states=64, nthreads=8):
+        """(E,14) x2 -> states (E,max_states,14), n_states (E,), ok (E,), newton_iters (E,); interpolate == True"""
+        frm = np.ascontiguousarray(frm, dtype=np.float64); to = np.ascontiguousarray(to, dtype=np.float64)
+        E = frm.shape[0]
+        st = np.zeros((E, max_states, 14))
+        n = np.zeros(E, dtype=np.int32); ok = np.zeros(E, dtype=np.uint8); its = np.zeros(E, dtype=np.int32)
+        self.lib.orc_discrete_geodesic_batch(C.byref(P), _dptr(frm), _dptr(to), E, max_states, _dptr(st),
+                                             n.ctypes.data_as(C.POINTER(C.c_int32)), ok.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                             its.ctypes.data_as(C.POINTER(C.c_int32)), nthreads)
+        return st, n, ok, its
 
     def sincos(self, x):
         s = C.c_double(); c = C.c_double()

@@ -74,6 +74,22 @@ def test_adapter_matches_oracle(ccmp_built, oracle_det, tmp_path):
     k += 1 + len(st_g)
     hdr = out[k].split()
     assert int(hdr[4]) == min(1, len(st_g)) and (int(hdr[2]) == 0 or len(st_g) == 1)  # everything rejected: only `from` survives
+    k += 1
+    assert out[k] == "geodesic_small_buffer ok %d n %d" % (int(ok_g), len(st_g))  # re-run, not cut
+    k += 1
+
+    def around(kind, salt, index, param):
+        amb = oracle_det.ambient_ref_batch(P, kind, 42 ^ salt, index, proj[0], param, 1)
+        _, x, _ = oracle_det.project(P, amb[0])
+        return oracle_det.enforce_bounds(x)
+
+    for i in range(6):
+        assert out[k] == "near %d" % i
+        x = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in out[k + 1].split()])
+        assert np.array_equal(x.view(np.uint64), around("near", 0x4E454152, i, 0.2).view(np.uint64))
+        k += 2
+    x = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in out[k + 1].split()])
+    assert out[k] == "gauss 0" and np.array_equal(x.view(np.uint64), around("gaussian", 0x47415553, 0, 0.05).view(np.uint64))
 
 
 OMPL_EXE = os.path.join(ROOT, "tests", "cpp", "adapter_ompl_check")
@@ -107,7 +123,12 @@ def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
     exe = _build_part2(ccmp_built)
     P = oracle_det.problem_from_bytes(bytes(load_config(config_path("Wine_Bottle"))))
     start = np.array(P.start_joint[:])
-    out = subprocess.run([exe] + ["%.17g" % v for v in start], check=True, capture_output=True, text=True).stdout.splitlines()
+    from closed_chain_motion_planner_amd import splitmix64
+
+    env = dict(os.environ, CCMP_SEED="0x5EED")  # the counterpart of ompl::RNG::setSeed: reproducible sampler streams
+    out = subprocess.run([exe] + ["%.17g" % v for v in start], check=True, capture_output=True, text=True, env=env).stdout.splitlines()
+    space_seed = splitmix64(0x5EED)  # first seed the process hands out
+    seed1, seed2 = splitmix64(space_seed), splitmix64(space_seed + 1)  # first and second sampler of the space
     assert out[0] == "throws 1 codim 2"
     assert out[1] == "name ProjectedKinematicChainSpace"
     xa0 = start + 0.05 * ((np.arange(14) % 3) - 1)
@@ -115,15 +136,24 @@ def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
     assert out[2] == "project %d satisfied %d" % (int(ok_a), int(oracle_det.is_satisfied(P, xa)))
     assert np.array_equal(_hex_row(out[3], "xa").view(np.uint64), xa.view(np.uint64))
     assert np.array_equal(_hex_row(out[4], "fa"), oracle_det.function(P, xa))
-    exp, _, _ = oracle_det.sample_project_batch(P, 0, 0, 1, 1)  # sampleUniform: seed 0, running index 0
+    exp, _, _ = oracle_det.sample_project_batch(P, seed1, 0, 1, 1)  # sampleUniform: the sampler's own seed, running index 0
     assert np.array_equal(_hex_row(out[5], "uniform").view(np.uint64), exp[0].view(np.uint64))
-    near0 = xa + np.where(np.arange(14) & 1, 0.2, -0.2) * 0.5
-    _, xn, _ = oracle_det.project(P, near0)
-    xn = oracle_det.enforce_bounds(xn)
-    assert out[6] == "near_satisfied %d" % int(oracle_det.is_satisfied(P, xn))
-    assert np.array_equal(_hex_row(out[7], "near").view(np.uint64), xn.view(np.uint64))
+    exp2, _, _ = oracle_det.sample_project_batch(P, seed2, 0, 1, 1)  # a second sampler of the same space: another stream
+    assert np.array_equal(_hex_row(out[6], "uniform2").view(np.uint64), exp2[0].view(np.uint64))
+    assert not np.array_equal(exp[0], exp2[0])
+
+    def around(kind, salt, index, param):
+        amb = oracle_det.ambient_ref_batch(P, kind, seed1 ^ salt, index, xa, param, 1)
+        _, x, _ = oracle_det.project(P, amb[0])
+        return oracle_det.enforce_bounds(x)
+
+    assert np.array_equal(_hex_row(out[7], "gauss").view(np.uint64), around("gaussian", 0x47415553, 0, 0.05).view(np.uint64))
+    assert np.array_equal(_hex_row(out[8], "near0").view(np.uint64), around("near", 0x4E454152, 0, 0.2).view(np.uint64))
+    xn = around("near", 0x4E454152, 1, 0.2)  # second draw around the same state: next index of the look-ahead buffer
+    assert out[9] == "near_satisfied %d" % int(oracle_det.is_satisfied(P, xn))
+    assert np.array_equal(_hex_row(out[10], "near").view(np.uint64), xn.view(np.uint64))
     ok_g, st_g, _ = oracle_det.discrete_geodesic(P, xa, xn, interpolate=True, max_states=256)
-    k = 8
+    k = 11
     n_full = len(st_g)
     assert out[k] == "geodesic accept 1000000 ok %d n %d checker_calls %d" % (int(ok_g), n_full, n_full - 1)
     for j in range(n_full):

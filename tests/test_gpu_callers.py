@@ -164,6 +164,62 @@ def test_sampler_mirror_stream_is_batch_independent(gpu_ctx, oracle_det):
     assert np.abs(a - near).max() < 0.5 and c.isSatisfied(a)
     s1.sampleGaussian(a, near, 0.05)
     assert c.isSatisfied(a)
+    # Near/Gaussian come from a look-ahead buffer around the current reference state; a changing reference refills it
+    # and no sample is ever handed out twice
+    seen = set()
+    other = near + 0.01
+    for k in range(80):
+        s1.sampleUniformNear(a, near if (k // 3) % 2 == 0 else other, 0.1)
+        seen.add(a.tobytes())
+    assert len(seen) == 80
+    # the first Near draw of a sampler == the oracle's sampleUniformNear with that sampler's stream, index 0
+    s3 = jy_ProjectedStateSampler(c, seed=77)
+    s3.sampleUniformNear(a, near, 0.2)
+    amb = oracle_det.ambient_ref_batch(P, "near", 77 ^ 0x4E454152, 0, near, 0.2, 1)
+    _, x, _ = oracle_det.project(P, amb[0])
+    assert np.array_equal(a.view(np.uint64), oracle_det.enforce_bounds(x).view(np.uint64))
+
+
+def test_samplers_of_one_space_have_their_own_streams(gpu_ctx):
+    """the planner's sampler, the valid-state sampler and a re-plan never repeat each other's samples"""
+    from closed_chain_motion_planner_amd import jy_ProjectedStateSpace
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    space = jy_ProjectedStateSpace(c)
+    s1, s2 = space.allocStateSampler(batch=16), space.allocDefaultStateSampler(batch=16)
+    a, b = np.empty(14), np.empty(14)
+    rows = set()
+    for _ in range(16):
+        s1.sampleUniform(a)
+        s2.sampleUniform(b)
+        rows.add(a.tobytes())
+        rows.add(b.tobytes())
+    assert s1.seed != s2.seed and len(rows) == 32
+
+
+def test_geodesic_longer_than_the_buffer_is_rerun_not_cut(gpu_ctx, oracle_det):
+    """n_states reports the true length; the host mirror re-runs an edge whose list did not fit, so that validity
+    is checked on every state and `true` is never returned for a cut list (small delta / long edges)"""
+    import torch
+    from closed_chain_motion_planner_amd import jy_ProjectedStateSpace
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    rows = load_path_rows("Wine_Bottle")
+    frm, to = rows[14], rows[21]
+    space = jy_ProjectedStateSpace(c, max_states=4)
+    space.setDelta(0.05)
+    P = _oracle_problem(oracle_det, c)
+    ok_cpu, st_cpu, _ = oracle_det.discrete_geodesic(P, frm, to, interpolate=True, max_states=256)
+    assert len(st_cpu) > 20
+    st, n, ok, _ = c.discrete_geodesic_batch(torch.as_tensor(frm.reshape(1, 14)).cuda(), torch.as_tensor(to.reshape(1, 14)).cuda(), 4)
+    assert int(n[0]) == len(st_cpu) and bool(ok[0]) == ok_cpu          # true length reported although only 4 fit
+    assert np.array_equal(st[0].cpu().numpy().view(np.uint64), st_cpu[:4].view(np.uint64))
+    seen = []
+    space.isValid = lambda s: seen.append(s.copy()) or True
+    geo = []
+    assert space.discreteGeodesic(frm, to, False, geo) == ok_cpu
+    assert len(geo) == len(st_cpu) and np.array_equal(np.array(geo).view(np.uint64), st_cpu.view(np.uint64))
+    assert len(seen) == len(st_cpu) - 1                                 # every state after `from` reached the checker
 
 
 def test_projector_is_graph_capturable(gpu_ctx, oracle_det):
