@@ -17,11 +17,22 @@
  *   Eigen JacobiSVD(2x14, ThinU|ThinV).solve, Quaterniond(Matrix3d), angularDistance, Isometry3d
  *   RBDL  Xrot / CalcBodyToBaseCoordinates / CalcBodyWorldOrientation
  *
- * PARITY PIN STATUS: the reference has no tests and cannot be built here (needs Eigen, OMPL,
- * RBDL, ROS — none installed, no network).  FK + residual + tolerances + delta are pinned by the
- * reference's recorded outputs (debug/Wine_Bottle_path.txt, debug/dumbbell_path.txt, config
- * start_joint rows; tests/golden/).  The Newton trajectory, FD Jacobian and SVD solve are
- * "parity unpinned": no reference artefact records them.
+ * PARITY PIN STATUS: pinned by outputs of the reference itself.  The reference has no tests and cannot be built
+ * here (needs Eigen, OMPL, RBDL, ROS — none installed, no network), but its recorded solution paths
+ * (debug/Wine_Bottle_path.txt, debug/dumbbell_path.txt; byte copies under tests/golden/paths/) are, between repeated
+ * rows, the states of its own discreteGeodesic(interpolate = true) printed with 6 significant digits
+ * (path.interpolate() + printAsMatrix, src/base/constraints/ConstrainedPlanningCommon.cpp:217-222).  Both builds of
+ * this file reproduce every recorded segment with the recorded NUMBER of states and every state to the print
+ * precision (Wine_Bottle, delta 0.25: 4 segments / 25 states, max 8.4e-6 rad; dumbbell, recorded with delta 0.5:
+ * 2 segments / 6 states, max 1.3e-4 rad, inside the spread that endpoints consistent with the printed digits
+ * produce) — tests/test_oracle_golden.py::test_recorded_paths_are_reproduced; a Newton step of 0.25 / 0.35, other
+ * tolerances or another delta miss by > 1e-4 (::test_recorded_path_rejects_a_wrong_projector).  That pins project()
+ * as a whole (FK, residual, FD stencil, min-norm solve, 0.30 step, stop rule, quirks), interpolate and the break
+ * tests of discreteGeodesic against the real RBDL / Eigen / OMPL build.  Also pinned: start_joint rows (f ~ 1e-6),
+ * the dumped roadmaps (tests/golden/roadmaps/), an independent 50-digit mpmath FK/residual (tests/golden/mp_vectors.json).
+ * Not pinned by any reference artefact: projections from uniform random samples (30+ Newton iterations) — there the
+ * iteration amplifies last-bit differences past 1e-6 rad whatever the implementation, and the samplers'
+ * random streams (OMPL's RNG is replaced by a counter-based generator).
  *
  * Two builds of the same source (oracle/Makefile):
  *   libccmp_oracle_libm.so  sin/cos/atan2 from glibc  — what the reference would call

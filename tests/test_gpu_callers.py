@@ -35,10 +35,11 @@ def test_discrete_geodesic_batch_bitwise(gpu_ctx, oracle_det):
     for e in range(len(frm)):
         ok_cpu, st_cpu, its_cpu = oracle_det.discrete_geodesic(P, frm[e], to[e], interpolate=True, max_states=maxs)
         assert n[e] == len(st_cpu) and bool(ok[e]) == ok_cpu and its[e] == its_cpu, e
-        assert np.array_equal(st[e, : n[e]].view(np.uint64), st_cpu.view(np.uint64)), e
+        m = min(int(n[e]), maxs)  # n is the true length: an edge that wanders for more than maxs states reports it
+        assert np.array_equal(st[e, :m].view(np.uint64), st_cpu[:m].view(np.uint64)), e
         n_ok += ok_cpu
     assert n[1] == 1 and ok[1] == 1
-    assert n.max() > 3  # some edge really traversed the manifold
+    assert n.max() > maxs  # one of these edges wanders for more states than the buffer holds — reported, not hidden
     print("geodesic: %d/%d edges reached their target, mean states %.1f, mean Newton iterations per edge %.1f"
           % (n_ok, len(frm), n.mean(), its.mean()))
 
@@ -205,7 +206,7 @@ def test_geodesic_longer_than_the_buffer_is_rerun_not_cut(gpu_ctx, oracle_det):
 
     c = _constraint("Wine_Bottle", gpu_ctx)
     rows = load_path_rows("Wine_Bottle")
-    frm, to = rows[14], rows[21]
+    frm, to = rows[15], rows[20]  # two recorded on-manifold states 1.2 rad apart
     space = jy_ProjectedStateSpace(c, max_states=4)
     space.setDelta(0.05)
     P = _oracle_problem(oracle_det, c)

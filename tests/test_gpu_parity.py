@@ -386,4 +386,5 @@ def test_stock_structure_kernels_and_general_kernels(gpu_ctx, oracle_det, calibr
         for e in range(len(frm)):
             ok_c, st_c, _ = oracle_det.discrete_geodesic(P, frm[e], to[e], interpolate=True, max_states=32)
             assert int(gok[e]) == int(ok_c) and int(n[e]) == len(st_c), (calibrated, stock, e)
-            assert np.array_equal(st[e, : n[e]].view(np.uint64), st_c.view(np.uint64))
+            m = min(int(n[e]), 32)  # n is the true length, also past the buffer
+            assert np.array_equal(st[e, :m].view(np.uint64), st_c[:m].view(np.uint64))
