@@ -6,21 +6,29 @@
 One "step" = one pass of the hot path over one batch of synthetic samples per GPU:
 project B uniform joint samples of config Wine_Bottle onto the closed-chain manifold
 (KinematicChainConstraint::project, reference arithmetic = FD-faithful mode, bit-identical to the
-CPU oracle), compact the valid states, and — for N > 1 — all-gather them over RCCL/xGMI.  Inputs
-are generated on the device before the timed region (resident in HBM).  Default workload is
-BASELINE.json configs[2] (Wine_Bottle, B = 262144, "HBM-roofline run"), which is also the per-GPU
-shard of the 8-GPU config (2097152 / 8); configs[1] (B = 4096) is timed as a secondary figure.
+CPU oracle), compact the valid states, and — for N > 1 — all-gather them over RCCL/xGMI (one
+fixed-capacity collective, no host synchronisation inside the step).  Inputs are generated on the
+device before the timed region (resident in HBM).  Default workload is BASELINE.json configs[2]
+(Wine_Bottle, B = 262144, "HBM-roofline run"), which is also the per-GPU shard of the 8-GPU config
+(2097152 / 8); configs[1] (B = 4096), configs[3] (stefan, both tolerance sets) and the extend step
+are timed as secondary figures, each with an in-run bitwise check against the det oracle.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(fresh child processes, one per GPU, rendezvous on 127.0.0.1) and relays rank 0's line; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
 
 Prints ONE JSON line on rank 0.  `value` is whole-job projections/s (all ranks' samples / max-over-
 ranks time).  `roofline` prices the dominant kernel against HBM as the metric asks (225 algorithmic
 bytes per projection); the path is FP64-VALU bound, so the honest efficiency figure
 `fp64` (2.4 kflop per Newton iteration x iterations / kernel time vs 78.6 TFLOP/s) sits beside it.
 `cpu_baseline` times the CPU oracle (glibc build = what the reference would call) on this box's
-host cores, rank 0, N = 1 only.
+host cores — the count actually usable, not the count the OS reports — rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +40,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
 BYTES_PER_PROJECTION = 225      # 112 B in + 112 B out + 1 B flag
 FLOP_PER_NEWTON_ITER = 2400.0   # analytic formulation = algorithmic minimum
 SEEDS = {4096: 0xC2, 262144: 0xC3}
+GATHER_CAPACITY = 0.5           # gather block = this fraction of the shard (about 22 % of uniform samples are valid)
 
 
 def parse():
@@ -48,12 +57,83 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets several ranks share one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, rendezvous over gloo on the CPU, print the launch facts and exit (no GPU work: "
+                         "checks the launcher on a box without GPUs)")
     return ap.parse_args()
 
 
-def cpu_baseline(obj, seed, ncores, gpu_check=None):
-    """CPU oracle (port of the reference algorithm, glibc sin/cos, FD Jacobian) on a bounded sample
-    of the same workload: first `sample` samples of the bench batch, all host cores."""
+# ---- N ranks from one command ------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """Parent of `python bench.py --gpus N`: N fresh child processes, one rank each; this process never touches a GPU
+    (no exec of a process that has initialised HIP).  Relays rank 0's JSON line; non-zero exit if any rank fails."""
+    from closed_chain_motion_planner_amd.build import build_library
+
+    build_library()  # hipcc needs no GPU; the ranks then find the library current and do not race to build it
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", CCMP_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        for p in procs:
+            rc = rc or p.wait()
+    except BaseException:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise
+    if rc != 0:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stdout.write(out0 or "")
+        sys.exit(rc if rc > 0 else 1)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+
+
+# ---- host cores -----------------------------------------------------------------------------------------------------------
+def usable_cores():
+    """(cores this process may use, how that was found, what the OS reports): scheduler affinity bounded by the cgroup's
+    CPU quota — a leased box reports every hardware thread of the machine but grants a share of them"""
+    reported = os.cpu_count() or 1
+    n, how = reported, "os.cpu_count"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, how = a, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:  # cgroup v2
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, how = max(1, int(quota)), "cgroup cpu quota"
+    return max(1, n), how, reported
+
+
+def cpu_baseline(obj, seed, gpu_check=None):
+    """CPU oracle (port of the reference algorithm, glibc sin/cos, FD Jacobian) on a bounded sample of the same
+    workload: the first `sample` samples of the bench batch on the host cores this process can really use.  Threads
+    take samples in dynamic chunks (oracle/ccmp_oracle.c: orc_run).  If the detected core count still does not scale
+    (a share enforced some other way), the count is halved until a short probe reaches 75 % parallel efficiency."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import yaml
     from oracle_binding import Oracle
@@ -61,53 +141,93 @@ def cpu_baseline(obj, seed, ncores, gpu_check=None):
     O = Oracle("libm")
     cfg = yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml")))
     P = O.problem(cfg)
-    # calibrate on 256 samples single-thread, then size the sample for ~20 s of CPU work
-    q = O.ambient_uniform_batch(P, seed, 0, 256)
-    t0 = time.time()
-    O.project_batch(P, q, 1)
-    t1 = time.time() - t0
-    per_core = 256 / t1
-    sample = int(max(1024, min(65536, per_core * 20.0)))
+
+    def rate(q, n):
+        t0 = time.perf_counter()
+        out = O.project_batch(P, q, n)
+        return len(q) / (time.perf_counter() - t0), out
+
+    rate(O.ambient_uniform_batch(P, seed, 0, 128), 1)  # page the library in, let the clocks ramp
+    per_core = max(rate(O.ambient_uniform_batch(P, seed, 0, 512), 1)[0] for _ in range(2))
+    cores, how, reported = usable_cores()
+    probes = []
+    while cores > 1:
+        qp = O.ambient_uniform_batch(P, seed, 0, int(max(1024, per_core * cores * 1.5)))  # ~1.5 s per probe
+        r = max(rate(qp, cores)[0] for _ in range(2))  # best of two: a probe must not lose cores to a noisy neighbour
+        probes.append({"threads": cores, "efficiency": r / (cores * per_core)})
+        if r >= 0.75 * cores * per_core:
+            break
+        cores, how = max(1, cores // 2), "scaling probe (detected count did not scale)"
+    sample = int(max(1024, min(131072, per_core * cores * 15.0)))  # ~15 s of CPU work
     q = O.ambient_uniform_batch(P, seed, 0, sample)
-    t0 = time.time()
-    _, ok, it = O.project_batch(P, q, ncores)
-    wall = time.time() - t0
+    value, (_, ok, it) = rate(q, cores)
     # the same algorithm with the analytic Jacobian on the CPU (fair algorithmic comparison for the fast mode)
     Pa = O.problem(cfg)
     Pa.jacobian_mode = 1
-    t0 = time.time()
-    O.project_batch(Pa, q, ncores)
-    wall_a = time.time() - t0
+    t0 = time.perf_counter()
+    O.project_batch(Pa, q, cores)
+    wall_a = time.perf_counter() - t0
     # in-run parity evidence: the det build of the oracle vs the GPU on the first 2048 samples of the batch
     parity = None
     if gpu_check is not None:
-        import numpy as np
-        Od = Oracle("det")
-        Pd = Od.problem_from_bytes(gpu_check["problem_bytes"])
-        n = min(2048, sample)
-        qd, okd, itd = Od.project_batch(Pd, gpu_check["q_in"][:n], ncores)  # the very inputs the GPU projected
-        d = np.abs(qd - gpu_check["q_out"][:n]).max(axis=1)
-        parity = {"samples": n, "max_abs_dq": float(d.max()), "n_gt_1e-6": int((d > 1e-6).sum()),
-                  "bit_identical": bool(np.array_equal(qd.view(np.uint64), gpu_check["q_out"][:n].view(np.uint64))),
-                  "ok_mismatches": int((okd != gpu_check["ok"][:n]).sum()),
-                  "iteration_mismatches": int((itd != gpu_check["iters"][:n]).sum())}
+        parity = det_parity(gpu_check["problem_bytes"], gpu_check["q_in"], gpu_check["q_out"], gpu_check["ok"], gpu_check["iters"], cores)
     return {
-        "analytic_jacobian_value": sample / wall_a, "parity_gpu_vs_det_oracle": parity,
-        "value": sample / wall, "unit": "projections/s", "cores": ncores, "kind": "port",
-        "sample": "first %d samples of the bench batch, FD-faithful C oracle (glibc libm, -O2), %d threads; "
-                  "single thread: %.1f projections/s" % (sample, ncores, per_core),
-        "single_thread_value": per_core, "mean_iters": float(it.mean()),
+        "value": value, "unit": "projections/s", "cores": cores, "kind": "port",
+        "sample": "first %d samples of the bench batch, FD-faithful C oracle (glibc libm, -O2), %d threads taking samples "
+                  "in dynamic chunks; single thread: %.1f projections/s" % (sample, cores, per_core),
+        "cores_reported_by_os": reported, "cores_found_by": how, "scaling_probes": probes,
+        "single_thread_value": per_core, "parallel_efficiency": value / (cores * per_core),
+        "analytic_jacobian_value": sample / wall_a, "mean_iters": float(it.mean()), "parity_gpu_vs_det_oracle": parity,
     }
+
+
+def det_parity(problem_bytes, q_in, q_out, ok, iters, threads):
+    """the det build of the oracle on the very inputs the GPU projected"""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import Oracle
+
+    Od = Oracle("det")
+    Pd = Od.problem_from_bytes(problem_bytes)
+    qd, okd, itd = Od.project_batch(Pd, q_in, threads)
+    d = np.abs(qd - q_out).max(axis=1)
+    return {"samples": len(q_in), "max_abs_dq": float(d.max()), "n_gt_1e-6": int((d > 1e-6).sum()),
+            "bit_identical": bool(np.array_equal(qd.view(np.uint64), q_out.view(np.uint64))),
+            "ok_mismatches": int((okd != ok).sum()), "iteration_mismatches": int((itd != iters).sum())}
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args.gpus)  # before anything touches a GPU
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print("error: --gpus %d but WORLD_SIZE=%d — launch with matching counts (or without WORLD_SIZE: "
+                  "bench.py starts the ranks itself)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:  # launcher plumbing only: every rank joins a CPU rendezvous, nothing touches a GPU
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t)
+            dist.destroy_process_group()
+        else:
+            t = torch.tensor([0.0])
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
+                              "self_launched": os.environ.get("CCMP_BENCH_CHILD") == "1"}), flush=True)
+        return
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -120,18 +240,15 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     from closed_chain_motion_planner_amd import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, Context, KinematicChainConstraint
     from closed_chain_motion_planner_amd.build import build_library
-    from closed_chain_motion_planner_amd.distributed import gather_valid
+    from closed_chain_motion_planner_amd.distributed import ValidGather
 
     # no-op when the in-tree .so is current; raises if it cannot be built.  One rank per node builds, the others wait:
     # eight ranks compiling into the same build directory would race.
     if world > 1:
-        if local_rank == 0:
+        if local_rank == 0 or args.force_device >= 0 and rank == 0:
             build_library()
         dist.barrier()
     else:
@@ -140,7 +257,8 @@ def main():
     ctx = Context(dev)
     if args.waves_per_cu:
         ctx.set_waves_per_cu(args.waves_per_cu)
-    c = KinematicChainConstraint.from_yaml(os.path.join(ROOT, "tests", "golden", "config", args.obj + ".yaml"), ctx=ctx)
+    cfg_path = lambda obj: os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml")
+    c = KinematicChainConstraint.from_yaml(cfg_path(args.obj), ctx=ctx)
     c.setJacobianMode(CCMP_JAC_FD if args.mode == "fd" else CCMP_JAC_ANALYTIC)
     if args.tol:
         c.setTolerance(*[float(v) for v in args.tol.split(",")])
@@ -151,6 +269,10 @@ def main():
     # global index space sharded contiguously over ranks (rank r owns [r*B, (r+1)*B))
     q_in = c.ambient_uniform_batch(seed, rank * B, B)
     q_out = torch.empty_like(q_in)
+    q_valid = torch.empty_like(q_in)
+    cnt = torch.zeros(1, dtype=torch.int64, device=q_in.device)
+    # N > 1: the compaction writes straight into the fixed-capacity send block of the all-gather (row 0 = count)
+    vg = ValidGather(max(1, int(B * GATHER_CAPACITY)), q_in.device) if world > 1 else None
     torch.cuda.synchronize()
 
     kernel_ms = []
@@ -161,18 +283,19 @@ def main():
         e0.record()
         _, ok, it = c.project_batch(q_in, out=q_out, want_iters=True)
         e1.record()
-        q_valid, cnt = c.compact_valid(q_out, ok)
-        gathered = None
-        if world > 1:
-            gathered, _ = gather_valid(q_valid, cnt)
+        if vg is None:
+            c.compact_valid(q_out, ok, out=q_valid, cnt=cnt)
+        else:
+            c.compact_valid(q_out, ok, out=vg.rows, cnt=vg.count)
+            vg.launch()  # one collective, enqueued behind the kernels: no host synchronisation in the step
         if record:
             kernel_ms.append((e0, e1))
-        return ok, it, q_valid, cnt, gathered
+        return ok, it
 
     if world > 1:
         # communicator set-up (RCCL builds its rings on the first collective): not a step, so that --warmup 0 still
         # times steps and not the rendezvous
-        gather_valid(torch.zeros((1, 14), dtype=torch.float64, device="cuda"), torch.ones(1, dtype=torch.int64, device="cuda"))
+        vg.launch()
     for _ in range(args.warmup):
         step(False)
     if world > 1:
@@ -180,7 +303,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ok, it, q_valid, cnt, gathered = step(True)
+        ok, it = step(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,7 +317,15 @@ def main():
     kms = sum(a.elapsed_time(b) for a, b in kernel_ms) / max(1, len(kernel_ms))
     sum_iters = float(it.to(torch.float64).sum().item())
     ok_frac = float(ok.to(torch.float64).mean().item())
-    n_valid = int(cnt.item())
+    gathered = None
+    if vg is not None:
+        counts = vg.counts()  # after the timed region: what the host tree would read when it consumes the states
+        n_valid = counts[rank]
+        gathered = {"valid_states_all_ranks": int(sum(counts)), "capacity_rows_per_rank": vg.capacity,
+                    "overflow": bool(max(counts) > vg.capacity), "bytes_sent_per_rank": int(vg.send.numel() * 8)}
+    else:
+        n_valid = int(cnt.item())
+    rccl_ranks = dist.get_world_size() if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)
 
     if rank != 0:
         if world > 1:
@@ -228,64 +359,32 @@ def main():
         "metric": "constraint projections/sec (dual-Panda %s)" % args.obj,
         "value": value, "unit": "projections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "rccl_ranks": rccl_ranks,
         "config": {
             "workload": "config/%s.yaml, batch=%d uniform joint samples per GPU (BASELINE configs[2]; per-GPU shard of "
                         "configs[4]), KinematicChainConstraint::project, tol (%g m, %g rad), cap 250" % (args.obj, B, c.problem.tol_pos, c.problem.tol_rot),
             "jacobian_mode": "finite-difference (reference arithmetic, bit-identical to the CPU oracle)"
             if args.mode == "fd" else "analytic (fast mode, not bit-comparable)",
-            "global_batch": world * B, "parallelism": "sample-sharded x%d, all-gather of valid states" % world,
+            "global_batch": world * B, "parallelism": "sample-sharded x%d, one fixed-capacity all-gather of valid states per step (%s)"
+                                                       % (world, args.backend if world > 1 else "none at N=1"),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel, "kernel_ms": kms,
-            "note": "metric asks for %HBM; the kernel is FP64-VALU bound (see fp64)",
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_ratio": (traffic / (BYTES_PER_PROJECTION * B)) if traffic else None,
+            "kernel": kernel, "kernel_ms": kms,
+            "note": "metric asks for %HBM; the kernel is FP64-VALU bound (see fp64); traffic above the algorithmic bytes comes from "
+                    "scattered 112-B rows in longest-first order and partial-sector flag writes, harmless at this fraction of HBM",
             "fp64": {"achieved": fp64_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fp64_tflops / FP64_VECTOR_PEAK_TFLOPS,
                      "algorithmic_flop": "2400 per Newton iteration x %.0f iterations per launch" % sum_iters},
             "newton_iterations_per_s": sum_iters / (kms * 1e-3), "valu_issue": valu, "fp64_executed": executed,
         },
-        "stats": {"ok_fraction": ok_frac, "mean_newton_iters": sum_iters / B, "valid_states_rank0": n_valid},
+        "stats": {"ok_fraction": ok_frac, "mean_newton_iters": sum_iters / B, "valid_states_rank0": n_valid, "gather": gathered},
     }
 
     if world == 1 and not args.no_secondary:
-        # BASELINE configs[1]: batch 4096 (latency-bound); and the other Jacobian mode at the same batch
-        def quick(mode, b, reps):
-            c.setJacobianMode(mode)
-            qi = c.ambient_uniform_batch(SEEDS.get(b, 0xC3), 0, b)
-            qo = torch.empty_like(qi)
-            c.project_batch(qi, out=qo)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                c.project_batch(qi, out=qo)
-            e1.record()
-            torch.cuda.synchronize()
-            return b * reps / (e0.elapsed_time(e1) * 1e-3)
-
-        main_mode = CCMP_JAC_FD if args.mode == "fd" else CCMP_JAC_ANALYTIC
-        other = CCMP_JAC_ANALYTIC if args.mode == "fd" else CCMP_JAC_FD
-        def single_latency_us(reps=40):
-            # the reference-signature call: one state through the host entry point (copy in, launch, synchronise, copy out)
-            import numpy as np
-            c.setJacobianMode(main_mode)
-            qs = c.ambient_uniform_batch(0xC1, 0, reps).cpu().numpy()
-            ts = []
-            for i in range(reps):
-                x = qs[i].copy()
-                t0 = time.perf_counter()
-                c.project(x)
-                ts.append(time.perf_counter() - t0)
-            return float(np.median(ts[4:]) * 1e6)
-
-        line["secondary"] = {
-            "batch4096_projections_per_s": quick(main_mode, 4096, 10),
-            "batch32768_projections_per_s": quick(main_mode, 32768, 10),
-            "single_project_call_median_us": single_latency_us(),
-            ("analytic" if args.mode == "fd" else "fd") + "_mode_projections_per_s": quick(other, B, 5),
-        }
-        c.setJacobianMode(main_mode)
+        line["secondary"] = secondary(args, c, ctx, B, torch, cfg_path)
 
     if world == 1 and not args.no_cpu_baseline:
         try:
@@ -293,12 +392,107 @@ def main():
             if args.mode == "fd" and not args.tol:
                 gpu_check = {"problem_bytes": bytes(c.problem), "q_in": q_in[:2048].cpu().numpy(), "q_out": q_out[:2048].cpu().numpy(),
                              "ok": ok[:2048].cpu().numpy(), "iters": it[:2048].cpu().numpy().astype("int32")}
-            line["cpu_baseline"] = cpu_baseline(args.obj, seed, os.cpu_count() or 1, gpu_check)
+            line["cpu_baseline"] = cpu_baseline(args.obj, seed, gpu_check)
         except Exception as e:  # the oracle is a checker; its absence must not fail the GPU bench
             line["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def secondary(args, c, ctx, B, torch, cfg_path):
+    """The other BASELINE configs and the callers' real shapes, timed with HIP events on the launch stream; every
+    reference-arithmetic figure carries an in-run bitwise check of a 1024-sample slice against the det oracle."""
+    import numpy as np
+    from closed_chain_motion_planner_amd import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, KinematicChainConstraint
+
+    threads = usable_cores()[0]
+    main_mode = CCMP_JAC_FD if args.mode == "fd" else CCMP_JAC_ANALYTIC
+    other = CCMP_JAC_ANALYTIC if args.mode == "fd" else CCMP_JAC_FD
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    def quick(con, mode, b, reps, check=False):
+        con.setJacobianMode(mode)
+        qi = con.ambient_uniform_batch(SEEDS.get(b, 0xC3), 0, b)
+        qo = torch.empty_like(qi)
+        sec = timed(lambda: con.project_batch(qi, out=qo), reps)
+        res = {"projections_per_s": b / sec, "ms": sec * 1e3}
+        if check and mode == CCMP_JAC_FD:
+            _, ok, it = con.project_batch(qi, out=qo)
+            try:
+                res["parity_vs_det_oracle"] = det_parity(bytes(con.problem), qi[:1024].cpu().numpy(), qo[:1024].cpu().numpy(),
+                                                         ok[:1024].cpu().numpy(), it[:1024].cpu().numpy().astype("int32"), threads)
+            except Exception as e:
+                res["parity_vs_det_oracle"] = {"error": repr(e)}
+            res["mean_newton_iters"] = float(it.to(torch.float64).mean().item())
+        return res
+
+    def single_latency_us(reps=40):
+        # the reference-signature call: one state through the host entry point (copy in, launch, synchronise, copy out)
+        c.setJacobianMode(main_mode)
+        qs = c.ambient_uniform_batch(0xC1, 0, reps).cpu().numpy()
+        ts = []
+        for i in range(reps):
+            x = qs[i].copy()
+            t0 = time.perf_counter()
+            c.project(x)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts[4:]) * 1e6)
+
+    def geodesic(n_edges=16384):
+        # growTree-shaped edges (src/planner/stefanBiPRM.cpp:307-351): from a valid projected state towards another
+        c.setJacobianMode(CCMP_JAC_FD)
+        q, ok, _, _ = c.sample_project_batch(0x6E0, 0, 12 * n_edges, want_iters=False)
+        good = q[ok == 1]
+        frm, to = good[:n_edges].contiguous(), good[n_edges: 2 * n_edges].contiguous()
+        sec = timed(lambda: c.discrete_geodesic_batch(frm, to, 64), 3)
+        st, n, gok, its = c.discrete_geodesic_batch(frm, to, 64)
+        res = {"edges_per_s": n_edges / sec, "ms": sec * 1e3, "edges": n_edges, "mean_states_per_edge": float(n.to(torch.float64).mean().item()),
+               "mean_newton_iters_per_edge": float(its.to(torch.float64).mean().item()), "reached_fraction": float(gok.to(torch.float64).mean().item())}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_binding import Oracle
+
+            Od = Oracle("det")
+            Pd = Od.problem_from_bytes(bytes(c.problem))
+            m = 1024
+            sc, nc, okc, itc = Od.discrete_geodesic_batch(Pd, frm[:m].cpu().numpy(), to[:m].cpu().numpy(), 64, threads)
+            sg, ng = st[:m].cpu().numpy(), n[:m].cpu().numpy()
+            same = all(np.array_equal(sg[e, : min(ng[e], 64)].view(np.uint64), sc[e, : min(nc[e], 64)].view(np.uint64)) for e in range(m))
+            res["parity_vs_det_oracle"] = {"edges": m, "bit_identical": bool(same and np.array_equal(ng, nc)),
+                                           "flag_mismatches": int((gok[:m].cpu().numpy() != okc).sum()),
+                                           "iteration_mismatches": int((its[:m].cpu().numpy() != itc).sum())}
+        except Exception as e:
+            res["parity_vs_det_oracle"] = {"error": repr(e)}
+        return res
+
+    out = {}
+    s4 = quick(c, main_mode, 4096, 10, check=True)
+    s32 = quick(c, main_mode, 32768, 10)
+    out["batch4096_projections_per_s"] = s4["projections_per_s"]
+    out["batch4096"] = s4
+    out["batch32768_projections_per_s"] = s32["projections_per_s"]
+    out["single_project_call_median_us"] = single_latency_us()
+    out[("analytic" if args.mode == "fd" else "fd") + "_mode_projections_per_s"] = quick(c, other, B, 5)["projections_per_s"]
+    c.setJacobianMode(main_mode)
+    # BASELINE configs[3]: stefan (arms left + top), the reference's tolerances and the tighter set the baseline asks for
+    st = KinematicChainConstraint.from_yaml(cfg_path("stefan"), ctx=ctx)
+    out["stefan_batch%d_tol_1e-3_5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True)
+    st.setTolerance(5e-4, 2.5e-3)
+    out["stefan_batch%d_tol_5e-4_2.5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True)
+    out["discrete_geodesic"] = geodesic()
+    c.setJacobianMode(main_mode)
+    return out
 
 
 if __name__ == "__main__":

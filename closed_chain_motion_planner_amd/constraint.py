@@ -326,14 +326,20 @@ class KinematicChainConstraint:
               "ccmp_enforce_bounds_batch")
         return q
 
-    def compact_valid(self, q, ok, stream=None):
-        """Rows of q with ok != 0, in order (what the host tree consumes)."""
+    def compact_valid(self, q, ok, stream=None, out=None, cnt=None):
+        """Rows of q with ok != 0, in order (what the host tree consumes).  `out` (optional, (cap,14) with cap <= B): a
+        fixed-capacity buffer — valid rows past its capacity are dropped, `cnt` still reports how many there were."""
         self._check_q(q)
         torch = _torch()
-        out = torch.empty_like(q)
-        cnt = torch.zeros(1, dtype=torch.int64, device=q.device)
-        check(_lib.lib().ccmp_compact_valid(self.ctx.handle, q.data_ptr(), ok.data_ptr(), q.shape[0], out.data_ptr(),
-                                            cnt.data_ptr(), _stream_handle(stream)), "ccmp_compact_valid")
+        if out is None:
+            out = torch.empty_like(q)
+        else:
+            self._check_q(out)
+        if cnt is None:
+            cnt = torch.zeros(1, dtype=torch.int64, device=q.device)
+        check(_lib.lib().ccmp_compact_valid_capped(self.ctx.handle, q.data_ptr(), ok.data_ptr(), q.shape[0], out.data_ptr(),
+                                                   out.shape[0], cnt.data_ptr(), _stream_handle(stream)),
+              "ccmp_compact_valid_capped")
         return out, cnt
 
     # -- single-state API with the reference's signatures ------------------------------------------

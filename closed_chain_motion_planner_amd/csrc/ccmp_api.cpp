@@ -46,8 +46,8 @@ hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambd
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int nblocks, hipStream_t st);
 hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st);
-hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, unsigned int *block_counts,
-                               unsigned long long *total, hipStream_t st);
+hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, size_t capacity,
+                               unsigned int *block_counts, unsigned long long *total, hipStream_t st);
 }
 
 namespace {
@@ -563,6 +563,12 @@ int ccmp_enforce_bounds_batch(ccmp_ctx *ctx, double *q, size_t B, void *hip_stre
 int ccmp_compact_valid(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t B, double *q_valid, uint64_t *count_dev,
                        void *hip_stream)
 {
+  return ccmp_compact_valid_capped(ctx, q, ok, B, q_valid, B, count_dev, hip_stream);
+}
+
+int ccmp_compact_valid_capped(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t B, double *q_valid, size_t capacity,
+                              uint64_t *count_dev, void *hip_stream)
+{
   if (!ctx || !count_dev) return CCMP_EINVAL;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
@@ -581,7 +587,7 @@ int ccmp_compact_valid(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t
     HIP_TRY(hipMalloc((void **)&ctx->scan, nblocks * sizeof(unsigned int)));
     ctx->scan_cap = nblocks;
   }
-  HIP_TRY(ccmp_launch_compact(q, ok, B, q_valid, ctx->scan, (unsigned long long *)count_dev, st));
+  HIP_TRY(ccmp_launch_compact(q, ok, B, q_valid, capacity, ctx->scan, (unsigned long long *)count_dev, st));
   return CCMP_OK;
 }
 

@@ -534,7 +534,8 @@ __global__ void compact_scan_kernel(unsigned int *__restrict__ block_counts, siz
   for (size_t k = lo; k < hi; k++) { unsigned int v = block_counts[k]; block_counts[k] = (unsigned int)run; run += v; }
 }
 __global__ void compact_scatter_kernel(const double *__restrict__ q, const uint8_t *__restrict__ ok, size_t B,
-                                       const unsigned int *__restrict__ block_offsets, double *__restrict__ out)
+                                       const unsigned int *__restrict__ block_offsets, double *__restrict__ out,
+                                       size_t capacity)
 {
   __shared__ unsigned int wsum[4];
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -547,8 +548,10 @@ __global__ void compact_scatter_kernel(const double *__restrict__ q, const uint8
   for (int k = 0; k < w; k++) base += wsum[k];
   if (v) {
     const unsigned int pos = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (pos < capacity) { // rows past the capacity of `out` are dropped; the total still counts them
 #pragma unroll
-    for (int e = 0; e < 14; e++) out[(size_t)pos * 14 + e] = q[i * 14 + e];
+      for (int e = 0; e < 14; e++) out[(size_t)pos * 14 + e] = q[i * 14 + e];
+    }
   }
 }
 
@@ -627,13 +630,13 @@ hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *o
   hipLaunchKernelGGL(detmath_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, out, n);
   return hipGetLastError();
 }
-hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, unsigned int *block_counts,
-                               unsigned long long *total, hipStream_t st)
+hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, size_t capacity,
+                               unsigned int *block_counts, unsigned long long *total, hipStream_t st)
 {
   const size_t nblocks = (B + 255) / 256;
   hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, ok, B, block_counts);
   hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, block_counts, nblocks, total);
-  hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, q, ok, B, block_counts, out);
+  hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, q, ok, B, block_counts, out, capacity);
   return hipGetLastError();
 }
 

@@ -6,11 +6,20 @@ The projector path shards embarrassingly: sample i of a global batch is a pure f
 contiguous index range [r*B/W, (r+1)*B/W) with no data-path exchange.  The only collective is the
 one the north star names: an all-gather that returns the VALID projected states to the host tree
 (which lives in one process per rank here; every rank ends up with all valid states, in global
-sample order).  Payload is compacted first: ~22 % of the states are valid, so the gather moves
-~6.5 MB per rank instead of 29.4 MB at 262144 samples per GPU.
+sample order).
+
+ONE collective per step and no host synchronisation inside it: every rank sends a fixed-capacity
+block — row 0 carries its count of valid states (a uint64 in the first 8 bytes), rows 1.. the
+compacted states — so nothing has to be known on the host before the all-gather is enqueued, and
+the gather runs on the stream behind the projector kernels.  The capacity is a fraction of the
+shard (about 22 % of uniform samples are valid; default capacity 50 %, i.e. 14.7 MB instead of
+29.4 MB per rank at 262144 samples per GPU); a count above the capacity is visible to every
+consumer in row 0 and `unpack` refuses to return a cut list.
 """
 import torch
 import torch.distributed as dist
+
+DIM = 14
 
 
 def shard_range(total, rank, world):
@@ -20,40 +29,71 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class ValidGather:
+    """Preallocated send / receive blocks of the all-gather of valid states.
+
+        vg = ValidGather(capacity, device)
+        constraint.compact_valid(q, ok, out=vg.rows, cnt=vg.count)   # compaction writes straight into the send block
+        vg.launch()                                                  # one all_gather, asynchronous, no host sync
+        ...
+        states, counts = vg.unpack()                                 # when the host tree consumes them
+
+    Works on CUDA tensors over RCCL and on CPU tensors over gloo (the CPU tests)."""
+
+    def __init__(self, capacity, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.capacity = int(capacity)
+        self.send = torch.zeros((self.capacity + 1, DIM), dtype=torch.float64, device=device)
+        self.recv = torch.zeros((self.world, self.capacity + 1, DIM), dtype=torch.float64, device=device)
+        self.rows = self.send[1:]                                  # (capacity, 14): the compacted valid states
+        self.count = self.send.view(torch.int64)[0, :1]            # uint64 count in the first 8 bytes of row 0
+
+    def launch(self):
+        dist.all_gather_into_tensor(self.recv.view(self.world * (self.capacity + 1), DIM), self.send, group=self.group)
+
+    def counts(self):
+        """per-rank counts of valid states (host synchronisation)"""
+        return [int(v) for v in self.recv.view(torch.int64)[:, 0, 0].cpu().tolist()]
+
+    def unpack(self):
+        """(states (sum(counts),14) in rank order = global sample order for contiguous shards, counts)"""
+        counts = self.counts()
+        if max(counts, default=0) > self.capacity:
+            raise OverflowError("a rank holds %d valid states, the gather blocks hold %d: repeat with a larger capacity"
+                                % (max(counts), self.capacity))
+        parts = [self.recv[r, 1: 1 + counts[r]] for r in range(self.world)]
+        return torch.cat(parts, dim=0), counts
+
+
 def gather_valid(q_valid, count, group=None):
-    """All-gather the first `count` rows of every rank's `q_valid` (padded (cap,14) tensor).
-
-    Returns (states, counts): states is (sum(counts), 14) in rank order — i.e. global sample order
-    for contiguous shards — and counts the per-rank row counts (python ints).  Works on CUDA
-    tensors over RCCL and on CPU tensors over gloo (used by the CPU tests).
-    Two collectives: counts (8 B per rank), then rows padded to the largest count.
-    """
-    world = dist.get_world_size(group)
-    cnt = count.reshape(1).to(torch.int64)
-    counts = torch.empty(world, dtype=torch.int64, device=cnt.device)
-    dist.all_gather_into_tensor(counts, cnt, group=group)
-    counts_host = [int(v) for v in counts.cpu().tolist()]
-    m = max(counts_host) if counts_host else 0
-    if m == 0:
-        return q_valid.new_empty((0, q_valid.shape[1])), counts_host
-    if q_valid.shape[0] < m:
-        raise ValueError("q_valid has %d rows, another rank holds %d" % (q_valid.shape[0], m))
-    send = q_valid[:m].contiguous()
-    recv = torch.empty((world, m, q_valid.shape[1]), dtype=q_valid.dtype, device=q_valid.device)
-    dist.all_gather_into_tensor(recv.view(world * m, q_valid.shape[1]), send, group=group)
-    parts = [recv[r, : counts_host[r]] for r in range(world)]
-    return torch.cat(parts, dim=0), counts_host
+    """Convenience form: all-gather the first `count` rows of every rank's `q_valid` ((cap,14), cap >= count; every
+    rank must pass the same cap).  One collective; the host synchronises once, at the end, to cut the padding.
+    Returns (states, counts)."""
+    vg = ValidGather(q_valid.shape[0], q_valid.device, group)
+    vg.rows.copy_(q_valid)
+    vg.count.copy_(count.reshape(1).to(torch.int64))
+    vg.launch()
+    return vg.unpack()
 
 
-def sample_project_sharded(constraint, seed, total, group=None, want_iters=False):
+def sample_project_sharded(constraint, seed, total, group=None, want_iters=False, capacity_fraction=0.5):
     """Global batch of `total` sampleUniform projections across the ranks of `group`.
 
-    Each rank projects its contiguous shard on its own GPU, compacts its valid states and joins the
-    all-gather.  Returns (all_valid_states, counts, local) where local = (q, ok, iters) of this rank.
-    """
+    Each rank projects its contiguous shard on its own GPU, compacts its valid states into the gather block and joins
+    the all-gather.  Returns (all_valid_states, counts, local) where local = (q, ok, iters) of this rank."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(total, rank, world)
+    biggest = -(-int(total) // world)  # every rank allocates the same block
     q, ok, it, _ = constraint.sample_project_batch(seed, lo, hi - lo, want_iters=want_iters)
-    q_valid, cnt = constraint.compact_valid(q, ok)
-    states, counts = gather_valid(q_valid, cnt, group)
+    vg = ValidGather(max(1, int(biggest * capacity_fraction)), q.device, group)
+    constraint.compact_valid(q, ok, out=vg.rows, cnt=vg.count)
+    vg.launch()
+    try:
+        states, counts = vg.unpack()
+    except OverflowError:  # an unusually valid shard: full-capacity blocks cannot overflow
+        vg = ValidGather(biggest, q.device, group)
+        constraint.compact_valid(q, ok, out=vg.rows, cnt=vg.count)
+        vg.launch()
+        states, counts = vg.unpack()
     return states, counts, (q, ok, it)

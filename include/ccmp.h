@@ -185,6 +185,10 @@ int ccmp_enforce_bounds_batch(ccmp_ctx *ctx, double *q, size_t B, void *hip_stre
  * uint64 */
 int ccmp_compact_valid(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t B, double *q_valid,
                        uint64_t *count_dev, void *hip_stream);
+/* the same into a buffer of `capacity` rows (fixed-size send buffers of the all-gather): valid rows past the capacity
+ * are dropped, *count_dev still reports how many there were — a count above the capacity tells the consumer */
+int ccmp_compact_valid_capped(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t B, double *q_valid,
+                              size_t capacity, uint64_t *count_dev, void *hip_stream);
 
 /* ---- host-pointer conveniences (H2D, kernel, D2H; synchronous) ---------------------------------- */
 int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, double *q_out, uint8_t *ok,

@@ -41,3 +41,41 @@ def test_bench_line_contract():
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1
     assert cb["parity_gpu_vs_det_oracle"]["bit_identical"] is True
     assert j["value"] > 1e6  # the north star's floor, even at this small batch
+
+
+def _run_bench(*argv, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT, env=e)
+
+
+def test_bench_starts_its_own_ranks(ccmp_built):
+    """`python bench.py --gpus N` as a bare command starts N ranks (fresh child processes, rendezvous on 127.0.0.1) and
+    relays rank 0's line; here the ranks only meet on the CPU (--launch-check): no GPU in this container."""
+    out = _run_bench("--gpus", "3", "--launch-check")
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert j == {"launch_check": True, "n_gpus": 3, "rank_sum": 3.0, "self_launched": True}
+    # a launcher that already set WORLD_SIZE must agree with --gpus: no silent single-rank line
+    out = _run_bench("--gpus", "8", "--launch-check", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+    out = _run_bench("--gpus", "1", "--launch-check")
+    assert out.returncode == 0 and json.loads(out.stdout.splitlines()[-1])["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_from_the_bare_command():
+    """the N > 1 step for real — projection, capped compaction into the gather block, one all-gather per step — as two
+    self-launched ranks sharing this box's one GPU over gloo (RCCL refuses two ranks on one device)"""
+    out = _run_bench("--gpus", "2", "--backend", "gloo", "--force-device", "0", "--steps", "1", "--warmup", "1", "--batch", "32768")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 65536 and j["rccl_ranks"] == 0  # gloo rehearsal, not RCCL
+    g = j["stats"]["gather"]
+    assert g["overflow"] is False and 0.15 * 65536 < g["valid_states_all_ranks"] < 0.3 * 65536
+    assert g["capacity_rows_per_rank"] == 16384 and j["value"] > 1e6

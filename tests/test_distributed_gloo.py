@@ -25,20 +25,35 @@ def _worker(rank, world, port, total, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from closed_chain_motion_planner_amd.distributed import gather_valid, shard_range
+    from closed_chain_motion_planner_amd.distributed import ValidGather, gather_valid, shard_range
 
     lo, hi = shard_range(total, rank, world)
+    cap = -(-total // world)  # every rank brings a block of the same capacity: the biggest shard
     # synthetic "projected" shard: row i carries its global index; every third sample is valid
     rows = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1).repeat(1, 14)
     ok = (torch.arange(lo, hi) % 3 == 0)
     valid = rows[ok]
-    padded = torch.zeros((hi - lo, 14), dtype=torch.float64)
+    padded = torch.zeros((cap, 14), dtype=torch.float64)
     padded[: valid.shape[0]] = valid
     states, counts = gather_valid(padded, torch.tensor(valid.shape[0]))
     # an empty rank must work too
     states0, counts0 = gather_valid(torch.zeros((4, 14), dtype=torch.float64), torch.tensor(0 if rank else 2))
+    # the steady-state form: preallocated blocks, one collective, count in row 0, nothing read on the host until
+    # unpack; a count above the capacity is reported by unpack instead of returning a cut list
+    vg = ValidGather(2, "cpu")
+    vg.rows.copy_(torch.full((2, 14), float(rank)))
+    vg.count.fill_(2 if rank == 0 else 1)
+    vg.launch()
+    st2, c2 = vg.unpack()
+    vg.count.fill_(5 if rank == 1 else 1)
+    vg.launch()
+    try:
+        vg.unpack()
+        overflow = False
+    except OverflowError:
+        overflow = True
     if rank == 0:
-        q.put((states.numpy(), counts, states0.shape[0], counts0))
+        q.put((states.numpy(), counts, states0.shape[0], counts0, st2[:, 0].tolist(), c2, overflow))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,7 +66,7 @@ def test_gather_valid_world2(total):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    states, counts, n0, counts0 = q.get(timeout=120)
+    states, counts, n0, counts0, st2, c2, overflow = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -59,6 +74,7 @@ def test_gather_valid_world2(total):
     assert states.shape == (len(exp), 14) and np.array_equal(states[:, 0], exp)  # global sample order
     assert sum(counts) == len(exp)
     assert n0 == 2 and counts0 == [2, 0]
+    assert st2 == [0.0, 0.0, 1.0] and c2 == [2, 1] and overflow is True
 
 
 def test_shard_range_partitions_exactly():
