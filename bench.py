@@ -450,11 +450,13 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         return float(np.median(ts[4:]) * 1e6)
 
     def geodesic(n_edges=16384):
-        # growTree-shaped edges (src/planner/stefanBiPRM.cpp:307-351): from a valid projected state towards another
+        # growTree-shaped edges (src/planner/stefanBiPRM.cpp:307-351: a milestone towards a near neighbour): from a valid
+        # projected state to a projected sampleUniformNear state within 0.6 rad per joint (about 1.3 rad apart, ~5 states
+        # per edge like the reference's recorded roadmap edges)
         c.setJacobianMode(CCMP_JAC_FD)
-        q, ok, _, _ = c.sample_project_batch(0x6E0, 0, 12 * n_edges, want_iters=False)
-        good = q[ok == 1]
-        frm, to = good[:n_edges].contiguous(), good[n_edges: 2 * n_edges].contiguous()
+        q, ok, _, _ = c.sample_project_batch(0x6E0, 0, 8 * n_edges, want_iters=False)
+        frm = q[ok == 1][:n_edges].contiguous()
+        to, _, _, _ = c.sample_near_project_batch(0x6E1, 0, frm, 0.6, n_edges, want_iters=False)
         sec = timed(lambda: c.discrete_geodesic_batch(frm, to, 64), 3)
         st, n, gok, its = c.discrete_geodesic_batch(frm, to, 64)
         res = {"edges_per_s": n_edges / sec, "ms": sec * 1e3, "edges": n_edges, "mean_states_per_edge": float(n.to(torch.float64).mean().item()),
