@@ -318,7 +318,7 @@ int ccmp_ctx_num_cus(const ccmp_ctx *ctx) { return ctx ? ctx->num_cus : 0; }
   hipStream_t st = (hipStream_t)hip_stream; \
   ccmp_consts K;                                               \
   ccmp_host::make_consts(*p, K);                               \
-  if (!ctx->stock_kernels) K.stock = 0
+  if (!ctx->stock_kernels) K.stock = K.twin_arms = 0
 
 int ccmp_function_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, double *f, size_t B, void *hip_stream)
 {

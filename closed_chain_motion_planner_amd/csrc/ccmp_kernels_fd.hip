@@ -49,6 +49,9 @@ constexpr int kRec = 165;             // 164 used; odd stride keeps the 10 group
 #ifndef CCMP_FD_WAVES_PER_SIMD
 #define CCMP_FD_WAVES_PER_SIMD 3
 #endif
+#ifndef CCMP_FD_ROWS
+#define CCMP_FD_ROWS 1 // STOCK instantiation: the chains at x by matrix rows, three lanes per arm (0 = every lane runs both chains whole)
+#endif
 
 // One arm's chain at x (sines/cosines from LDS), joint indices at compile time (the STOCK instantiation skips the
 // products with the stock Panda's exact zeros, ccmp_kin.h).  With STORE the writer lane keeps the frame in front of
@@ -95,6 +98,75 @@ __device__ __forceinline__ void chain_at_x(const ccmp_consts &K, double *rec, bo
     }
   }
   tool_pose_t<STOCK>(K, ARM, R, o, &T[0], &T[9]);
+}
+
+// ---- the chains at x, one matrix ROW per lane (STOCK instantiation: twin arms, diag(+-1) base frames) ---------------
+// Row r of (R * Rj) needs row r of R only, and o[r] += R[r,:] * offset likewise: lane `row` of an arm's three lanes
+// carries one row of the running frame (3 + 1 doubles) and does a third of every product — per element the same
+// operations on the same operands as mul33 / mulvec_acc, hence the same bits.  Lanes 0..2 of a group run arm 0,
+// lanes 3..5 arm 1, side by side (both arms read arm 0's constants: they are bit-identical, K.twin_arms); only the
+// joint's rotation matrix (13 operations) is computed by every lane.  175 + 19 operations per lane for BOTH chains
+// and tool poses instead of 2 x (343 + 48) when every lane ran both chains whole.  The lanes of arm `store_arm` keep
+// the frame in front of every joint in LDS (R row before the joint's rotation, o including the joint's offset) for
+// that arm's Jacobian columns; with TOOL every lane also leaves its row of the arm's world tool pose in LDS.
+template <bool TOOL, int I>
+__device__ __forceinline__ void chain_rows_from(const ccmp_consts &K, double *rec, const double *sc, int row, bool store,
+                                                double &R0, double &R1, double &R2, double &o)
+{
+  if constexpr (I < 7) {
+    constexpr int NZ = kStockOff[I];
+    if (NZ & 1) o = CCMP_FMA(R0, K.offset[0][I][0], o);
+    if (NZ & 2) o = CCMP_FMA(R1, K.offset[0][I][1], o);
+    if (NZ & 4) o = CCMP_FMA(R2, K.offset[0][I][2], o);
+    if (store) {
+      rec[kPre + I * 12 + 3 * row] = R0;
+      rec[kPre + I * 12 + 3 * row + 1] = R1;
+      rec[kPre + I * 12 + 3 * row + 2] = R2;
+      rec[kPre + I * 12 + 9 + row] = o;
+    }
+    const double s = sc[2 * I], c = sc[2 * I + 1];
+    double n0, n1, n2;
+    if constexpr (kStockZ[I] != 0) { // mul_zrot, one row
+      const double t = 1.0 - c;
+      const double w = t + c;
+      const double ns = -s;
+      n0 = CCMP_FMA(R1, s, R0 * c);
+      n1 = CCMP_FMA(R1, c, R0 * ns);
+      n2 = R2 * w;
+    } else { // rot_sc + one row of mul33
+      double Rj[9];
+      rot_sc(K.axis[0][I], K.aprod[0][I], s, c, Rj);
+      n0 = dot3(R0, Rj[0], R1, Rj[3], R2, Rj[6]);
+      n1 = dot3(R0, Rj[1], R1, Rj[4], R2, Rj[7]);
+      n2 = dot3(R0, Rj[2], R1, Rj[5], R2, Rj[8]);
+    }
+    R0 = n0; R1 = n1; R2 = n2;
+    chain_rows_from<TOOL, I + 1>(K, rec, sc, row, store, R0, R1, R2, o);
+  }
+}
+template <bool TOOL>
+__device__ __forceinline__ void chain_rows(const ccmp_consts &K, double *rec, int arm, int row, bool live, int store_arm,
+                                           double d_lane, double bp_lane)
+{
+  double R0 = row == 0 ? 1.0 : 0.0, R1 = row == 1 ? 1.0 : 0.0, R2 = row == 2 ? 1.0 : 0.0, o = 0.0;
+  chain_rows_from<TOOL, 0>(K, rec, rec + kSC + 14 * arm, row, live && arm == store_arm, R0, R1, R2, o);
+  if constexpr (TOOL) { // tool_pose_t<true>, diag(+-1) base frame, one row
+    double pf = o;
+    if (kStockEe & 1) pf = CCMP_FMA(R0, K.ee[0][0], pf);
+    if (kStockEe & 2) pf = CCMP_FMA(R1, K.ee[0][1], pf);
+    if (kStockEe & 4) pf = CCMP_FMA(R2, K.ee[0][2], pf);
+    const double *Rt = K.R_tool[0];
+    const double f0 = dot3(R0, Rt[0], R1, Rt[3], R2, Rt[6]);
+    const double f1 = dot3(R0, Rt[1], R1, Rt[4], R2, Rt[7]);
+    const double f2 = dot3(R0, Rt[2], R1, Rt[5], R2, Rt[8]);
+    if (live) {
+      double *T = rec + kEE + 12 * arm;
+      T[3 * row] = d_lane * f0;
+      T[3 * row + 1] = d_lane * f1;
+      T[3 * row + 2] = d_lane * f2;
+      T[9 + row] = CCMP_FMA(d_lane, pf, bp_lane);
+    }
+  }
 }
 
 // OMPL's default Constraint::jacobian, evaluation part, for the 7 columns of one arm: each lane evaluates
@@ -204,6 +276,16 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
   const bool writer = live && r == 0;
   const bool plus = r < 3;                    // y1 side of the stencil; r>=3 is the y2 side
   const int nstep = (plus ? r : r - 3) + 1;   // how many h-steps this lane's point is away
+  // chains at x by rows (STOCK): lane r of a group carries row r % 3 of arm r / 3; its entry of the arm's diag(+-1)
+  // base rotation and of the base translation are the only lane-dependent constants
+  const int arm_l = plus ? 0 : 1, row_l = plus ? r : r - 3;
+  double d_lane = 0.0, bp_lane = 0.0;
+  if constexpr (STOCK) {
+    d_lane = arm_l ? (row_l == 0 ? K.base_R[1][0] : (row_l == 1 ? K.base_R[1][4] : K.base_R[1][8]))
+                   : (row_l == 0 ? K.base_R[0][0] : (row_l == 1 ? K.base_R[0][4] : K.base_R[0][8]));
+    bp_lane = arm_l ? (row_l == 0 ? K.base_p[1][0] : (row_l == 1 ? K.base_p[1][1] : K.base_p[1][2]))
+                    : (row_l == 0 ? K.base_p[0][0] : (row_l == 1 ? K.base_p[0][1] : K.base_p[0][2]));
+  }
 
   unsigned long long idx = 0;
   int iter = 0, updates = 0;
@@ -290,15 +372,23 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     double f0, f1;
     {
       double T0[12], T1[12], f[2];
-      chain_at_x<1, false, STOCK>(K, rec, writer, T1);
-      if (writer) {
+      if constexpr (STOCK && CCMP_FD_ROWS) {
+        // both chains and both tool poses, one matrix row per lane; arm 0's prefix frames stay in LDS for its columns
+        chain_rows<true>(K, rec, arm_l, row_l, live, 0, d_lane, bp_lane);
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 12; k++) rec[kEE + 12 + k] = T1[k];
-      }
-      chain_at_x<0, true, STOCK>(K, rec, writer, T0); // arm 0's prefix frames stay in LDS for its columns
-      if (writer) {
+        for (int k = 0; k < 12; k++) { T0[k] = rec[kEE + k]; T1[k] = rec[kEE + 12 + k]; }
+      } else {
+        chain_at_x<1, false, STOCK>(K, rec, writer, T1);
+        if (writer) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) rec[kEE + k] = T0[k];
+          for (int k = 0; k < 12; k++) rec[kEE + 12 + k] = T1[k];
+        }
+        chain_at_x<0, true, STOCK>(K, rec, writer, T0); // arm 0's prefix frames stay in LDS for its columns
+        if (writer) {
+#pragma unroll
+          for (int k = 0; k < 12; k++) rec[kEE + k] = T0[k];
+        }
       }
       chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
       f0 = f[0]; f1 = f[1];
@@ -356,7 +446,9 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     __syncthreads();
     stencil_combine<0>(rec, r, live);
     __syncthreads();
-    {
+    if constexpr (STOCK && CCMP_FD_ROWS) {
+      chain_rows<false>(K, rec, arm_l, row_l, live, 1, d_lane, bp_lane); // re-run by rows: arm 1's lanes stage ITS prefix frames
+    } else {
       double T1[12];
       chain_at_x<1, true, STOCK>(K, rec, writer, T1); // re-run arm 1's chain to stage ITS prefix frames
     }
@@ -570,10 +662,10 @@ hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const doubl
   hipLaunchKernelGGL((project_fd_kernel<MODE, STOCK>), dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
                      (unsigned long long)B, queue, seed, first, pool, queue + 1, dump_threshold, order)
   if (mode == 0) {
-    if (K->stock) CCMP_LAUNCH_GROUP(0, true);
+    if (K->stock && K->twin_arms) CCMP_LAUNCH_GROUP(0, true);
     else CCMP_LAUNCH_GROUP(0, false);
   } else {
-    if (K->stock) CCMP_LAUNCH_GROUP(1, true);
+    if (K->stock && K->twin_arms) CCMP_LAUNCH_GROUP(1, true);
     else CCMP_LAUNCH_GROUP(1, false);
   }
 #undef CCMP_LAUNCH_GROUP

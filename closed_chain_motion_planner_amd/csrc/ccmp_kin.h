@@ -40,7 +40,8 @@ struct ccmp_consts {
   int32_t max_iter;
   int32_t base_diag; /* bit a: base_R[a] is exactly diag(+-1, +-1, +-1) (every shipped t_wb, grasping_point.cpp:11-20) */
   int32_t stock;     /* both arms carry the stock Panda structure (see kStockZ below): launchers pick the STOCK kernels */
-  int32_t pad;
+  int32_t twin_arms; /* stock, both arms have bit-identical chain constants (axis, offset, ee, R_tool) and both t_wb are
+                        diag(+-1): the throughput kernel's STOCK instantiation reads arm 0's constants for either arm */
 };
 
 namespace ccmp {

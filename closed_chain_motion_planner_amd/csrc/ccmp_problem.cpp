@@ -131,6 +131,10 @@ void make_consts_impl(const ccmp_problem &P, ccmp_consts &K)
     if (diag) K.base_diag |= 1 << a;
   }
   K.stock = is_stock_structure(P) ? 1 : 0;
+  K.twin_arms = (K.stock && K.base_diag == 3 && memcmp(P.axis[0], P.axis[1], sizeof P.axis[0]) == 0 &&
+                 memcmp(P.offset[0], P.offset[1], sizeof P.offset[0]) == 0 && memcmp(P.ee[0], P.ee[1], sizeof P.ee[0]) == 0 &&
+                 memcmp(P.R_tool[0], P.R_tool[1], sizeof P.R_tool[0]) == 0)
+                    ? 1 : 0;
   for (int k = 0; k < 3; k++) K.init_p[k] = P.init_p[k];
   ccmp::quat_of(P.init_R, K.init_q);
   for (int i = 0; i < 7; i++) {
