@@ -49,6 +49,9 @@ constexpr int kRec = 165;             // 164 used; odd stride keeps the 10 group
 #ifndef CCMP_FD_WAVES_PER_SIMD
 #define CCMP_FD_WAVES_PER_SIMD 3
 #endif
+#ifndef CCMP_FD_STOCK_COLUMNS
+#define CCMP_FD_STOCK_COLUMNS 1 // STOCK instantiation: Jacobian columns skip the products with the stock Panda's exact zeros
+#endif
 #ifndef CCMP_FD_ROWS
 #define CCMP_FD_ROWS 1 // STOCK instantiation: the chains at x by matrix rows, three lanes per arm (0 = every lane runs both chains whole)
 #endif
@@ -169,6 +172,31 @@ __device__ __forceinline__ void chain_rows(const ccmp_consts &K, double *rec, in
   }
 }
 
+// ---- suffix steps of the stock Panda (STOCK instantiation) -----------------------------------------------------------
+// The joints alternate: 0, 2, 4 rotate about exactly (0, 0, 1); 1, 3, 5 and 6 about a general axis; most offset
+// components are exactly zero (ccmp_kin.h: kStockZ, kStockOff).  With run-time (wave-uniform) joint indices the steps
+// come in three shapes, each skipping only products with components that are exact zeros for EVERY joint it serves
+// (a product with an exact zero that is not skipped adds an exact zero: same bits either way):
+//   z step       joints 2, 4     o += R[:,0] off.x + R[:,2] off.z  (joint 2: off.x == 0),  R = R * Rz(q)
+//   general step joints 1, 3, 5  o += R[:,0] off.x                 (joints 1, 5: off.x == 0), R = R * Rot(axis, q)
+//   last step    joint 6         o += R[:,0] off.x,                                           R = R * Rot(axis, q)
+__device__ __forceinline__ void stock_z_step(const ccmp_consts &K, int i, double s, double c, const double *R, double *Rn, double *o)
+{
+  const double ox = K.offset[0][i][0], oz = K.offset[0][i][2];
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = CCMP_FMA(R[3 * r + 2], oz, CCMP_FMA(R[3 * r], ox, o[r]));
+  mul_zrot(R, s, c, Rn);
+}
+__device__ __forceinline__ void stock_g_step(const ccmp_consts &K, int i, double s, double c, const double *R, double *Rn, double *o)
+{
+  const double ox = K.offset[0][i][0];
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = CCMP_FMA(R[3 * r], ox, o[r]);
+  double Rj[9];
+  rot_sc(K.axis[0][i], K.aprod[0][i], s, c, Rj);
+  mul33(R, Rj, Rn);
+}
+
 // OMPL's default Constraint::jacobian, evaluation part, for the 7 columns of one arm: each lane evaluates
 // its stencil point of column j from the cached prefix frame and parks the residual pair in LDS.
 template <int ARM, bool STOCK>
@@ -191,29 +219,71 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
 #pragma unroll
     for (int k = 0; k < 3; k++) o[k] = rec[kPre + j * 12 + 9 + k];
     ccmp_sincos(y, &s, &c);
-    {
-      double Rj[9], Rn[9];
-      rot_sc(K.axis[ARM][j], K.aprod[ARM][j], s, c, Rj);
-      mul33(R, Rj, Rn);
-#pragma unroll
-      for (int k = 0; k < 9; k++) R[k] = Rn[k];
-    }
-    {
-      // suffix joints two at a time, R -> Rn -> R: no register copies of the frame between steps (61 instead of
-      // 76 instructions per joint; -0.6 % run time, A/B)
+    const double *sc = rec + kSC + 2 * ARM * 7;
+    if constexpr (STOCK && CCMP_FD_STOCK_COLUMNS) {
+      // twin arms: arm 0's constants serve both.  Joint indices are wave-uniform scalars; the branches are scalar.
+      // The frame ends every step in R (R -> Rn -> R, or in place): no register copies between steps.
+      double Rn[9];
       int i = j + 1;
-      if ((7 - i) & 1) {
-        joint_step(K, ARM, i, rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], R, o);
-        i++;
-      }
-      for (; i < 7; i += 2) {
-        double Rj[9], Rn[9];
-        mulvec_acc(R, K.offset[ARM][i], o);
-        rot_sc(K.axis[ARM][i], K.aprod[ARM][i], rec[kSC + 2 * (ARM * 7 + i)], rec[kSC + 2 * (ARM * 7 + i) + 1], Rj);
+      if ((j & 1) == 0 && j < 6) { // joints 0, 2, 4: R = R * Rz(y), row by row in place (mul_zrot's operations)
+        const double t = 1.0 - c;
+        const double w = t + c;
+        const double ns = -s;
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+          const double a = R[3 * rr], b = R[3 * rr + 1];
+          R[3 * rr] = CCMP_FMA(b, s, a * c);
+          R[3 * rr + 1] = CCMP_FMA(b, c, a * ns);
+          R[3 * rr + 2] = R[3 * rr + 2] * w;
+        }
+      } else {
+        double Rj[9];
+        rot_sc(K.axis[0][j], K.aprod[0][j], s, c, Rj);
         mul33(R, Rj, Rn);
-        mulvec_acc(Rn, K.offset[ARM][i + 1], o);
-        rot_sc(K.axis[ARM][i + 1], K.aprod[ARM][i + 1], rec[kSC + 2 * (ARM * 7 + i + 1)], rec[kSC + 2 * (ARM * 7 + i + 1) + 1], Rj);
-        mul33(Rn, Rj, R);
+        if (j < 6) { // j = 1, 3, 5: the next joint (2, 4 or 6) takes the frame back to R
+          if (i < 6) stock_z_step(K, i, sc[2 * i], sc[2 * i + 1], Rn, R, o);
+          else stock_g_step(K, 6, sc[12], sc[13], Rn, R, o);
+          i++;
+        } else { // j = 6: no suffix
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = Rn[k];
+        }
+      }
+      for (; i < 5; i += 2) { // (1, 2), (3, 4): general step then z step, R -> Rn -> R
+        stock_g_step(K, i, sc[2 * i], sc[2 * i + 1], R, Rn, o);
+        stock_z_step(K, i + 1, sc[2 * i + 2], sc[2 * i + 3], Rn, R, o);
+      }
+      if (i == 5) { // (5, 6): joint 5 has no offset at all
+        double Rj[9];
+        rot_sc(K.axis[0][5], K.aprod[0][5], sc[10], sc[11], Rj);
+        mul33(R, Rj, Rn);
+        stock_g_step(K, 6, sc[12], sc[13], Rn, R, o);
+      }
+    } else {
+      {
+        double Rj[9], Rn[9];
+        rot_sc(K.axis[ARM][j], K.aprod[ARM][j], s, c, Rj);
+        mul33(R, Rj, Rn);
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = Rn[k];
+      }
+      {
+        // suffix joints two at a time, R -> Rn -> R: no register copies of the frame between steps (61 instead of
+        // 76 instructions per joint; -0.6 % run time, A/B)
+        int i = j + 1;
+        if ((7 - i) & 1) {
+          joint_step(K, ARM, i, sc[2 * i], sc[2 * i + 1], R, o);
+          i++;
+        }
+        for (; i < 7; i += 2) {
+          double Rj[9], Rn[9];
+          mulvec_acc(R, K.offset[ARM][i], o);
+          rot_sc(K.axis[ARM][i], K.aprod[ARM][i], sc[2 * i], sc[2 * i + 1], Rj);
+          mul33(R, Rj, Rn);
+          mulvec_acc(Rn, K.offset[ARM][i + 1], o);
+          rot_sc(K.axis[ARM][i + 1], K.aprod[ARM][i + 1], sc[2 * i + 2], sc[2 * i + 3], Rj);
+          mul33(Rn, Rj, R);
+        }
       }
     }
     double Tw[12], t[2];
