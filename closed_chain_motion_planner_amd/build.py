@@ -1,7 +1,8 @@
 """Builds libccmp.so (HIP kernels for gfx950 + the C-ABI host code) in-tree with hipcc.
 
 Translation units with deliberately different flags:
-  ccmp_kernels_fd.hip    -ffp-contract=off -DCCMP_USE_FMA   canonical, bit-reproducible arithmetic (throughput kernel)
+  ccmp_kernels_fd.hip    -ffp-contract=off -DCCMP_USE_FMA   canonical, bit-reproducible arithmetic (throughput kernel);
+                         -DCCMP_LEAN_SQRT: ccmp_detmath.h's wave-uniform fast path of the IEEE square root (same bits, -1.9 %)
   ccmp_kernels_wave.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one-wave-per-sample kernels
   ccmp_kernels_flat.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one 128-thread block per sample (latency kernel)
   ccmp_problem.cpp       -ffp-contract=off -DCCMP_USE_FMA   host set-up (problem, constants) in the same rounding model
@@ -24,7 +25,7 @@ _UNITS = [
     # loop into VGPR pairs and then spills them to scratch (168 VGPRs + 30 spilled dwords); without it the
     # throughput kernel needs 133 VGPRs and no scratch (measured +3.3 %, in-process A/B).  The wave kernels are
     # 2.7 % slower with the option, hence their own unit.
-    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+    ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
      + os.environ.get("CCMP_FD_EXTRA_FLAGS", "").split()),
     ("ccmp_kernels_wave.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
     # max-ilp scheduling: -0.6 % (throughput kernel) ... -1.5 % (latency kernel, single state), in-process A/B

@@ -45,7 +45,35 @@
  * a Newton iterate that large is a diverged sample, never a valid projection. */
 #define CCMP_SINCOS_MAX 1647099.0
 
-CCMP_HD double ccmp_sqrt(double x) { return __builtin_sqrt(x); } /* IEEE correctly rounded on both sides */
+/* IEEE correctly rounded square root on both sides.  On gfx950 the compiler expands __builtin_sqrt into v_rsq_f64, nine
+ * fused steps and — for arguments below 2^-767, whose intermediates would go subnormal — a scaling by 2^256 / 2^-128
+ * around them, plus a pass-through for zero and infinity: 20 instructions, 8 of them spent on cases the kernels meet
+ * only at an exact zero.  CCMP_LEAN_SQRT runs the same nine steps directly when NO lane of the wavefront holds such an
+ * argument (wave-uniform test on the exponent field: 2 instructions) — without the scaling the steps are the very same
+ * operations on the very same values, hence the same bits — and the compiler's full expansion otherwise. */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CCMP_LEAN_SQRT)
+static __device__ __forceinline__ double ccmp_sqrt(double x)
+{
+  const unsigned hi = (unsigned)__double2hiint(x);
+  /* 2^-767 <= x < inf  <=>  0x10000000 <= high dword < 0x7ff00000 (sign bit clear) */
+  const bool plain = (hi - 0x10000000u) < (0x7ff00000u - 0x10000000u);
+  if (__builtin_amdgcn_ballot_w64(!plain) == 0ull) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = CCMP_FMA(-h, g, 0.5);
+    g = CCMP_FMA(g, r, g);
+    h = CCMP_FMA(h, r, h);
+    double d = CCMP_FMA(-g, g, x);
+    g = CCMP_FMA(d, h, g);
+    d = CCMP_FMA(-g, g, x);
+    return CCMP_FMA(d, h, g);
+  }
+  return __builtin_sqrt(x);
+}
+#else
+CCMP_HD double ccmp_sqrt(double x) { return __builtin_sqrt(x); }
+#endif
 CCMP_HD double ccmp_abs(double x) { return __builtin_fabs(x); }
 
 /* sin(x+y) and cos(x+y), |x| <= pi/4 (+ a hair), y the tail of the reduced argument. */

@@ -41,6 +41,13 @@ def test_device_arithmetic_is_bitwise_host(gpu_ctx, oracle_det):
     y = np.concatenate([rng.uniform(-8, 8, n // 2), rng.standard_normal(n // 4), rng.uniform(-1e3, 1e3, n // 4)])
     x[:6] = [0.0, -0.0, np.pi / 2, 1e6, 2e6, np.inf]
     y[:6] = [0.0, 1.0, 0.0, 3.0, 1.0, 1.0]
+    # square roots over the whole exponent range: 2^-766 .. 2^1023 goes through the wave-uniform fast path of
+    # ccmp_sqrt (no argument of the wavefront below 2^-767), the block after it — down to subnormals — through the
+    # compiler's scaled expansion; both must be the correctly rounded root
+    k = 4096
+    x[1024:1024 + k] = np.ldexp(rng.uniform(1, 2, k), rng.integers(-766, 1023, k))
+    x[1024 + k:1024 + 2 * k] = np.ldexp(rng.uniform(1, 2, k), rng.integers(-1074, -766, k))
+    x[1024 + 2 * k:1024 + 2 * k + 3] = [2.0 ** -767, np.nextafter(2.0 ** -767, 0), 5e-324]
     xd, yd = torch.as_tensor(x).cuda(), torch.as_tensor(y).cuda()
     out = torch.empty((n, 5), dtype=torch.float64, device="cuda")
     _lib.check(_lib.lib().ccmp_detmath_probe(gpu_ctx.handle, xd.data_ptr(), yd.data_ptr(), out.data_ptr(), n, None),
@@ -55,7 +62,8 @@ def test_device_arithmetic_is_bitwise_host(gpu_ctx, oracle_det):
     for i in range(n):
         L.orc_sincos(x[i], C.byref(s), C.byref(c))
         exp[i, 0], exp[i, 1] = s.value, c.value
-        exp[i, 2] = L.orc_atan2_nn(abs(x[i]), abs(y[i]))
+        with np.errstate(all="ignore"):
+            exp[i, 2] = L.orc_atan2_nn(abs(x[i]), abs(y[i]))
     exp[:, 3] = np.sqrt(np.abs(x))
     with np.errstate(all="ignore"):
         exp[:, 4] = x / y
