@@ -26,16 +26,20 @@ hipError_t ccmp_launch_project_wave(const ccmp_consts *K, int src, const double 
 hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
-                                    const unsigned long long *pool_count, int wrap_output, int nblocks, hipStream_t st);
+                                    const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
+                                    unsigned int done_seq, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                     unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
 hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                    unsigned int *hist, unsigned int *order, unsigned long long *queue,
                                    unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
-hipError_t ccmp_launch_function(const ccmp_consts *K, const double *q, double *f, size_t B, hipStream_t st);
-hipError_t ccmp_launch_is_satisfied(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, hipStream_t st);
-hipError_t ccmp_launch_joint_valid(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, hipStream_t st);
+hipError_t ccmp_launch_function(const ccmp_consts *K, const double *q, double *f, size_t B, unsigned int *done_flag,
+                                unsigned int done_seq, hipStream_t st);
+hipError_t ccmp_launch_is_satisfied(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, unsigned int *done_flag,
+                                    unsigned int done_seq, hipStream_t st);
+hipError_t ccmp_launch_joint_valid(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, unsigned int *done_flag,
+                                   unsigned int done_seq, hipStream_t st);
 hipError_t ccmp_launch_ambient_uniform(const ccmp_consts *K, unsigned long long seed, unsigned long long first,
                                        double *q, size_t B, hipStream_t st);
 hipError_t ccmp_launch_enforce_bounds(double *q, size_t B, hipStream_t st);
@@ -96,6 +100,11 @@ struct ccmp_ctx {
   size_t stage_cap = 0;
   void *pin = nullptr;     // pinned, device-mapped host block for small *_host calls (single states of the reference signature)
   void *pin_dev = nullptr; // the same block as the kernels see it
+  // completion word of single-state calls (last 64 bytes of the pinned block): the latency kernel publishes done_seq
+  // behind its results and the host polls it instead of waiting for the stream's completion signal
+  unsigned int done_seq = 0;
+  bool done_armed = false; // set by project_common when the launch it made will publish done_seq
+  bool want_done = false;  // set by the host entry point that is going to poll
 };
 
 namespace {
@@ -129,6 +138,7 @@ int ensure_stage(ccmp_ctx *ctx, size_t bytes)
 // block (a single project(x) is then memcpy + launch + synchronize + memcpy: no staged pageable copies, ~3 driver
 // calls fewer); larger batches go through device staging with asynchronous copies.
 constexpr size_t kPinBytes = 64 * 1024;
+constexpr size_t kPinData = kPinBytes - 64; // the last 64 bytes hold the completion word
 struct HostIO {
   ccmp_ctx *ctx;
   char *dev = nullptr;  // what the kernels get
@@ -138,9 +148,10 @@ struct HostIO {
   explicit HostIO(ccmp_ctx *c) : ctx(c) {}
   int begin(size_t bytes)
   {
-    if (bytes <= kPinBytes) {
+    if (bytes <= kPinData) {
       if (!ctx->pin) {
-        HIP_TRY(hipHostMalloc(&ctx->pin, kPinBytes, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc(&ctx->pin, kPinBytes, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ctx->pin, 0, kPinBytes);
         hipError_t e = hipHostGetDevicePointer(&ctx->pin_dev, ctx->pin, 0);
         if (e != hipSuccess) { (void)hipHostFree(ctx->pin); ctx->pin = nullptr; return hip_fail(e, "hipHostGetDevicePointer"); }
       }
@@ -166,11 +177,36 @@ struct HostIO {
   }
   int finish()
   {
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    bool done = false;
+    if (host && ctx->done_armed) {
+      // the one-block latency kernel wrote its results into this pinned block and then published done_seq: poll the
+      // word (a store from the GPU is visible here ~1 us after it retires) instead of waiting for the completion
+      // signal of the stream; bounded — a kernel that never publishes is caught by the synchronise below
+      const volatile unsigned int *flag = (const volatile unsigned int *)(host + kPinData);
+      for (long spin = 0; spin < 4000000; spin++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->done_seq) { done = true; break; }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+    }
+    ctx->done_armed = false;
+    ctx->want_done = false;
+    if (!done) HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n_outs; i++) memcpy(outs[i].dst, host + outs[i].off, outs[i].n);
     return CCMP_OK;
   }
 };
+
+// single-state calls from the host entry points: the kernel publishes ctx->done_seq in the pinned block behind its
+// result and HostIO::finish polls that word (NULL = this launch does not publish)
+unsigned int *arm_done_word(ccmp_ctx *ctx, size_t B)
+{
+  if (!ctx->want_done || B != 1 || !ctx->pin_dev) return nullptr;
+  ctx->done_seq++;
+  ctx->done_armed = true;
+  return (unsigned int *)((char *)ctx->pin_dev + kPinData);
+}
 
 int projector_blocks(const ccmp_ctx *ctx, size_t B, int samples_per_wave, int default_wpc)
 {
@@ -325,7 +361,8 @@ int ccmp_function_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, d
   CCMP_PROLOGUE();
   if (B == 0) return CCMP_OK;
   if (!q || !f) return CCMP_EINVAL;
-  HIP_TRY(ccmp_launch_function(&K, q, f, B, st));
+  unsigned int *flag = arm_done_word(ctx, B);
+  HIP_TRY(ccmp_launch_function(&K, q, f, B, flag, ctx->done_seq, st));
   return CCMP_OK;
 }
 
@@ -414,9 +451,11 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (!pl.latency_static) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
 
   if (pl.group_blocks == 0) { // small batches and single states
-    if (ctx->flat_kernel)
+    if (ctx->flat_kernel) {
+      unsigned int *flag = arm_done_word(ctx, B);
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
-                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, st));
+                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, st));
+    }
     else
       HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count,
                                        mode, pl.latency_blocks, st));
@@ -444,7 +483,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (pl.handover) { // the pool's fill count is read on the device: the latency kernel's surplus blocks exit at once
     if (ctx->flat_kernel)
       HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
-                                       pl.latency_blocks, st));
+                                       pl.latency_blocks, nullptr, 0, st));
     else
       HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
                                        pl.latency_blocks, st));
@@ -525,7 +564,8 @@ int ccmp_is_satisfied_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *
   CCMP_PROLOGUE();
   if (B == 0) return CCMP_OK;
   if (!q || !ok) return CCMP_EINVAL;
-  HIP_TRY(ccmp_launch_is_satisfied(&K, q, ok, B, st));
+  unsigned int *flag = arm_done_word(ctx, B);
+  HIP_TRY(ccmp_launch_is_satisfied(&K, q, ok, B, flag, ctx->done_seq, st));
   return CCMP_OK;
 }
 
@@ -534,7 +574,8 @@ int ccmp_joint_valid_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
   CCMP_PROLOGUE();
   if (B == 0) return CCMP_OK;
   if (!q || !ok) return CCMP_EINVAL;
-  HIP_TRY(ccmp_launch_joint_valid(&K, q, ok, B, st));
+  unsigned int *flag = arm_done_word(ctx, B);
+  HIP_TRY(ccmp_launch_joint_valid(&K, q, ok, B, flag, ctx->done_seq, st));
   return CCMP_OK;
 }
 
@@ -618,9 +659,10 @@ int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, 
   int rc = io.begin(off_it + B * sizeof(uint16_t));
   if (rc != CCMP_OK) return rc;
   if ((rc = io.in(0, q_in, qb)) != CCMP_OK) return rc;
+  ctx->want_done = (B == 1 && io.host != nullptr); // single state: poll the kernel's completion word (HostIO::finish)
   rc = ccmp_project_batch(ctx, p, (const double *)io.dev, (double *)io.dev, (uint8_t *)(io.dev + off_ok), (uint16_t *)(io.dev + off_it), B,
                           ctx->stream);
-  if (rc != CCMP_OK) return rc;
+  if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
   if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return rc;
   if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
   if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return rc;
@@ -640,6 +682,7 @@ int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, do
   int rc = io.begin(off_f + B * 2 * sizeof(double));
   if (rc != CCMP_OK) return rc;
   if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
+  ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_function_batch(ctx, p, (const double *)io.dev, (double *)(io.dev + off_f), B, ctx->stream);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.out(f, off_f, B * 2 * sizeof(double))) != CCMP_OK) return rc;
@@ -659,6 +702,7 @@ int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
   int rc = io.begin(off_ok + B);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
+  ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_is_satisfied_batch(ctx, p, (const double *)io.dev, (uint8_t *)(io.dev + off_ok), B, ctx->stream);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
@@ -678,6 +722,7 @@ int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q,
   int rc = io.begin(off_ok + B);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
+  ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_joint_valid_batch(ctx, p, (const double *)io.dev, (uint8_t *)(io.dev + off_ok), B, ctx->stream);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;

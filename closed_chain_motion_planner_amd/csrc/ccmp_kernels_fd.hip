@@ -552,7 +552,17 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
 
 
 // ---- simple per-lane kernels (one sample per lane; all bit-identical to the oracle) -------------
-__global__ __launch_bounds__(64) void function_kernel(const ccmp_consts K, const double *__restrict__ q, double *__restrict__ f, size_t B)
+// publish the completion word of a single-state call behind its result (pinned host memory, polled by the host)
+__device__ __forceinline__ void publish_done(unsigned int *done_flag, unsigned int done_seq)
+{
+  if (done_flag != nullptr) {
+    __threadfence_system();
+    __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ __launch_bounds__(64) void function_kernel(const ccmp_consts K, const double *__restrict__ q, double *__restrict__ f, size_t B,
+                                                      unsigned int *done_flag, unsigned int done_seq)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -562,10 +572,12 @@ __global__ __launch_bounds__(64) void function_kernel(const ccmp_consts K, const
   residual(K, x, out);
   f[2 * i] = out[0];
   f[2 * i + 1] = out[1];
+  publish_done(done_flag, done_seq);
 }
 
 // KinematicChainConstraint::isSatisfied (ConstraintFunction.h:114-120)
-__global__ __launch_bounds__(64) void is_satisfied_kernel(const ccmp_consts K, const double *__restrict__ q, uint8_t *__restrict__ ok, size_t B)
+__global__ __launch_bounds__(64) void is_satisfied_kernel(const ccmp_consts K, const double *__restrict__ q, uint8_t *__restrict__ ok, size_t B,
+                                                          unsigned int *done_flag, unsigned int done_seq)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -575,10 +587,12 @@ __global__ __launch_bounds__(64) void is_satisfied_kernel(const ccmp_consts K, c
   residual(K, x, f);
   const bool finite = (f[0] - f[0] == 0.0) && (f[1] - f[1] == 0.0);
   ok[i] = (uint8_t)(finite && f[0] <= K.tol_pos && f[1] <= K.tol_rot);
+  publish_done(done_flag, done_seq);
 }
 
 // KinematicChainConstraint::jointValid (ConstraintFunction.h:43-55)
-__global__ void joint_valid_kernel(const ccmp_consts K, const double *__restrict__ q, uint8_t *__restrict__ ok, size_t B)
+__global__ void joint_valid_kernel(const ccmp_consts K, const double *__restrict__ q, uint8_t *__restrict__ ok, size_t B,
+                                   unsigned int *done_flag, unsigned int done_seq)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
@@ -590,6 +604,7 @@ __global__ void joint_valid_kernel(const ccmp_consts K, const double *__restrict
     if (v > K.ube[jj]) good = false;
   }
   ok[i] = (uint8_t)good;
+  publish_done(done_flag, done_seq);
 }
 
 __global__ void ambient_uniform_kernel(const ccmp_consts K, unsigned long long seed, unsigned long long first,
@@ -742,19 +757,26 @@ hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const doubl
   return hipGetLastError();
 }
 
-hipError_t ccmp_launch_function(const ccmp_consts *K, const double *q, double *f, size_t B, hipStream_t st)
+// done_flag (nullable) is honoured for B == 1 only: the single working thread publishes done_seq behind its result
+hipError_t ccmp_launch_function(const ccmp_consts *K, const double *q, double *f, size_t B, unsigned int *done_flag,
+                                unsigned int done_seq, hipStream_t st)
 {
-  hipLaunchKernelGGL(function_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, *K, q, f, B);
+  if (B != 1) done_flag = nullptr;
+  hipLaunchKernelGGL(function_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, *K, q, f, B, done_flag, done_seq);
   return hipGetLastError();
 }
-hipError_t ccmp_launch_is_satisfied(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, hipStream_t st)
+hipError_t ccmp_launch_is_satisfied(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, unsigned int *done_flag,
+                                    unsigned int done_seq, hipStream_t st)
 {
-  hipLaunchKernelGGL(is_satisfied_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, *K, q, ok, B);
+  if (B != 1) done_flag = nullptr;
+  hipLaunchKernelGGL(is_satisfied_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, *K, q, ok, B, done_flag, done_seq);
   return hipGetLastError();
 }
-hipError_t ccmp_launch_joint_valid(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, hipStream_t st)
+hipError_t ccmp_launch_joint_valid(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, unsigned int *done_flag,
+                                   unsigned int done_seq, hipStream_t st)
 {
-  hipLaunchKernelGGL(joint_valid_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, *K, q, ok, B);
+  if (B != 1) done_flag = nullptr;
+  hipLaunchKernelGGL(joint_valid_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, *K, q, ok, B, done_flag, done_seq);
   return hipGetLastError();
 }
 hipError_t ccmp_launch_ambient_uniform(const ccmp_consts *K, unsigned long long seed, unsigned long long first,

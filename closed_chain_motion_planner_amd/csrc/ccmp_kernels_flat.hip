@@ -231,7 +231,7 @@ __global__ __launch_bounds__(128, 2) void project_fd_flat_kernel(
     const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
-    const unsigned long long *__restrict__ pool_count, int wrap_output)
+    const unsigned long long *__restrict__ pool_count, int wrap_output, unsigned int *done_flag, unsigned int done_seq)
 {
   __shared__ __attribute__((aligned(16))) double lds[fRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -292,6 +292,12 @@ __global__ __launch_bounds__(128, 2) void project_fd_flat_kernel(
     }
     __syncthreads();
     if (!queue) t += gridDim.x;
+  }
+  // single-state calls through the host entry point (one block): the results sit in pinned host memory; publish a
+  // sequence number behind them so that the host can poll a word instead of waiting for the stream's completion signal
+  if (done_flag != nullptr && tid == 0) {
+    __threadfence_system();
+    __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -407,11 +413,13 @@ extern "C" {
 hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
-                                    const unsigned long long *pool_count, int wrap_output, int nblocks, hipStream_t st)
+                                    const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
+                                    unsigned int done_seq, hipStream_t st)
 {
+  if (nblocks != 1) done_flag = nullptr; // the completion word is written by the one block of a single-state call
 #define CCMP_LAUNCH_FLAT(SRC, STOCK)                                                                                             \
   hipLaunchKernelGGL((project_fd_flat_kernel<SRC, STOCK>), dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
-                     (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output)
+                     (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output, done_flag, done_seq)
   if (src == 0) {
     if (K->stock) CCMP_LAUNCH_FLAT(0, true);
     else CCMP_LAUNCH_FLAT(0, false);
