@@ -3,9 +3,11 @@
 // Same Newton iteration, stopping rule and quirks as KinematicChainConstraint::project
 // (include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:57-82), but the 2x14
 // Jacobian is the exact derivative of the residual instead of OMPL's 84-evaluation
-// finite-difference stencil: ~35x less arithmetic per iteration.  Built with FP contraction ON.
-// NOT bit-comparable with the reference arithmetic: the reference iteration amplifies 1e-8
-// Jacobian differences along the trajectory, so this mode lands on a different
+// finite-difference stencil: ~35x less arithmetic per iteration.  Built in the canonical rounding model
+// (-ffp-contract=off -DCCMP_USE_FMA, like the reference-arithmetic units): bit-identical to the CPU oracle run with
+// ORC_JAC_ANALYTIC (oracle/ccmp_oracle.c: orc_jacobian_analytic restates this file's operation order), which is
+// how the mode is verified.  NOT bit-comparable with the REFERENCE arithmetic: the reference iteration amplifies
+// 1e-8 Jacobian differences along the trajectory, so this mode lands on a different
 // point of the same manifold for ~20 % of uniform samples.  It is an opt-in fast mode; the default
 // mode is the FD-faithful kernel in ccmp_kernels_fd.hip.
 //
@@ -157,9 +159,9 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K, c
       for (int i = 0; i < 7; i++) {
         const double *zi = z[arm][i];
         const double r0 = pl[0] - oj[arm][i][0], r1 = pl[1] - oj[arm][i][1], r2 = pl[2] - oj[arm][i][2];
-        const double cx = zi[1] * r2 - zi[2] * r1;
-        const double cy = zi[2] * r0 - zi[0] * r2;
-        const double cz = zi[0] * r1 - zi[1] * r0;
+        const double cx = CCMP_FMA(zi[1], r2, -(zi[2] * r1));
+        const double cy = CCMP_FMA(zi[2], r0, -(zi[0] * r2));
+        const double cz = CCMP_FMA(zi[0], r1, -(zi[1] * r0));
         J[arm * 7 + i] = sgn * dot3(al[0], cx, al[1], cy, al[2], cz);
         J[14 + arm * 7 + i] = sgn * dot3(bl[0], zi[0], bl[1], zi[1], bl[2], zi[2]);
       }

@@ -359,10 +359,10 @@ static void fk_frames(const orc_problem *P, int arm, const double q[7], double z
   m3_vec_acc(P->base_R[arm], o, pw);
 }
 
-/* Exact derivative of the residual: row0 = u^T dp_c/dq, row1 = n^T dw_c/dq.
- * Not what the reference computes (it differentiates numerically); used for the CPU "analytic"
- * baseline and to cross-check the FD stencil. */
-void orc_jacobian_analytic(const orc_problem *P, const double x[14], double J[28])
+/* Exact derivative of the residual: row0 = u^T dp_c/dq, row1 = n^T dw_c/dq, formulated in WORLD
+ * coordinates.  Not what the reference computes (it differentiates numerically); kept as the independent cross-check
+ * of the FD stencil and of orc_jacobian_analytic below (tests compare the two to ~1e-13). */
+void orc_jacobian_analytic_world(const orc_problem *P, const double x[14], double J[28])
 {
   double z[2][7][3], o[2][7][3], R1[9], p1[3], R2[9], p2[3], Rc[9], pc[3], f[2], d[4];
   fk_frames(P, 0, x, z[0], o[0], R1, p1);
@@ -389,6 +389,72 @@ void orc_jacobian_analytic(const orc_problem *P, const double x[14], double J[28
       double cz = zi[0] * r[1] - zi[1] * r[0];
       J[0 * 14 + arm * 7 + i] = sgn * DOT3(a[0], cx, a[1], cy, a[2], cz);
       J[1 * 14 + arm * 7 + i] = sgn * DOT3(b[0], zi[0], b[1], zi[1], b[2], zi[2]);
+    }
+  }
+}
+
+/* The analytic mode of the product (jacobian_mode = CCMP_JAC_ANALYTIC, csrc/ccmp_kernels_fast.hip) — this library's own
+ * extension, no counterpart in the reference.  The same derivative as above with every joint's axis and origin kept
+ * in its ARM'S BASE frame and the probe vectors carried there (what a GPU lane can do without world-frame copies of
+ * all fourteen joint frames), operation for operation in the order the kernel runs them, so that the det build can be
+ * compared with the kernel bit for bit:
+ *   u = (pc - p0) * (1 / f0),  n = dq_vec * (sign(dq_w) / |dq_vec|)          (chain frame)
+ *   aw = R2 u, bw = R2 n                                                     (world)
+ *   per arm: al = Rb^T aw, bl = Rb^T bw, pl = Rb^T (p1 - pb)                 (arm base frame)
+ *   per joint: z_i = R_(i) axis_i, o_i = joint origin, both in the base frame;
+ *              J0 = +-al . (z_i x (pl - o_i)),  J1 = +-bl . z_i             (+ arm 0, - arm 1) */
+void orc_jacobian_analytic(const orc_problem *P, const double x[14], double J[28])
+{
+  double z[2][7][3], oj[2][7][3], Rw[2][9], pw[2][3];
+  for (int arm = 0; arm < 2; arm++) {
+    double R[9], o[3] = {0, 0, 0};
+    m3_identity(R);
+    for (int i = 0; i < 7; i++) {
+      double Rj[9], Rn[9];
+      m3_vec_acc(R, P->offset[arm][i], o);
+      m3_vec(R, P->axis[arm][i], z[arm][i]);
+      for (int k = 0; k < 3; k++) oj[arm][i][k] = o[k];
+      rot_axis(P->axis[arm][i], x[7 * arm + i], Rj);
+      m3_mul(R, Rj, Rn);
+      memcpy(R, Rn, sizeof Rn);
+    }
+    double Rf[9];
+    m3_vec_acc(R, P->ee[arm], o);
+    m3_mul(R, P->R_tool[arm], Rf);
+    m3_mul(P->base_R[arm], Rf, Rw[arm]);
+    for (int k = 0; k < 3; k++) pw[arm][k] = P->base_p[arm][k];
+    m3_vec_acc(P->base_R[arm], o, pw[arm]);
+  }
+  double Rc[9], pc[3], f[2], d[4];
+  chain_of(Rw[0], pw[0], Rw[1], pw[1], Rc, pc);
+  residual_of_chain(P, Rc, pc, f, d);
+  double u[3] = {0, 0, 0}, n[3] = {0, 0, 0}, aw[3], bw[3];
+  if (f[0] > 0.0) {
+    const double inv = 1.0 / f[0];
+    for (int k = 0; k < 3; k++) u[k] = (pc[k] - P->init_p[k]) * inv;
+  }
+  const double vn = sqrt(DOT3(d[0], d[0], d[1], d[1], d[2], d[2]));
+  if (vn > 0.0) {
+    const double sg = (d[3] < 0.0 ? -1.0 : 1.0) / vn;
+    for (int k = 0; k < 3; k++) n[k] = d[k] * sg;
+  }
+  m3_vec(Rw[1], u, aw);
+  m3_vec(Rw[1], n, bw);
+  for (int arm = 0; arm < 2; arm++) {
+    double al[3], bl[3], pl[3], dp[3];
+    for (int k = 0; k < 3; k++) dp[k] = pw[0][k] - P->base_p[arm][k];
+    m3t_vec(P->base_R[arm], aw, al);
+    m3t_vec(P->base_R[arm], bw, bl);
+    m3t_vec(P->base_R[arm], dp, pl);
+    const double sgn = arm == 0 ? 1.0 : -1.0;
+    for (int i = 0; i < 7; i++) {
+      const double *zi = z[arm][i];
+      const double r0 = pl[0] - oj[arm][i][0], r1 = pl[1] - oj[arm][i][1], r2 = pl[2] - oj[arm][i][2];
+      const double cx = FMA(zi[1], r2, -(zi[2] * r1));
+      const double cy = FMA(zi[2], r0, -(zi[0] * r2));
+      const double cz = FMA(zi[0], r1, -(zi[1] * r0));
+      J[0 * 14 + arm * 7 + i] = sgn * DOT3(al[0], cx, al[1], cy, al[2], cz);
+      J[1 * 14 + arm * 7 + i] = sgn * DOT3(bl[0], zi[0], bl[1], zi[1], bl[2], zi[2]);
     }
   }
 }

@@ -100,7 +100,10 @@ void orc_set_start(orc_problem *P, const double q0[14]); /* setInitialPosition +
 void orc_fk(const orc_problem *P, int arm, const double q[7], double R[9], double p[3]); /* world pose */
 void orc_function(const orc_problem *P, const double x[14], double f[2]);
 void orc_jacobian_fd(const orc_problem *P, const double x[14], double J[28]);       /* J[r*14+j] */
+/* the product's analytic mode (its own extension), in the kernel's operation order: bit-comparable with the HIP kernel */
 void orc_jacobian_analytic(const orc_problem *P, const double x[14], double J[28]);
+/* the same derivative formulated in world coordinates: independent cross-check (agrees to ~1e-13, not bitwise) */
+void orc_jacobian_analytic_world(const orc_problem *P, const double x[14], double J[28]);
 void orc_solve_minnorm(const double J[28], const double f[2], double dx[14]);
 int orc_project(const orc_problem *P, double x[14], int32_t *iters); /* 1 = true, 0 = false */
 int orc_joint_valid(const orc_problem *P, const double x[14]);

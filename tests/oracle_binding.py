@@ -72,6 +72,7 @@ class Oracle:
         lib.orc_function.argtypes = [pp, dp, dp]
         lib.orc_jacobian_fd.argtypes = [pp, dp, dp]
         lib.orc_jacobian_analytic.argtypes = [pp, dp, dp]
+        lib.orc_jacobian_analytic_world.argtypes = [pp, dp, dp]
         lib.orc_solve_minnorm.argtypes = [dp, dp, dp]
         lib.orc_project.argtypes = [pp, dp, C.POINTER(C.c_int32)]
         lib.orc_project.restype = C.c_int
@@ -140,9 +141,12 @@ class Oracle:
         return f
 
     def jacobian(self, P, x, analytic=False):
+        """analytic: False = OMPL's FD stencil, True = the product's analytic mode (kernel order), "world" = the
+        independent world-frame formulation of the same derivative"""
         x = np.ascontiguousarray(x, dtype=np.float64)
         J = np.empty(28)
-        (self.lib.orc_jacobian_analytic if analytic else self.lib.orc_jacobian_fd)(C.byref(P), _dptr(x), _dptr(J))
+        fn = {False: self.lib.orc_jacobian_fd, True: self.lib.orc_jacobian_analytic, "world": self.lib.orc_jacobian_analytic_world}[analytic]
+        fn(C.byref(P), _dptr(x), _dptr(J))
         return J.reshape(2, 14)
 
     def solve_minnorm(self, J, f):

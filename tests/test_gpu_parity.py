@@ -232,8 +232,41 @@ def test_single_state_surface(gpu_ctx, oracle_det):
         c.setTolerance(0.0, 1e-3)
 
 
+@pytest.mark.parametrize("obj,B", [("Wine_Bottle", 4096), ("stefan", 1500), ("dumbbell", 1024)])
+def test_analytic_mode_bitwise(gpu_ctx, oracle_det, obj, B):
+    """The analytic mode is built in the canonical rounding model: joints, flags and iteration counts are bit-identical
+    to the CPU oracle run with ORC_JAC_ANALYTIC (orc_jacobian_analytic restates the kernel's operation order; the
+    independent world-frame formulation agrees with it to 5e-13, tests/test_oracle_golden.py) — C2-sized batch,
+    both kernel instantiations (stock structure and general), the fused sampler, and calibrated arms."""
+    import torch
+    from closed_chain_motion_planner_amd import _lib
+
+    c = _constraint(obj, gpu_ctx, mode=1)
+    for calibrated in (False, True):
+        if calibrated:
+            dh = (C.c_double * 28)(*[1e-3 * ((5 * i) % 7 - 3) for i in range(28)])
+            assert _lib.lib().ccmp_set_calibration(C.byref(c.problem), 0, dh) == 0
+        P = _oracle_problem(oracle_det, c)
+        assert P.jacobian_mode == 1
+        q = oracle_det.ambient_uniform_batch(P, 0xA7, 0, B)
+        q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+        for stock in (1, 0):
+            gpu_ctx.set_option("stock_kernels", stock)
+            try:
+                q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
+            finally:
+                gpu_ctx.set_option("stock_kernels", 1)
+            assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64)), (obj, calibrated, stock)
+            assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu)
+            assert np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
+    qs, oks, its, _ = c.sample_project_batch(0xA7, 0, 777)
+    e_q, e_ok, e_it = oracle_det.sample_project_batch(P, 0xA7, 0, 777, NCPU)
+    assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
+
+
 def test_analytic_mode_statistics(gpu_ctx, oracle_det):
-    """the opt-in fast mode: same manifold, same acceptance statistics; not bit-comparable"""
+    """the opt-in fast mode against the REFERENCE arithmetic (FD oracle): same manifold, same acceptance statistics;
+    not bit-comparable with it (bit-identity with the oracle's own analytic mode: test_analytic_mode_bitwise)"""
     import torch
 
     c = _constraint("Wine_Bottle", gpu_ctx, mode=1)

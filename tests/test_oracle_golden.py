@@ -110,8 +110,9 @@ def test_fd_jacobian_matches_analytic(oracle_det):
     worst = 0.0
     for i in range(40):
         x = oracle_det.ambient_uniform(P, 11, i)
-        Jf, Ja = oracle_det.jacobian(P, x), oracle_det.jacobian(P, x, analytic=True)
+        Jf, Ja, Jw = oracle_det.jacobian(P, x), oracle_det.jacobian(P, x, analytic=True), oracle_det.jacobian(P, x, analytic="world")
         worst = max(worst, np.abs(Jf - Ja).max())
+        assert np.abs(Ja - Jw).max() < 5e-13  # base-frame (kernel order) and world-frame formulations of the same derivative
     assert worst < 5e-7  # FD noise ~ eps/h
 
 
