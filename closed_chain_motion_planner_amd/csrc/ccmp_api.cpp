@@ -271,7 +271,7 @@ int ccmp_ctx_create(int device, ccmp_ctx **out)
   ctx->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate"); }
-  e = hipMalloc((void **)&ctx->queue, 64);
+  e = hipMalloc((void **)&ctx->queue, 8 * sizeof(unsigned long long) + 64 * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64: analytic kernel
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return hip_fail(e, "hipMalloc(queue)"); }
   *out = ctx;
   return CCMP_OK;
@@ -441,8 +441,8 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (!q_out || !ok || (mode == 0 && !q_in)) return CCMP_EINVAL;
   if ((((uintptr_t)q_in) | ((uintptr_t)q_out)) & 15u) return CCMP_EINVAL; // rows are moved in 16-byte pieces
   if (p->jacobian_mode != CCMP_JAC_FD) {
-    const int nblocks = projector_blocks(ctx, B, 64, 4);
-    HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue, seed, first, nblocks, st));
+    const int nblocks = projector_blocks(ctx, B, 64, 4); // one wavefront per SIMD (256 + 190 registers per lane)
+    HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, nblocks, st));
     return CCMP_OK;
   }
   const FdPlan pl = plan_fd_batch(ctx, B, ctx->order != nullptr);

@@ -11,8 +11,8 @@
 // point of the same manifold for ~20 % of uniform samples.  It is an opt-in fast mode; the default
 // mode is the FD-faithful kernel in ccmp_kernels_fd.hip.
 //
-// Decomposition: one sample per lane, everything in registers; a lane that finishes a sample takes its next
-// one (static stride over the batch) while its neighbours keep iterating (iteration counts spread 15..250).
+// Decomposition: one sample per lane, state in registers; lanes that finish a sample are refilled together from
+// wave-level ticket queues while their neighbours keep iterating (iteration counts spread 15..250).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,6 +23,9 @@ using namespace ccmp;
 
 namespace {
 
+constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
+constexpr int kFastQueues = 64; // queue words of the analytic kernel (ccmp_api.cpp allocates and clears as many)
+
 // Forward chain of one arm in its own base frame, keeping every joint's axis z_i and origin o_i; joint indices are
 // compile-time so that the STOCK instantiation can skip the products with the stock Panda's exact zeros (ccmp_kin.h).
 template <bool STOCK, int I>
@@ -30,6 +33,7 @@ __device__ __forceinline__ void chain_frames_from(const ccmp_consts &K, const in
                                                   double *R, double *o)
 {
   if constexpr (I < 7) {
+    asm volatile("" ::: "memory"); // the joint's constants are read from LDS here, not hoisted out of the Newton loop into registers
     double s, c;
     ccmp_sincos(q[I], &s, &c);
     mulvec_acc_nz<STOCK ? kStockOff[I] : 7>(R, K.offset[arm][I], o);
@@ -56,37 +60,63 @@ __device__ __forceinline__ void chain_frames(const ccmp_consts &K, const int arm
 }
 
 template <int MODE, bool STOCK>
-__global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K, const double *__restrict__ q_in,
+__global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K_arg, const double *__restrict__ q_in,
                                                           double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
                                                           uint16_t *__restrict__ iters_out,
                                                           double *__restrict__ q_ambient, unsigned long long B,
                                                           unsigned long long *queue, unsigned long long seed,
                                                           unsigned long long first_index)
 {
+  // the constants as an LDS copy read by broadcast: with compile-time joint indices the compiler would otherwise hoist
+  // every scalar load of the kernarg copy out of the Newton loop and spill ~300 SGPRs into VGPR lanes (1170 v_readlane /
+  // v_writelane of 4600 vector instructions); the compiler barriers in chain_frames_from keep the LDS reads at their joints (they also keep the
+  // scheduler from interleaving all fourteen joints at once, which costs 512 registers and scratch)
+  __shared__ double ktab[kConstsDoubles + 1];
+  {
+    const double *src = reinterpret_cast<const double *>(&K_arg);
+    for (int k = threadIdx.x; k < kConstsDoubles; k += 64) ktab[k] = src[k];
+  }
+  __syncthreads();
+  const ccmp_consts &K = *reinterpret_cast<const ccmp_consts *>(ktab);
   double x[14];
-  unsigned long long idx = 0, next = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  (void)queue;
+  unsigned long long idx = 0;
   int iter = 0, updates = 0;
   double norm1 = 0.0, norm2 = 0.0;
   bool active = false, drained = false;
+  // Work distribution: iteration counts spread 15..250, so a fixed list of samples per lane leaves most lanes idle
+  // while the unluckiest one works through its list (at 262144 samples: 23 % lane utilisation at 8 wavefronts per CU).
+  // Lanes that need a sample are served together: one atomic per wavefront and refill event takes as many tickets as
+  // lanes are free.  kFastQueues queue words, each owning a contiguous slice of the batch, keep the atomics off a
+  // single address; a wavefront starts on its own word and moves on to the next ones when that slice is used up.
+  const int lane = threadIdx.x;
+  int qk = blockIdx.x % kFastQueues, tried = 0;
 
   for (;;) {
-    if (!active && !drained) {
-      // static striding, not a shared queue head: one word saturates at ~88 single-lane dequeues per microsecond,
-      // which at 262144 samples would cost as much as the projections themselves
-      const unsigned long long t = next;
-      next += (unsigned long long)gridDim.x * blockDim.x;
-      if (t < B) {
+    unsigned long long need = __builtin_amdgcn_ballot_w64(!active && !drained);
+    while (need != 0ull) {
+      const unsigned long long lo = B * (unsigned long long)qk / kFastQueues, hi = B * (unsigned long long)(qk + 1) / kFastQueues;
+      const int n = __builtin_popcountll(need);
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(queue + qk, (unsigned long long)n);
+      base = __shfl(base, 0);  // ticket of the first free lane, relative to the slice
+      const bool mine = (need >> lane) & 1ull;
+      const unsigned long long t = lo + base + (unsigned long long)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+      if (mine && t < hi) {
         idx = t; active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
 #pragma unroll
         for (int e = 0; e < 14; e++) {
           if (MODE == 0) x[e] = q_in[idx * 14 + e];
           else {
-            x[e] = ambient_uniform(K, seed, first_index + idx, e);
+            x[e] = ambient_uniform(K_arg, seed, first_index + idx, e);
             if (q_ambient) q_ambient[idx * 14 + e] = x[e];
           }
         }
-      } else drained = true;
+      }
+      need = __builtin_amdgcn_ballot_w64(!active && !drained);
+      if (need != 0ull) { // this slice is used up: try the next one; after a full round every slice is dry
+        if (++tried >= kFastQueues) { drained = true; break; }
+        qk = (qk + 1) % kFastQueues;
+      }
     }
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
 
@@ -155,6 +185,7 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K, c
       mulTvec(K.base_R[arm], bw, bl);
       mulTvec(K.base_R[arm], dp, pl);
       const double sgn = arm == 0 ? 1.0 : -1.0;
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int i = 0; i < 7; i++) {
         const double *zi = z[arm][i];
@@ -183,7 +214,7 @@ extern "C" hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, c
                                                unsigned long long *queue, unsigned long long seed,
                                                unsigned long long first, int nblocks, hipStream_t st)
 {
-  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+  hipError_t e = hipMemsetAsync(queue, 0, kFastQueues * sizeof(unsigned long long), st);
   if (e != hipSuccess) return e;
 #define CCMP_LAUNCH_FAST(MODE, STOCK)                                                                                              \
   hipLaunchKernelGGL((project_fast_kernel<MODE, STOCK>), dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \

@@ -39,6 +39,7 @@ def run(obj, B):
     LA = _lib.lib()
     LB = C.CDLL(LIBB)
     P = load_config(os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml"))
+    P.jacobian_mode = int(os.environ.get("AB_MODE", "0"))  # 1: analytic mode (AB_UNIT=ccmp_kernels_fast.hip)
     libs = {}
     for name, L in (("A", LA), ("B", LB)):
         h = C.c_void_p()
