@@ -5,7 +5,7 @@ Only the projector hot path of jkw0701/closed_chain_motion_planner: 
 interface.  Importing the package needs neither a GPU nor the built library; using it does.
 """
 from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem  # noqa: F401
-from .constraint import ArmModel, Context, KinematicChainConstraint, load_config  # noqa: F401
+from .constraint import ArmModel, Communicator, Context, KinematicChainConstraint, load_config  # noqa: F401
 
 from .space import (check_motion, format_graphml, format_graphviz, format_path_matrix, geodesic_interpolate,  # noqa: F401
                     jy_ProjectedStateSampler, jy_ProjectedStateSpace, next_sampler_seed, parse_graphml, parse_path_matrix,

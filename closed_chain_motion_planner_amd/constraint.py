@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem, check
 
-__all__ = ["Context", "KinematicChainConstraint", "ArmModel", "load_config", "CCMP_JAC_FD", "CCMP_JAC_ANALYTIC"]
+__all__ = ["Context", "Communicator", "KinematicChainConstraint", "ArmModel", "load_config", "CCMP_JAC_FD", "CCMP_JAC_ANALYTIC"]
 
 
 def _torch():
@@ -63,6 +63,32 @@ class Context:
     def close(self):
         if self._h:
             _lib.lib().ccmp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Communicator:
+    """ccmp_comm: one process, one context per GPU, RCCL (ncclCommInitAll) underneath — the collective form of the
+    single-process sharding."""
+
+    def __init__(self, contexts):
+        self.contexts = list(contexts)
+        self._h = C.c_void_p()
+        arr = (C.c_void_p * len(self.contexts))(*[cx.handle for cx in self.contexts])
+        check(_lib.lib().ccmp_comm_create(arr, len(self.contexts), C.byref(self._h)), "ccmp_comm_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            _lib.lib().ccmp_comm_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -402,6 +428,41 @@ class KinematicChainConstraint:
                                                           it.ctypes.data_as(C.POINTER(C.c_uint16)), B),
               "ccmp_sample_project_sharded_host")
         return out, ok, it
+
+    def _sharded(self, comm, mode, q, seed, first_index, B, block_rows, want_full):
+        n = len(comm.contexts)
+        shard = -(-B // n)
+        block_rows = int(block_rows) if block_rows else max(1, shard)
+        out = np.empty((B, 14)) if want_full else None
+        ok = np.zeros(B, dtype=np.uint8) if want_full else None
+        it = np.zeros(B, dtype=np.uint16) if want_full else None
+        valid = np.empty((n * block_rows, 14))
+        counts = (C.c_uint64 * n)()
+        nv = C.c_uint64(0)
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+        u16 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint16)) if a is not None else None
+        dp = lambda a: _dptr(a) if a is not None else None
+        if mode == 0:
+            rc = _lib.lib().ccmp_project_sharded(comm.handle, C.byref(self.problem), _dptr(q), B, dp(out), u8(ok), u16(it), block_rows,
+                                                 _dptr(valid), valid.shape[0], counts, C.byref(nv))
+        else:
+            rc = _lib.lib().ccmp_sample_project_sharded(comm.handle, C.byref(self.problem), int(seed), int(first_index), B, dp(out), u8(ok),
+                                                        u16(it), block_rows, _dptr(valid), valid.shape[0], counts, C.byref(nv))
+        if rc == -8:
+            raise OverflowError("a shard holds %d valid states, the gather blocks hold %d rows" % (max(counts), block_rows))
+        check(rc, "ccmp_project_sharded" if mode == 0 else "ccmp_sample_project_sharded")
+        return valid[: nv.value].copy(), list(counts), (out, ok, it)
+
+    def project_sharded(self, q, comm, block_rows=None, want_full=True):
+        """(B,14) numpy over the communicator's GPUs with the RCCL all-gather of the valid states: returns
+        (valid states in global order, per-shard counts, (q_out, ok, iters))"""
+        self._need_problem()
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        return self._sharded(comm, 0, q, 0, 0, q.shape[0], block_rows, want_full)
+
+    def sample_project_sharded(self, seed, first_index, B, comm, block_rows=None, want_full=True):
+        self._need_problem()
+        return self._sharded(comm, 1, None, seed, first_index, int(B), block_rows, want_full)
 
     def project_host(self, q):
         """(B,14) numpy in -> (q_out, ok, iters) numpy out through the host-pointer entry point."""

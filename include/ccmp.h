@@ -35,7 +35,9 @@ enum {
   CCMP_EIO = -3,    /* cannot read the YAML file                                                 */
   CCMP_EPARSE = -4, /* YAML key missing or malformed                                             */
   CCMP_ENODEV = -5, /* no HIP device / device index out of range                                 */
-  CCMP_ENOMEM = -6
+  CCMP_ENOMEM = -6,
+  CCMP_ECOMM = -7,    /* RCCL call failed or librccl.so could not be opened; see ccmp_last_hip_error()  */
+  CCMP_EOVERFLOW = -8 /* more valid states than the gather blocks / the output buffer hold: retry larger */
 };
 
 enum { CCMP_JAC_FD = 0, CCMP_JAC_ANALYTIC = 1 };
@@ -210,13 +212,34 @@ int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from,
 /* Contiguous shards of the batch go to the n contexts (1 <= n <= 64, one per device; the same device may appear twice),
  * each shard is uploaded, projected and downloaded on its context's own stream, all concurrently; returns
  * when every shard is back.  No collective is needed: every GPU returns its shard straight to the host
- * tree.  Results are bit-identical to a single-GPU call.  (The one-process-per-GPU form with an RCCL
- * all-gather of the valid states lives above the ABI: closed_chain_motion_planner_amd/distributed.py.) */
+ * tree.  Results are bit-identical to a single-GPU call.  (With the collective: ccmp_project_sharded below; the
+ * one-process-per-GPU form lives above the ABI: closed_chain_motion_planner_amd/distributed.py.) */
 int ccmp_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, const double *q_in, double *q_out,
                               uint8_t *ok, uint16_t *iters, size_t B);
 /* sampleUniform x B across the contexts; sample i is a function of (seed, first_index + i) only */
 int ccmp_sample_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
                                      double *q_out, uint8_t *ok, uint16_t *iters, size_t B);
+
+/* ---- one process, several GPUs, with the collective (ccmp_project_sharded) ------------------------- */
+/* A communicator over the devices of n contexts (one context per device, 1 <= n <= 64): ncclCommInitAll in this
+ * process — RCCL over xGMI inside a node; librccl.so is opened at run time, libccmp.so does not link against it. */
+typedef struct ccmp_comm ccmp_comm;
+int ccmp_comm_create(ccmp_ctx *const *ctxs, int n, ccmp_comm **out);
+void ccmp_comm_destroy(ccmp_comm *comm);
+/* project(x) x B (host buffers), contiguous shards over the communicator's GPUs; every GPU compacts its VALID states
+ * into a block of block_rows rows (+ one leading row that carries its count) and ONE ncclAllGather brings all blocks
+ * to every GPU; GPU 0 hands them to the host: valid_out[0..*n_valid) (capacity valid_capacity rows) = the valid
+ * states of all shards in global sample order, counts[g] (nullable, n entries) = valid states of shard g.  q_out / ok /
+ * iters (all nullable) additionally receive the full per-sample results, each GPU returning its shard directly.
+ * CCMP_EOVERFLOW if a shard holds more valid states than block_rows or the total exceeds valid_capacity (counts and
+ * *n_valid are filled: retry with room).  Bit-identical to a single-GPU call. */
+int ccmp_project_sharded(ccmp_comm *comm, const ccmp_problem *p, const double *q_in, size_t B, double *q_out, uint8_t *ok,
+                         uint16_t *iters, size_t block_rows, double *valid_out, size_t valid_capacity, uint64_t *counts,
+                         uint64_t *n_valid);
+/* sampleUniform x B the same way; sample i is a function of (seed, first_index + i) only */
+int ccmp_sample_project_sharded(ccmp_comm *comm, const ccmp_problem *p, uint64_t seed, uint64_t first_index, size_t B,
+                                double *q_out, uint8_t *ok, uint16_t *iters, size_t block_rows, double *valid_out,
+                                size_t valid_capacity, uint64_t *counts, uint64_t *n_valid);
 
 /* ---- diagnostics ---------------------------------------------------------------------------------- */
 /* runs ccmp_detmath.h's sincos/atan2/sqrt/div on the device: out[i] = {sin,cos,atan2_nn(|x|,|y|),

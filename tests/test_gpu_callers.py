@@ -273,6 +273,32 @@ def test_single_process_sharding_over_contexts(gpu_ctx, oracle_det):
     assert np.array_equal(s_out.view(np.uint64), e_out.view(np.uint64)) and np.array_equal(s_ok, e_ok)
 
 
+def test_single_process_rccl_all_gather(gpu_ctx, oracle_det):
+    """ccmp_project_sharded / ccmp_sample_project_sharded: projection, capped compaction into the
+    gather block, ONE ncclAllGather, valid states back in global order.  This box has one GPU and RCCL wants one rank
+    per device, so the communicator has a single rank here (the all-gather is then a copy through RCCL); the shard
+    arithmetic for n > 1 is the code path of ccmp_project_sharded_host, tested above with three contexts."""
+    from closed_chain_motion_planner_amd import Communicator, Context
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    with pytest.raises(Exception):
+        Communicator([gpu_ctx, Context(0)])  # two ranks on one device: refused before RCCL is asked
+    comm = Communicator([gpu_ctx])
+    B = 3001
+    q = oracle_det.ambient_uniform_batch(P, 0x5B, 0, B)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+    valid, counts, (out, ok, it) = c.project_sharded(q, comm)
+    assert np.array_equal(out.view(np.uint64), q_cpu.view(np.uint64)) and np.array_equal(ok, ok_cpu) and np.array_equal(it, it_cpu)
+    assert counts == [int(ok_cpu.sum())] and np.array_equal(valid.view(np.uint64), q_cpu[ok_cpu == 1].view(np.uint64))
+    v2, c2, _ = c.sample_project_sharded(0x5B, 0, B, comm, block_rows=1000, want_full=False)
+    e_q, e_ok, _ = oracle_det.sample_project_batch(P, 0x5B, 0, B, NCPU)
+    assert c2 == [int(e_ok.sum())] and np.array_equal(v2.view(np.uint64), e_q[e_ok == 1].view(np.uint64))
+    with pytest.raises(OverflowError):  # a block too small for the shard's valid states is reported, never cut silently
+        c.sample_project_sharded(0x5B, 0, B, comm, block_rows=100, want_full=False)
+    comm.close()
+
+
 def test_check_motion_and_geodesic_interpolate(gpu_ctx, oracle_det):
     from closed_chain_motion_planner_amd import check_motion, geodesic_interpolate, jy_ProjectedStateSpace
 

@@ -29,6 +29,14 @@ def test_exports_every_declared_symbol(L, ccmp_built):
     assert L.ccmp_version() == 100
 
 
+def test_library_does_not_link_rccl(ccmp_built):
+    """the collective entry points open librccl at run time: planners that never shard pay no dependency"""
+    import subprocess
+
+    out = subprocess.run(["ldd", ccmp_built], capture_output=True, text=True).stdout
+    assert "rccl" not in out and "nccl" not in out and "libamdhip64" in out
+
+
 def test_abi_has_no_torch_or_cxx_types(ccmp_built):
     hdr = open(os.path.join(ROOT, "include", "ccmp.h")).read()
     code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # signatures only, comments stripped
