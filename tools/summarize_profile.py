@@ -39,7 +39,10 @@ def main():
     tag = sys.argv[1]
     kernel_subs = (sys.argv[2] if len(sys.argv) > 2 else "project_fd_kernel,project_fd_flat_kernel,scout_kernel").split(",")
     kernel_sub = "+".join(kernel_subs)
-    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 262144          # units (projections / edges) per launch
+    unit_bytes = int(sys.argv[4]) if len(sys.argv) > 4 else 225         # algorithmic bytes per unit (225 per projection)
+    workload = sys.argv[5] if len(sys.argv) > 5 else "bench.py (C3)"   # what tools/profile.sh ran
+    headline = workload.startswith("bench.py")                          # only the headline profile feeds bench.py's roofline.traffic
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -63,7 +66,7 @@ def main():
         meta = m or meta
     fetch_kib, write_kib = allc.get("FETCH_SIZE"), allc.get("WRITE_SIZE")
     avg_ms = float(krow["AverageNs"]) / 1e6
-    algo = 225 * batch
+    algo = unit_bytes * batch
     traffic_lo = (fetch_kib + write_kib) * 1024 if fetch_kib is not None and write_kib is not None else None
     traffic_hi = (2 * fetch_kib + write_kib) * 1024 if traffic_lo is not None else None
     summary = {
@@ -75,21 +78,22 @@ def main():
         "hbm_bytes_per_launch_raw": traffic_lo, "hbm_bytes_per_launch_fetch_doubled": traffic_hi,
     }
     json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
-    if traffic_hi is not None:
+    if traffic_hi is not None and headline:
         json.dump({"kernel": kernel_sub, "batch": batch, "hbm_bytes_per_launch": traffic_hi, "tag": tag,
                    "valu_wave_insts_per_launch": allc.get("SQ_INSTS_VALU"),
                    "note": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, gfx950 FETCH_SIZE x2 correction "
                            "(upper bound for this kernel's 8-B-per-lane loads)"},
                   open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
     with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
-        f.write("# rocprofv3 summary `%s` — kernel `%s`, batch %d\n\n" % (tag, kernel_sub, batch))
-        f.write("Command: `bash tools/profile.sh %s` (= `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 "
-                "--warmup 1 ...`, then separate `--pmc` passes).\n\n" % tag)
+        f.write("# rocprofv3 summary `%s` — kernel `%s`, %d units per launch, workload %s\n\n" % (tag, kernel_sub, batch, workload))
+        f.write("Command: `bash tools/profile.sh %s%s` (= `rocprofv3 --kernel-trace --stats -- python3 ...`, then separate `--pmc` "
+                "passes; launch-record VGPR_Count is rocprofv3's figure = allocated VGPRs / 2 here, the ISA metadata holds the "
+                "register count quoted in DESIGN.md).\n\n" % (tag, "" if headline else " " + workload))
         f.write("| quantity | value |\n|---|---|\n")
         f.write("| calls / avg / min / max | %d / %.3f ms / %.3f ms / %.3f ms |\n" % (summary["calls"], avg_ms, summary["min_ms"], summary["max_ms"]))
-        f.write("| projections/s (kernel only) | %.3e |\n" % summary["projections_per_s_kernel"])
-        f.write("| algorithmic bytes per launch (225 B x %d) | %.1f MB -> %.3f GB/s = %.5f %% of 8 TB/s |\n"
-                % (batch, algo / 1e6, summary["achieved_GBps_algorithmic"], summary["achieved_GBps_algorithmic"] / 80.0))
+        f.write("| units/s (kernel only) | %.3e |\n" % summary["projections_per_s_kernel"])
+        f.write("| algorithmic bytes per launch (%d B x %d) | %.1f MB -> %.3f GB/s = %.5f %% of 8 TB/s |\n"
+                % (unit_bytes, batch, algo / 1e6, summary["achieved_GBps_algorithmic"], summary["achieved_GBps_algorithmic"] / 80.0))
         if traffic_lo is not None:
             f.write("| HBM traffic per launch (FETCH+WRITE raw / FETCH doubled) | %.1f MB / %.1f MB |\n" % (traffic_lo / 1e6, traffic_hi / 1e6))
         for name, calls, ms in parts:
@@ -116,9 +120,10 @@ def main():
                               + allc.get("SQ_INSTS_VALU_TRANS_F64", 0)) / allc["SQ_INSTS_VALU"]))
             summary["executed_fp64_flop_per_launch"] = fl
             json.dump(summary, open(os.path.join(dst, tag + "_summary.json"), "w"), indent=1)
-            tj = json.load(open(os.path.join(dst, "traffic_latest.json")))
-            tj["executed_fp64_flop_per_launch"] = fl
-            json.dump(tj, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+            if headline:
+                tj = json.load(open(os.path.join(dst, "traffic_latest.json")))
+                tj["executed_fp64_flop_per_launch"] = fl
+                json.dump(tj, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
         if "SQ_WAVE_CYCLES" in allc and "SQ_ACTIVE_INST_VALU" in allc:
             f.write("\nDerived: VALU-active share of wave lifetime = %.3f; " % (allc["SQ_ACTIVE_INST_VALU"] / allc["SQ_WAVE_CYCLES"]))
             if "SQ_WAIT_ANY" in allc:

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""One parametrised timing harness for the GPU box (development aid; bench.py is the contract).
+
+    python tools/timeit.py sizes   [obj] [--schedules]    run time against batch size (1 .. 1048576), default policy;
+                                                           --schedules adds latency-kernel-only and throughput-only columns
+    python tools/timeit.py single                          latency of the reference-signature single-state calls
+    python tools/timeit.py geodesic [E ...]                batched discreteGeodesic (near-neighbour edges)
+    python tools/timeit.py analytic                        analytic mode against batch size and waves per CU
+    python tools/timeit.py host                            PCIe-inclusive rate of ccmp_project_host (pageable / pinned)
+    python tools/timeit.py sampler                         project_batch vs the fused sampler
+    python tools/timeit.py soak                            25 repeats of the default policy, outputs compared bit for bit
+    python tools/timeit.py scout                           FP32 scout's predictions against the true iteration counts
+    python tools/timeit.py run <workload> [reps]           a fixed workload for rocprofv3 (tools/profile.sh):
+                                                           c3 | flat4096 | flat1 | geodesic | analytic | stefan
+"""
+import ctypes as C
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from closed_chain_motion_planner_amd import Context, KinematicChainConstraint, _lib  # noqa: E402
+
+CFG = "tests/golden/config/%s.yaml"
+
+
+def timed(fn, reps=3):
+    """best of `reps`, HIP events on the launch stream"""
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+def near_edges(c, E, seed=0x6E0, dist=0.6):
+    """growTree-shaped edges: a valid projected state -> a projected sampleUniformNear state within `dist` per joint"""
+    q, ok, _, _ = c.sample_project_batch(seed, 0, 8 * E, want_iters=False)
+    frm = q[ok == 1][:E].contiguous()
+    to, _, _, _ = c.sample_near_project_batch(seed + 1, 0, frm, dist, E, want_iters=False)
+    return frm, to
+
+
+def sizes(argv):
+    obj = next((a for a in argv if not a.startswith("-")), "Wine_Bottle")
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+    variants = [("default", None)]
+    if "--schedules" in argv:
+        variants += [("latency-only", (2, 0)), ("throughput-only", (0, 0))]
+    for B in (1, 64, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576):
+        q = c.ambient_uniform_batch(0xC2 if B <= 16384 else 0xC3, 0, B)
+        out = torch.empty_like(q)
+        res = []
+        for name, sched in variants:
+            if sched is None:
+                ctx.set_schedule(1)
+            else:
+                if name == "latency-only" and B > 65536:
+                    continue
+                ctx.set_schedule(*sched)
+            ms = timed(lambda: c.project_batch(q, out=out), reps=3 if B > 65536 else 5)
+            res.append("%s %8.3f ms (%.3e/s)" % (name, ms, B / ms * 1e3))
+        ctx.set_schedule(1)
+        print("%s B=%-8d " % (obj, B) + "   ".join(res), flush=True)
+
+
+def single(argv):
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    q = c.ambient_uniform_batch(1, 0, 64).cpu().numpy()
+    for name, fn in (("project", c.project), ("function", c.function), ("isSatisfied", c.isSatisfied), ("jointValid", c.jointValid)):
+        ts = []
+        for i in range(64):
+            x = q[i].copy()
+            t0 = time.perf_counter()
+            fn(x)
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts[4:]) * 1e6
+        print("%-12s median %.1f us  p90 %.1f us  min %.1f us" % (name, np.median(ts), np.percentile(ts, 90), ts.min()))
+    x0 = np.array(c.problem.start_joint[:])
+    ts = []
+    for i in range(40):  # near-manifold projections (the geodesic regime): few Newton iterations
+        x = x0 + 0.02 * np.sin(np.arange(14) + i)
+        t0 = time.perf_counter()
+        c.project(x)
+        ts.append(time.perf_counter() - t0)
+    print("project near the manifold: median %.1f us" % (np.median(np.array(ts[4:])) * 1e6))
+
+
+def geodesic(argv):
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    for E in [int(a) for a in argv] or [5, 64, 1024, 16384]:
+        frm, to = near_edges(c, E)
+        ms = timed(lambda: c.discrete_geodesic_batch(frm, to, 64), reps=3)
+        st, n, okg, its = c.discrete_geodesic_batch(frm, to, 64)
+        print("E=%-6d %8.3f ms  %.3e edges/s  mean states %.2f  reached %.3f  Newton iterations per edge %.1f"
+              % (E, ms, E / ms * 1e3, n.float().mean().item(), okg.float().mean().item(), its.float().mean().item()), flush=True)
+
+
+def analytic(argv):
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    c.setJacobianMode(1)
+    for B in (4096, 262144, 1048576):
+        q = c.ambient_uniform_batch(0xC3, 0, B)
+        out = torch.empty_like(q)
+        res = []
+        for wpc in (2, 4, 8):
+            ctx.set_waves_per_cu(wpc)
+            ms = timed(lambda: c.project_batch(q, out=out), reps=5)
+            res.append("wpc%d %7.3f ms (%.3e/s)" % (wpc, ms, B / ms * 1e3))
+        print("analytic B=%-8d " % B + "  ".join(res), flush=True)
+
+
+def host(argv):
+    ctx = Context(0)
+    L = _lib.lib()
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    B = 262144
+    q = c.ambient_uniform_batch(0xC3, 0, B).cpu()
+    for name, pin in (("pageable", False), ("pinned", True)):
+        mk = (lambda t: t.pin_memory()) if pin else (lambda t: t)
+        qi, qo = mk(q.clone()), mk(torch.empty_like(q))
+        ok, it = mk(torch.empty(B, dtype=torch.uint8)), mk(torch.empty(B, dtype=torch.int16))
+        ts = []
+        for _ in range(6):
+            t0 = time.perf_counter()
+            rc = L.ccmp_project_host(ctx.handle, C.byref(c.problem), C.cast(qi.data_ptr(), C.POINTER(C.c_double)),
+                                     C.cast(qo.data_ptr(), C.POINTER(C.c_double)), C.cast(ok.data_ptr(), C.POINTER(C.c_uint8)),
+                                     C.cast(it.data_ptr(), C.POINTER(C.c_uint16)), B)
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0
+        ms = np.median(ts[1:]) * 1e3
+        print("%-9s host buffers: %.2f ms per 262144 -> %.2e projections/s (device-resident: bench.py)" % (name, ms, B / ms * 1e3))
+
+
+def sampler(argv):
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    B = 262144
+    q = c.ambient_uniform_batch(0xC3, 0, B)
+    out = torch.empty_like(q)
+    a = timed(lambda: c.project_batch(q, out=out), reps=4)
+    b = timed(lambda: c.sample_project_batch(0xC3, 0, B), reps=4)
+    print("project_batch %.3f ms   sample_project_batch (fused sampler + wrap) %.3f ms" % (a, b))
+
+
+def soak(argv):
+    ctx = Context(0)
+    for obj, B in (("Wine_Bottle", 262144), ("stefan", 98304), ("dumbbell", 40000), ("Wine_Bottle", 20000)):
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        q = c.ambient_uniform_batch(0x50A, 0, B)
+        ref = c.project_batch(q)
+        bad = sum(not all(torch.equal(a, b) for a, b in zip(c.project_batch(q), ref)) for _ in range(25))
+        print(obj, B, "repeats differing from the first run:", bad, flush=True)
+
+
+def scout(argv):
+    ctx = Context(0)
+    L = _lib.lib()
+    L.ccmp_ctx_debug_lpt_pred.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    for obj in ("Wine_Bottle", "stefan"):
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        B = 262144
+        q = c.ambient_uniform_batch(0xC3, 0, B)
+        ctx.set_lpt(1, 0)
+        _, _, it = c.project_batch(q)
+        pred = np.zeros(B, dtype=np.uint16)
+        assert L.ccmp_ctx_debug_lpt_pred(ctx.handle, pred.ctypes.data, B) == 0
+        it, p = it.cpu().numpy().astype(np.int32), pred.astype(np.int32)
+        big = it > 80
+        print("%s scout vs FD iterations: equal %.3f  |d|<=2 %.3f  corr %.4f; of the %d samples with > 80 iterations the scout says > 60 for %.3f"
+              % (obj, (p == it).mean(), (np.abs(p - it) <= 2).mean(), np.corrcoef(p, it)[0, 1], big.sum(), (p[big] > 60).mean()))
+
+
+def run(argv):
+    """fixed workloads for the profiler: one kernel family each, `reps` launches"""
+    what = argv[0]
+    reps = int(argv[1]) if len(argv) > 1 else 3
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % ("stefan" if what == "stefan" else "Wine_Bottle"), ctx=ctx)
+    if what in ("c3", "stefan"):
+        q = c.ambient_uniform_batch(0xC3, 0, 262144)
+        fn = lambda: c.project_batch(q)
+    elif what == "flat4096":
+        q = c.ambient_uniform_batch(0xC2, 0, 4096)
+        fn = lambda: c.project_batch(q)
+    elif what == "flat1":
+        x = c.ambient_uniform_batch(0xC1, 0, 64).cpu().numpy()
+        fn = lambda: [c.project(x[i].copy()) for i in range(64)]
+    elif what == "geodesic":
+        frm, to = near_edges(c, 16384)
+        fn = lambda: c.discrete_geodesic_batch(frm, to, 64)
+    elif what == "analytic":
+        c.setJacobianMode(1)
+        q = c.ambient_uniform_batch(0xC3, 0, 262144)
+        fn = lambda: c.project_batch(q)
+    else:
+        raise SystemExit(__doc__)
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    print("%s: %.3f ms per repetition" % (what, (time.perf_counter() - t0) / reps * 1e3))
+
+
+if __name__ == "__main__":
+    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, host, sampler, soak, scout, run)}
+    if len(sys.argv) < 2 or sys.argv[1] not in cmds:
+        raise SystemExit(__doc__)
+    cmds[sys.argv[1]](sys.argv[2:])
