@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """One parametrised timing harness for the GPU box (development aid; bench.py is the contract).
 
-    python tools/timeit.py sizes   [obj] [--schedules]    run time against batch size (1 .. 1048576), default policy;
+    python tools/measure.py sizes   [obj] [--schedules]    run time against batch size (1 .. 1048576), default policy;
                                                            --schedules adds latency-kernel-only and throughput-only columns
-    python tools/timeit.py single                          latency of the reference-signature single-state calls
-    python tools/timeit.py geodesic [E ...]                batched discreteGeodesic (near-neighbour edges)
-    python tools/timeit.py analytic                        analytic mode against batch size and waves per CU
-    python tools/timeit.py host                            PCIe-inclusive rate of ccmp_project_host (pageable / pinned)
-    python tools/timeit.py sampler                         project_batch vs the fused sampler
-    python tools/timeit.py soak                            25 repeats of the default policy, outputs compared bit for bit
-    python tools/timeit.py scout                           FP32 scout's predictions against the true iteration counts
-    python tools/timeit.py run <workload> [reps]           a fixed workload for rocprofv3 (tools/profile.sh):
+    python tools/measure.py single                          latency of the reference-signature single-state calls
+    python tools/measure.py geodesic [E ...]                batched discreteGeodesic (near-neighbour edges)
+    python tools/measure.py analytic                        analytic mode against batch size and waves per CU
+    python tools/measure.py host                            PCIe-inclusive rate of ccmp_project_host (pageable / pinned)
+    python tools/measure.py sampler                         project_batch vs the fused sampler
+    python tools/measure.py soak                            25 repeats of the default policy, outputs compared bit for bit
+    python tools/measure.py scout                           FP32 scout's predictions against the true iteration counts
+    python tools/measure.py run <workload> [reps]           a fixed workload for rocprofv3 (tools/profile.sh):
                                                            c3 | flat4096 | flat1 | geodesic | analytic | stefan
 """
 import ctypes as C
