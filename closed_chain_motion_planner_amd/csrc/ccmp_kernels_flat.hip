@@ -352,7 +352,8 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
       if (max_states > 0) out[tid] = a; // geodesic->push_back(cloneState(from))
     }
     __syncthreads();
-    int n = 1, its = 0; // counts every state, stored or not: n_states > max_states reports a list that did not fit
+    int n = 1, its = 0;
+    bool fits = true; // false: an accepted state found the list full — the edge stops there and reports max_states + 1
     double dist = lds_distance(rec + gPrev, rec + gTo), total = 0.0;
     if (dist > delta) {
       const double maxd = dist * lambda;
@@ -384,12 +385,15 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
         if (total > maxd) break;                         // wandered too far
         const double newDist = lds_distance(rec + fX, rec + gTo);
         if (newDist >= dist) break;                      // no closer than before
+        // an edge that creeps (hundreds of accepted states, each a hair closer: seen at 1 in 16384 near-neighbour edges,
+        // 952 states) must not hold the whole launch: when the list is full the edge stops and says so
+        if (n >= max_states) { fits = false; n = max_states + 1; break; }
         dist = newDist;
         __syncthreads();
         if (tid < 14) {
           const double v = rec[fX + tid];
           rec[gPrev + tid] = v;
-          if (n < max_states) out[(unsigned long long)n * 14ull + tid] = v;
+          out[(unsigned long long)n * 14ull + tid] = v;
         }
         n++;
         __syncthreads();
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
     }
     if (tid == 0) {
       n_states[t] = n;
-      ok_out[t] = (uint8_t)(dist <= delta);
+      ok_out[t] = (uint8_t)(fits && dist <= delta);
       if (newton_iters) newton_iters[t] = its;
     }
     __syncthreads();

@@ -146,16 +146,21 @@ class jy_ProjectedStateSpace:
         states, n, ok, _ = self.constraint_.discrete_geodesic_batch(f, t, self.max_states)
         n, ok = n.cpu().numpy(), ok.cpu().numpy()
         rows = [None] * len(n)
-        long = np.nonzero(n > self.max_states)[0]
-        if len(long):
-            # n_states is the true length: these lists were cut at max_states.  Run them again with room for the
-            # longest — a cut list must never reach the validity test or the caller as if it were complete.
+        long, cap = np.nonzero(n > self.max_states)[0], self.max_states
+        while len(long):
+            # n_states == max_states + 1: these lists did not fit and the traversal stopped there.  Run them again with
+            # four times the room — a cut list must never reach the validity test or the caller as if it were complete.
+            cap *= 4
             idx = torch.as_tensor(long, device=f.device)
-            s2, n2, _, _ = self.constraint_.discrete_geodesic_batch(f[idx].contiguous(), t[idx].contiguous(), int(n[long].max()))
-            s2, n2 = s2.cpu().numpy(), n2.cpu().numpy()
+            s2, n2, ok2, _ = self.constraint_.discrete_geodesic_batch(f[idx].contiguous(), t[idx].contiguous(), cap)
+            s2, n2, ok2 = s2.cpu().numpy(), n2.cpu().numpy(), ok2.cpu().numpy()
+            again = []
             for k, e in enumerate(long):
-                assert n2[k] == n[e]
-                rows[e] = s2[k, : n2[k]]
+                if n2[k] > cap:
+                    again.append(e)
+                else:
+                    rows[e], n[e], ok[e] = s2[k, : n2[k]], n2[k], ok2[k]
+            long = np.array(again, dtype=np.int64)
         states = states.cpu().numpy()
         delta = self.constraint_.problem.delta
         out = []

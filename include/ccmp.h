@@ -171,11 +171,12 @@ int ccmp_sample_gaussian_project_batch(ccmp_ctx *ctx, const ccmp_problem *p, uin
 int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, int q_stride, double *t_wo, size_t B,
                             void *hip_stream);
 /* jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96), E edges at once:
- * states[e][0..min(n_states[e], max_states)) (capacity max_states each) = `from`, then every accepted state;
- * n_states[e] = the TRUE length of the geodesic, also when it exceeds max_states: n_states[e] > max_states means
- * the list was cut and the call must be repeated with a larger buffer before anything is concluded from it (the
- * adapter and the Python mirror do that); ok[e] = the reference's return value.  Runs as the reference does with interpolate == true; for interpolate ==
- * false the host truncates at the first state its StateValidityChecker rejects. */
+ * states[e][0..n_states[e]) (capacity max_states each) = `from`, then every accepted state; ok[e] = the reference's
+ * return value.  An edge whose list would need more than max_states entries stops there and reports n_states[e] =
+ * max_states + 1 (ok[e] = 0): repeat it with a larger buffer before anything is concluded from it (the adapter and the
+ * Python mirror do) — a creeping edge (observed: 952 accepted states, each a hair closer to the target) must not hold
+ * a whole launch, and a cut list must never look complete.  Runs as the reference does with interpolate == true; for
+ * interpolate == false the host truncates at the first state its StateValidityChecker rejects. */
 int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                         double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream);
 /* the ambient sampler alone (RealVectorStateSampler::sampleUniform over KinematicChain.h:75-100) */

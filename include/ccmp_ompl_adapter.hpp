@@ -250,9 +250,10 @@ inline bool discreteGeodesic(const Projector &proj, const double *from14, const 
       check(ccmp_geodesic_host(proj.ctx(), &proj.problem(), from14, to14, 1, max_states, states.data(), &n, &ok), "ccmp_geodesic_host");
     }
     if (n <= max_states) break;
-    // n is the true length: the list did not fit (small delta, long edge).  A cut list must never reach the
-    // validity test or the caller as if it were complete — run the edge again with room for all of it.
-    max_states = n;
+    // n == max_states + 1: the list did not fit and the traversal stopped there (small delta, long or creeping edge).
+    // A cut list must never reach the validity test or the caller as if it were complete — run the edge again with
+    // four times the room.
+    max_states *= 4;
   }
   bool good = ok != 0;
   int keep = n;

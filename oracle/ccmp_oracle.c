@@ -655,8 +655,8 @@ int orc_discrete_geodesic(const orc_problem *P, const double from[14], const dou
                           int interpolate, orc_valid_fn valid, void *user, double *out,
                           int max_states, int *n_states, int64_t *newton_iters)
 {
-  /* n counts every state of the geodesic (`from` included) whether or not it fits: n_states > max_states tells the
-   * caller that the list was cut at max_states and must be re-run with a larger buffer */
+  /* when an accepted state finds the list full the traversal stops and reports max_states + 1 states (and false):
+   * the caller re-runs the edge with a larger buffer — a creeping edge must not run on unbounded */
   int n = 1;
   int64_t its = 0;
   if (out && max_states > 0) memcpy(out, from, 14 * sizeof(double));
@@ -682,9 +682,14 @@ int orc_discrete_geodesic(const orc_problem *P, const double from[14], const dou
     if (total > max) break;
     const double newDist = orc_distance(scratch, to);
     if (newDist >= dist) break;
+    if (out && n >= max_states) {
+      if (n_states) *n_states = max_states + 1;
+      if (newton_iters) *newton_iters = its;
+      return 0;
+    }
     dist = newDist;
     memcpy(previous, scratch, sizeof previous);
-    if (out && n < max_states) memcpy(out + 14 * n, scratch, 14 * sizeof(double));
+    if (out) memcpy(out + 14 * n, scratch, 14 * sizeof(double));
     n++;
   } while (dist >= tolerance);
   if (n_states) *n_states = n;

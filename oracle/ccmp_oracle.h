@@ -123,7 +123,8 @@ double orc_log(double x);
 /* sampleUniform = ambient sample -> project (result ignored) -> enforceBounds */
 int orc_sample_uniform(const orc_problem *P, uint64_t seed, uint64_t index, double q[14], int32_t *iters);
 /* discreteGeodesic; valid(state, user) may be NULL (= always valid).  Returns the bool of the
- * reference; *n_states counts the states of the geodesic (first one is `from`); only the first max_states are written to out. */
+ * reference; *n_states counts the states of the geodesic (first one is `from`); a traversal that
+ * would need more than max_states stops there, returns 0 and reports max_states + 1. */
 typedef int (*orc_valid_fn)(const double q[14], void *user);
 int orc_discrete_geodesic(const orc_problem *P, const double from[14], const double to[14],
                           int interpolate, orc_valid_fn valid, void *user, double *out,
@@ -136,7 +137,7 @@ void orc_project_batch(const orc_problem *P, const double *q_in, double *q_out, 
                        int32_t *iters, size_t B, int nthreads);
 void orc_sample_project_batch(const orc_problem *P, uint64_t seed, uint64_t first_index,
                               double *q_out, uint8_t *ok, int32_t *iters, size_t B, int nthreads);
-/* E edges of discreteGeodesic (interpolate == true); n_states[e] is the true length, also beyond max_states */
+/* E edges of discreteGeodesic (interpolate == true); n_states[e] == max_states + 1: the list did not fit */
 void orc_discrete_geodesic_batch(const orc_problem *P, const double *from, const double *to, size_t E, int max_states,
                                  double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, int nthreads);
 /* elementary functions of this build (libm or detmath) exposed for tests */

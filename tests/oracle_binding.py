@@ -212,8 +212,8 @@ class Oracle:
         n = C.c_int(0); its = C.c_int64(0)
         ok = self.lib.orc_discrete_geodesic(C.byref(P), _dptr(a), _dptr(b), int(interpolate), None, None,
                                             _dptr(out), max_states, C.byref(n), C.byref(its))
-        if n.value > max_states:  # the list did not fit: n_states reports the true length
-            return self.discrete_geodesic(P, a, b, interpolate, max_states=n.value)
+        if n.value > max_states:  # the list did not fit (max_states + 1): run the edge again with room
+            return self.discrete_geodesic(P, a, b, interpolate, max_states=4 * max_states)
         return bool(ok), out[: n.value].copy(), its.value
 
     def compute_t_wo(self, P, q7):

@@ -426,6 +426,8 @@ def test_stock_structure_kernels_and_general_kernels(gpu_ctx, oracle_det, calibr
         st, n, gok = st.cpu().numpy(), n.cpu().numpy(), gok.cpu().numpy()
         for e in range(len(frm)):
             ok_c, st_c, _ = oracle_det.discrete_geodesic(P, frm[e], to[e], interpolate=True, max_states=32)
+            if n[e] > 32:  # did not fit: stopped at the full list (the oracle binding re-ran the edge with room)
+                assert n[e] == 33 and gok[e] == 0 and len(st_c) > 32 and np.array_equal(st[e].view(np.uint64), st_c[:32].view(np.uint64))
+                continue
             assert int(gok[e]) == int(ok_c) and int(n[e]) == len(st_c), (calibrated, stock, e)
-            m = min(int(n[e]), 32)  # n is the true length, also past the buffer
-            assert np.array_equal(st[e, :m].view(np.uint64), st_c[:m].view(np.uint64))
+            assert np.array_equal(st[e, : n[e]].view(np.uint64), st_c.view(np.uint64))

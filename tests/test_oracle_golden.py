@@ -398,12 +398,15 @@ def test_det_and_libm_builds_on_the_recorded_extend_workload(oracle_det, oracle_
 
 
 def test_geodesic_reports_a_list_that_does_not_fit(oracle_det):
-    """n_states is the true length of the geodesic, also beyond max_states (a cut list must never look complete)"""
+    """a traversal that needs more than max_states entries stops there and reports max_states + 1 with false (a cut list
+    must never look complete, and a creeping edge must not run on unbounded); the binding re-runs with room"""
     cfg = load_cfg("Wine_Bottle")
     P = oracle_det.problem(cfg)
     rows = load_path_rows("Wine_Bottle")
     full_ok, full, _ = oracle_det.discrete_geodesic(P, rows[14], rows[21], interpolate=True, max_states=64)
     st, n, ok, _ = oracle_det.discrete_geodesic_batch(P, rows[14:15], rows[21:22], 3, 1)
-    assert n[0] == len(full) == 7 and bool(ok[0]) == full_ok and np.array_equal(st[0, :3], full[:3])
+    assert len(full) == 7 and n[0] == 4 and ok[0] == 0 and np.array_equal(st[0, :3], full[:3])
+    st, n, ok, _ = oracle_det.discrete_geodesic_batch(P, rows[14:15], rows[21:22], 7, 1)  # exactly enough room
+    assert n[0] == 7 and bool(ok[0]) == full_ok and np.array_equal(st[0], full)
     ok2, st2, _ = oracle_det.discrete_geodesic(P, rows[14], rows[21], interpolate=True, max_states=2)  # binding re-runs
     assert ok2 == full_ok and np.array_equal(st2, full)
