@@ -76,9 +76,11 @@ int hip_fail(hipError_t e, const char *what)
 
 } // namespace
 
-// scheduling defaults (sweeps: tools/time_small.py, tools/time_mid.py, tools/time_lpt3.py)
-constexpr size_t kDefaultSmallBatch = 24576;   // up to here the latency kernel alone is quickest
-constexpr size_t kDefaultLptMinBatch = 28672;  // from about one fill of the throughput kernel (30720 samples) on, ordering pays for the scout
+// scheduling defaults (round-2 sweep with the faster throughput kernel, Wine_Bottle, ms — latency kernel alone / throughput
+// kernel + hand-over / the same behind the scout's longest-first order: 8192: 1.48 / 1.48 / 1.59; 16384: 2.54 / 2.36 / 2.63;
+// 32768: 4.23 / 3.32 / 3.39; 49152: 6.24 / 4.48 / 4.01; 65536: 8.06 / 5.54 / 4.98)
+constexpr size_t kDefaultSmallBatch = 12288;   // up to here the latency kernel alone is quickest
+constexpr size_t kDefaultLptMinBatch = 40960;  // from here on the longest-first order pays for the scout pass
 
 struct ccmp_ctx {
   int device = 0;
