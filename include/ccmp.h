@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CCMP_VERSION 100
+#define CCMP_VERSION 200
 
 enum {
   CCMP_OK = 0,
