@@ -893,6 +893,8 @@ int ccmp_sample_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_pr
 // over xGMI; GPU 0 then holds every shard's valid states and hands them to the host tree in global sample order.
 // librccl is opened at run time (dlopen): libccmp.so has no link-time dependency on it, and a process that already
 // carries an RCCL (PyTorch's) shares that copy.
+} // extern "C"
+
 namespace {
 
 struct RcclApi {
@@ -934,6 +936,8 @@ int rccl_fail(ncclResult_t r, const char *what)
 }
 
 } // namespace
+
+extern "C" {
 
 struct ccmp_comm {
   int n = 0;
