@@ -76,11 +76,18 @@ int hip_fail(hipError_t e, const char *what)
 
 } // namespace
 
-// scheduling defaults (round-2 sweep with the faster throughput kernel, Wine_Bottle, ms — latency kernel alone / throughput
-// kernel + hand-over / the same behind the scout's longest-first order: 8192: 1.48 / 1.48 / 1.59; 16384: 2.54 / 2.36 / 2.63;
-// 32768: 4.23 / 3.32 / 3.39; 49152: 6.24 / 4.48 / 4.01; 65536: 8.06 / 5.54 / 4.98)
-constexpr size_t kDefaultSmallBatch = 12288;   // up to here the latency kernel alone is quickest
-constexpr size_t kDefaultLptMinBatch = 40960;  // from here on the longest-first order pays for the scout pass
+// scheduling defaults (round-2 sweeps with the faster throughput kernel, Wine_Bottle / stefan, in-process, ms):
+//   B        latency kernel alone   throughput + hand-over at once   + hand-over below 80 % occupancy   scout + 80 %
+//   8192     1.46 / 2.39            1.41 / 2.41                      1.59 / 2.64                        1.78 / 2.86
+//   12288    1.96 / 3.14            1.91 / 3.14                      1.84 / 2.90                        1.93 / 3.06
+//   16384    2.27 / 3.98            2.37 / 3.92                      2.06 / 3.39                        2.16 / 3.37
+//   20480    3.21 / 4.80            3.03 / 4.77                      2.35 / 3.83                        2.34 / 3.68
+//   28672    4.01 / 6.26            3.20 / 5.42                      3.02 / 4.93                        2.85 / 4.45
+//   32768    4.24 / 7.10            3.44 / 5.69                      3.43 / 5.38                        3.09 / 4.88
+// (from 49152 on the scout with immediate hand-over is best or equal; from 120000 on no hand-over at all)
+constexpr size_t kDefaultSmallBatch = 10240;   // up to here the latency kernel alone is quickest
+constexpr size_t kDefaultLptMinBatch = 26624;  // from here on the longest-first order pays for the scout pass
+constexpr size_t kOccupancyHandoverBelow = 40960; // smaller batches: keep the throughput kernel going while >= 80 % of its slots are busy
 
 struct ccmp_ctx {
   int device = 0;
@@ -324,7 +331,7 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
     if (value != 0 && value != 1) return CCMP_EINVAL;
     ctx->stock_kernels = (int)value;
   } else if (!strcmp(name, "handover_threshold")) { // -1 = automatic, 0..10 = hand a wave over once <= this many groups are busy
-    if (value < -1 || value > 10) return CCMP_EINVAL;
+    if (value < -1 || value > 110) return CCMP_EINVAL; // 11..110: occupancy-driven, hand over below (value - 10) % of the group slots
     ctx->dump_threshold = (int)value;
   } else {
     return CCMP_EINVAL;
@@ -409,9 +416,10 @@ static FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order)
   // last fill of a 262144-sample batch it predicts <= 21 iterations and the truth is <= 23): nothing worth handing
   // over is left (-3 % at 262144 Wine_Bottle without it, tools/time_lpt3.py).  An explicit threshold keeps hand-over.
   if (pl.scout && (ctx->lpt == 2 || (ctx->dump_threshold < 0 && B >= 120000))) pl.handover = false;
-  // Once the queue is dry the samples still in flight go to the latency kernel at once (it iterates ~20x faster than
-  // a fully occupied throughput wave); sweeps: tools/time_mid.py, tools/time_lpt3.py.
-  pl.dump_threshold = ctx->dump_threshold >= 0 ? ctx->dump_threshold : 10;
+  // the samples still in flight go to the latency kernel (it iterates ~15x faster than a fully occupied throughput wave but
+  // spends twice the SIMD-cycles per iteration): at once for large batches; for batches of about one fill of the
+  // throughput kernel only when the samples in flight no longer fill 80 % of its group slots (value 90 = 10 + 80 %)
+  pl.dump_threshold = ctx->dump_threshold >= 0 ? ctx->dump_threshold : (B < kOccupancyHandoverBelow ? 90 : 10);
   if (pl.handover) {
     const size_t in_flight = (size_t)pl.group_blocks * 10;
     pl.latency_blocks = (int)(in_flight < lat_cap ? in_flight : lat_cap);

@@ -413,6 +413,16 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
       head = shfl_u64(head, 0);
       dry = head >= B;
     }
+    // occupancy-driven hand-over (dump_threshold > 10: its excess over 10 is a percentage): with the queue dry the waves
+    // keep iterating while the samples in flight — B minus the finished count in queue[3] — still fill that share of
+    // the launch's group slots, and all hand over together once they do not
+    if (pool != nullptr && dry && dump_threshold > 10) {
+      unsigned long long done = 0;
+      if (lane == 0) done = __hip_atomic_load(queue + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      done = shfl_u64(done, 0);
+      const unsigned long long in_flight = B - done, slots = (unsigned long long)gridDim.x * kGroupsPerWave;
+      if (in_flight * 100ull >= slots * (unsigned long long)(dump_threshold - 10)) dry = false;
+    }
     if (pool != nullptr && dry &&
         __builtin_popcountll(__builtin_amdgcn_ballot_w64(active && r == 0)) <= dump_threshold) {
       unsigned long long slot = 0;
@@ -505,6 +515,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
         const bool gbad = ((badmask >> leader) & 0x3Full) != 0ull;
         ok_out[idx] = (uint8_t)((!gbad) && (norm1 < K.tol_pos) && (norm2 < K.tol_rot));
         if (iters_out) iters_out[idx] = (uint16_t)updates;
+        if (pool != nullptr && dump_threshold > 10) atomicAdd(queue + 3, 1ull); // finished count of the occupancy-driven hand-over
       }
       if (fin) active = false;
     }

@@ -112,12 +112,13 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx);
 int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
 /* projector scheduling: hand_over 0 = throughput kernel (10 samples per wavefront) only, 1 = that kernel until the
  * sample queue drains, then the latency kernel on the samples still in flight (default), 2 = latency kernel only;
- * batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = built-in default, 12288).
+ * batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = built-in default, 10240).
  * Results are bit-identical under every setting. */
 #define CCMP_DEFAULT ((size_t)-1)
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
-/* tuning knobs (results never change): "handover_threshold" (-1 = automatic, 0..10: hand a wave's samples to the
- * latency kernel once the queue is dry and at most this many of its 10 groups are busy), "flat_kernel" (latency
+/* tuning knobs (results never change): "handover_threshold" (-1 = automatic; 0..10: hand a wave's samples to the
+ * latency kernel once the queue is dry and at most this many of its 10 groups are busy; 11..110: occupancy-driven —
+ * all waves hand over together once the samples in flight fill less than (value - 10) per cent of the launch's group slots), "flat_kernel" (latency
  * work — small batches, single states, handed-over samples: 1 = one sample per 128-thread block with every
  * evaluation of an iteration in one round (default), 0 = one wavefront per sample), "stock_kernels" (1 = when both arms
  * carry the exact-zero structure of the uncalibrated Panda, run kernels that skip the products with those zeros —
@@ -126,7 +127,7 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
 /* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
  * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is
  * processed longest first, straggler hand-over kept up to 120000 samples and dropped above (default); 2 = the same
- * without hand-over at any size.  Used for batches of at least min_batch samples (CCMP_DEFAULT = built-in default, 40960).  Results are bit-identical under
+ * without hand-over at any size.  Used for batches of at least min_batch samples (CCMP_DEFAULT = built-in default, 26624).  Results are bit-identical under
  * every setting. */
 int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch);
 int ccmp_ctx_device(const ccmp_ctx *ctx);

@@ -115,11 +115,12 @@ def test_project_fd_bitwise(gpu_ctx, oracle_det, obj, B, seed):
 
 @pytest.mark.parametrize("flat", [1, 0])
 @pytest.mark.parametrize("schedule,small,lpt,thr", [(0, 0, 0, -1), (1, 0, 0, -1), (1, 0, 0, 2), (2, 0, 0, -1), (1, 8192, 0, -1),
-                                                    (1, 0, 1, -1), (1, 0, 1, 10), (0, 0, 2, -1)])
+                                                    (1, 0, 1, -1), (1, 0, 1, 10), (0, 0, 2, -1), (1, 0, 0, 90), (1, 0, 1, 45)])
 def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, lpt, thr, flat):
     """group kernel only / group kernel + straggler hand-over to the latency kernel / latency kernel only /
-    default policy / FP32-scout longest-first with and without hand-over, each with the one-round 128-thread
-    latency kernel (flat) and with the one-wavefront-per-sample kernel: all bit-identical to the oracle."""
+    default policy / FP32-scout longest-first with and without hand-over / occupancy-driven hand-over (thr > 10: hand
+    over once the samples in flight fill less than thr - 10 per cent of the group slots), each with the one-round
+    128-thread latency kernel (flat) and with the one-wavefront-per-sample kernel: all bit-identical to the oracle."""
     if flat == 0 and schedule == 0:
         pytest.skip("group kernel only: no latency kernel involved")
     import torch
