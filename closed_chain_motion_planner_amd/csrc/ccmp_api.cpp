@@ -35,7 +35,8 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned int done_seq, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
-                                    unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
+                                    unsigned long long seed, unsigned long long first, int lane_blocks, int rows_blocks,
+                                    double *pool, int cap_iter, hipStream_t st);
 hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                    unsigned int *hist, unsigned int *order, unsigned long long *queue,
                                    unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
@@ -105,6 +106,9 @@ struct ccmp_ctx {
   size_t lpt_min_batch = kDefaultLptMinBatch; // below this the scout costs more than the tail it removes
   void *lpt_buf = nullptr;             // pred (u16 x B) | hist (u32 x 1024) | order (u32 x B)
   size_t lpt_cap = 0;                  // in samples
+  int analytic_cap = 96;               // analytic mode: samples past this many iterations go to the rows kernel (0 = never)
+  size_t analytic_small_batch = 16384; // analytic mode: at or below, the rows kernel alone
+  size_t analytic_handover_max = 131072; // analytic mode: hand-over for batches up to here (larger ones: one-lane kernel alone)
   int dump_threshold = -1;             // hand a wave's samples over once the queue is dry and <= this many groups are busy; -1 = auto
   size_t small_batch = kDefaultSmallBatch;    // at or below: latency kernel on everything
   unsigned int *scan = nullptr;        // compaction block counts
@@ -287,7 +291,7 @@ int ccmp_ctx_create(int device, ccmp_ctx **out)
   ctx->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate"); }
-  e = hipMalloc((void **)&ctx->queue, 8 * sizeof(unsigned long long) + 64 * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64: analytic kernel
+  e = hipMalloc((void **)&ctx->queue, (8 + 64 + 2) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64 + 2: analytic kernels
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return hip_fail(e, "hipMalloc(queue)"); }
   *out = ctx;
   return CCMP_OK;
@@ -330,6 +334,15 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "stock_kernels")) { // 1 = kernels specialised for the stock Panda structure when it applies (default)
     if (value != 0 && value != 1) return CCMP_EINVAL;
     ctx->stock_kernels = (int)value;
+  } else if (!strcmp(name, "analytic_cap")) { // analytic mode: hand samples past this many iterations to the rows kernel (0 = never)
+    if (value < 0 || value > 65535) return CCMP_EINVAL;
+    ctx->analytic_cap = (int)value;
+  } else if (!strcmp(name, "analytic_handover_max")) { // analytic mode: hand-over for batches up to this many samples
+    if (value < 0) return CCMP_EINVAL;
+    ctx->analytic_handover_max = (size_t)value;
+  } else if (!strcmp(name, "analytic_small_batch")) { // analytic mode: at or below this many samples the rows kernel alone
+    if (value < 0) return CCMP_EINVAL;
+    ctx->analytic_small_batch = (size_t)value;
   } else if (!strcmp(name, "handover_threshold")) { // -1 = automatic, 0..10 = hand a wave over once <= this many groups are busy
     if (value < -1 || value > 110) return CCMP_EINVAL; // 11..110: occupancy-driven, hand over below (value - 10) % of the group slots
     ctx->dump_threshold = (int)value;
@@ -458,8 +471,30 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (!q_out || !ok || (mode == 0 && !q_in)) return CCMP_EINVAL;
   if ((((uintptr_t)q_in) | ((uintptr_t)q_out)) & 15u) return CCMP_EINVAL; // rows are moved in 16-byte pieces
   if (p->jacobian_mode != CCMP_JAC_FD) {
-    const int nblocks = projector_blocks(ctx, B, 64, 4); // one wavefront per SIMD (256 + 190 registers per lane)
-    HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, nblocks, st));
+    // Analytic mode.  One sample per lane (one wavefront per SIMD) is the throughput kernel; it runs a sample at ~7 us per
+    // iteration whatever the occupancy, so its longest sample bounds the launch.  With twin stock arms the six-lanes-per-
+    // sample rows kernel (~4 us per iteration, 2.5x the SIMD-cycles per sample-iteration) takes small batches alone and,
+    // for mid-size batches, the samples that pass analytic_cap iterations.  In-process sweep (Wine_Bottle / stefan, ms;
+    // one-lane alone | hand-over past 96 iterations | rows alone): 4096: 1.43 / 1.79 | 1.23 / 1.48 | 0.95 / 1.19;
+    // 16384: 1.44 / 1.81 | 1.25 / 1.51 | 1.00 / 1.48; 65536: 1.91 / 1.96 | 1.63 / 1.65 | 1.73 / 2.38; 262144: 2.71 / 3.41 |
+    // 2.56 / 3.43 | -; 1048576: 5.75 / 8.68 | 5.83 / 8.98 | -.  Other problems (calibrated arms, tilted bases): one-lane alone.
+    const int lane_blocks = projector_blocks(ctx, B, 64, 4);
+    if (!K.twin_arms || ctx->analytic_cap <= 0 || (B > ctx->analytic_handover_max && B > ctx->analytic_small_batch)) {
+      HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, lane_blocks, 0, nullptr,
+                                       0, st));
+      return CCMP_OK;
+    }
+    const size_t rows_cap = (size_t)ctx->num_cus * 8; // waves of the rows kernel: two per SIMD (16.5 KB of LDS each)
+    if (B <= ctx->analytic_small_batch) {
+      const size_t want = (B + 9) / 10;
+      HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, 0,
+                                       (int)(want < rows_cap ? want : rows_cap), nullptr, 0, st));
+      return CCMP_OK;
+    }
+    int rc = ensure_pool(ctx, B); // every sample may be handed over
+    if (rc != CCMP_OK) return rc;
+    HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, lane_blocks, (int)rows_cap,
+                                     ctx->pool, ctx->analytic_cap, st));
     return CCMP_OK;
   }
   const FdPlan pl = plan_fd_batch(ctx, B, ctx->order != nullptr);

@@ -25,6 +25,7 @@ namespace {
 
 constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
 constexpr int kFastQueues = 64; // queue words of the analytic kernel (ccmp_api.cpp allocates and clears as many)
+constexpr int kPoolEntry = 18;  // hand-over record: x[14], idx, (iter, updates), norm1, norm2 (as ccmp_fd_common.h)
 
 // Forward chain of one arm in its own base frame, keeping every joint's axis z_i and origin o_i; joint indices are
 // compile-time so that the STOCK instantiation can skip the products with the stock Panda's exact zeros (ccmp_kin.h).
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K_ar
                                                           uint16_t *__restrict__ iters_out,
                                                           double *__restrict__ q_ambient, unsigned long long B,
                                                           unsigned long long *queue, unsigned long long seed,
-                                                          unsigned long long first_index)
+                                                          unsigned long long first_index, double *__restrict__ pool,
+                                                          unsigned long long *pool_count, int cap_iter)
 {
   // the constants as an LDS copy read by broadcast: with compile-time joint indices the compiler would otherwise hoist
   // every scalar load of the kernarg copy out of the Newton loop and spill ~300 SGPRs into VGPR lanes (1170 v_readlane /
@@ -92,6 +94,21 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K_ar
   int qk = blockIdx.x % kFastQueues, tried = 0;
 
   for (;;) {
+    // ---- hand-over: this kernel runs a sample on ONE lane at ~7 us per iteration whatever the occupancy, so the serial
+    // chain of its longest sample bounds the launch (250 iterations: 1.85 ms).  A sample that has used cap_iter iterations
+    // leaves its state (x, index, counters — at the loop top, where function(x) and the loop test come next) in the pool
+    // for the six-lanes-per-sample kernel below, which iterates ~3x faster per sample.
+    if (pool != nullptr && active && iter >= cap_iter) {
+      const unsigned long long slot = atomicAdd(pool_count, 1ull);
+      double *ent = pool + slot * kPoolEntry;
+#pragma unroll
+      for (int e = 0; e < 14; e++) ent[e] = x[e];
+      ent[14] = __longlong_as_double((long long)idx);
+      ent[15] = __hiloint2double(updates, iter);
+      ent[16] = norm1;
+      ent[17] = norm2;
+      active = false; // the refill below gives the lane its next sample in this same pass
+    }
     unsigned long long need = __builtin_amdgcn_ballot_w64(!active && !drained);
     while (need != 0ull) {
       const unsigned long long lo = B * (unsigned long long)qk / kFastQueues, hi = B * (unsigned long long)(qk + 1) / kFastQueues;
@@ -207,25 +224,282 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K_ar
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// project_fast_rows_kernel — the analytic mode's LATENCY kernel: six lanes per sample, ten samples per wavefront.
+// Lane r of a group carries row r % 3 of arm r / 3's chain frame (the decomposition of the reference-arithmetic
+// throughput kernel's phase 1, ccmp_kernels_fd.hip): per joint the lane computes the joint's rotation matrix (13
+// operations, all lanes alike) and ONE row of the frame product, its component of the joint axis z_i = R axis_i and of the
+// joint origin; axes and origins of all fourteen joints, the two tool poses and the Jacobian pass through LDS.  An
+// iteration is ~1.35 k instructions per lane instead of ~3.6 k (2.3 us instead of 7.4 us when a wave has its SIMD to
+// itself), at 2.5x the SIMD-cycles per sample-iteration: used for the samples the one-lane kernel hands over, and alone for
+// small batches.  Every value is produced by the same operations on the same operands as in the one-lane kernel and in
+// the oracle (orc_jacobian_analytic): bit-identical.  Twin stock arms and diag(+-1) base frames only (K.twin_arms).
+// SRC 0: q_in; SRC 1: ambient sampler; SRC 2: the hand-over pool.
+constexpr int rGroup = 6, rGroups = 10;
+constexpr int rX = 0, rSC = 14, rZO = 42, rT = 126, rJ = 150, rRec = 179; // doubles per group: x, sin/cos, (z, o)[2][7], poses, J; odd stride
+
+template <int I>
+__device__ __forceinline__ void rows_chain_from(const ccmp_consts &K, double *rec, const double *sc, int arm, int row, bool live,
+                                                double &R0, double &R1, double &R2, double &o)
+{
+  if constexpr (I < 7) {
+    asm volatile("" ::: "memory");
+    constexpr int NZ = kStockOff[I];
+    if (NZ & 1) o = CCMP_FMA(R0, K.offset[0][I][0], o);
+    if (NZ & 2) o = CCMP_FMA(R1, K.offset[0][I][1], o);
+    if (NZ & 4) o = CCMP_FMA(R2, K.offset[0][I][2], o);
+    const double *a = K.axis[0][I];
+    // this lane's component of z_i = R axis_i (a stock z joint: the third column of R) and of the joint origin
+    const double zr = kStockZ[I] ? R2 : dot3(R0, a[0], R1, a[1], R2, a[2]);
+    if (live) {
+      rec[rZO + (arm * 7 + I) * 6 + row] = zr;
+      rec[rZO + (arm * 7 + I) * 6 + 3 + row] = o;
+    }
+    const double s = sc[2 * I], c = sc[2 * I + 1];
+    double n0, n1, n2;
+    if constexpr (kStockZ[I] != 0) { // mul_zrot, one row
+      const double t = 1.0 - c;
+      const double w = t + c;
+      const double ns = -s;
+      n0 = CCMP_FMA(R1, s, R0 * c);
+      n1 = CCMP_FMA(R1, c, R0 * ns);
+      n2 = R2 * w;
+    } else { // rot_sc + one row of mul33
+      double Rj[9];
+      rot_sc(a, K.aprod[0][I], s, c, Rj);
+      n0 = dot3(R0, Rj[0], R1, Rj[3], R2, Rj[6]);
+      n1 = dot3(R0, Rj[1], R1, Rj[4], R2, Rj[7]);
+      n2 = dot3(R0, Rj[2], R1, Rj[5], R2, Rj[8]);
+    }
+    R0 = n0; R1 = n1; R2 = n2;
+    rows_chain_from<I + 1>(K, rec, sc, arm, row, live, R0, R1, R2, o);
+  }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
+    const ccmp_consts K_arg, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
+    uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
+    unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
+    const unsigned long long *__restrict__ pool_count, int wrap_output)
+{
+  __shared__ double ktab[kConstsDoubles + 1];
+  __shared__ double lds[rGroups * rRec];
+  {
+    const double *src = reinterpret_cast<const double *>(&K_arg);
+    for (int k = threadIdx.x; k < kConstsDoubles; k += 64) ktab[k] = src[k];
+  }
+  __syncthreads();
+  const ccmp_consts &K = *reinterpret_cast<const ccmp_consts *>(ktab);
+  const int lane = threadIdx.x;
+  const int g = lane / rGroup, r = lane - rGroup * g;
+  const bool live = g < rGroups;
+  const int leader = live ? rGroup * g : 0;
+  double *rec = lds + (live ? g : 0) * rRec; // idle lanes alias group 0 for reads, never write
+  const int arm = r < 3 ? 0 : 1, row = r < 3 ? r : r - 3;
+  const double d_lane = K.base_R[arm][4 * row], bp_lane = K.base_p[arm][row];
+  const unsigned long long total = (SRC == 2) ? *pool_count : B;
+
+  unsigned long long idx = 0;
+  int iter = 0, updates = 0;
+  double norm1 = 0.0, norm2 = 0.0;
+  bool active = false, drained = false;
+
+  for (;;) {
+    // ---- refill: groups without a sample pull the next ticket ---------------------------------------------------
+    {
+      const bool want = live && !active && !drained;
+      unsigned long long t = 0;
+      if (want && r == 0) t = atomicAdd(queue, 1ull);
+      t = __shfl(t, leader);
+      if (want) {
+        if (t < total) {
+          active = true;
+          if (SRC == 2) {
+            const double *ent = pool + t * kPoolEntry;
+            idx = (unsigned long long)__double_as_longlong(ent[14]);
+            iter = __double2hiint(ent[15]);
+            updates = __double2loint(ent[15]);
+            norm1 = ent[16];
+            norm2 = ent[17];
+            for (int e = r; e < 14; e += rGroup) rec[rX + e] = ent[e];
+          } else {
+            idx = t; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+            for (int e = r; e < 14; e += rGroup) {
+              double v;
+              if (SRC == 0) v = q_in[idx * 14 + e];
+              else {
+                v = ambient_uniform(K, seed, first_index + idx, e);
+                if (q_ambient) q_ambient[idx * 14 + e] = v;
+              }
+              rec[rX + e] = v;
+            }
+          }
+        } else drained = true;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+    __syncthreads();
+    // ---- function(x): sines / cosines (6 lanes, 3 rounds), both chains by rows, tool poses by rows ------------------
+    for (int e = r; e < 14; e += rGroup) {
+      double s, c;
+      ccmp_sincos(rec[rX + e], &s, &c);
+      if (live) { rec[rSC + 2 * e] = s; rec[rSC + 2 * e + 1] = c; }
+    }
+    __syncthreads();
+    {
+      double R0 = row == 0 ? 1.0 : 0.0, R1 = row == 1 ? 1.0 : 0.0, R2 = row == 2 ? 1.0 : 0.0, o = 0.0;
+      rows_chain_from<0>(K, rec, rec + rSC + 14 * arm, arm, row, live, R0, R1, R2, o);
+      asm volatile("" ::: "memory");
+      double pf = o; // tool_pose_t<true>, diag(+-1) base frame, one row
+      if (kStockEe & 1) pf = CCMP_FMA(R0, K.ee[0][0], pf);
+      if (kStockEe & 2) pf = CCMP_FMA(R1, K.ee[0][1], pf);
+      if (kStockEe & 4) pf = CCMP_FMA(R2, K.ee[0][2], pf);
+      const double *Rt = K.R_tool[0];
+      const double f0 = dot3(R0, Rt[0], R1, Rt[3], R2, Rt[6]);
+      const double f1 = dot3(R0, Rt[1], R1, Rt[4], R2, Rt[7]);
+      const double f2 = dot3(R0, Rt[2], R1, Rt[5], R2, Rt[8]);
+      if (live) {
+        double *T = rec + rT + 12 * arm;
+        T[3 * row] = d_lane * f0;
+        T[3 * row + 1] = d_lane * f1;
+        T[3 * row + 2] = d_lane * f2;
+        T[9 + row] = CCMP_FMA(d_lane, pf, bp_lane);
+      }
+    }
+    __syncthreads();
+    double T0[12], T1[12], f[2], dq[4], pc[3];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { T0[k] = rec[rT + k]; T1[k] = rec[rT + 12 + k]; }
+    chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, dq, pc);
+    // ---- loop condition of ConstraintFunction.h:68, quirks included ----------------------------------------------
+    bool cont = false;
+    if (active) {
+      const bool c1 = f[0] > K.tol_pos;
+      norm1 = c1 ? 1.0 : 0.0;
+      bool resid = c1;
+      if (!c1) { norm2 = f[1]; resid = f[1] > K.tol_rot; }
+      if (resid) { cont = iter < K.max_iter; iter++; }
+    }
+    {
+      const bool fin = active && !cont;
+      bool bad = false;
+      if (fin) {
+        for (int e = r; e < 14; e += rGroup) {
+          const double v = rec[rX + e];
+          const int jj = e < 7 ? e : e - 7;
+          if (v < K.lbe[jj]) bad = true;
+          if (v > K.ube[jj]) bad = true;
+          q_out[idx * 14 + e] = wrap_output ? wrap_pi(v) : v;
+        }
+      }
+      const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);
+      if (fin && r == 0) {
+        const bool gbad = ((badmask >> leader) & 0x3Full) != 0ull;
+        ok_out[idx] = (uint8_t)((!gbad) && (norm1 < K.tol_pos) && (norm2 < K.tol_rot));
+        if (iters_out) iters_out[idx] = (uint16_t)updates;
+      }
+      if (fin) active = false;
+    }
+    if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue;
+    // ---- analytic Jacobian: probes (every lane, its arm), then this lane's 2-3 joints of its arm ---------------------
+    {
+      double u[3] = {0, 0, 0}, n[3] = {0, 0, 0}, aw[3], bw[3];
+      if (f[0] > 0.0) {
+        const double inv = 1.0 / f[0];
+#pragma unroll
+        for (int k = 0; k < 3; k++) u[k] = (pc[k] - K.init_p[k]) * inv;
+      }
+      const double vn = ccmp_sqrt(dot3(dq[0], dq[0], dq[1], dq[1], dq[2], dq[2]));
+      if (vn > 0.0) {
+        const double sg = (dq[3] < 0.0 ? -1.0 : 1.0) / vn;
+#pragma unroll
+        for (int k = 0; k < 3; k++) n[k] = dq[k] * sg;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        aw[k] = dot3(T1[3 * k], u[0], T1[3 * k + 1], u[1], T1[3 * k + 2], u[2]);
+        bw[k] = dot3(T1[3 * k], n[0], T1[3 * k + 1], n[1], T1[3 * k + 2], n[2]);
+      }
+      // base_R[arm] is diag(d0, d1, d2) here, but the probes take the general transposed product (the oracle's
+      // m3t_vec): exact zeros are added, the bits are those of the one-lane kernel
+      double al[3], bl[3], pl[3], dp[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) dp[k] = T0[9 + k] - K.base_p[arm][k];
+      mulTvec(K.base_R[arm], aw, al);
+      mulTvec(K.base_R[arm], bw, bl);
+      mulTvec(K.base_R[arm], dp, pl);
+      const double sgn = arm == 0 ? 1.0 : -1.0;
+#pragma unroll
+      for (int nn = 0; nn < 3; nn++) {
+        const int i = row + 3 * nn; // joints row, row + 3, row + 6 of this lane's arm
+        if (i < 7 && live) {
+          const double *zo = rec + rZO + (arm * 7 + i) * 6;
+          const double z0 = zo[0], z1 = zo[1], z2 = zo[2];
+          const double r0 = pl[0] - zo[3], r1 = pl[1] - zo[4], r2 = pl[2] - zo[5];
+          const double cx = CCMP_FMA(z1, r2, -(z2 * r1));
+          const double cy = CCMP_FMA(z2, r0, -(z0 * r2));
+          const double cz = CCMP_FMA(z0, r1, -(z1 * r0));
+          rec[rJ + arm * 7 + i] = sgn * dot3(al[0], cx, al[1], cy, al[2], cz);
+          rec[rJ + 14 + arm * 7 + i] = sgn * dot3(bl[0], z0, bl[1], z1, bl[2], z2);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- Newton update: x -= 0.30 * J.jacobiSvd().solve(f) ---------------------------------------------------------
+    {
+      double Jr[28], dx[14];
+#pragma unroll
+      for (int k = 0; k < 28; k++) Jr[k] = rec[rJ + k];
+      solve_minnorm(Jr, f[0], f[1], dx);
+      if (cont) {
+#pragma unroll
+        for (int e = 0; e < 14; e++)
+          if (e % rGroup == r) rec[rX + e] = CCMP_FMA(-K.step, dx[e], rec[rX + e]);
+        updates++;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 } // namespace
 
+// One-lane kernel (+ hand-over of the samples past cap_iter iterations to the rows kernel when pool != NULL), or the
+// rows kernel alone (lane_blocks == 0).  queue: kFastQueues words for the one-lane kernel, then one word for the rows
+// kernel's tickets and one for the pool's fill count.
 extern "C" hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out,
                                                uint8_t *ok, uint16_t *iters, double *q_ambient, size_t B,
                                                unsigned long long *queue, unsigned long long seed,
-                                               unsigned long long first, int nblocks, hipStream_t st)
+                                               unsigned long long first, int lane_blocks, int rows_blocks, double *pool,
+                                               int cap_iter, hipStream_t st)
 {
-  hipError_t e = hipMemsetAsync(queue, 0, kFastQueues * sizeof(unsigned long long), st);
+  hipError_t e = hipMemsetAsync(queue, 0, (kFastQueues + 2) * sizeof(unsigned long long), st);
   if (e != hipSuccess) return e;
-#define CCMP_LAUNCH_FAST(MODE, STOCK)                                                                                              \
-  hipLaunchKernelGGL((project_fast_kernel<MODE, STOCK>), dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
-                     (unsigned long long)B, queue, seed, first)
-  if (mode == 0) {
-    if (K->stock) CCMP_LAUNCH_FAST(0, true);
-    else CCMP_LAUNCH_FAST(0, false);
-  } else {
-    if (K->stock) CCMP_LAUNCH_FAST(1, true);
-    else CCMP_LAUNCH_FAST(1, false);
-  }
+  unsigned long long *rows_queue = queue + kFastQueues, *pool_count = queue + kFastQueues + 1;
+  if (lane_blocks > 0) {
+#define CCMP_LAUNCH_FAST(MODE, STOCK)                                                                                                \
+  hipLaunchKernelGGL((project_fast_kernel<MODE, STOCK>), dim3(lane_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
+                     (unsigned long long)B, queue, seed, first, pool, pool_count, cap_iter)
+    if (mode == 0) {
+      if (K->stock) CCMP_LAUNCH_FAST(0, true);
+      else CCMP_LAUNCH_FAST(0, false);
+    } else {
+      if (K->stock) CCMP_LAUNCH_FAST(1, true);
+      else CCMP_LAUNCH_FAST(1, false);
+    }
 #undef CCMP_LAUNCH_FAST
+    if (pool != nullptr && rows_blocks > 0) // the pool's fill count is read on the device: surplus waves exit at once
+      hipLaunchKernelGGL((project_fast_rows_kernel<2>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode);
+  } else {
+    if (mode == 0)
+      hipLaunchKernelGGL((project_fast_rows_kernel<0>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode);
+    else
+      hipLaunchKernelGGL((project_fast_rows_kernel<1>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode);
+  }
   return hipGetLastError();
 }

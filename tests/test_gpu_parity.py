@@ -265,6 +265,32 @@ def test_analytic_mode_bitwise(gpu_ctx, oracle_det, obj, B):
     assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
 
 
+@pytest.mark.parametrize("cap,small", [(0, 0), (20, 0), (64, 0), (96, 1 << 30)])
+def test_analytic_schedules_are_bitwise_identical(gpu_ctx, oracle_det, cap, small):
+    """analytic mode's kernels: the one-lane kernel alone / with hand-over of the samples past `cap` iterations to the
+    six-lanes-per-sample kernel (lanes hand over at different times: the refill after a hand-over is what once lost
+    samples) / the six-lane kernel alone with several samples per group — all bit-identical to the oracle's analytic mode"""
+    import torch
+
+    c = _constraint("stefan", gpu_ctx, mode=1)
+    P = _oracle_problem(oracle_det, c)
+    B = 60000  # > 20480 group slots of the six-lane kernel: its groups refill
+    q = c.ambient_uniform_batch(0xA9, 0, B)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q.cpu().numpy(), NCPU)
+    gpu_ctx.set_option("analytic_cap", cap)
+    gpu_ctx.set_option("analytic_small_batch", small)
+    try:
+        out = torch.full_like(q, 777.0)
+        _, ok, it = c.project_batch(q, out=out)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_option("analytic_cap", 96)
+        gpu_ctx.set_option("analytic_small_batch", 16384)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+    assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
+    assert it_cpu.max() == 250 and (it_cpu < 20).any()
+
+
 def test_analytic_mode_statistics(gpu_ctx, oracle_det):
     """the opt-in fast mode against the REFERENCE arithmetic (FD oracle): same manifold, same acceptance statistics;
     not bit-comparable with it (bit-identity with the oracle's own analytic mode: test_analytic_mode_bitwise)"""

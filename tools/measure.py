@@ -111,15 +111,26 @@ def analytic(argv):
     ctx = Context(0)
     c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
     c.setJacobianMode(1)
-    for B in (4096, 262144, 1048576):
-        q = c.ambient_uniform_batch(0xC3, 0, B)
-        out = torch.empty_like(q)
-        res = []
-        for wpc in (2, 4, 8):
-            ctx.set_waves_per_cu(wpc)
+    caps = [int(a) for a in argv] or [0, 32, 48, 64]
+    for obj in ("Wine_Bottle", "stefan"):
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        c.setJacobianMode(1)
+        for B in (1024, 4096, 16384, 65536, 262144, 1048576):
+            q = c.ambient_uniform_batch(0xC3, 0, B)
+            out = torch.empty_like(q)
+            res = []
+            ctx.set_option("analytic_handover_max", 1 << 40)
+            for cap in caps:  # 0: one-lane kernel alone; else hand-over past `cap` iterations
+                ctx.set_option("analytic_cap", cap)
+                for small in ((0, 1 << 30) if cap == caps[-1] and B <= 65536 else (0,)):
+                    ctx.set_option("analytic_small_batch", small)
+                    ms = timed(lambda: c.project_batch(q, out=out), reps=5)
+                    res.append("%s %7.3f ms (%.3e/s)" % ("rows-only" if small else "cap%d" % cap, ms, B / ms * 1e3))
+            ctx.set_option("analytic_cap", 96)
+            ctx.set_option("analytic_small_batch", 16384)
+            ctx.set_option("analytic_handover_max", 131072)
             ms = timed(lambda: c.project_batch(q, out=out), reps=5)
-            res.append("wpc%d %7.3f ms (%.3e/s)" % (wpc, ms, B / ms * 1e3))
-        print("analytic B=%-8d " % B + "  ".join(res), flush=True)
+            print("analytic %s B=%-8d " % (obj, B) + "  ".join(res) + "  DEFAULT %7.3f ms (%.3e/s)" % (ms, B / ms * 1e3), flush=True)
 
 
 def host(argv):
