@@ -112,7 +112,7 @@ class jy_ProjectedStateSpace:
     list at the first rejected state — exactly where the reference's loop would have stopped
     (jy_ProjectedStateSpace.cpp:65-68)."""
 
-    def __init__(self, constraint, isValid=None, max_states=256, seed=None):
+    def __init__(self, constraint, isValid=None, max_states=64, seed=None):
         self.constraint_ = constraint
         self.isValid = isValid
         self.max_states = int(max_states)

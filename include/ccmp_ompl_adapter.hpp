@@ -235,10 +235,12 @@ private:
 
 // jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96) for one edge on raw
 // buffers.  `valid` (nullable) is the host StateValidityChecker; it is consulted only when !interpolate,
-// in order, and the list is cut at the first rejected state — where the reference's loop breaks.
+// in order, and the list is cut at the first rejected state — where the reference's loop breaks.  The traversal on the
+// GPU stops when max_states states are listed (edges of the reference's roadmaps have 3-7 states; the work spent beyond a
+// state the checker rejects is bounded by this) and an edge that needs more is run again with four times the room.
 template <class ValidFn>
 inline bool discreteGeodesic(const Projector &proj, const double *from14, const double *to14, bool interpolate, ValidFn valid,
-                             std::vector<std::vector<double>> *geodesic, int max_states = 256)
+                             std::vector<std::vector<double>> *geodesic, int max_states = 64)
 {
   std::vector<double> states;
   int32_t n = 0;
