@@ -16,11 +16,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def latest(pattern):
+    """the newest run of a pass (gpurun merges every call's output into the same directory; process ids repeat across boxes)"""
+    files = glob.glob(pattern)
+    return sorted(files, key=os.path.getmtime)[-1:] if files else []
+
+
 def counters(d, kernel_subs):
     """mean per projector launch = sum over the launch's kernels (group kernel + straggler kernel)"""
     per = {ks: collections.defaultdict(list) for ks in kernel_subs}
     meta = {}
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in latest(os.path.join(d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             for ks in kernel_subs:
                 if ks in r["Kernel_Name"]:
@@ -46,7 +52,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    stats = latest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
     krow = None
     parts = []
