@@ -287,7 +287,7 @@ def main():
             c.compact_valid(q_out, ok, out=q_valid, cnt=cnt)
         else:
             c.compact_valid(q_out, ok, out=vg.rows, cnt=vg.count)
-            vg.launch()  # one collective, enqueued behind the kernels: no host synchronisation in the step
+            vg.launch()  # one asynchronous collective behind this step's kernels; the next step's kernels do not wait for it
         if record:
             kernel_ms.append((e0, e1))
         return ok, it
@@ -296,6 +296,7 @@ def main():
         # communicator set-up (RCCL builds its rings on the first collective): not a step, so that --warmup 0 still
         # times steps and not the rendezvous
         vg.launch()
+        vg.wait()
     for _ in range(args.warmup):
         step(False)
     if world > 1:
@@ -304,6 +305,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ok, it = step(True)
+    if vg is not None:
+        vg.wait()  # every step's all-gather belongs to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -322,7 +325,7 @@ def main():
         counts = vg.counts()  # after the timed region: what the host tree would read when it consumes the states
         n_valid = counts[rank]
         gathered = {"valid_states_all_ranks": int(sum(counts)), "capacity_rows_per_rank": vg.capacity,
-                    "overflow": bool(max(counts) > vg.capacity), "bytes_sent_per_rank": int(vg.send.numel() * 8)}
+                    "overflow": bool(max(counts) > vg.capacity), "bytes_sent_per_rank": int((vg.capacity + 1) * 14 * 8)}
     else:
         n_valid = int(cnt.item())
     rccl_ranks = dist.get_world_size() if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)

@@ -8,7 +8,7 @@ one the north star names: an all-gather that returns the VALID projected states 
 (which lives in one process per rank here; every rank ends up with all valid states, in global
 sample order).
 
-ONE collective per step and no host synchronisation inside it: every rank sends a fixed-capacity
+ONE collective per step, asynchronous, and no host synchronisation inside the step: every rank sends a fixed-capacity
 block — row 0 carries its count of valid states (a uint64 in the first 8 bytes), rows 1.. the
 compacted states — so nothing has to be known on the host before the all-gather is enqueued, and
 the gather runs on the stream behind the projector kernels.  The capacity is a fraction of the
@@ -30,39 +30,82 @@ def shard_range(total, rank, world):
 
 
 class ValidGather:
-    """Preallocated send / receive blocks of the all-gather of valid states.
+    """Preallocated send / receive blocks of the all-gather of valid states, `depth` of them used in turn.
 
         vg = ValidGather(capacity, device)
         constraint.compact_valid(q, ok, out=vg.rows, cnt=vg.count)   # compaction writes straight into the send block
         vg.launch()                                                  # one all_gather, asynchronous, no host sync
-        ...
-        states, counts = vg.unpack()                                 # when the host tree consumes them
+        ...                                                          # next batch: vg.rows / vg.count are the NEXT block
+        states, counts = vg.unpack()                                 # when the host tree consumes the last launch
 
-    Works on CUDA tensors over RCCL and on CPU tensors over gloo (the CPU tests)."""
+    The collective is issued asynchronously (over RCCL it runs on the process group's own stream behind the work already
+    queued on the current stream), so the projector kernels of the next batch do not wait for it; a block is handed out
+    again only after the collective that last used it has been waited for.  Works on CUDA tensors over RCCL and on CPU
+    tensors over gloo (the CPU tests)."""
 
-    def __init__(self, capacity, device, group=None):
+    def __init__(self, capacity, device, group=None, depth=2):
         self.group = group
         self.world = dist.get_world_size(group)
         self.capacity = int(capacity)
-        self.send = torch.zeros((self.capacity + 1, DIM), dtype=torch.float64, device=device)
-        self.recv = torch.zeros((self.world, self.capacity + 1, DIM), dtype=torch.float64, device=device)
-        self.rows = self.send[1:]                                  # (capacity, 14): the compacted valid states
-        self.count = self.send.view(torch.int64)[0, :1]            # uint64 count in the first 8 bytes of row 0
+        self.depth = int(depth)
+        self._send = [torch.zeros((self.capacity + 1, DIM), dtype=torch.float64, device=device) for _ in range(self.depth)]
+        self._recv = [torch.zeros((self.world, self.capacity + 1, DIM), dtype=torch.float64, device=device) for _ in range(self.depth)]
+        self._work = [None] * self.depth
+        self._k = 0       # block the next compaction writes into
+        self._last = 0    # block of the most recent launch
+
+    def _acquire(self):
+        i = self._k % self.depth
+        if self._work[i] is not None:  # the collective that last read this block must be through with it
+            self._work[i].wait()
+            self._work[i] = None
+        return i
+
+    @property
+    def send(self):
+        return self._send[self._acquire()]
+
+    @property
+    def rows(self):
+        """(capacity, 14): where the compacted valid states of the next launch go"""
+        return self.send[1:]
+
+    @property
+    def count(self):
+        """uint64 count of the next launch, in the first 8 bytes of row 0 of its send block"""
+        return self.send.view(torch.int64)[0, :1]
+
+    @property
+    def recv(self):
+        self.wait()
+        return self._recv[self._last]
 
     def launch(self):
-        dist.all_gather_into_tensor(self.recv.view(self.world * (self.capacity + 1), DIM), self.send, group=self.group)
+        i = self._acquire()
+        self._work[i] = dist.all_gather_into_tensor(self._recv[i].view(self.world * (self.capacity + 1), DIM), self._send[i],
+                                                    group=self.group, async_op=True)
+        self._last = i
+        self._k += 1
+
+    def wait(self):
+        """every launched collective has completed (over RCCL: the current stream waits; no host synchronisation)"""
+        for i in range(self.depth):
+            if self._work[i] is not None:
+                self._work[i].wait()
+                self._work[i] = None
 
     def counts(self):
-        """per-rank counts of valid states (host synchronisation)"""
+        """per-rank counts of valid states of the last launch (host synchronisation)"""
         return [int(v) for v in self.recv.view(torch.int64)[:, 0, 0].cpu().tolist()]
 
     def unpack(self):
-        """(states (sum(counts),14) in rank order = global sample order for contiguous shards, counts)"""
+        """(states (sum(counts),14) in rank order = global sample order for contiguous shards, counts) of the last launch"""
         counts = self.counts()
         if max(counts, default=0) > self.capacity:
             raise OverflowError("a rank holds %d valid states, the gather blocks hold %d: repeat with a larger capacity"
                                 % (max(counts), self.capacity))
-        parts = [self.recv[r, 1: 1 + counts[r]] for r in range(self.world)]
+        recv = self.recv
+        parts = [recv[r, 1: 1 + counts[r]] for r in range(self.world)]
         return torch.cat(parts, dim=0), counts
 
 
@@ -70,7 +113,7 @@ def gather_valid(q_valid, count, group=None):
     """Convenience form: all-gather the first `count` rows of every rank's `q_valid` ((cap,14), cap >= count; every
     rank must pass the same cap).  One collective; the host synchronises once, at the end, to cut the padding.
     Returns (states, counts)."""
-    vg = ValidGather(q_valid.shape[0], q_valid.device, group)
+    vg = ValidGather(q_valid.shape[0], q_valid.device, group, depth=1)
     vg.rows.copy_(q_valid)
     vg.count.copy_(count.reshape(1).to(torch.int64))
     vg.launch()

@@ -45,6 +45,13 @@ def _worker(rank, world, port, total, q):
     vg.count.fill_(2 if rank == 0 else 1)
     vg.launch()
     st2, c2 = vg.unpack()
+    # two launches in flight use the two blocks in turn; unpack returns the last one
+    for k in range(3):
+        vg.rows.copy_(torch.full((2, 14), float(10 * k + rank)))
+        vg.count.fill_(1)
+        vg.launch()
+    st3, c3 = vg.unpack()
+    assert st3[:, 0].tolist() == [20.0, 21.0] and c3 == [1, 1]
     vg.count.fill_(5 if rank == 1 else 1)
     vg.launch()
     try:
