@@ -3,8 +3,8 @@
 // Part 1 (always available, no third-party headers): ccmp::Projector, an RAII owner of a
 // ccmp_ctx + ccmp_problem with the reference's method names on raw double[14] buffers;
 // ccmp::SampleBuffer / ccmp::RefSampleBuffer, refill-on-empty batches of GPU-projected samples;
-// ccmp::discreteGeodesic; and the dump formats of the reference's planner run (ccmp::printAsMatrix,
-// ccmp::printGraphML, ccmp::printGraphviz).
+// ccmp::discreteGeodesic; ccmp::ShardedProjector (one process, several GPUs, RCCL all-gather of the valid states); and
+// the dump formats of the reference's planner run (ccmp::printAsMatrix, ccmp::printGraphML, ccmp::printGraphviz).
 //
 // Part 2 (compiled only with -DCCMP_WITH_OMPL, i.e. inside the reference's catkin workspace where
 // OMPL and Eigen exist): drop-in replacements that keep the reference's class names and virtual
@@ -21,6 +21,7 @@
 #ifndef CCMP_OMPL_ADAPTER_HPP
 #define CCMP_OMPL_ADAPTER_HPP
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -275,6 +276,82 @@ inline bool discreteGeodesic(const Projector &proj, const double *from14, const 
   }
   return good;
 }
+
+// One planner process, several GPUs (the reference's shape: src/main.cpp is one process): one context per device and an
+// RCCL communicator over them.  sampleProjectSharded / projectSharded spread a batch over the GPUs in contiguous shards,
+// every GPU compacts its valid states into a fixed-capacity block and ONE all-gather brings them together; the valid
+// states come back in global sample order — what the host tree consumes.  Results are bit-identical to one GPU.
+class ShardedProjector {
+public:
+  // devices: one entry per GPU (RCCL wants distinct devices)
+  ShardedProjector(const std::string &yaml_path, const std::vector<int> &devices)
+  {
+    check(ccmp_problem_from_yaml(yaml_path.c_str(), &problem_), "ccmp_problem_from_yaml");
+    try {
+      for (int d : devices) {
+        ccmp_ctx *c = nullptr;
+        check(ccmp_ctx_create(d, &c), "ccmp_ctx_create");
+        ctxs_.push_back(c);
+      }
+      check(ccmp_comm_create(ctxs_.data(), (int)ctxs_.size(), &comm_), "ccmp_comm_create");
+    } catch (...) {
+      release();
+      throw;
+    }
+  }
+  ~ShardedProjector() { release(); }
+  ShardedProjector(const ShardedProjector &) = delete;
+  ShardedProjector &operator=(const ShardedProjector &) = delete;
+  ccmp_problem &problem() { return problem_; }
+  size_t devices() const { return ctxs_.size(); }
+
+  // jy_ProjectedStateSampler::sampleUniform x B over the GPUs: returns the valid states (row-major [n][14], global sample
+  // order); counts (optional) receives the valid states per shard.  A shard holding more valid states than the block
+  // (block_fraction of the shard; ~22 % of uniform samples are valid) is retried once with full-size blocks.
+  std::vector<double> sampleProjectSharded(uint64_t seed, uint64_t first_index, size_t B, std::vector<uint64_t> *counts = nullptr,
+                                           double block_fraction = 0.5)
+  {
+    return run(nullptr, seed, first_index, B, counts, block_fraction);
+  }
+  // KinematicChainConstraint::project x B (host buffer q_in [B][14]) over the GPUs: the valid projected states
+  std::vector<double> projectSharded(const double *q_in, size_t B, std::vector<uint64_t> *counts = nullptr, double block_fraction = 0.5)
+  {
+    return run(q_in, 0, 0, B, counts, block_fraction);
+  }
+
+private:
+  std::vector<double> run(const double *q_in, uint64_t seed, uint64_t first, size_t B, std::vector<uint64_t> *counts, double fraction)
+  {
+    std::lock_guard<std::mutex> hold(mu_);
+    const size_t n = ctxs_.size(), shard = (B + n - 1) / n;
+    std::vector<uint64_t> cnt(n, 0);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      const size_t rows = attempt == 0 ? std::max<size_t>(1, (size_t)(shard * fraction)) : std::max<size_t>(1, shard);
+      std::vector<double> valid(n * rows * 14);
+      uint64_t nv = 0;
+      const int rc = q_in ? ccmp_project_sharded(comm_, &problem_, q_in, B, nullptr, nullptr, nullptr, rows, valid.data(), n * rows, cnt.data(), &nv)
+                          : ccmp_sample_project_sharded(comm_, &problem_, seed, first, B, nullptr, nullptr, nullptr, rows, valid.data(), n * rows,
+                                                        cnt.data(), &nv);
+      if (rc == CCMP_EOVERFLOW && attempt == 0) continue;
+      check(rc, "ccmp_project_sharded");
+      valid.resize((size_t)nv * 14);
+      if (counts) *counts = cnt;
+      return valid;
+    }
+    return {};
+  }
+  void release()
+  {
+    if (comm_) ccmp_comm_destroy(comm_);
+    comm_ = nullptr;
+    for (ccmp_ctx *c : ctxs_) ccmp_ctx_destroy(c);
+    ctxs_.clear();
+  }
+  std::vector<ccmp_ctx *> ctxs_;
+  ccmp_comm *comm_ = nullptr;
+  ccmp_problem problem_;
+  std::mutex mu_;
+};
 
 // ---- dump formats of the reference's planner run ----------------------------------------------------------------------
 // PathGeometric::printAsMatrix as ConstrainedProblem::solveOnce writes `<obj>_path.txt`

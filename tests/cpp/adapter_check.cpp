@@ -81,6 +81,14 @@ int main(int argc, char **argv)
       std::printf("gauss 0\n");
       print_hex(g, 14);
     }
+    // one process, "several" GPUs with the collective: this box has one, so the communicator has one rank
+    {
+      ccmp::ShardedProjector S(argv[1], std::vector<int>{0});
+      std::vector<uint64_t> counts;
+      std::vector<double> valid = S.sampleProjectSharded(42, 0, 500, &counts);
+      std::printf("sharded n_valid %zu counts %zu first %llu\n", valid.size() / 14, counts.size(), (unsigned long long)counts[0]);
+      for (size_t i = 0; i < valid.size() / 14 && i < 3; i++) print_hex(&valid[14 * i], 14);
+    }
   } catch (const std::exception &e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

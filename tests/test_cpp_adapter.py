@@ -90,6 +90,16 @@ def test_adapter_matches_oracle(ccmp_built, oracle_det, tmp_path):
         k += 2
     x = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in out[k + 1].split()])
     assert out[k] == "gauss 0" and np.array_equal(x.view(np.uint64), around("gaussian", 0x47415553, 0, 0.05).view(np.uint64))
+    k += 2
+    # ccmp::ShardedProjector: the valid states of 500 sampleUniform draws through the RCCL all-gather, in sample order
+    e_q, e_ok, _ = oracle_det.sample_project_batch(P, 42, 0, 500, 4)
+    exp_valid = e_q[e_ok == 1]
+    while not out[k].startswith("sharded"):  # RCCL prints its version banner on stdout when the communicator is created
+        k += 1
+    assert out[k] == "sharded n_valid %d counts 1 first %d" % (len(exp_valid), len(exp_valid))
+    for i in range(3):
+        x = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in out[k + 1 + i].split()])
+        assert np.array_equal(x.view(np.uint64), exp_valid[i].view(np.uint64))
 
 
 OMPL_EXE = os.path.join(ROOT, "tests", "cpp", "adapter_ompl_check")
