@@ -7,6 +7,7 @@ Translation units with deliberately different flags:
   ccmp_kernels_flat.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one 128-thread block per sample (latency kernel)
   ccmp_problem.cpp       -ffp-contract=off -DCCMP_USE_FMA   host set-up (problem, constants) in the same rounding model
   ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   context, scheduling, launches
+  ccmp_comm.cpp                                             one process / several GPUs: RCCL communicator and sharded entry points
   ccmp_kernels_fast.hip  -ffp-contract=off -DCCMP_USE_FMA   analytic fast mode, bit-identical to the oracle's analytic mode
   ccmp_kernels_scout.hip -ffast-math                        FP32 iteration-count predictor + ordering (never touches results)
 """
@@ -34,8 +35,9 @@ _UNITS = [
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_problem.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
+    ("ccmp_comm.cpp", ["-O2", "-x", "hip"]),
 ]
-_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_host.h", os.path.join("..", "..", "include", "ccmp.h")]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_host.h", "ccmp_ctx.h", os.path.join("..", "..", "include", "ccmp.h")]
 
 
 def hipcc_path():

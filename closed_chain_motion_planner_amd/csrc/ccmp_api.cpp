@@ -5,19 +5,35 @@
 // isSatisfied batches run on the GPU or fail with CCMP_ENODEV / CCMP_EHIP.
 #include <hip/hip_runtime.h>
 
-#include <dlfcn.h>
-
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
-#include <vector>
-
-#include <rccl/rccl.h> // types and prototypes only: the library itself is opened at run time (no link dependency)
 
 #include "../../include/ccmp.h"
+#include "ccmp_ctx.h"
 #include "ccmp_host.h"
 #include "ccmp_kin.h"
+
+using ccmp_host::DeviceGuard;
+using ccmp_host::ensure_stage;
+using ccmp_host::g_hip_err;
+using ccmp_host::hip_fail;
+
+namespace ccmp_host {
+thread_local char g_hip_err[256] = "";
+
+int ensure_stage(ccmp_ctx *ctx, size_t bytes)
+{
+  if (ctx->stage_cap >= bytes) return CCMP_OK;
+  if (ctx->stage) (void)hipFree(ctx->stage);
+  ctx->stage = nullptr;
+  ctx->stage_cap = 0;
+  HIP_TRY(hipMalloc(&ctx->stage, bytes));
+  ctx->stage_cap = bytes;
+  return CCMP_OK;
+}
+}  // namespace ccmp_host
 
 extern "C" {
 hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
@@ -60,97 +76,11 @@ hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, dou
                                unsigned int *block_counts, unsigned long long *total, hipStream_t st);
 }
 
-namespace {
 
-thread_local char g_hip_err[256] = "";
-
-int hip_fail(hipError_t e, const char *what)
-{
-  snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
-  return CCMP_EHIP;
-}
-#define HIP_TRY(call)                                   \
-  do {                                                  \
-    hipError_t e_ = (call);                             \
-    if (e_ != hipSuccess) return hip_fail(e_, #call);   \
-  } while (0)
-
-} // namespace
-
-// scheduling defaults (round-2 sweeps with the faster throughput kernel, Wine_Bottle / stefan, in-process, ms):
-//   B        latency kernel alone   throughput + hand-over at once   + hand-over below 80 % occupancy   scout + 80 %
-//   8192     1.46 / 2.39            1.41 / 2.41                      1.59 / 2.64                        1.78 / 2.86
-//   12288    1.96 / 3.14            1.91 / 3.14                      1.84 / 2.90                        1.93 / 3.06
-//   16384    2.27 / 3.98            2.37 / 3.92                      2.06 / 3.39                        2.16 / 3.37
-//   20480    3.21 / 4.80            3.03 / 4.77                      2.35 / 3.83                        2.34 / 3.68
-//   28672    4.01 / 6.26            3.20 / 5.42                      3.02 / 4.93                        2.85 / 4.45
-//   32768    4.24 / 7.10            3.44 / 5.69                      3.43 / 5.38                        3.09 / 4.88
-// (from 49152 on the scout with immediate hand-over is best or equal; from 120000 on no hand-over at all)
-constexpr size_t kDefaultSmallBatch = 10240;   // up to here the latency kernel alone is quickest
-constexpr size_t kDefaultLptMinBatch = 26624;  // from here on the longest-first order pays for the scout pass
-constexpr size_t kOccupancyHandoverBelow = 40960; // smaller batches: keep the throughput kernel going while >= 80 % of its slots are busy
-
-struct ccmp_ctx {
-  int device = 0;
-  int num_cus = 0;
-  int waves_per_cu = 0;
-  hipStream_t stream = nullptr;
-  unsigned long long *queue = nullptr; // work-queue heads of the projector kernels (4 words)
-  double *pool = nullptr;              // straggler hand-over records (group kernel -> wave kernel)
-  size_t pool_cap = 0;                 // in records
-  int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
-  const unsigned int *order = nullptr; // experimental: externally supplied processing order
-  int flat_kernel = 1;                 // latency work (small batches, hand-over): 1 = one-round 128-thread kernel, 0 = single-wave kernel
-  int stock_kernels = 1;               // 0: always the general kernels, also for the stock Panda structure (tests, A/B)
-  int lpt = 1;                         // 0: in-order; 1: FP32 scout + longest-predicted-first, hand-over kept; 2: same, no hand-over
-  size_t lpt_min_batch = kDefaultLptMinBatch; // below this the scout costs more than the tail it removes
-  void *lpt_buf = nullptr;             // pred (u16 x B) | hist (u32 x 1024) | order (u32 x B)
-  size_t lpt_cap = 0;                  // in samples
-  int analytic_cap = 96;               // analytic mode: samples past this many iterations go to the rows kernel (0 = never)
-  size_t analytic_small_batch = 16384; // analytic mode: at or below, the rows kernel alone
-  size_t analytic_handover_max = 131072; // analytic mode: hand-over for batches up to here (larger ones: one-lane kernel alone)
-  int dump_threshold = -1;             // hand a wave's samples over once the queue is dry and <= this many groups are busy; -1 = auto
-  size_t small_batch = kDefaultSmallBatch;    // at or below: latency kernel on everything
-  unsigned int *scan = nullptr;        // compaction block counts
-  size_t scan_cap = 0;
-  // staging for the *_host conveniences
-  void *stage = nullptr;
-  size_t stage_cap = 0;
-  void *pin = nullptr;     // pinned, device-mapped host block for small *_host calls (single states of the reference signature)
-  void *pin_dev = nullptr; // the same block as the kernels see it
-  // completion word of single-state calls (last 64 bytes of the pinned block): the latency kernel publishes done_seq
-  // behind its results and the host polls it instead of waiting for the stream's completion signal
-  unsigned int done_seq = 0;
-  bool done_armed = false; // set by project_common when the launch it made will publish done_seq
-  bool want_done = false;  // set by the host entry point that is going to poll
-};
 
 namespace {
 
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = false;
-  explicit DeviceGuard(int dev)
-  {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    ok = hipSetDevice(dev) == hipSuccess;
-  }
-  ~DeviceGuard()
-  {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
 
-int ensure_stage(ccmp_ctx *ctx, size_t bytes)
-{
-  if (ctx->stage_cap >= bytes) return CCMP_OK;
-  if (ctx->stage) (void)hipFree(ctx->stage);
-  ctx->stage = nullptr;
-  ctx->stage_cap = 0;
-  HIP_TRY(hipMalloc(&ctx->stage, bytes));
-  ctx->stage_cap = bytes;
-  return CCMP_OK;
-}
 
 // Host buffers of the *_host entry points.  Up to kPinBytes the kernels work directly on a pinned, device-mapped host
 // block (a single project(x) is then memcpy + launch + synchronize + memcpy: no staged pageable copies, ~3 driver
@@ -928,238 +858,6 @@ int ccmp_sample_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_pr
                                      double *q_out, uint8_t *ok, uint16_t *iters, size_t B)
 {
   return sharded_common(ctxs, n, p, 1, nullptr, q_out, ok, iters, seed, first_index, B);
-}
-
-// ---- one process, several GPUs, RCCL all-gather of the valid states ---------------------------------------------------
-// The reference's planner is ONE process (src/main.cpp); this is SURVEY.md §8b's ccmp_project_sharded: every GPU projects
-// its contiguous shard, compacts its valid states into a fixed-capacity block (row 0 = count) and joins ONE ncclAllGather
-// over xGMI; GPU 0 then holds every shard's valid states and hands them to the host tree in global sample order.
-// librccl is opened at run time (dlopen): libccmp.so has no link-time dependency on it, and a process that already
-// carries an RCCL (PyTorch's) shares that copy.
-} // extern "C"
-
-namespace {
-
-struct RcclApi {
-  void *handle = nullptr;
-  decltype(&ncclCommInitAll) CommInitAll = nullptr;
-  decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclAllGather) AllGather = nullptr;
-  decltype(&ncclGroupStart) GroupStart = nullptr;
-  decltype(&ncclGroupEnd) GroupEnd = nullptr;
-  decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  bool ok = false;
-};
-
-RcclApi &rccl()
-{
-  static RcclApi api = [] {
-    RcclApi a;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (a.handle) break;
-    }
-    if (!a.handle) return a;
-    a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.handle, "ncclCommInitAll");
-    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
-    a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
-    a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
-    a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
-    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
-    a.ok = a.CommInitAll && a.CommDestroy && a.AllGather && a.GroupStart && a.GroupEnd && a.GetErrorString;
-    return a;
-  }();
-  return api;
-}
-
-int rccl_fail(ncclResult_t r, const char *what)
-{
-  snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
-  return CCMP_ECOMM;
-}
-
-} // namespace
-
-extern "C" {
-
-struct ccmp_comm {
-  int n = 0;
-  std::vector<ccmp_ctx *> ctxs;
-  std::vector<ncclComm_t> comms;
-  std::vector<double *> send, recv; // per GPU: (cap + 1) x 14 and n x (cap + 1) x 14 doubles
-  size_t cap = 0;                   // rows per block
-  double *host_recv = nullptr;      // pinned staging of GPU 0's gathered blocks
-  size_t host_cap = 0;
-};
-
-int ccmp_comm_create(ccmp_ctx *const *ctxs, int n, ccmp_comm **out)
-{
-  if (!ctxs || !out || n < 1 || n > 64) return CCMP_EINVAL;
-  *out = nullptr;
-  std::vector<int> devs(n);
-  for (int g = 0; g < n; g++) {
-    if (!ctxs[g]) return CCMP_EINVAL;
-    devs[g] = ctxs[g]->device;
-    for (int h = 0; h < g; h++)
-      if (devs[h] == devs[g]) return CCMP_EINVAL; // RCCL wants one rank per device
-  }
-  if (!rccl().ok) {
-    snprintf(g_hip_err, sizeof g_hip_err, "librccl.so could not be opened: %s", dlerror() ? dlerror() : "symbols missing");
-    return CCMP_ECOMM;
-  }
-  ccmp_comm *c = new (std::nothrow) ccmp_comm();
-  if (!c) return CCMP_ENOMEM;
-  c->n = n;
-  c->ctxs.assign(ctxs, ctxs + n);
-  c->comms.assign(n, nullptr);
-  c->send.assign(n, nullptr);
-  c->recv.assign(n, nullptr);
-  ncclResult_t r = rccl().CommInitAll(c->comms.data(), n, devs.data());
-  if (r != ncclSuccess) { delete c; return rccl_fail(r, "ncclCommInitAll"); }
-  *out = c;
-  return CCMP_OK;
-}
-
-void ccmp_comm_destroy(ccmp_comm *c)
-{
-  if (!c) return;
-  for (int g = 0; g < c->n; g++) {
-    DeviceGuard guard(c->ctxs[g]->device);
-    (void)hipStreamSynchronize(c->ctxs[g]->stream);
-    if (c->comms[g]) (void)rccl().CommDestroy(c->comms[g]);
-    if (c->send[g]) (void)hipFree(c->send[g]);
-    if (c->recv[g]) (void)hipFree(c->recv[g]);
-  }
-  if (c->host_recv) (void)hipHostFree(c->host_recv);
-  delete c;
-}
-
-static int comm_ensure_blocks(ccmp_comm *c, size_t cap)
-{
-  if (c->cap >= cap && c->send[0]) return CCMP_OK;
-  const size_t block = (cap + 1) * 14 * sizeof(double);
-  for (int g = 0; g < c->n; g++) {
-    DeviceGuard guard(c->ctxs[g]->device);
-    if (!guard.ok) return CCMP_ENODEV;
-    if (c->send[g]) (void)hipFree(c->send[g]);
-    if (c->recv[g]) (void)hipFree(c->recv[g]);
-    c->send[g] = c->recv[g] = nullptr;
-    HIP_TRY(hipMalloc((void **)&c->send[g], block));
-    HIP_TRY(hipMalloc((void **)&c->recv[g], block * (size_t)c->n));
-  }
-  if (c->host_recv) (void)hipHostFree(c->host_recv);
-  c->host_recv = nullptr;
-  HIP_TRY(hipHostMalloc((void **)&c->host_recv, block * (size_t)c->n, hipHostMallocDefault));
-  c->cap = cap;
-  return CCMP_OK;
-}
-
-static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, const double *q_in, uint64_t seed, uint64_t first_index,
-                               size_t B, double *q_out, uint8_t *ok, uint16_t *iters, size_t block_rows, double *valid_out,
-                               size_t valid_capacity, uint64_t *counts, uint64_t *n_valid)
-{
-  if (!c || !p || !valid_out || !n_valid || block_rows < 1) return CCMP_EINVAL;
-  if (mode == 0 && !q_in) return CCMP_EINVAL;
-  *n_valid = 0;
-  if (B == 0) return CCMP_OK;
-  const int n = c->n;
-  int rc = comm_ensure_blocks(c, block_rows);
-  if (rc != CCMP_OK) return rc;
-  const size_t cap = c->cap, block_doubles = (cap + 1) * 14;
-  struct Shard { size_t lo, nb, off_ok, off_it; };
-  std::vector<Shard> sh(n);
-  // phase 1: every GPU uploads (mode 0), projects and compacts its shard into its send block, all on its own stream
-  for (int g = 0; g < n && rc == CCMP_OK; g++) {
-    const size_t base = B / (size_t)n, rem = B % (size_t)n;
-    sh[g].lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem);
-    sh[g].nb = base + ((size_t)g < rem ? 1 : 0);
-    ccmp_ctx *ctx = c->ctxs[g];
-    DeviceGuard guard(ctx->device);
-    if (!guard.ok) { rc = CCMP_ENODEV; break; }
-    const size_t nb = sh[g].nb, qb = nb * 14 * sizeof(double);
-    sh[g].off_ok = (qb + 255) & ~(size_t)255;
-    sh[g].off_it = (sh[g].off_ok + nb + 255) & ~(size_t)255;
-    hipError_t e = hipMemsetAsync(c->send[g], 0, 14 * sizeof(double), ctx->stream); // row 0: count 0 for an empty shard
-    if (e != hipSuccess) { rc = hip_fail(e, "hipMemsetAsync(send block)"); break; }
-    if (nb == 0) continue;
-    if ((rc = ensure_stage(ctx, sh[g].off_it + nb * sizeof(uint16_t))) != CCMP_OK) break;
-    char *stage = (char *)ctx->stage;
-    if (mode == 0) {
-      e = hipMemcpyAsync(stage, q_in + sh[g].lo * 14, qb, hipMemcpyHostToDevice, ctx->stream);
-      if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync(H2D shard)"); break; }
-      rc = ccmp_project_batch(ctx, p, (const double *)stage, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
-                              (uint16_t *)(stage + sh[g].off_it), nb, ctx->stream);
-    } else {
-      rc = ccmp_sample_project_batch(ctx, p, seed, first_index + sh[g].lo, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
-                                     (uint16_t *)(stage + sh[g].off_it), nullptr, nb, ctx->stream);
-    }
-    if (rc != CCMP_OK) break;
-    rc = ccmp_compact_valid_capped(ctx, (const double *)stage, (const uint8_t *)(stage + sh[g].off_ok), nb, c->send[g] + 14, cap,
-                                   (uint64_t *)c->send[g], ctx->stream);
-  }
-  // phase 2: ONE all-gather of the fixed-capacity blocks over the n devices (grouped: one call per rank of this process)
-  if (rc == CCMP_OK) {
-    ncclResult_t r = rccl().GroupStart();
-    for (int g = 0; g < n && r == ncclSuccess; g++)
-      r = rccl().AllGather(c->send[g], c->recv[g], block_doubles, ncclDouble, c->comms[g], c->ctxs[g]->stream);
-    ncclResult_t r2 = rccl().GroupEnd();
-    if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail(r != ncclSuccess ? r : r2, "ncclAllGather");
-  }
-  // phase 3: GPU 0 returns the gathered blocks; every GPU returns its shard's full results if the caller wants them
-  if (rc == CCMP_OK) {
-    DeviceGuard guard(c->ctxs[0]->device);
-    hipError_t e = hipMemcpyAsync(c->host_recv, c->recv[0], block_doubles * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
-                                  c->ctxs[0]->stream);
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H gathered blocks)");
-  }
-  for (int g = 0; g < n && rc == CCMP_OK; g++) {
-    if (sh[g].nb == 0 || (!q_out && !ok && !iters)) continue;
-    ccmp_ctx *ctx = c->ctxs[g];
-    DeviceGuard guard(ctx->device);
-    const char *stage = (const char *)ctx->stage;
-    hipError_t e = hipSuccess;
-    if (q_out) e = hipMemcpyAsync(q_out + sh[g].lo * 14, stage, sh[g].nb * 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && ok) e = hipMemcpyAsync(ok + sh[g].lo, stage + sh[g].off_ok, sh[g].nb, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && iters)
-      e = hipMemcpyAsync(iters + sh[g].lo, stage + sh[g].off_it, sh[g].nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H shard)");
-  }
-  for (int g = 0; g < n; g++) { // wait for every stream, also on the error path
-    DeviceGuard guard(c->ctxs[g]->device);
-    hipError_t e = hipStreamSynchronize(c->ctxs[g]->stream);
-    if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize(shard)");
-  }
-  if (rc != CCMP_OK) return rc;
-  // unpack in rank order = global sample order for contiguous shards
-  size_t total = 0;
-  bool overflow = false;
-  for (int g = 0; g < n; g++) {
-    const double *blk = c->host_recv + (size_t)g * block_doubles;
-    uint64_t cnt;
-    memcpy(&cnt, blk, sizeof cnt);
-    if (counts) counts[g] = cnt;
-    if (cnt > cap) { overflow = true; continue; }
-    if (total + cnt <= valid_capacity) memcpy(valid_out + total * 14, blk + 14, (size_t)cnt * 14 * sizeof(double));
-    total += (size_t)cnt;
-  }
-  *n_valid = total;
-  if (overflow || total > valid_capacity) return CCMP_EOVERFLOW; // counts[] tells the caller how much room is needed
-  return CCMP_OK;
-}
-
-int ccmp_project_sharded(ccmp_comm *comm, const ccmp_problem *p, const double *q_in, size_t B, double *q_out, uint8_t *ok,
-                         uint16_t *iters, size_t block_rows, double *valid_out, size_t valid_capacity, uint64_t *counts,
-                         uint64_t *n_valid)
-{
-  return comm_project_common(comm, p, 0, q_in, 0, 0, B, q_out, ok, iters, block_rows, valid_out, valid_capacity, counts, n_valid);
-}
-
-int ccmp_sample_project_sharded(ccmp_comm *comm, const ccmp_problem *p, uint64_t seed, uint64_t first_index, size_t B, double *q_out,
-                                uint8_t *ok, uint16_t *iters, size_t block_rows, double *valid_out, size_t valid_capacity,
-                                uint64_t *counts, uint64_t *n_valid)
-{
-  return comm_project_common(comm, p, 1, nullptr, seed, first_index, B, q_out, ok, iters, block_rows, valid_out, valid_capacity, counts,
-                             n_valid);
 }
 
 } // extern "C"

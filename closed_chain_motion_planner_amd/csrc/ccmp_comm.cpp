@@ -1,0 +1,255 @@
+// ccmp_comm.cpp — one process, several GPUs, with the collective: ccmp_comm_* and ccmp_project_sharded /
+// ccmp_sample_project_sharded of include/ccmp.h.  Host code only; librccl is opened at run time.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <rccl/rccl.h> // types and prototypes only: the library itself is opened at run time (no link dependency)
+
+#include "../../include/ccmp.h"
+#include "ccmp_ctx.h"
+
+using ccmp_host::DeviceGuard;
+using ccmp_host::ensure_stage;
+using ccmp_host::g_hip_err;
+using ccmp_host::hip_fail;
+
+extern "C" {
+// ---- one process, several GPUs, RCCL all-gather of the valid states ---------------------------------------------------
+// The reference's planner is ONE process (src/main.cpp); this is SURVEY.md §8b's ccmp_project_sharded: every GPU projects
+// its contiguous shard, compacts its valid states into a fixed-capacity block (row 0 = count) and joins ONE ncclAllGather
+// over xGMI; GPU 0 then holds every shard's valid states and hands them to the host tree in global sample order.
+// librccl is opened at run time (dlopen): libccmp.so has no link-time dependency on it, and a process that already
+// carries an RCCL (PyTorch's) shares that copy.
+} // extern "C"
+
+namespace {
+
+struct RcclApi {
+  void *handle = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+
+RcclApi &rccl()
+{
+  static RcclApi api = [] {
+    RcclApi a;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.handle) break;
+    }
+    if (!a.handle) return a;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.handle, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+    a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+    a.ok = a.CommInitAll && a.CommDestroy && a.AllGather && a.GroupStart && a.GroupEnd && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+
+int rccl_fail(ncclResult_t r, const char *what)
+{
+  snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+  return CCMP_ECOMM;
+}
+
+} // namespace
+
+extern "C" {
+
+struct ccmp_comm {
+  int n = 0;
+  std::vector<ccmp_ctx *> ctxs;
+  std::vector<ncclComm_t> comms;
+  std::vector<double *> send, recv; // per GPU: (cap + 1) x 14 and n x (cap + 1) x 14 doubles
+  size_t cap = 0;                   // rows per block
+  double *host_recv = nullptr;      // pinned staging of GPU 0's gathered blocks
+  size_t host_cap = 0;
+};
+
+int ccmp_comm_create(ccmp_ctx *const *ctxs, int n, ccmp_comm **out)
+{
+  if (!ctxs || !out || n < 1 || n > 64) return CCMP_EINVAL;
+  *out = nullptr;
+  std::vector<int> devs(n);
+  for (int g = 0; g < n; g++) {
+    if (!ctxs[g]) return CCMP_EINVAL;
+    devs[g] = ctxs[g]->device;
+    for (int h = 0; h < g; h++)
+      if (devs[h] == devs[g]) return CCMP_EINVAL; // RCCL wants one rank per device
+  }
+  if (!rccl().ok) {
+    snprintf(g_hip_err, sizeof g_hip_err, "librccl.so could not be opened: %s", dlerror() ? dlerror() : "symbols missing");
+    return CCMP_ECOMM;
+  }
+  ccmp_comm *c = new (std::nothrow) ccmp_comm();
+  if (!c) return CCMP_ENOMEM;
+  c->n = n;
+  c->ctxs.assign(ctxs, ctxs + n);
+  c->comms.assign(n, nullptr);
+  c->send.assign(n, nullptr);
+  c->recv.assign(n, nullptr);
+  ncclResult_t r = rccl().CommInitAll(c->comms.data(), n, devs.data());
+  if (r != ncclSuccess) { delete c; return rccl_fail(r, "ncclCommInitAll"); }
+  *out = c;
+  return CCMP_OK;
+}
+
+void ccmp_comm_destroy(ccmp_comm *c)
+{
+  if (!c) return;
+  for (int g = 0; g < c->n; g++) {
+    DeviceGuard guard(c->ctxs[g]->device);
+    (void)hipStreamSynchronize(c->ctxs[g]->stream);
+    if (c->comms[g]) (void)rccl().CommDestroy(c->comms[g]);
+    if (c->send[g]) (void)hipFree(c->send[g]);
+    if (c->recv[g]) (void)hipFree(c->recv[g]);
+  }
+  if (c->host_recv) (void)hipHostFree(c->host_recv);
+  delete c;
+}
+
+static int comm_ensure_blocks(ccmp_comm *c, size_t cap)
+{
+  if (c->cap >= cap && c->send[0]) return CCMP_OK;
+  const size_t block = (cap + 1) * 14 * sizeof(double);
+  for (int g = 0; g < c->n; g++) {
+    DeviceGuard guard(c->ctxs[g]->device);
+    if (!guard.ok) return CCMP_ENODEV;
+    if (c->send[g]) (void)hipFree(c->send[g]);
+    if (c->recv[g]) (void)hipFree(c->recv[g]);
+    c->send[g] = c->recv[g] = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->send[g], block));
+    HIP_TRY(hipMalloc((void **)&c->recv[g], block * (size_t)c->n));
+  }
+  if (c->host_recv) (void)hipHostFree(c->host_recv);
+  c->host_recv = nullptr;
+  HIP_TRY(hipHostMalloc((void **)&c->host_recv, block * (size_t)c->n, hipHostMallocDefault));
+  c->cap = cap;
+  return CCMP_OK;
+}
+
+static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, const double *q_in, uint64_t seed, uint64_t first_index,
+                               size_t B, double *q_out, uint8_t *ok, uint16_t *iters, size_t block_rows, double *valid_out,
+                               size_t valid_capacity, uint64_t *counts, uint64_t *n_valid)
+{
+  if (!c || !p || !valid_out || !n_valid || block_rows < 1) return CCMP_EINVAL;
+  if (mode == 0 && !q_in) return CCMP_EINVAL;
+  *n_valid = 0;
+  if (B == 0) return CCMP_OK;
+  const int n = c->n;
+  int rc = comm_ensure_blocks(c, block_rows);
+  if (rc != CCMP_OK) return rc;
+  const size_t cap = c->cap, block_doubles = (cap + 1) * 14;
+  struct Shard { size_t lo, nb, off_ok, off_it; };
+  std::vector<Shard> sh(n);
+  // phase 1: every GPU uploads (mode 0), projects and compacts its shard into its send block, all on its own stream
+  for (int g = 0; g < n && rc == CCMP_OK; g++) {
+    const size_t base = B / (size_t)n, rem = B % (size_t)n;
+    sh[g].lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem);
+    sh[g].nb = base + ((size_t)g < rem ? 1 : 0);
+    ccmp_ctx *ctx = c->ctxs[g];
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) { rc = CCMP_ENODEV; break; }
+    const size_t nb = sh[g].nb, qb = nb * 14 * sizeof(double);
+    sh[g].off_ok = (qb + 255) & ~(size_t)255;
+    sh[g].off_it = (sh[g].off_ok + nb + 255) & ~(size_t)255;
+    hipError_t e = hipMemsetAsync(c->send[g], 0, 14 * sizeof(double), ctx->stream); // row 0: count 0 for an empty shard
+    if (e != hipSuccess) { rc = hip_fail(e, "hipMemsetAsync(send block)"); break; }
+    if (nb == 0) continue;
+    if ((rc = ensure_stage(ctx, sh[g].off_it + nb * sizeof(uint16_t))) != CCMP_OK) break;
+    char *stage = (char *)ctx->stage;
+    if (mode == 0) {
+      e = hipMemcpyAsync(stage, q_in + sh[g].lo * 14, qb, hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync(H2D shard)"); break; }
+      rc = ccmp_project_batch(ctx, p, (const double *)stage, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
+                              (uint16_t *)(stage + sh[g].off_it), nb, ctx->stream);
+    } else {
+      rc = ccmp_sample_project_batch(ctx, p, seed, first_index + sh[g].lo, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
+                                     (uint16_t *)(stage + sh[g].off_it), nullptr, nb, ctx->stream);
+    }
+    if (rc != CCMP_OK) break;
+    rc = ccmp_compact_valid_capped(ctx, (const double *)stage, (const uint8_t *)(stage + sh[g].off_ok), nb, c->send[g] + 14, cap,
+                                   (uint64_t *)c->send[g], ctx->stream);
+  }
+  // phase 2: ONE all-gather of the fixed-capacity blocks over the n devices (grouped: one call per rank of this process)
+  if (rc == CCMP_OK) {
+    ncclResult_t r = rccl().GroupStart();
+    for (int g = 0; g < n && r == ncclSuccess; g++)
+      r = rccl().AllGather(c->send[g], c->recv[g], block_doubles, ncclDouble, c->comms[g], c->ctxs[g]->stream);
+    ncclResult_t r2 = rccl().GroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail(r != ncclSuccess ? r : r2, "ncclAllGather");
+  }
+  // phase 3: GPU 0 returns the gathered blocks; every GPU returns its shard's full results if the caller wants them
+  if (rc == CCMP_OK) {
+    DeviceGuard guard(c->ctxs[0]->device);
+    hipError_t e = hipMemcpyAsync(c->host_recv, c->recv[0], block_doubles * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
+                                  c->ctxs[0]->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H gathered blocks)");
+  }
+  for (int g = 0; g < n && rc == CCMP_OK; g++) {
+    if (sh[g].nb == 0 || (!q_out && !ok && !iters)) continue;
+    ccmp_ctx *ctx = c->ctxs[g];
+    DeviceGuard guard(ctx->device);
+    const char *stage = (const char *)ctx->stage;
+    hipError_t e = hipSuccess;
+    if (q_out) e = hipMemcpyAsync(q_out + sh[g].lo * 14, stage, sh[g].nb * 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && ok) e = hipMemcpyAsync(ok + sh[g].lo, stage + sh[g].off_ok, sh[g].nb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && iters)
+      e = hipMemcpyAsync(iters + sh[g].lo, stage + sh[g].off_it, sh[g].nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H shard)");
+  }
+  for (int g = 0; g < n; g++) { // wait for every stream, also on the error path
+    DeviceGuard guard(c->ctxs[g]->device);
+    hipError_t e = hipStreamSynchronize(c->ctxs[g]->stream);
+    if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize(shard)");
+  }
+  if (rc != CCMP_OK) return rc;
+  // unpack in rank order = global sample order for contiguous shards
+  size_t total = 0;
+  bool overflow = false;
+  for (int g = 0; g < n; g++) {
+    const double *blk = c->host_recv + (size_t)g * block_doubles;
+    uint64_t cnt;
+    memcpy(&cnt, blk, sizeof cnt);
+    if (counts) counts[g] = cnt;
+    if (cnt > cap) { overflow = true; continue; }
+    if (total + cnt <= valid_capacity) memcpy(valid_out + total * 14, blk + 14, (size_t)cnt * 14 * sizeof(double));
+    total += (size_t)cnt;
+  }
+  *n_valid = total;
+  if (overflow || total > valid_capacity) return CCMP_EOVERFLOW; // counts[] tells the caller how much room is needed
+  return CCMP_OK;
+}
+
+int ccmp_project_sharded(ccmp_comm *comm, const ccmp_problem *p, const double *q_in, size_t B, double *q_out, uint8_t *ok,
+                         uint16_t *iters, size_t block_rows, double *valid_out, size_t valid_capacity, uint64_t *counts,
+                         uint64_t *n_valid)
+{
+  return comm_project_common(comm, p, 0, q_in, 0, 0, B, q_out, ok, iters, block_rows, valid_out, valid_capacity, counts, n_valid);
+}
+
+int ccmp_sample_project_sharded(ccmp_comm *comm, const ccmp_problem *p, uint64_t seed, uint64_t first_index, size_t B, double *q_out,
+                                uint8_t *ok, uint16_t *iters, size_t block_rows, double *valid_out, size_t valid_capacity,
+                                uint64_t *counts, uint64_t *n_valid)
+{
+  return comm_project_common(comm, p, 1, nullptr, seed, first_index, B, q_out, ok, iters, block_rows, valid_out, valid_capacity, counts,
+                             n_valid);
+}
+
+} // extern "C"

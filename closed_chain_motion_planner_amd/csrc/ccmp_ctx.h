@@ -1,0 +1,98 @@
+/* ccmp_ctx.h — internals shared by the host translation units of libccmp (ccmp_api.cpp, ccmp_comm.cpp); not part of
+ * the public ABI. */
+#ifndef CCMP_CTX_H
+#define CCMP_CTX_H
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdio>
+
+#include "../../include/ccmp.h"
+
+namespace ccmp_host {
+
+/* text of the last HIP / RCCL failure on this thread (ccmp_last_hip_error) */
+extern thread_local char g_hip_err[256];
+
+inline int hip_fail(hipError_t e, const char *what)
+{
+  snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+  return CCMP_EHIP;
+}
+#define HIP_TRY(call)                                            \
+  do {                                                           \
+    hipError_t e_ = (call);                                      \
+    if (e_ != hipSuccess) return ccmp_host::hip_fail(e_, #call); \
+  } while (0)
+
+/* makes `dev` current for the lifetime of the guard and restores the previous device */
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard()
+  {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+}  // namespace ccmp_host
+
+// scheduling defaults (round-2 sweeps with the faster throughput kernel, Wine_Bottle / stefan, in-process, ms):
+//   B        latency kernel alone   throughput + hand-over at once   + hand-over below 80 % occupancy   scout + 80 %
+//   8192     1.46 / 2.39            1.41 / 2.41                      1.59 / 2.64                        1.78 / 2.86
+//   12288    1.96 / 3.14            1.91 / 3.14                      1.84 / 2.90                        1.93 / 3.06
+//   16384    2.27 / 3.98            2.37 / 3.92                      2.06 / 3.39                        2.16 / 3.37
+//   20480    3.21 / 4.80            3.03 / 4.77                      2.35 / 3.83                        2.34 / 3.68
+//   28672    4.01 / 6.26            3.20 / 5.42                      3.02 / 4.93                        2.85 / 4.45
+//   32768    4.24 / 7.10            3.44 / 5.69                      3.43 / 5.38                        3.09 / 4.88
+// (from 49152 on the scout with immediate hand-over is best or equal; from 120000 on no hand-over at all)
+constexpr size_t kDefaultSmallBatch = 10240;   // up to here the latency kernel alone is quickest
+constexpr size_t kDefaultLptMinBatch = 26624;  // from here on the longest-first order pays for the scout pass
+constexpr size_t kOccupancyHandoverBelow = 40960; // smaller batches: keep the throughput kernel going while >= 80 % of its slots are busy
+
+struct ccmp_ctx {
+  int device = 0;
+  int num_cus = 0;
+  int waves_per_cu = 0;
+  hipStream_t stream = nullptr;
+  unsigned long long *queue = nullptr; // work-queue heads of the projector kernels (4 words)
+  double *pool = nullptr;              // straggler hand-over records (group kernel -> wave kernel)
+  size_t pool_cap = 0;                 // in records
+  int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
+  const unsigned int *order = nullptr; // experimental: externally supplied processing order
+  int flat_kernel = 1;                 // latency work (small batches, hand-over): 1 = one-round 128-thread kernel, 0 = single-wave kernel
+  int stock_kernels = 1;               // 0: always the general kernels, also for the stock Panda structure (tests, A/B)
+  int lpt = 1;                         // 0: in-order; 1: FP32 scout + longest-predicted-first, hand-over kept; 2: same, no hand-over
+  size_t lpt_min_batch = kDefaultLptMinBatch; // below this the scout costs more than the tail it removes
+  void *lpt_buf = nullptr;             // pred (u16 x B) | hist (u32 x 1024) | order (u32 x B)
+  size_t lpt_cap = 0;                  // in samples
+  int analytic_cap = 96;               // analytic mode: samples past this many iterations go to the rows kernel (0 = never)
+  size_t analytic_small_batch = 16384; // analytic mode: at or below, the rows kernel alone
+  size_t analytic_handover_max = 131072; // analytic mode: hand-over for batches up to here (larger ones: one-lane kernel alone)
+  int dump_threshold = -1;             // hand a wave's samples over once the queue is dry and <= this many groups are busy; -1 = auto
+  size_t small_batch = kDefaultSmallBatch;    // at or below: latency kernel on everything
+  unsigned int *scan = nullptr;        // compaction block counts
+  size_t scan_cap = 0;
+  // staging for the *_host conveniences
+  void *stage = nullptr;
+  size_t stage_cap = 0;
+  void *pin = nullptr;     // pinned, device-mapped host block for small *_host calls (single states of the reference signature)
+  void *pin_dev = nullptr; // the same block as the kernels see it
+  // completion word of single-state calls (last 64 bytes of the pinned block): the latency kernel publishes done_seq
+  // behind its results and the host polls it instead of waiting for the stream's completion signal
+  unsigned int done_seq = 0;
+  bool done_armed = false; // set by project_common when the launch it made will publish done_seq
+  bool want_done = false;  // set by the host entry point that is going to poll
+};
+
+namespace ccmp_host {
+/* device staging of the *_host conveniences, grown on demand */
+int ensure_stage(ccmp_ctx *ctx, size_t bytes);
+}  // namespace ccmp_host
+
+#endif /* CCMP_CTX_H */
