@@ -137,3 +137,22 @@ def test_latency_kernels_agree_and_repeat(gpu_ctx, obj, seed):
     finally:
         gpu_ctx.set_schedule(1)
         gpu_ctx.set_option("flat_kernel", 1)
+
+
+@pytest.mark.parametrize("obj,n", [("Wine_Bottle", 11000), ("Wine_Bottle", 20480), ("stefan", 30000), ("Wine_Bottle", 50000)])
+def test_default_policy_at_mid_sizes_is_bitwise_the_oracle(gpu_ctx, oracle_det, obj, n):
+    """the default scheduling policy where its regimes meet — the latency kernel alone (<= 10 240), the throughput kernel
+    with the occupancy-driven hand-over (all waves hand over together once the samples in flight fill < 80 % of the group
+    slots), the same behind the scout's longest-first order (>= 26 624), hand-over at once (>= 40 960) — against the
+    oracle, every sample, bit for bit"""
+    import torch
+
+    c = _constraint(obj, gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q = c.ambient_uniform_batch(0x3D + n, 0, n)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q.cpu().numpy(), NCPU)
+    out = torch.full_like(q, 777.0)
+    _, ok, it = c.project_batch(q, out=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+    assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
