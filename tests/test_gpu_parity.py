@@ -344,6 +344,21 @@ def test_non_finite_and_out_of_range_inputs_terminate(gpu_ctx, oracle_det):
         same = (out.view(np.uint64) == q_cpu.view(np.uint64)) | (np.isnan(out) & np.isnan(q_cpu))
         assert same.all() and np.array_equal(ok, ok_cpu) and np.array_equal(it.astype(np.int32), it_cpu)
     assert not c.isSatisfied(q[3]) and not c.isSatisfied(q[17])  # f.allFinite() is part of isSatisfied
+    # the analytic mode's kernels (six lanes per sample at this size; one lane per sample) terminate the same way
+    c.setJacobianMode(1)
+    Pa = _oracle_problem(oracle_det, c)
+    qa_cpu, oka_cpu, ita_cpu = oracle_det.project_batch(Pa, q, 4)
+    for small in (1 << 30, 0):
+        gpu_ctx.set_option("analytic_small_batch", small)
+        try:
+            out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
+            torch.cuda.synchronize()
+        finally:
+            gpu_ctx.set_option("analytic_small_batch", 16384)
+        out, ok, it = out.cpu().numpy(), ok.cpu().numpy(), it.cpu().numpy()
+        same = (out.view(np.uint64) == qa_cpu.view(np.uint64)) | (np.isnan(out) & np.isnan(qa_cpu))
+        assert same.all() and np.array_equal(ok, oka_cpu) and np.array_equal(it.astype(np.int32), ita_cpu)
+        assert (ok[bad] == 0).all() and (it[bad] == 0).all()
 
 
 def test_iteration_cap_and_loose_tolerance(gpu_ctx, oracle_det):
