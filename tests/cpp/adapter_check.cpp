@@ -4,6 +4,7 @@
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "ccmp_ompl_adapter.hpp"
@@ -80,6 +81,36 @@ int main(int argc, char **argv)
       gb.next(g, &out[0], 0.05);
       std::printf("gauss 0\n");
       print_hex(g, 14);
+    }
+    // several threads on ONE Projector (the reference touches its constraint from the goal-sampling thread and from
+    // checkForSolution beside constructRoadmap): the context's pinned I/O block is shared, the Projector's mutex
+    // serialises the calls — every thread must get the serial results
+    {
+      std::vector<double> serial(q.size());
+      std::vector<int> serial_ok(B);
+      for (size_t i = 0; i < B; i++) {
+        std::memcpy(&serial[14 * i], &q[14 * i], 14 * sizeof(double));
+        serial_ok[i] = P.project(&serial[14 * i]) ? 1 : 0;
+      }
+      int mismatches = 0;
+      std::vector<std::thread> th;
+      std::vector<int> bad(4, 0);
+      for (int t = 0; t < 4; t++)
+        th.emplace_back([&, t] {
+          for (int rep = 0; rep < 8; rep++)
+            for (size_t i = 0; i < B; i++) {
+              double x[14];
+              std::memcpy(x, &q[14 * i], sizeof x);
+              const bool ok = P.project(x);
+              if ((ok ? 1 : 0) != serial_ok[i] || std::memcmp(x, &serial[14 * i], sizeof x) != 0) bad[t]++;
+              double f[2];
+              P.function(x, f);
+              if (P.isSatisfied(x) != (f[0] <= 1e-3 && f[1] <= 5e-3)) bad[t]++;
+            }
+        });
+      for (auto &h : th) h.join();
+      for (int t = 0; t < 4; t++) mismatches += bad[t];
+      std::printf("threads mismatches %d\n", mismatches);
     }
     // one process, "several" GPUs with the collective: this box has one, so the communicator has one rank
     {

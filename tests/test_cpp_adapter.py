@@ -14,7 +14,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "adapter_check")
 
 def _build(ccmp_built):
     libdir = os.path.dirname(ccmp_built)
-    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_check.cpp"),
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_check.cpp"),
            "-L", libdir, "-lccmp", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
     subprocess.run(cmd, check=True)
     return EXE
@@ -92,6 +92,8 @@ def test_adapter_matches_oracle(ccmp_built, oracle_det, tmp_path):
     assert out[k] == "gauss 0" and np.array_equal(x.view(np.uint64), around("gaussian", 0x47415553, 0, 0.05).view(np.uint64))
     k += 2
     # ccmp::ShardedProjector: the valid states of 500 sampleUniform draws through the RCCL all-gather, in sample order
+    assert out[k] == "threads mismatches 0"  # four threads on one Projector: the mutex serialises the shared context
+    k += 1
     e_q, e_ok, _ = oracle_det.sample_project_batch(P, 42, 0, 500, 4)
     exp_valid = e_q[e_ok == 1]
     while not out[k].startswith("sharded"):  # RCCL prints its version banner on stdout when the communicator is created
