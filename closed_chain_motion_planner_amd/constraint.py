@@ -292,9 +292,11 @@ class KinematicChainConstraint:
                                                  out.data_ptr(), q.shape[0], _stream_handle(stream)), "ccmp_compute_t_wo_batch")
         return out
 
-    def discrete_geodesic_batch(self, frm, to, max_states=64, stream=None):
+    def discrete_geodesic_batch(self, frm, to, max_states=64, stream=None, check_target=False):
         """`jy_ProjectedStateSpace::discreteGeodesic` for E edges (jy_ProjectedStateSpace.cpp:32-96), run as with
-        interpolate == true.  Returns (states (E,max_states,14), n_states (E,), ok (E,), newton_iters (E,))."""
+        interpolate == true.  Returns (states (E,max_states,14), n_states (E,), ok (E,), newton_iters (E,)).
+        check_target: `checkMotion` in one launch — isSatisfied(to) && discreteGeodesic(from, to)
+        (src/planner/stefanBiPRM.cpp:397-398); an edge whose target is not satisfied reports ok = 0, n_states = 1."""
         self._need_problem()
         self._check_q(frm)
         self._check_q(to)
@@ -304,9 +306,10 @@ class KinematicChainConstraint:
         n = torch.empty(E, dtype=torch.int32, device=frm.device)
         ok = torch.empty(E, dtype=torch.uint8, device=frm.device)
         its = torch.empty(E, dtype=torch.int32, device=frm.device)
-        check(_lib.lib().ccmp_geodesic_batch(self.ctx.handle, C.byref(self.problem), frm.data_ptr(), to.data_ptr(), E,
-                                             int(max_states), states.data_ptr(), n.data_ptr(), ok.data_ptr(), its.data_ptr(),
-                                             _stream_handle(stream)), "ccmp_geodesic_batch")
+        fn = _lib.lib().ccmp_check_motion_batch if check_target else _lib.lib().ccmp_geodesic_batch
+        check(fn(self.ctx.handle, C.byref(self.problem), frm.data_ptr(), to.data_ptr(), E, int(max_states), states.data_ptr(),
+                 n.data_ptr(), ok.data_ptr(), its.data_ptr(), _stream_handle(stream)),
+              "ccmp_check_motion_batch" if check_target else "ccmp_geodesic_batch")
         return states, n, ok, its
 
     def ambient_uniform_batch(self, seed, first_index, B, stream=None):

@@ -70,7 +70,7 @@ hipError_t ccmp_launch_ambient_ref(const ccmp_consts *K, int kind, unsigned long
 hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride, double *out, size_t B, hipStream_t st);
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
-                                int nblocks, hipStream_t st);
+                                int check_target, int nblocks, hipStream_t st);
 hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st);
 hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, size_t capacity,
                                unsigned int *block_counts, unsigned long long *total, hipStream_t st);
@@ -526,8 +526,8 @@ int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *
   return CCMP_OK;
 }
 
-int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
-                        double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream)
+static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                           double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, int check_target, void *hip_stream)
 {
   CCMP_PROLOGUE();
   if (E == 0) return CCMP_OK;
@@ -537,8 +537,21 @@ int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from
   // one 128-thread block per edge; the hardware dispatcher balances edges of different length (the kernel strides
   // over the edges if the grid is capped)
   const size_t nb = E < ((size_t)1 << 20) ? E : ((size_t)1 << 20);
-  HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, (int)nb, st));
+  HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target, (int)nb,
+                               st));
   return CCMP_OK;
+}
+
+int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                        double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream)
+{
+  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, 0, hip_stream);
+}
+
+int ccmp_check_motion_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                            double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream)
+{
+  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, 1, hip_stream);
 }
 
 int ccmp_is_satisfied_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B, void *hip_stream)
@@ -759,8 +772,8 @@ int ccmp_sample_ref_project_host(ccmp_ctx *ctx, const ccmp_problem *p, int kind,
   return io.finish();
 }
 
-int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
-                       double *states, int32_t *n_states, uint8_t *ok)
+static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                                double *states, int32_t *n_states, uint8_t *ok, int check_target)
 {
   if (!ctx || !p) return CCMP_EINVAL;
   if (E == 0) return CCMP_OK;
@@ -778,13 +791,25 @@ int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from,
   if (rc != CCMP_OK) return rc;
   if ((rc = io.in(0, from, eb)) != CCMP_OK) return rc;
   if ((rc = io.in(off_to, to, eb)) != CCMP_OK) return rc;
-  rc = ccmp_geodesic_batch(ctx, p, (const double *)io.dev, (const double *)(io.dev + off_to), E, max_states, (double *)(io.dev + off_st),
-                           (int32_t *)(io.dev + off_n), (uint8_t *)(io.dev + off_ok), nullptr, ctx->stream);
+  rc = geodesic_common(ctx, p, (const double *)io.dev, (const double *)(io.dev + off_to), E, max_states, (double *)(io.dev + off_st),
+                       (int32_t *)(io.dev + off_n), (uint8_t *)(io.dev + off_ok), nullptr, check_target, ctx->stream);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.out(states, off_st, sb)) != CCMP_OK) return rc;
   if ((rc = io.out(n_states, off_n, E * sizeof(int32_t))) != CCMP_OK) return rc;
   if ((rc = io.out(ok, off_ok, E)) != CCMP_OK) return rc;
   return io.finish();
+}
+
+int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                       double *states, int32_t *n_states, uint8_t *ok)
+{
+  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, 0);
+}
+
+int ccmp_check_motion_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                           double *states, int32_t *n_states, uint8_t *ok)
+{
+  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, 1);
 }
 
 static int sharded_common(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, int mode, const double *q_in, double *q_out,

@@ -123,7 +123,7 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
 
 template <bool STOCK>
 __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab, double *rec, int tid,
-                                            int &iter, int &updates, double &norm1, double &norm2)
+                                            int &iter, int &updates, double &norm1, double &norm2, int max_iter)
 {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform arm
   const int lane = tid & 63;
@@ -166,7 +166,7 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
       norm1 = c1 ? 1.0 : 0.0;
       bool resid = c1;
       if (!c1) { norm2 = f1; resid = f1 > K.tol_rot; }
-      if (resid) { cont = iter < K.max_iter; iter++; }
+      if (resid) { cont = iter < max_iter; iter++; }
     }
     if (!cont) return (norm1 < K.tol_pos) && (norm2 < K.tol_rot);
     // ---- D + E on wave 0 alone: the stencil combination needs 28 lanes, the min-norm solve is a serial computation
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(128, 2) void project_fd_flat_kernel(
       }
     }
     __syncthreads();
-    const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2);
+    const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2, K.max_iter);
     const bool jv = flat_joint_valid(KL, rec, tid);
     if (tid < 14) {
       const double v = rec[fX + tid];
@@ -327,7 +327,7 @@ template <bool STOCK>
 __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
-    int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters)
+    int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target)
 {
   __shared__ __attribute__((aligned(16))) double lds[gRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -354,8 +354,22 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
     __syncthreads();
     int n = 1, its = 0;
     bool fits = true; // false: an accepted state found the list full — the edge stops there and reports max_states + 1
+    bool target_ok = true;
+    if (check_target) {
+      // ConstrainedMotionValidator::checkMotion (src/planner/stefanBiPRM.cpp:397-398): isSatisfied(s2) first —
+      // function(to) through one evaluation pass of the Newton routine (iteration cap 0: no update), then
+      // KinematicChainConstraint::isSatisfied's test (finite, f0 <= tol1, f1 <= tol2; ConstraintFunction.h:114-120)
+      if (tid < 14) rec[fX + tid] = rec[gTo + tid];
+      __syncthreads();
+      int iter0 = 0, upd0 = 0;
+      double n1 = 0.0, n2 = 0.0;
+      (void)flat_newton<STOCK>(K, KL, steptab, rec, tid, iter0, upd0, n1, n2, 0);
+      const double f0 = rec[fF], f1 = rec[fF + 1];
+      target_ok = (f0 - f0 == 0.0) && (f1 - f1 == 0.0) && f0 <= K.tol_pos && f1 <= K.tol_rot;
+      __syncthreads();
+    }
     double dist = lds_distance(rec + gPrev, rec + gTo), total = 0.0;
-    if (dist > delta) {
+    if (target_ok && dist > delta) {
       const double maxd = dist * lambda;
       for (int guard = 0; guard < 1000000; guard++) { // the reference loop ends by itself; guard bounds a non-finite input
         if (tid < 14) { // WrapperStateSpace::interpolate(previous, to, delta_ / dist, scratch)
@@ -375,7 +389,7 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
         __syncthreads();
         int iter = 0, updates = 0;
         double norm1 = 0.0, norm2 = 0.0;
-        const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2);
+        const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2, K.max_iter);
         const bool jv = flat_joint_valid(KL, rec, tid);
         its += updates;
         if (!(conv && jv)) break;                        // not on manifold
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(128, 2) void geodesic_flat_kernel(
     }
     if (tid == 0) {
       n_states[t] = n;
-      ok_out[t] = (uint8_t)(fits && dist <= delta);
+      ok_out[t] = (uint8_t)(target_ok && fits && dist <= delta);
       if (newton_iters) newton_iters[t] = its;
     }
     __syncthreads();
@@ -440,14 +454,14 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
 
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
-                                int nblocks, hipStream_t st)
+                                int check_target, int nblocks, hipStream_t st)
 {
   if (K->stock)
     hipLaunchKernelGGL(geodesic_flat_kernel<true>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters);
+                       max_states, states, n_states, ok, newton_iters, check_target);
   else
     hipLaunchKernelGGL(geodesic_flat_kernel<false>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters);
+                       max_states, states, n_states, ok, newton_iters, check_target);
   return hipGetLastError();
 }
 

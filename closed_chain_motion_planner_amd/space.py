@@ -137,13 +137,14 @@ class jy_ProjectedStateSpace:
     def distance(self, a, b):
         return float(np.sqrt(np.sum((np.asarray(a) - np.asarray(b)) ** 2)))
 
-    def discreteGeodesicBatch(self, frm, to, interpolate=False):
-        """numpy (E,14) x2 -> list of (ok, states (n,14)) per edge"""
+    def discreteGeodesicBatch(self, frm, to, interpolate=False, check_target=False):
+        """numpy (E,14) x2 -> list of (ok, states (n,14)) per edge; check_target: isSatisfied(to) is tested first, in the
+        same launch (checkMotion)"""
         torch = _torch()
         dev = "cuda:%d" % self.constraint_.ctx.device
         f = torch.as_tensor(np.ascontiguousarray(frm, dtype=np.float64)).to(dev)
         t = torch.as_tensor(np.ascontiguousarray(to, dtype=np.float64)).to(dev)
-        states, n, ok, _ = self.constraint_.discrete_geodesic_batch(f, t, self.max_states)
+        states, n, ok, _ = self.constraint_.discrete_geodesic_batch(f, t, self.max_states, check_target=check_target)
         n, ok = n.cpu().numpy(), ok.cpu().numpy()
         rows = [None] * len(n)
         long, cap = np.nonzero(n > self.max_states)[0], self.max_states
@@ -152,7 +153,8 @@ class jy_ProjectedStateSpace:
             # four times the room — a cut list must never reach the validity test or the caller as if it were complete.
             cap *= 4
             idx = torch.as_tensor(long, device=f.device)
-            s2, n2, ok2, _ = self.constraint_.discrete_geodesic_batch(f[idx].contiguous(), t[idx].contiguous(), cap)
+            s2, n2, ok2, _ = self.constraint_.discrete_geodesic_batch(f[idx].contiguous(), t[idx].contiguous(), cap,
+                                                                      check_target=check_target)
             s2, n2, ok2 = s2.cpu().numpy(), n2.cpu().numpy(), ok2.cpu().numpy()
             again = []
             for k, e in enumerate(long):
@@ -176,8 +178,9 @@ class jy_ProjectedStateSpace:
             out.append((good, st.copy()))
         return out
 
-    def discreteGeodesic(self, frm, to, interpolate=False, geodesic=None):
-        good, st = self.discreteGeodesicBatch(np.asarray(frm).reshape(1, 14), np.asarray(to).reshape(1, 14), interpolate)[0]
+    def discreteGeodesic(self, frm, to, interpolate=False, geodesic=None, check_target=False):
+        good, st = self.discreteGeodesicBatch(np.asarray(frm).reshape(1, 14), np.asarray(to).reshape(1, 14), interpolate,
+                                              check_target)[0]
         if geodesic is not None:
             del geodesic[:]
             geodesic.extend(st)
@@ -187,7 +190,7 @@ class jy_ProjectedStateSpace:
 def check_motion(space, s1, s2):
     """OMPL `ConstrainedMotionValidator::checkMotion(s1, s2)` as the reference's planner calls it
     (src/planner/stefanBiPRM.cpp:397-398,463-464): isSatisfied(s2) && discreteGeodesic(s1, s2)."""
-    return bool(space.constraint_.isSatisfied(s2)) and bool(space.discreteGeodesic(s1, s2, False, None))
+    return bool(space.discreteGeodesic(s1, s2, False, None, check_target=True))  # both tests in one launch
 
 
 def geodesic_interpolate(states, t):

@@ -183,6 +183,12 @@ int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *
  * interpolate == false the host truncates at the first state its StateValidityChecker rejects. */
 int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                         double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream);
+/* OMPL ConstrainedMotionValidator::checkMotion as the reference's planner calls it (src/planner/stefanBiPRM.cpp:397-398,
+ * 463-464; jy_MotionValidator, jy_ProjectedStateSpace.h:57-69): isSatisfied(to) && discreteGeodesic(from, to) in ONE
+ * launch — same outputs as ccmp_geodesic_batch, except that an edge whose target fails isSatisfied reports ok = 0 and
+ * only `from` (n_states = 1) without being traversed */
+int ccmp_check_motion_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                            double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream);
 /* the ambient sampler alone (RealVectorStateSampler::sampleUniform over KinematicChain.h:75-100) */
 int ccmp_ambient_uniform_batch(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
                                double *q_out, size_t B, void *hip_stream);
@@ -212,6 +218,8 @@ int ccmp_sample_ref_project_host(ccmp_ctx *ctx, const ccmp_problem *p, int kind,
 /* states: [E][max_states][14], n_states: [E], ok: [E] (host buffers) */
 int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                        double *states, int32_t *n_states, uint8_t *ok);
+int ccmp_check_motion_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                           double *states, int32_t *n_states, uint8_t *ok);
 
 /* ---- one process, several GPUs (the reference's planner is a single process) ------------------------- */
 /* Contiguous shards of the batch go to the n contexts (1 <= n <= 64, one per device; the same device may appear twice),

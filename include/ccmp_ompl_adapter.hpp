@@ -239,9 +239,11 @@ private:
 // in order, and the list is cut at the first rejected state — where the reference's loop breaks.  The traversal on the
 // GPU stops when max_states states are listed (edges of the reference's roadmaps have 3-7 states; the work spent beyond a
 // state the checker rejects is bounded by this) and an edge that needs more is run again with four times the room.
+// check_target: ConstrainedMotionValidator::checkMotion in one launch — isSatisfied(to) is tested first and an edge whose
+// target fails it returns false with only `from` in the list (src/planner/stefanBiPRM.cpp:397-398).
 template <class ValidFn>
 inline bool discreteGeodesic(const Projector &proj, const double *from14, const double *to14, bool interpolate, ValidFn valid,
-                             std::vector<std::vector<double>> *geodesic, int max_states = 64)
+                             std::vector<std::vector<double>> *geodesic, int max_states = 64, bool check_target = false)
 {
   std::vector<double> states;
   int32_t n = 0;
@@ -250,7 +252,9 @@ inline bool discreteGeodesic(const Projector &proj, const double *from14, const 
     states.resize((size_t)max_states * 14);
     {
       std::lock_guard<std::mutex> hold(proj.mutex());
-      check(ccmp_geodesic_host(proj.ctx(), &proj.problem(), from14, to14, 1, max_states, states.data(), &n, &ok), "ccmp_geodesic_host");
+      check((check_target ? ccmp_check_motion_host : ccmp_geodesic_host)(proj.ctx(), &proj.problem(), from14, to14, 1, max_states,
+                                                                         states.data(), &n, &ok),
+            "ccmp_geodesic_host");
     }
     if (n <= max_states) break;
     // n == max_states + 1: the list did not fit and the traversal stopped there (small delta, long or creeping edge).
@@ -542,6 +546,15 @@ public:
   bool discreteGeodesic(const ompl::base::State *from, const ompl::base::State *to, bool interpolate = false,
                         std::vector<ompl::base::State *> *geodesic = nullptr) const override
   {
+    return traverse(from, to, interpolate, geodesic, false);
+  }
+  // checkMotion's two tests — isSatisfied(s2) && discreteGeodesic(s1, s2, false) — in one GPU launch
+  bool checkMotion(const ompl::base::State *s1, const ompl::base::State *s2) const { return traverse(s1, s2, false, nullptr, true); }
+
+private:
+  bool traverse(const ompl::base::State *from, const ompl::base::State *to, bool interpolate, std::vector<ompl::base::State *> *geodesic,
+                bool check_target) const
+  {
     double a[14], b[14];
     const auto &fa = *from->as<StateType>();
     const auto &tb = *to->as<StateType>();
@@ -558,7 +571,7 @@ public:
                                              for (int i = 0; i < 14; ++i) x[i] = q[i];
                                              return svc->isValid(scratch);
                                            },
-                                           geodesic ? &states : nullptr);
+                                           geodesic ? &states : nullptr, 64, check_target);
     freeState(scratch);
     if (geodesic) {
       geodesic->clear();
@@ -572,19 +585,20 @@ public:
     return ok;
   }
 
-private:
   std::shared_ptr<KinematicChainConstraint> chain_;
   uint64_t seed_;
   mutable std::atomic<uint64_t> samplers_{0};
 };
 
-// jy_MotionValidator (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:57-69): unchanged logic,
-// isSatisfied(s2) is one single-state launch and the traversal runs in jy_ProjectedStateSpace::discreteGeodesic above.
+// jy_MotionValidator (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:57-69): the same result —
+// isSatisfied(s2) && discreteGeodesic(s1, s2, false) — from one launch (jy_ProjectedStateSpace::checkMotion above); a
+// space of another type falls back to the reference's two calls.
 class jy_MotionValidator : public ompl::base::ConstrainedMotionValidator {
 public:
   jy_MotionValidator(const ompl::base::SpaceInformationPtr &si) : ompl::base::ConstrainedMotionValidator(si) {}
   bool checkMotion(const ompl::base::State *s1, const ompl::base::State *s2) const override
   {
+    if (const auto *space = dynamic_cast<const jy_ProjectedStateSpace *>(&ss_)) return space->checkMotion(s1, s2);
     return ss_.getConstraint()->isSatisfied(s2) && ss_.discreteGeodesic(s1, s2, false);
   }
 };

@@ -3,7 +3,7 @@ discreteGeodesic, Near/Gaussian samplers, compute_t_wo; plus the host mirrors bu
 import numpy as np
 import pytest
 
-from conftest import NCPU, config_path, load_cfg, load_path_rows
+from conftest import NCPU, config_path, load_cfg, load_path_rows, load_roadmap
 from test_gpu_parity import _constraint, _oracle_problem
 
 pytestmark = pytest.mark.gpu
@@ -300,6 +300,37 @@ def test_single_process_rccl_all_gather(gpu_ctx, oracle_det):
     with pytest.raises(OverflowError):  # a block too small for the shard's valid states is reported, never cut silently
         c.sample_project_sharded(0x5B, 0, B, comm, block_rows=100, want_full=False)
     comm.close()
+
+
+def test_check_motion_batch_is_both_tests_in_one_launch(gpu_ctx, oracle_det):
+    """ccmp_check_motion_batch == isSatisfied(to) && discreteGeodesic(from, to) (stefanBiPRM.cpp:397-398), per edge, bit for
+    bit: targets on the manifold are traversed exactly as by ccmp_geodesic_batch; targets that fail isSatisfied (IK-style
+    milestones ~1e-2 off, a target one ulp-ish above the tolerance, a NaN) return false with only `from`"""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    frm, to = _edges(oracle_det, P, 64, 0x6E4)
+    nodes = load_roadmap("Wine_Bottle")[0]
+    to[:8] = nodes[2:10]                      # IK milestones of the reference's roadmap: mostly off the manifold
+    to[8] = np.nan
+    to[9] = frm[9]                            # the edge to itself
+    maxs = 48
+    a = c.discrete_geodesic_batch(torch.as_tensor(frm).cuda(), torch.as_tensor(to).cuda(), maxs)
+    b = c.discrete_geodesic_batch(torch.as_tensor(frm).cuda(), torch.as_tensor(to).cuda(), maxs, check_target=True)
+    st_a, n_a, ok_a, it_a = [t.cpu().numpy() for t in a]
+    st_b, n_b, ok_b, it_b = [t.cpu().numpy() for t in b]
+    n_unsat = 0
+    for e in range(len(frm)):
+        sat = oracle_det.is_satisfied(P, to[e])
+        if sat:
+            assert n_b[e] == n_a[e] and ok_b[e] == ok_a[e] and it_b[e] == it_a[e]
+            m = min(int(n_a[e]), maxs)
+            assert np.array_equal(st_b[e, :m].view(np.uint64), st_a[e, :m].view(np.uint64))
+        else:
+            n_unsat += 1
+            assert ok_b[e] == 0 and n_b[e] == 1 and it_b[e] == 0 and np.array_equal(st_b[e, 0], frm[e])
+    assert n_unsat >= 5 and ok_b[9] == 1 and n_b[9] == 1
 
 
 def test_check_motion_and_geodesic_interpolate(gpu_ctx, oracle_det):
