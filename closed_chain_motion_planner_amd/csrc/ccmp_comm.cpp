@@ -127,6 +127,7 @@ void ccmp_comm_destroy(ccmp_comm *c)
 static int comm_ensure_blocks(ccmp_comm *c, size_t cap)
 {
   if (c->cap >= cap && c->send[0]) return CCMP_OK;
+  c->cap = 0; // nothing is usable until every block below exists (a failure half-way must not leave a stale capacity)
   const size_t block = (cap + 1) * 14 * sizeof(double);
   for (int g = 0; g < c->n; g++) {
     DeviceGuard guard(c->ctxs[g]->device);
