@@ -11,4 +11,6 @@ from .space import (check_motion, format_graphml, format_graphviz, format_path_m
                     jy_ProjectedStateSampler, jy_ProjectedStateSpace, next_sampler_seed, parse_graphml, parse_path_matrix,
                     splitmix64)
 
-__version__ = "0.2.0"
+from .scene import ProxyScene, ProxyValidityChecker, default_allowed, skeleton_spheres  # noqa: F401
+
+__version__ = "0.2.1"

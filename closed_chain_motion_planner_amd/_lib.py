@@ -48,6 +48,16 @@ class CcmpProblem(C.Structure):
         return CcmpProblem.from_buffer_copy(bytes(self))
 
 
+class CcmpSphere(C.Structure):
+    """ccmp_sphere of include/ccmp.h"""
+    _fields_ = [("frame", C.c_int32), ("group", C.c_int32), ("c", C.c_double * 3), ("r", C.c_double)]
+
+
+class CcmpBox(C.Structure):
+    """ccmp_box of include/ccmp.h"""
+    _fields_ = [("group", C.c_int32), ("reserved", C.c_int32), ("c", C.c_double * 3), ("R", C.c_double * 9), ("half", C.c_double * 3)]
+
+
 CCMP_JAC_FD = 0
 CCMP_JAC_ANALYTIC = 1
 
@@ -60,6 +70,7 @@ EXPORTS = [
     "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_check_motion_batch", "ccmp_check_motion_host", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid", "ccmp_compact_valid_capped",
     "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_sample_project_host", "ccmp_sample_ref_project_host", "ccmp_geodesic_host", "ccmp_project_sharded_host", "ccmp_sample_project_sharded_host",
     "ccmp_comm_create", "ccmp_comm_destroy", "ccmp_project_sharded", "ccmp_sample_project_sharded", "ccmp_ctx_set_order_experimental",
+    "ccmp_scene_create", "ccmp_scene_destroy", "ccmp_scene_num_pairs", "ccmp_clearance_batch", "ccmp_clearance_host",
     "ccmp_ctx_debug_lpt_pred", "ccmp_detmath_probe", "ccmp_strerror",
     "ccmp_last_hip_error", "ccmp_version", "ccmp_problem_sizeof",
 ]
@@ -135,6 +146,11 @@ def lib():
                                   C.POINTER(C.c_uint64)], C.c_int),
         "ccmp_sample_project_sharded": ([vp, pp, C.c_uint64, C.c_uint64, C.c_size_t, dp, u8p, u16p, C.c_size_t, dp, C.c_size_t,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], C.c_int),
+        "ccmp_scene_create": ([vp, C.POINTER(CcmpSphere), C.c_int, C.POINTER(CcmpBox), C.c_int, C.POINTER(C.c_uint32), C.POINTER(vp)], C.c_int),
+        "ccmp_scene_destroy": ([vp], None),
+        "ccmp_scene_num_pairs": ([vp], C.c_int),
+        "ccmp_clearance_batch": ([vp, pp, vp, vp, vp, C.c_size_t, C.c_double, vp, vp, vp, vp], C.c_int),
+        "ccmp_clearance_host": ([vp, pp, vp, dp, C.c_size_t, C.c_double, dp, C.POINTER(C.c_int32), u8p], C.c_int),
         "ccmp_ctx_set_order_experimental": ([vp, vp], C.c_int),
         "ccmp_ctx_debug_lpt_pred": ([vp, vp, C.c_size_t], C.c_int),
         "ccmp_detmath_probe": ([vp, vp, vp, vp, C.c_size_t, vp], C.c_int),

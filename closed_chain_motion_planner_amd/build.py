@@ -10,6 +10,8 @@ Translation units with deliberately different flags:
   ccmp_comm.cpp                                             one process / several GPUs: RCCL communicator and sharded entry points
   ccmp_kernels_fast.hip  -ffp-contract=off -DCCMP_USE_FMA   analytic fast mode, bit-identical to the oracle's analytic mode
   ccmp_kernels_scout.hip -ffast-math                        FP32 iteration-count predictor + ordering (never touches results)
+  ccmp_kernels_scene.hip -ffp-contract=off -DCCMP_USE_FMA   proxy-geometry clearance (pre-filter ahead of the host's MoveIt test)
+  ccmp_scene.cpp                                            proxy scenes: validation, pair list, launches
 """
 import os
 import shutil
@@ -36,8 +38,10 @@ _UNITS = [
     ("ccmp_problem.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
     ("ccmp_comm.cpp", ["-O2", "-x", "hip"]),
+    ("ccmp_kernels_scene.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT"]),
+    ("ccmp_scene.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]
-_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_host.h", "ccmp_ctx.h", os.path.join("..", "..", "include", "ccmp.h")]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
 
 
 def hipcc_path():

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CCMP_VERSION 200
+#define CCMP_VERSION 210
 
 enum {
   CCMP_OK = 0,
@@ -253,6 +253,61 @@ int ccmp_project_sharded(ccmp_comm *comm, const ccmp_problem *p, const double *q
 int ccmp_sample_project_sharded(ccmp_comm *comm, const ccmp_problem *p, uint64_t seed, uint64_t first_index, size_t B,
                                 double *q_out, uint8_t *ok, uint16_t *iters, size_t block_rows, double *valid_out,
                                 size_t valid_capacity, uint64_t *counts, uint64_t *n_valid);
+
+/* ---- proxy-geometry clearance: a pre-filter in FRONT of the MoveIt validity test ----------------------------------- */
+/* KinematicChainValidityChecker::isValid (src/kinematics/KinematicChain.cpp:94-123) sets both arms' joints, updates the
+ * robot state and asks MoveIt's PlanningScene::checkCollision under an AllowedCollisionMatrix.  MoveIt, FCL and the
+ * robot's URDF meshes stay on the host (out of scope to accelerate); what runs here is the cheap test a
+ * planner puts in front of it ("per-arm collision pre-filter (capsule/sphere proxies) ahead of MoveIt
+ * isValidImpl"): spheres rigidly attached to link frames of the two arms (or to the world), static oriented boxes (the
+ * reference's "sub_table", KinematicChain.cpp:25-30), a 32 x 32 allowed-pair matrix between user-chosen groups (the
+ * reference's acm_, KinematicChain.cpp:9,86-91), and for every state the smallest signed distance over all pairs that
+ * are not allowed.  With proxies INSCRIBED in the real geometry a negative clearance proves a collision (the state can
+ * be dropped without asking MoveIt); with CIRCUMSCRIBED proxies a positive clearance proves freedom.  The proxies are
+ * the caller's: the reference ships no link geometry (robot_description comes from the ROS parameter server), so this
+ * entry point cannot be — and is not — compared with MoveIt; it is bit-exact against oracle/ccmp_oracle.c:orc_clearance,
+ * whose frames are the projector's own forward kinematics.
+ *
+ * Frames: CCMP_FRAME_WORLD, or CCMP_FRAME(arm, k) with arm 0 / 1 in state order and
+ *   k = 0..6  the RBDL body of joint k (panda_link1..7): origin at the joint, axes parallel to the arm base at q = 0
+ *             (panda_rbdl.cpp:117-147: the bodies are chained by pure translations)
+ *   k = 7     the hand frame PandaModel::getTransform returns (panda_rbdl.cpp:24-42): 0.107 m beyond joint 6, turned -45 deg
+ *   k = 8     the arm's base (panda_link0), t_wb of grasping_point.cpp:11-20 */
+#define CCMP_FRAME_WORLD (-1)
+#define CCMP_FRAME(arm, k) ((arm) * 9 + (k))
+#define CCMP_MAX_SPHERES 64
+#define CCMP_MAX_BOXES 8
+typedef struct ccmp_sphere {
+  int32_t frame; /* CCMP_FRAME_WORLD or CCMP_FRAME(arm, k) */
+  int32_t group; /* 0..31: row / column of the allowed-pair matrix */
+  double c[3];   /* centre in that frame, metres */
+  double r;      /* radius, >= 0 */
+} ccmp_sphere;
+typedef struct ccmp_box { /* static, oriented, in the world frame */
+  int32_t group;
+  int32_t reserved;
+  double c[3];    /* centre */
+  double R[9];    /* row-major rotation, box axes -> world */
+  double half[3]; /* half extents along the box axes */
+} ccmp_box;
+typedef struct ccmp_scene ccmp_scene;
+/* allowed[g] bit h set = pairs between groups g and h are never tested (either direction counts; NULL = nothing allowed).
+ * Never tested either: two proxies on the same frame, and two proxies that are both static (world or an arm's base).
+ * Pairs are numbered sphere i < sphere j in the caller's order first, then (sphere i, box b). */
+int ccmp_scene_create(ccmp_ctx *ctx, const ccmp_sphere *spheres, int n_spheres, const ccmp_box *boxes, int n_boxes,
+                      const uint32_t allowed[32], ccmp_scene **out);
+void ccmp_scene_destroy(ccmp_scene *scene);
+int ccmp_scene_num_pairs(const ccmp_scene *scene);
+/* clearance[i] = min over tested pairs of (distance between centres - r_i - r_j), or (distance from the sphere centre to the
+ * box, 0 inside) - r_i; +inf when nothing is tested; NaN for a state with a non-finite joint value.  pair[i] (nullable)
+ * = i_sphere | (j << 8) of the first pair in the numbering above that attains it, j = 64 + box index for a box, -1 when
+ * there is none.  free_out[i] (nullable) = (ok_in == NULL || ok_in[i]) && clearance[i] > margin — it can go straight into
+ * ccmp_compact_valid behind a projection.  Device pointers, asynchronous on hip_stream. */
+int ccmp_clearance_batch(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *scene, const double *q, const uint8_t *ok_in,
+                         size_t B, double margin, double *clearance, int32_t *pair, uint8_t *free_out, void *hip_stream);
+/* the same on host buffers (a single state: what a StateValidityChecker wrapper calls before MoveIt) */
+int ccmp_clearance_host(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *scene, const double *q, size_t B, double margin,
+                        double *clearance, int32_t *pair, uint8_t *free_out);
 
 /* ---- diagnostics ---------------------------------------------------------------------------------- */
 /* runs ccmp_detmath.h's sincos/atan2/sqrt/div on the device: out[i] = {sin,cos,atan2_nn(|x|,|y|),

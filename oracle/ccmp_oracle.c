@@ -714,6 +714,96 @@ void orc_compute_t_wo(const orc_problem *P, const double q_left[7], double R[9],
   m3_vec_acc(Rw, pi_, p);
 }
 
+/* ---- proxy-geometry clearance (see ccmp_oracle.h) -------------------------------------------------------------- */
+/* frames of one arm in the arm's base: bodies 0..6 (R after joint k's rotation, origin at joint k) and the hand frame */
+static void arm_frames(const orc_problem *P, int arm, const double q[7], double Rk[8][9], double ok[8][3])
+{
+  double R[9], o[3] = {0, 0, 0};
+  m3_identity(R);
+  for (int i = 0; i < 7; i++) {
+    double Rj[9], Rn[9];
+    m3_vec_acc(R, P->offset[arm][i], o);
+    rot_axis(P->axis[arm][i], q[i], Rj);
+    m3_mul(R, Rj, Rn);
+    memcpy(R, Rn, sizeof Rn);
+    memcpy(Rk[i], R, sizeof R);
+    memcpy(ok[i], o, sizeof o);
+  }
+  m3_vec_acc(R, P->ee[arm], o);
+  m3_mul(R, P->R_tool[arm], Rk[7]);
+  memcpy(ok[7], o, sizeof o);
+}
+
+void orc_proxy_centres(const orc_problem *P, const orc_sphere *sph, int ns, const double x[14], double *centres)
+{
+  double Rk[2][8][9], ok[2][8][3];
+  arm_frames(P, 0, x, Rk[0], ok[0]);
+  arm_frames(P, 1, x + 7, Rk[1], ok[1]);
+  for (int s = 0; s < ns; s++) {
+    double *w = centres + 3 * s;
+    const int f = sph[s].frame;
+    if (f < 0) { memcpy(w, sph[s].c, 3 * sizeof(double)); continue; }
+    const int arm = f / 9, k = f % 9;
+    double v[3];
+    if (k == 8) memcpy(v, sph[s].c, sizeof v);                 /* arm base: only t_wb applies */
+    else {
+      memcpy(v, ok[arm][k], sizeof v);
+      m3_vec_acc(Rk[arm][k], sph[s].c, v);                     /* origin + R * c, in the arm's base */
+    }
+    for (int c = 0; c < 3; c++) w[c] = P->base_p[arm][c];
+    m3_vec_acc(P->base_R[arm], v, w);                          /* t_wb * */
+  }
+}
+
+static int frame_is_static(int f) { return f < 0 || f % 9 == 8; }
+
+int orc_clearance(const orc_problem *P, const orc_sphere *sph, int ns, const orc_box *box, int nb, const uint32_t allowed[32],
+                  const double x[14], double *clearance, int32_t *pair)
+{
+  double cw[64][3];
+  double best = INFINITY;
+  int32_t best_pair = -1;
+  int tested = 0, finite = 1;
+  for (int k = 0; k < 14; k++) if (!(x[k] - x[k] == 0.0)) finite = 0;
+  if (finite) orc_proxy_centres(P, sph, ns, x, &cw[0][0]);
+  for (int i = 0; i < ns; i++)
+    for (int j = i + 1; j < ns; j++) {
+      if (sph[i].frame == sph[j].frame) continue;
+      if (frame_is_static(sph[i].frame) && frame_is_static(sph[j].frame)) continue;
+      if (allowed && (((allowed[sph[i].group] >> sph[j].group) & 1u) || ((allowed[sph[j].group] >> sph[i].group) & 1u))) continue;
+      tested++;
+      if (!finite) continue;
+      const double d0 = cw[i][0] - cw[j][0], d1 = cw[i][1] - cw[j][1], d2 = cw[i][2] - cw[j][2];
+      const double clr = sqrt(DOT3(d0, d0, d1, d1, d2, d2)) - (sph[i].r + sph[j].r);
+      if (clr < best) { best = clr; best_pair = i | (j << 8); }
+    }
+  for (int i = 0; i < ns; i++)
+    for (int b = 0; b < nb; b++) {
+      if (frame_is_static(sph[i].frame)) continue;
+      if (allowed && (((allowed[sph[i].group] >> box[b].group) & 1u) || ((allowed[box[b].group] >> sph[i].group) & 1u))) continue;
+      tested++;
+      if (!finite) continue;
+      double d[3], l[3], e[3];
+      for (int c = 0; c < 3; c++) d[c] = cw[i][c] - box[b].c[c];
+      m3t_vec(box[b].R, d, l);                                  /* into the box's axes */
+      for (int c = 0; c < 3; c++) {
+        const double a = fabs(l[c]) - box[b].half[c];
+        e[c] = a > 0.0 ? a : 0.0;
+      }
+      const double clr = sqrt(DOT3(e[0], e[0], e[1], e[1], e[2], e[2])) - sph[i].r;
+      if (clr < best) { best = clr; best_pair = i | ((64 + b) << 8); }
+    }
+  *clearance = finite ? best : NAN;
+  if (pair) *pair = finite ? best_pair : -1;
+  return tested;
+}
+
+void orc_clearance_batch(const orc_problem *P, const orc_sphere *sph, int ns, const orc_box *box, int nb, const uint32_t allowed[32],
+                         const double *q, size_t B, double *clearance, int32_t *pair)
+{
+  for (size_t i = 0; i < B; i++) (void)orc_clearance(P, sph, ns, box, nb, allowed, q + 14 * i, clearance + i, pair ? pair + i : NULL);
+}
+
 /* ---- batch drivers ---------------------------------------------------------------------------- */
 /* Threads take samples in small dynamic chunks from a shared counter: iteration counts spread 15..250 per
  * sample, so a static B/n partition leaves most threads idle while the unluckiest one finishes. */

@@ -131,6 +131,22 @@ int orc_discrete_geodesic(const orc_problem *P, const double from[14], const dou
                           int max_states, int *n_states, int64_t *newton_iters);
 void orc_compute_t_wo(const orc_problem *P, const double q_left[7], double R[9], double p[3]);
 
+/* --- proxy-geometry clearance (the product's pre-filter in front of the MoveIt validity test; include/ccmp.h) ----------
+ * Not a restatement of reference code: MoveIt's checkCollision (src/kinematics/KinematicChain.cpp:101-123) and the robot
+ * meshes are absent.  What IS the reference's here is the kinematics the proxies ride on — the body frames of
+ * PandaModel's RBDL chain (panda_rbdl.cpp:117-147) and t_wb — so this checker places every sphere with the same FK that
+ * orc_fk is pinned with, then measures distances.  Layouts match ccmp_sphere / ccmp_box. */
+typedef struct orc_sphere { int32_t frame; int32_t group; double c[3]; double r; } orc_sphere;
+typedef struct orc_box { int32_t group; int32_t reserved; double c[3]; double R[9]; double half[3]; } orc_box;
+/* world position of every sphere centre at state x */
+void orc_proxy_centres(const orc_problem *P, const orc_sphere *sph, int ns, const double x[14], double *centres /* [ns][3] */);
+/* smallest signed distance over the tested pairs (+inf: none; NaN: non-finite state) and the first pair attaining it
+ * (i | j << 8, j = 64 + box; -1: none); returns the number of pairs tested */
+int orc_clearance(const orc_problem *P, const orc_sphere *sph, int ns, const orc_box *box, int nb, const uint32_t allowed[32],
+                  const double x[14], double *clearance, int32_t *pair);
+void orc_clearance_batch(const orc_problem *P, const orc_sphere *sph, int ns, const orc_box *box, int nb, const uint32_t allowed[32],
+                         const double *q, size_t B, double *clearance, int32_t *pair);
+
 /* --- batch drivers (pthreads, dynamic chunks from a shared counter; for parity runs and the CPU baseline timing) --- */
 void orc_function_batch(const orc_problem *P, const double *q, double *f, size_t B, int nthreads);
 void orc_project_batch(const orc_problem *P, const double *q_in, double *q_out, uint8_t *ok,

@@ -46,6 +46,30 @@ class OrcProblem(C.Structure):
     ]
 
 
+class OrcSphere(C.Structure):
+    """orc_sphere == ccmp_sphere"""
+    _fields_ = [("frame", C.c_int32), ("group", C.c_int32), ("c", C.c_double * 3), ("r", C.c_double)]
+
+
+class OrcBox(C.Structure):
+    """orc_box == ccmp_box"""
+    _fields_ = [("group", C.c_int32), ("reserved", C.c_int32), ("c", C.c_double * 3), ("R", C.c_double * 9), ("half", C.c_double * 3)]
+
+
+def pack_proxies(spheres, boxes, allowed):
+    """spheres: iterable of (frame, group, centre, radius); boxes: (group, centre, R 3x3, half); allowed: 32 ints or None"""
+    sa = (OrcSphere * max(1, len(spheres)))()
+    for k, (frame, group, c, r) in enumerate(spheres):
+        sa[k] = OrcSphere(int(frame), int(group), (C.c_double * 3)(*[float(v) for v in c]), float(r))
+    ba = (OrcBox * max(1, len(boxes)))()
+    for k, (group, c, R, half) in enumerate(boxes):
+        ba[k] = OrcBox(int(group), 0, (C.c_double * 3)(*[float(v) for v in c]),
+                       (C.c_double * 9)(*[float(v) for v in np.asarray(R, dtype=np.float64).reshape(9)]),
+                       (C.c_double * 3)(*[float(v) for v in half]))
+    al = None if allowed is None else (C.c_uint32 * 32)(*[int(v) & 0xFFFFFFFF for v in allowed])
+    return sa, len(spheres), ba, len(boxes), al
+
+
 def build_oracle():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 
@@ -101,6 +125,12 @@ class Oracle:
                                                  C.POINTER(C.c_int32), C.c_size_t, C.c_int]
         lib.orc_discrete_geodesic_batch.argtypes = [pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32),
                                                     C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_int]
+        lib.orc_proxy_centres.argtypes = [pp, C.POINTER(OrcSphere), C.c_int, dp, dp]
+        lib.orc_clearance.argtypes = [pp, C.POINTER(OrcSphere), C.c_int, C.POINTER(OrcBox), C.c_int, C.POINTER(C.c_uint32), dp, dp,
+                                      C.POINTER(C.c_int32)]
+        lib.orc_clearance.restype = C.c_int
+        lib.orc_clearance_batch.argtypes = [pp, C.POINTER(OrcSphere), C.c_int, C.POINTER(OrcBox), C.c_int, C.POINTER(C.c_uint32), dp,
+                                            C.c_size_t, dp, C.POINTER(C.c_int32)]
         lib.orc_sincos.argtypes = [C.c_double, dp, dp]
         lib.orc_atan2_nn.argtypes = [C.c_double, C.c_double]
         lib.orc_atan2_nn.restype = C.c_double
@@ -221,6 +251,30 @@ class Oracle:
         R = np.empty(9); p = np.empty(3)
         self.lib.orc_compute_t_wo(C.byref(P), _dptr(q), _dptr(R), _dptr(p))
         return R.reshape(3, 3), p
+
+    # -- proxy-geometry clearance ---------------------------------------------------------------
+    def proxy_centres(self, P, spheres, x):
+        sa, ns, _, _, _ = pack_proxies(spheres, [], None)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty((ns, 3))
+        self.lib.orc_proxy_centres(C.byref(P), sa, ns, _dptr(x), _dptr(out))
+        return out
+
+    def clearance(self, P, spheres, boxes, allowed, x):
+        """-> (clearance, pair code, number of pairs tested)"""
+        sa, ns, ba, nb, al = pack_proxies(spheres, boxes, allowed)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        clr = C.c_double(0.0); pair = C.c_int32(0)
+        n = self.lib.orc_clearance(C.byref(P), sa, ns, ba, nb, al, _dptr(x), C.byref(clr), C.byref(pair))
+        return clr.value, pair.value, n
+
+    def clearance_batch(self, P, spheres, boxes, allowed, q):
+        sa, ns, ba, nb, al = pack_proxies(spheres, boxes, allowed)
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B = q.shape[0]
+        clr = np.empty(B); pair = np.empty(B, dtype=np.int32)
+        self.lib.orc_clearance_batch(C.byref(P), sa, ns, ba, nb, al, _dptr(q), B, _dptr(clr), pair.ctypes.data_as(C.POINTER(C.c_int32)))
+        return clr, pair
 
     # -- batch --------------------------------------------------------------------------------
     def function_batch(self, P, q, nthreads=8):
