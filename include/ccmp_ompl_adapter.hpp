@@ -3,7 +3,8 @@
 // Part 1 (always available, no third-party headers): ccmp::Projector, an RAII owner of a
 // ccmp_ctx + ccmp_problem with the reference's method names on raw double[14] buffers;
 // ccmp::SampleBuffer / ccmp::RefSampleBuffer, refill-on-empty batches of GPU-projected samples;
-// ccmp::discreteGeodesic; ccmp::ShardedProjector (one process, several GPUs, RCCL all-gather of the valid states); and
+// ccmp::discreteGeodesic; ccmp::ShardedProjector (one process, several GPUs, RCCL all-gather of the valid states);
+// ccmp::ProxyScene (sphere / box pre-filter ahead of the MoveIt validity test); and
 // the dump formats of the reference's planner run (ccmp::printAsMatrix, ccmp::printGraphML, ccmp::printGraphviz).
 //
 // Part 2 (compiled only with -DCCMP_WITH_OMPL, i.e. inside the reference's catkin workspace where
@@ -357,6 +358,63 @@ private:
   std::mutex mu_;
 };
 
+// ---- proxy-geometry pre-filter in front of KinematicChainValidityChecker::isValid ---------------------------------
+// (src/kinematics/KinematicChain.cpp:94-123: MoveIt's checkCollision under acm_).  Spheres on link frames, static
+// boxes, an allowed-pair matrix (include/ccmp.h: ccmp_scene_create); clearance() is the smallest signed distance over
+// the tested pairs.  With spheres inscribed in the links a negative clearance proves a collision, so the state can be
+// refused without asking MoveIt; everything else still goes to MoveIt (PrefilteredValidityChecker in part 2).
+class ProxyScene {
+public:
+  ProxyScene(const Projector &proj, const std::vector<ccmp_sphere> &spheres, const std::vector<ccmp_box> &boxes,
+             const uint32_t *allowed32 = nullptr)
+    : proj_(proj)
+  {
+    check(ccmp_scene_create(proj.ctx(), spheres.data(), (int)spheres.size(), boxes.data(), (int)boxes.size(), allowed32, &scene_),
+          "ccmp_scene_create");
+  }
+  ~ProxyScene() { ccmp_scene_destroy(scene_); }
+  ProxyScene(const ProxyScene &) = delete;
+  ProxyScene &operator=(const ProxyScene &) = delete;
+  int numPairs() const { return ccmp_scene_num_pairs(scene_); }
+  // one state; pair (nullable) = i | j << 8 of the closest pair (j >= 64: box j - 64), -1 if nothing is tested
+  double clearance(const double *x14, int32_t *pair = nullptr) const
+  {
+    double clr = 0.0;
+    std::lock_guard<std::mutex> hold(proj_.mutex());
+    check(ccmp_clearance_host(proj_.ctx(), &proj_.problem(), scene_, x14, 1, 0.0, &clr, pair, nullptr), "ccmp_clearance_host");
+    return clr;
+  }
+  // B host states: clearance[B], free[B] = clearance > margin (both caller-owned; pair nullable)
+  void clearanceBatch(const double *q, size_t B, double margin, double *clearance, int32_t *pair, uint8_t *free_out) const
+  {
+    std::lock_guard<std::mutex> hold(proj_.mutex());
+    check(ccmp_clearance_host(proj_.ctx(), &proj_.problem(), scene_, q, B, margin, clearance, pair, free_out), "ccmp_clearance_host");
+  }
+  const ccmp_scene *handle() const { return scene_; }
+
+  // AllowedCollisionMatrix::setEntry(g, h, true) on a 32-word matrix
+  static void allow(uint32_t *allowed32, int g, int h)
+  {
+    allowed32[g] |= 1u << h;
+    allowed32[h] |= 1u << g;
+  }
+  // the reference constructor's "sub_table" (KinematicChain.cpp:25-30: addBox(dim (0.65, 1.0, 0.2), pose (0.65, 0, 1.1)))
+  static ccmp_box subTable(int group)
+  {
+    ccmp_box b;
+    std::memset(&b, 0, sizeof b);
+    b.group = group;
+    b.c[0] = 0.65; b.c[1] = 0.0; b.c[2] = 1.1;
+    b.R[0] = b.R[4] = b.R[8] = 1.0;
+    b.half[0] = 0.325; b.half[1] = 0.5; b.half[2] = 0.1;
+    return b;
+  }
+
+private:
+  const Projector &proj_;
+  ccmp_scene *scene_ = nullptr;
+};
+
 // ---- dump formats of the reference's planner run ----------------------------------------------------------------------
 // PathGeometric::printAsMatrix as ConstrainedProblem::solveOnce writes `<obj>_path.txt`
 // (src/base/constraints/ConstrainedPlanningCommon.cpp:219-222) and scripts/execute_path.py:65-87 / visualize_path.py
@@ -616,6 +674,35 @@ inline jy_ProjectedStateSampler::jy_ProjectedStateSampler(const jy_ProjectedStat
   : jy_ProjectedStateSampler(space, std::move(sampler), space->nextSamplerSeed())
 {
 }
+
+// A StateValidityChecker that asks the proxy scene first and the exact checker (the reference's
+// KinematicChainValidityChecker, i.e. MoveIt) only for states the proxies do not already refuse:
+//   si->setStateValidityChecker(std::make_shared<PrefilteredValidityChecker>(si, scene, valid_checker_));
+// `reject_below` = 0 with inscribed proxies; the answer for every state MoveIt is asked about is MoveIt's.
+class PrefilteredValidityChecker : public ompl::base::StateValidityChecker {
+public:
+  PrefilteredValidityChecker(const ompl::base::SpaceInformationPtr &si, std::shared_ptr<ccmp::ProxyScene> scene,
+                             ompl::base::StateValidityCheckerPtr exact, double reject_below = 0.0)
+    : ompl::base::StateValidityChecker(si), scene_(std::move(scene)), exact_(std::move(exact)), reject_below_(reject_below)
+  {
+  }
+  bool isValid(const ompl::base::State *state) const override
+  {
+    const auto &q = *state->as<ompl::base::ConstrainedStateSpace::StateType>();  // an Eigen::Map over the 14 joints, as in
+    const double clr = scene_->clearance(&q[0]);                                 // KinematicChain.cpp:94-99
+    if (!(clr > reject_below_)) { rejected_++; return false; }
+    asked_++;
+    return exact_ ? exact_->isValid(state) : true;
+  }
+  uint64_t rejectedByProxies() const { return rejected_.load(); }
+  uint64_t askedExact() const { return asked_.load(); }
+
+private:
+  std::shared_ptr<ccmp::ProxyScene> scene_;
+  ompl::base::StateValidityCheckerPtr exact_;
+  double reject_below_;
+  mutable std::atomic<uint64_t> rejected_{0}, asked_{0};
+};
 #endif  // CCMP_WITH_OMPL
 
 #endif  // CCMP_OMPL_ADAPTER_HPP

@@ -112,6 +112,26 @@ int main(int argc, char **argv)
       for (int t = 0; t < 4; t++) mismatches += bad[t];
       std::printf("threads mismatches %d\n", mismatches);
     }
+    // proxy scene in front of the host's validity test: one sphere on either hand, one on arm 1's forearm, the
+    // reference's sub_table; hands allowed against each other
+    {
+      std::vector<ccmp_sphere> sph(3);
+      std::memset(sph.data(), 0, sph.size() * sizeof(ccmp_sphere));
+      sph[0].frame = CCMP_FRAME(0, 7); sph[0].group = 0; sph[0].r = 0.04;
+      sph[1].frame = CCMP_FRAME(1, 7); sph[1].group = 1; sph[1].r = 0.04;
+      sph[2].frame = CCMP_FRAME(1, 3); sph[2].group = 2; sph[2].c[2] = 0.1; sph[2].r = 0.06;
+      std::vector<ccmp_box> boxes{ccmp::ProxyScene::subTable(3)};
+      uint32_t allowed[32] = {0};
+      ccmp::ProxyScene::allow(allowed, 0, 1);
+      ccmp::ProxyScene scene(P, sph, boxes, allowed);
+      std::printf("scene pairs %d\n", scene.numPairs());
+      for (size_t i = 0; i < B && i < 4; i++) {
+        int32_t pair = 0;
+        const double clr = scene.clearance(&q[14 * i], &pair);
+        std::printf("clearance %zu pair %d\n", i, (int)pair);
+        print_hex(&clr, 1);
+      }
+    }
     // one process, "several" GPUs with the collective: this box has one, so the communicator has one rank
     {
       ccmp::ShardedProjector S(argv[1], std::vector<int>{0});

@@ -141,6 +141,21 @@ int main(int argc, char **argv)
     std::printf("checkMotion %d %d\n", mv.checkMotion(a, b) ? 1 : 0, mv.checkMotion(b, a) ? 1 : 0);
     const bool gi = space->discreteGeodesic(a, b, true);
     std::printf("geodesic_interpolate ok %d\n", gi ? 1 : 0);
+    // proxy pre-filter in front of the exact checker: a sphere on either hand's fingertips, hands NOT allowed against
+    // each other -> state a (hands a bottle's width apart) is refused by the proxies alone when they are fat, and handed
+    // to the exact checker when they are thin
+    for (double radius : {0.2, 0.01}) {
+      std::vector<ccmp_sphere> sph(2);
+      std::memset(sph.data(), 0, sph.size() * sizeof(ccmp_sphere));
+      sph[0].frame = CCMP_FRAME(0, 7); sph[0].group = 0; sph[0].r = radius;
+      sph[1].frame = CCMP_FRAME(1, 7); sph[1].group = 1; sph[1].r = radius;
+      auto scene = std::make_shared<ccmp::ProxyScene>(constraint->impl(), sph, std::vector<ccmp_box>{});
+      auto exact = std::make_shared<CountingChecker>(1000000);
+      PrefilteredValidityChecker pre(si_ptr, scene, exact);
+      const bool v = pre.isValid(a);
+      std::printf("prefilter radius %.2f valid %d exact_calls %d rejected %llu\n", radius, v ? 1 : 0, exact->calls_,
+                  (unsigned long long)pre.rejectedByProxies());
+    }
     space->freeState(a);
     space->freeState(b);
   } catch (const std::exception &e) {

@@ -10,8 +10,12 @@
 #include "ompl/base/Constraint.h"
 #include "ompl/base/StateSampler.h"
 namespace ompl { namespace base {
+class SpaceInformation;
+typedef std::shared_ptr<SpaceInformation> SpaceInformationPtr;
 class StateValidityChecker {
 public:
+  StateValidityChecker() = default;
+  explicit StateValidityChecker(const SpaceInformationPtr &) {}
   virtual ~StateValidityChecker() = default;
   virtual bool isValid(const State *state) const = 0;
 };
@@ -27,7 +31,6 @@ private:
   StateValidityCheckerPtr svc_;
   std::shared_ptr<StateSpace> space_;
 };
-typedef std::shared_ptr<SpaceInformation> SpaceInformationPtr;
 class StateSpace {
 public:
   virtual ~StateSpace() = default;
