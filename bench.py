@@ -481,6 +481,41 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             res["parity_vs_det_oracle"] = {"error": repr(e)}
         return res
 
+    def proxy_clearance():
+        # the pre-filter ahead of the host's MoveIt test: default skeleton spheres + sub_table on the
+        # states a sampleUniform batch produces, chained behind the projection's flags
+        from closed_chain_motion_planner_amd.scene import ProxyValidityChecker
+
+        c.setJacobianMode(CCMP_JAC_FD)
+        sc = ProxyValidityChecker(c).scene
+        q, ok, _, _ = c.sample_project_batch(0xC1EA, 0, B, want_iters=False)
+        sec = timed(lambda: sc.clearance_batch(q, 0.0, ok=ok, want_pair=True), 10)
+        clr, pair, free = sc.clearance_batch(q, 0.0, ok=ok)
+        res = {"states_per_s": B / sec, "ms": sec * 1e3, "states": B, "spheres": len(sc.spheres), "boxes": len(sc.boxes),
+               "pairs_per_state": sc.num_pairs, "pair_tests_per_s": B * sc.num_pairs / sec,
+               "kept_fraction_of_valid": float(free.to(torch.float64).sum().item() / max(1.0, ok.to(torch.float64).sum().item()))}
+        xs = q[:3].cpu().numpy()
+        ts = []
+        for i in range(24):
+            t0 = time.perf_counter()
+            sc.clearance(xs[i % 3])
+            ts.append(time.perf_counter() - t0)
+        res["single_state_call_median_us"] = float(np.median(ts[4:]) * 1e6)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_binding import Oracle
+
+            Od = Oracle("det")
+            Pd = Od.problem_from_bytes(bytes(c.problem))
+            m = 2048
+            co, po = Od.clearance_batch(Pd, sc.spheres, sc.boxes, sc.allowed, q[:m].cpu().numpy())
+            cg = clr[:m].cpu().numpy()
+            res["parity_vs_det_oracle"] = {"states": m, "bit_identical": bool(np.array_equal(cg.view(np.uint64), co.view(np.uint64))
+                                                                                 and np.array_equal(pair[:m].cpu().numpy(), po))}
+        except Exception as e:
+            res["parity_vs_det_oracle"] = {"error": repr(e)}
+        return res
+
     out = {}
     s4 = quick(c, main_mode, 4096, 10, check=True)
     s32 = quick(c, main_mode, 32768, 10)
@@ -496,6 +531,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
     st.setTolerance(5e-4, 2.5e-3)
     out["stefan_batch%d_tol_5e-4_2.5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True)
     out["discrete_geodesic"] = geodesic()
+    out["proxy_clearance"] = proxy_clearance()
     c.setJacobianMode(main_mode)
     return out
 

@@ -85,8 +85,8 @@ namespace {
 // Host buffers of the *_host entry points.  Up to kPinBytes the kernels work directly on a pinned, device-mapped host
 // block (a single project(x) is then memcpy + launch + synchronize + memcpy: no staged pageable copies, ~3 driver
 // calls fewer); larger batches go through device staging with asynchronous copies.
-constexpr size_t kPinBytes = 64 * 1024;
-constexpr size_t kPinData = kPinBytes - 64; // the last 64 bytes hold the completion word
+using ccmp_host::kPinBytes;
+using ccmp_host::kPinData;
 struct HostIO {
   ccmp_ctx *ctx;
   char *dev = nullptr;  // what the kernels get
@@ -273,6 +273,9 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "analytic_small_batch")) { // analytic mode: at or below this many samples the rows kernel alone
     if (value < 0) return CCMP_EINVAL;
     ctx->analytic_small_batch = (size_t)value;
+  } else if (!strcmp(name, "clearance_per_state_max")) { // proxy clearance: one block per state up to this many states
+    if (value < 0) return CCMP_EINVAL;
+    ctx->clearance_per_state_max = (size_t)value;
   } else if (!strcmp(name, "handover_threshold")) { // -1 = automatic, 0..10 = hand a wave over once <= this many groups are busy
     if (value < -1 || value > 110) return CCMP_EINVAL; // 11..110: occupancy-driven, hand over below (value - 10) % of the group slots
     ctx->dump_threshold = (int)value;
@@ -769,6 +772,34 @@ int ccmp_sample_ref_project_host(ccmp_ctx *ctx, const ccmp_problem *p, int kind,
   if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return rc;
   if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
   if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return rc;
+  return io.finish();
+}
+
+// proxy-geometry clearance on host states (ccmp_scene.cpp holds the scene and the device-pointer entry); a single state
+// goes through the pinned block: memcpy, launch, synchronise, memcpy
+int ccmp_clearance_host(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *scene, const double *q, size_t B, double margin,
+                        double *clearance, int32_t *pair, uint8_t *free_out)
+{
+  if (!ctx || !p || !scene) return CCMP_EINVAL;
+  if (B == 0) return CCMP_OK;
+  if (!q || !clearance) return CCMP_EINVAL;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return CCMP_ENODEV;
+  const size_t qb = B * 14 * sizeof(double);
+  const size_t off_c = (qb + 255) & ~(size_t)255;
+  const size_t off_p = (off_c + B * sizeof(double) + 255) & ~(size_t)255;
+  const size_t off_f = (off_p + B * sizeof(int32_t) + 255) & ~(size_t)255;
+  HostIO io(ctx);
+  int rc = io.begin(off_f + B);
+  if (rc != CCMP_OK) return rc;
+  if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
+  ctx->want_done = (B == 1 && io.host != nullptr);
+  rc = ccmp_clearance_batch(ctx, p, scene, (const double *)io.dev, nullptr, B, margin, (double *)(io.dev + off_c),
+                            (int32_t *)(io.dev + off_p), (uint8_t *)(io.dev + off_f), ctx->stream);
+  if (rc != CCMP_OK) return rc;
+  if ((rc = io.out(clearance, off_c, B * sizeof(double))) != CCMP_OK) return rc;
+  if (pair && (rc = io.out(pair, off_p, B * sizeof(int32_t))) != CCMP_OK) return rc;
+  if (free_out && (rc = io.out(free_out, off_f, B)) != CCMP_OK) return rc;
   return io.finish();
 }
 

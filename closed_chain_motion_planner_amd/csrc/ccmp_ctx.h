@@ -74,6 +74,7 @@ struct ccmp_ctx {
   int analytic_cap = 96;               // analytic mode: samples past this many iterations go to the rows kernel (0 = never)
   size_t analytic_small_batch = 16384; // analytic mode: at or below, the rows kernel alone
   size_t analytic_handover_max = 131072; // analytic mode: hand-over for batches up to here (larger ones: one-lane kernel alone)
+  size_t clearance_per_state_max = 8192; // proxy clearance: up to here one block per state, above 64-state tiles
   int dump_threshold = -1;             // hand a wave's samples over once the queue is dry and <= this many groups are busy; -1 = auto
   size_t small_batch = kDefaultSmallBatch;    // at or below: latency kernel on everything
   unsigned int *scan = nullptr;        // compaction block counts
@@ -91,6 +92,9 @@ struct ccmp_ctx {
 };
 
 namespace ccmp_host {
+/* the pinned, device-mapped block of the small *_host calls: its last 64 bytes hold the completion word */
+constexpr size_t kPinBytes = 64 * 1024;
+constexpr size_t kPinData = kPinBytes - 64;
 /* device staging of the *_host conveniences, grown on demand */
 int ensure_stage(ccmp_ctx *ctx, size_t bytes);
 }  // namespace ccmp_host

@@ -13,8 +13,9 @@ using ccmp::kSceneSlots;
 using ccmp::scene_dev;
 
 extern "C" {
-hipError_t ccmp_launch_clearance(const ccmp_consts *K, const scene_dev *scene_dev_ptr, int n_spheres, const double *q, const uint8_t *ok_in,
-                                 size_t B, double margin, double *clearance, int32_t *pair, uint8_t *free_out, int nblocks, hipStream_t st);
+hipError_t ccmp_launch_clearance(const ccmp_consts *K, const scene_dev *scene_dev_ptr, int n_spheres, int n_pairs, const double *q, const uint8_t *ok_in,
+                                 size_t B, double margin, double *clearance, int32_t *pair, uint8_t *free_out, int nblocks, int per_state,
+                                 unsigned int *done_flag, unsigned int done_seq, hipStream_t st);
 size_t ccmp_clearance_lds_bytes(int n_spheres);
 }
 
@@ -71,6 +72,7 @@ int ccmp_scene_create(ccmp_ctx *ctx, const ccmp_sphere *spheres, int n_spheres, 
       const int k = next[slot_of(spheres[i].frame)]++;
       stored_of[i] = k;
       H.user[k] = i;
+      H.slot[k] = slot_of(spheres[i].frame);
       memcpy(H.c[k], spheres[i].c, sizeof H.c[k]);
       H.r[k] = spheres[i].r;
     }
@@ -89,14 +91,17 @@ int ccmp_scene_create(ccmp_ctx *ctx, const ccmp_sphere *spheres, int n_spheres, 
       if (pair_allowed(allowed, spheres[i].group, spheres[j].group)) continue;
       H.pair_ij[np] = (uint32_t)stored_of[i] | ((uint32_t)stored_of[j] << 8);
       H.pair_code[np] = i | (j << 8);
+      H.pair_rsum[np] = spheres[i].r + spheres[j].r;
       np++;
     }
+  H.n_pairs_ss = np;
   for (int i = 0; i < n_spheres; i++)
     for (int b = 0; b < n_boxes; b++) {
       if (static_frame(spheres[i].frame)) continue;
       if (pair_allowed(allowed, spheres[i].group, boxes[b].group)) continue;
       H.pair_ij[np] = (uint32_t)stored_of[i] | ((uint32_t)(CCMP_MAX_SPHERES + b) << 8);
       H.pair_code[np] = i | ((CCMP_MAX_SPHERES + b) << 8);
+      H.pair_rsum[np] = spheres[i].r;
       np++;
     }
   H.n_pairs = np;
@@ -136,8 +141,23 @@ int ccmp_clearance_batch(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene 
   if (!guard.ok) return CCMP_ENODEV;
   ccmp_consts K;
   make_consts(*p, K);
+  if (B <= ctx->clearance_per_state_max) {
+    // small batches: one block per state (the parallelism of a single state; what a validity-checker wrapper calls)
+    size_t blocks = B;
+    const size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    unsigned int *flag = nullptr;
+    if (ctx->want_done && B == 1 && ctx->pin_dev) {
+      ctx->done_seq++;
+      ctx->done_armed = true;
+      flag = (unsigned int *)((char *)ctx->pin_dev + ccmp_host::kPinData);
+    }
+    HIP_TRY(ccmp_launch_clearance(&K, scene->dev, scene->host.n_spheres, scene->host.n_pairs, q, ok_in, B, margin, clearance, pair, free_out, (int)blocks, 1,
+                                  flag, ctx->done_seq, (hipStream_t)hip_stream));
+    return CCMP_OK;
+  }
   // one 256-thread block per tile of 64 states; the centres of a tile take 1.5 KB of LDS per sphere, so a CU holds
-  // 160 KB / that many blocks
+  // 160 KB / that many blocks (and at most eight: 2048 threads)
   const size_t lds = ccmp_clearance_lds_bytes(scene->host.n_spheres);
   size_t per_cu = (160 * 1024) / lds;
   if (per_cu < 1) per_cu = 1;
@@ -145,34 +165,8 @@ int ccmp_clearance_batch(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene 
   size_t blocks = (B + 63) / 64;
   const size_t cap = (size_t)ctx->num_cus * per_cu;
   if (blocks > cap) blocks = cap;
-  HIP_TRY(ccmp_launch_clearance(&K, scene->dev, scene->host.n_spheres, q, ok_in, B, margin, clearance, pair, free_out, (int)blocks,
-                                (hipStream_t)hip_stream));
-  return CCMP_OK;
-}
-
-int ccmp_clearance_host(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *scene, const double *q, size_t B, double margin,
-                        double *clearance, int32_t *pair, uint8_t *free_out)
-{
-  if (!ctx || !p || !scene) return CCMP_EINVAL;
-  if (B == 0) return CCMP_OK;
-  if (!q || !clearance) return CCMP_EINVAL;
-  DeviceGuard guard(ctx->device);
-  if (!guard.ok) return CCMP_ENODEV;
-  const size_t qb = B * 14 * sizeof(double);
-  const size_t off_c = (qb + 255) & ~(size_t)255;
-  const size_t off_p = (off_c + B * sizeof(double) + 255) & ~(size_t)255;
-  const size_t off_f = (off_p + B * sizeof(int32_t) + 255) & ~(size_t)255;
-  int rc = ensure_stage(ctx, off_f + B);
-  if (rc != CCMP_OK) return rc;
-  char *dev = (char *)ctx->stage;
-  HIP_TRY(hipMemcpyAsync(dev, q, qb, hipMemcpyHostToDevice, ctx->stream));
-  rc = ccmp_clearance_batch(ctx, p, scene, (const double *)dev, nullptr, B, margin, (double *)(dev + off_c), (int32_t *)(dev + off_p),
-                            (uint8_t *)(dev + off_f), ctx->stream);
-  if (rc != CCMP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(clearance, dev + off_c, B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (pair) HIP_TRY(hipMemcpyAsync(pair, dev + off_p, B * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-  if (free_out) HIP_TRY(hipMemcpyAsync(free_out, dev + off_f, B, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ccmp_launch_clearance(&K, scene->dev, scene->host.n_spheres, scene->host.n_pairs, q, ok_in, B, margin, clearance, pair, free_out, (int)blocks, 0,
+                                nullptr, 0, (hipStream_t)hip_stream));
   return CCMP_OK;
 }
 

@@ -14,9 +14,10 @@ constexpr int kSceneMaxPairs = CCMP_MAX_SPHERES * (CCMP_MAX_SPHERES - 1) / 2 + C
 /* Spheres are stored sorted by frame slot (slot = frame code, world last), so that a wavefront walking one arm's chain
  * places the spheres of a frame the moment that frame exists; `user` maps a stored index back to the caller's. */
 struct scene_dev {
-  int32_t n_spheres, n_boxes, n_pairs, reserved;
+  int32_t n_spheres, n_boxes, n_pairs, n_pairs_ss; /* the first n_pairs_ss pairs are sphere-sphere, the rest sphere-box */
   int32_t slot_begin[kSceneSlots + 1];
   int32_t user[CCMP_MAX_SPHERES];
+  int32_t slot[CCMP_MAX_SPHERES]; /* frame slot of each stored sphere (the per-state kernel walks to it) */
   double c[CCMP_MAX_SPHERES][3];
   double r[CCMP_MAX_SPHERES];
   double box_c[CCMP_MAX_BOXES][3];
@@ -27,6 +28,7 @@ struct scene_dev {
    * to the caller (the caller's own indices) */
   uint32_t pair_ij[kSceneMaxPairs];
   int32_t pair_code[kSceneMaxPairs];
+  double pair_rsum[kSceneMaxPairs]; /* r_i + r_j (sphere-sphere) or r_i (sphere-box): what is subtracted from the distance */
 };
 
 }  // namespace ccmp

@@ -9,6 +9,14 @@ from test_gpu_parity import _constraint, _oracle_problem
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["per_state", "tiles", "default"])
+def kernel_choice(request, gpu_ctx):
+    """both kernels on every case: one block per state (small batches by default) and 64-state tiles (large ones)"""
+    gpu_ctx.set_option("clearance_per_state_max", {"per_state": 1 << 30, "tiles": 0, "default": 8192}[request.param])
+    yield request.param
+    gpu_ctx.set_option("clearance_per_state_max", 8192)
+
+
 def _bits_equal(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
@@ -22,7 +30,7 @@ def _states(oracle, P, n, seed):
 
 
 @pytest.mark.parametrize("obj", OBJECTS)
-def test_default_scene_bitwise(gpu_ctx, oracle_det, obj):
+def test_default_scene_bitwise(gpu_ctx, oracle_det, obj, kernel_choice):
     import torch
     from closed_chain_motion_planner_amd import scene as S
 
@@ -42,7 +50,7 @@ def test_default_scene_bitwise(gpu_ctx, oracle_det, obj):
                                                                                       100.0 * (clr_o > 0).mean()))
 
 
-def test_full_scene_ragged_batches_and_flags(gpu_ctx, oracle_det):
+def test_full_scene_ragged_batches_and_flags(gpu_ctx, oracle_det, kernel_choice):
     """64 spheres on every kind of frame (the > 64 KB LDS configuration), 8 boxes (turned ones among them), a random
     allowed-pair matrix; batch sizes around the 64-state tile; ok_in and margin; a non-finite state"""
     import torch
@@ -80,7 +88,7 @@ def test_full_scene_ragged_batches_and_flags(gpu_ctx, oracle_det):
     assert (pair_o >> 8 >= 64).any() and (pair_o >> 8 < 64).any()  # boxes and spheres both
 
 
-def test_degenerate_scenes(gpu_ctx, oracle_det):
+def test_degenerate_scenes(gpu_ctx, oracle_det, kernel_choice):
     import torch
     from closed_chain_motion_planner_amd import CcmpError
     from closed_chain_motion_planner_amd import scene as S
@@ -108,7 +116,7 @@ def test_degenerate_scenes(gpu_ctx, oracle_det):
         S.ProxyScene(c, [], [(0, (0, 0, 0), np.eye(3), (0.1, -0.1, 0.1))], None)
 
 
-def test_host_entry_and_checker_mirror(gpu_ctx, oracle_det):
+def test_host_entry_and_checker_mirror(gpu_ctx, oracle_det, kernel_choice):
     """one state through the host entry point (what a StateValidityChecker wrapper calls), the reference-shaped mirror,
     and the pipeline project -> pre-filter -> compact on the device"""
     import torch

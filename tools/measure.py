@@ -11,7 +11,7 @@
     python tools/measure.py soak                            25 repeats of the default policy, outputs compared bit for bit
     python tools/measure.py scout                           FP32 scout's predictions against the true iteration counts
     python tools/measure.py run <workload> [reps]           a fixed workload for rocprofv3 (tools/profile.sh):
-                                                           c3 | flat4096 | flat1 | geodesic | analytic | stefan
+                                                           c3 | flat4096 | flat1 | geodesic | analytic | stefan | clearance
 """
 import ctypes as C
 import sys
@@ -194,6 +194,34 @@ def scout(argv):
               % (obj, (p == it).mean(), (np.abs(p - it) <= 2).mean(), np.corrcoef(p, it)[0, 1], big.sum(), (p[big] > 60).mean()))
 
 
+def clearance(argv):
+    """proxy clearance: run time against batch size for both kernels (one block per state / 64-state tiles) + single-state call"""
+    from closed_chain_motion_planner_amd.scene import ProxyValidityChecker
+
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % (argv[0] if argv else "Wine_Bottle"), ctx=ctx)
+    sc = ProxyValidityChecker(c).scene
+    print("spheres %d pairs %d" % (len(sc.spheres), sc.num_pairs))
+    for B in (1, 64, 1024, 4096, 8192, 16384, 32768, 65536, 262144, 1048576):
+        q = c.ambient_uniform_batch(0xC3, 0, B)
+        row = []
+        for name, lim in (("per_state", 1 << 30), ("tiles", 0)):
+            if name == "per_state" and B > 65536:
+                row.append(float("nan"))
+                continue
+            ctx.set_option("clearance_per_state_max", lim)
+            row.append(timed(lambda: sc.clearance_batch(q, 0.0), 10))
+        print("B %8d  per-state %8.4f ms   tiles %8.4f ms" % (B, row[0], row[1]))
+    ctx.set_option("clearance_per_state_max", 8192)
+    x = c.ambient_uniform_batch(0xC1, 0, 8).cpu().numpy()
+    ts = []
+    for i in range(200):
+        t0 = time.perf_counter()
+        sc.clearance(x[i % 8])
+        ts.append(time.perf_counter() - t0)
+    print("single-state host call: median %.1f us" % (np.median(ts[20:]) * 1e6))
+
+
 def run(argv):
     """fixed workloads for the profiler: one kernel family each, `reps` launches"""
     what = argv[0]
@@ -216,6 +244,12 @@ def run(argv):
         c.setJacobianMode(1)
         q = c.ambient_uniform_batch(0xC3, 0, 262144)
         fn = lambda: c.project_batch(q)
+    elif what == "clearance":
+        from closed_chain_motion_planner_amd.scene import ProxyValidityChecker
+
+        sc = ProxyValidityChecker(c).scene
+        q = c.ambient_uniform_batch(0xC3, 0, 262144)
+        fn = lambda: sc.clearance_batch(q, 0.0)
     else:
         raise SystemExit(__doc__)
     fn()
@@ -228,7 +262,7 @@ def run(argv):
 
 
 if __name__ == "__main__":
-    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, host, sampler, soak, scout, run)}
+    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, host, sampler, soak, scout, clearance, run)}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
     cmds[sys.argv[1]](sys.argv[2:])
