@@ -94,7 +94,8 @@ int ccmp_comm_create(ccmp_ctx *const *ctxs, int n, ccmp_comm **out)
       if (devs[h] == devs[g]) return CCMP_EINVAL; // RCCL wants one rank per device
   }
   if (!rccl().ok) {
-    snprintf(g_hip_err, sizeof g_hip_err, "librccl.so could not be opened: %s", dlerror() ? dlerror() : "symbols missing");
+    const char *why = rccl().handle ? nullptr : dlerror(); // dlerror() clears itself: read it once
+    snprintf(g_hip_err, sizeof g_hip_err, "librccl.so could not be opened: %s", why ? why : "symbols missing");
     return CCMP_ECOMM;
   }
   ccmp_comm *c = new (std::nothrow) ccmp_comm();

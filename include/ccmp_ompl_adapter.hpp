@@ -363,6 +363,7 @@ private:
 // boxes, an allowed-pair matrix (include/ccmp.h: ccmp_scene_create); clearance() is the smallest signed distance over
 // the tested pairs.  With spheres inscribed in the links a negative clearance proves a collision, so the state can be
 // refused without asking MoveIt; everything else still goes to MoveIt (PrefilteredValidityChecker in part 2).
+// The scene borrows the Projector (context, problem, mutex): keep the Projector alive for as long as the scene is used.
 class ProxyScene {
 public:
   ProxyScene(const Projector &proj, const std::vector<ccmp_sphere> &spheres, const std::vector<ccmp_box> &boxes,
