@@ -49,10 +49,12 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
                                     unsigned int done_seq, hipStream_t st);
+hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                     unsigned long long seed, unsigned long long first, int lane_blocks, int rows_blocks,
-                                    double *pool, int cap_iter, hipStream_t st);
+                                    double *pool, int cap_iter, const unsigned int *order, const unsigned int *split_ptr,
+                                    int front_blocks, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipStream_t st);
 hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                    unsigned int *hist, unsigned int *order, unsigned long long *queue,
                                    unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st);
@@ -221,8 +223,14 @@ int ccmp_ctx_create(int device, ccmp_ctx **out)
   ctx->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate"); }
-  e = hipMalloc((void **)&ctx->queue, (8 + 64 + 2) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64 + 2: analytic kernels
+  e = hipMalloc((void **)&ctx->queue, (8 + 64 + 4) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64 + 3: analytic kernels; 1: split count
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return hip_fail(e, "hipMalloc(queue)"); }
+  // side stream of the analytic mode's split launches (latency kernel beside the throughput kernel) and the two events
+  // that order it against the caller's stream
+  e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming);
+  if (e != hipSuccess) { ccmp_ctx_destroy(ctx); return hip_fail(e, "side stream / events"); }
   *out = ctx;
   return CCMP_OK;
 }
@@ -238,6 +246,9 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx)
   if (ctx->scan) (void)hipFree(ctx->scan);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+  if (ctx->fork) (void)hipEventDestroy(ctx->fork);
+  if (ctx->join) (void)hipEventDestroy(ctx->join);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -270,6 +281,24 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "analytic_handover_max")) { // analytic mode: hand-over for batches up to this many samples
     if (value < 0) return CCMP_EINVAL;
     ctx->analytic_handover_max = (size_t)value;
+  } else if (!strcmp(name, "analytic_split")) { // analytic mode, large batches: latency kernel beside the throughput kernel (0/1)
+    if (value != 0 && value != 1) return CCMP_EINVAL;
+    ctx->analytic_split = (int)value;
+  } else if (!strcmp(name, "analytic_split_min")) {
+    if (value < 0) return CCMP_EINVAL;
+    ctx->analytic_split_min = (size_t)value;
+  } else if (!strcmp(name, "analytic_split_max")) {
+    if (value < 0) return CCMP_EINVAL;
+    ctx->analytic_split_max = (size_t)value;
+  } else if (!strcmp(name, "analytic_split_cap")) { // split launch: the one-lane kernel hands over past this many iterations
+    if (value < 1 || value > 65535) return CCMP_EINVAL;
+    ctx->analytic_split_cap = (int)value;
+  } else if (!strcmp(name, "analytic_split_front")) { // wavefronts (= SIMDs) of the front kernel in a split launch
+    if (value < 1 || value > 512) return CCMP_EINVAL;
+    ctx->analytic_split_front = (int)value;
+  } else if (!strcmp(name, "analytic_split_pred")) { // predicted iterations from which a sample goes to the front kernel
+    if (value < 1 || value > 1023) return CCMP_EINVAL;
+    ctx->analytic_split_pred = (int)value;
   } else if (!strcmp(name, "analytic_small_batch")) { // analytic mode: at or below this many samples the rows kernel alone
     if (value < 0) return CCMP_EINVAL;
     ctx->analytic_small_batch = (size_t)value;
@@ -412,22 +441,46 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     // 16384: 1.44 / 1.81 | 1.25 / 1.51 | 1.00 / 1.48; 65536: 1.91 / 1.96 | 1.63 / 1.65 | 1.73 / 2.38; 262144: 2.71 / 3.41 |
     // 2.56 / 3.43 | -; 1048576: 5.75 / 8.68 | 5.83 / 8.98 | -.  Other problems (calibrated arms, tilted bases): one-lane alone.
     const int lane_blocks = projector_blocks(ctx, B, 64, 4);
+    // Large batches, twin stock arms: the FP32 scout orders the batch longest-predicted-first; the samples predicted past
+    // analytic_split_pred iterations (at most the front kernel's resident capacity) run on the six-lane kernel on the side
+    // stream WHILE the one-lane kernel takes the rest, longest first — the launch no longer ends on the serial chain of a
+    // 250-iteration sample started late — and what the one-lane kernel still hands over is finished behind both.
+    if (K.twin_arms && ctx->analytic_split && ctx->analytic_cap > 0 && ctx->lpt > 0 && !ctx->order && B >= ctx->analytic_split_min &&
+        B <= ctx->analytic_split_max && B < 0xffffffffull) {
+      int rc = ensure_lpt_buffers(ctx, B);
+      if (rc == CCMP_OK) rc = ensure_pool(ctx, B);
+      if (rc != CCMP_OK) return rc;
+      char *base = (char *)ctx->lpt_buf;
+      uint16_t *pred = (uint16_t *)base;
+      unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
+      unsigned int *ord = (unsigned int *)((char *)hist + 4096);
+      unsigned int *split = (unsigned int *)(ctx->queue + 8 + 64 + 3);
+      HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus, st));
+      // the front kernel gets analytic_split_front wavefronts, one SIMD each (a one-lane wave fills a SIMD's registers, so
+      // the one-lane kernel is launched that many wavefronts short); ten samples per wavefront, one round
+      const int front_blocks = ctx->analytic_split_front;
+      HIP_TRY(ccmp_launch_split_count(hist, ctx->analytic_split_pred, (unsigned int)front_blocks * 10u, split, st));
+      const int lanes = lane_blocks > ctx->num_cus * 4 - front_blocks ? ctx->num_cus * 4 - front_blocks : lane_blocks;
+      HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, lanes, ctx->num_cus * 8,
+                                       ctx->pool, ctx->analytic_split_cap, ord, split, front_blocks, ctx->side, ctx->fork, ctx->join, st));
+      return CCMP_OK;
+    }
     if (!K.twin_arms || ctx->analytic_cap <= 0 || (B > ctx->analytic_handover_max && B > ctx->analytic_small_batch)) {
       HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, lane_blocks, 0, nullptr,
-                                       0, st));
+                                       0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, st));
       return CCMP_OK;
     }
     const size_t rows_cap = (size_t)ctx->num_cus * 8; // waves of the rows kernel: two per SIMD (16.5 KB of LDS each)
     if (B <= ctx->analytic_small_batch) {
       const size_t want = (B + 9) / 10;
       HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, 0,
-                                       (int)(want < rows_cap ? want : rows_cap), nullptr, 0, st));
+                                       (int)(want < rows_cap ? want : rows_cap), nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, st));
       return CCMP_OK;
     }
     int rc = ensure_pool(ctx, B); // every sample may be handed over
     if (rc != CCMP_OK) return rc;
     HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, lane_blocks, (int)rows_cap,
-                                     ctx->pool, ctx->analytic_cap, st));
+                                     ctx->pool, ctx->analytic_cap, nullptr, nullptr, 0, nullptr, nullptr, nullptr, st));
     return CCMP_OK;
   }
   const FdPlan pl = plan_fd_batch(ctx, B, ctx->order != nullptr);

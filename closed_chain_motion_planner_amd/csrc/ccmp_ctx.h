@@ -74,6 +74,13 @@ struct ccmp_ctx {
   int analytic_cap = 96;               // analytic mode: samples past this many iterations go to the rows kernel (0 = never)
   size_t analytic_small_batch = 16384; // analytic mode: at or below, the rows kernel alone
   size_t analytic_handover_max = 131072; // analytic mode: hand-over for batches up to here (larger ones: one-lane kernel alone)
+  int analytic_split = 1;                // analytic mode: scout order + six-lane kernel beside the one-lane kernel for large batches
+  size_t analytic_split_min = 100000, analytic_split_max = 300000; // batch sizes of the split launch (sweep in ccmp_api.cpp)
+  int analytic_split_front = 128;        // wavefronts of the six-lane kernel beside the one-lane kernel
+  int analytic_split_cap = 160;          // split launch: mispredicted samples leave the one-lane kernel past this many iterations
+  int analytic_split_pred = 90;          // predicted iterations from which a sample goes to the six-lane kernel
+  hipStream_t side = nullptr;            // side stream of split launches
+  hipEvent_t fork = nullptr, join = nullptr;
   size_t clearance_per_state_max = 8192; // proxy clearance: up to here one block per state, above 64-state tiles
   int dump_threshold = -1;             // hand a wave's samples over once the queue is dry and <= this many groups are busy; -1 = auto
   size_t small_batch = kDefaultSmallBatch;    // at or below: latency kernel on everything

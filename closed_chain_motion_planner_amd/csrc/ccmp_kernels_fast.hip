@@ -67,7 +67,9 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K_ar
                                                           double *__restrict__ q_ambient, unsigned long long B,
                                                           unsigned long long *queue, unsigned long long seed,
                                                           unsigned long long first_index, double *__restrict__ pool,
-                                                          unsigned long long *pool_count, int cap_iter)
+                                                          unsigned long long *pool_count, int cap_iter,
+                                                          const unsigned int *__restrict__ order,
+                                                          const unsigned int *__restrict__ split_ptr)
 {
   // the constants as an LDS copy read by broadcast: with compile-time joint indices the compiler would otherwise hoist
   // every scalar load of the kernarg copy out of the Newton loop and spill ~300 SGPRs into VGPR lanes (1170 v_readlane /
@@ -92,6 +94,12 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K_ar
   // single address; a wavefront starts on its own word and moves on to the next ones when that slice is used up.
   const int lane = threadIdx.x;
   int qk = blockIdx.x % kFastQueues, tried = 0;
+  // With a processing order (longest predicted first, ccmp_kernels_scout.hip) this kernel takes positions [split, B) of it
+  // — the front goes to the six-lane kernel on a second stream — and the queue words own INTERLEAVED positions
+  // (word k: split + k, split + k + 64, …), so that every wavefront, whichever word it starts on, begins with the longest
+  // samples left and the launch ends on the shortest.
+  const unsigned long long split = (order != nullptr && split_ptr != nullptr) ? (unsigned long long)*split_ptr : 0ull;
+  const unsigned long long n_mine = B > split ? B - split : 0ull;
 
   for (;;) {
     // ---- hand-over: this kernel runs a sample on ONE lane at ~7 us per iteration whatever the occupancy, so the serial
@@ -111,15 +119,24 @@ __global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K_ar
     }
     unsigned long long need = __builtin_amdgcn_ballot_w64(!active && !drained);
     while (need != 0ull) {
-      const unsigned long long lo = B * (unsigned long long)qk / kFastQueues, hi = B * (unsigned long long)(qk + 1) / kFastQueues;
       const int n = __builtin_popcountll(need);
       unsigned long long base = 0;
       if (lane == 0) base = atomicAdd(queue + qk, (unsigned long long)n);
-      base = __shfl(base, 0);  // ticket of the first free lane, relative to the slice
+      base = __shfl(base, 0);  // ticket of the first free lane, relative to the word's share
       const bool mine = (need >> lane) & 1ull;
-      const unsigned long long t = lo + base + (unsigned long long)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+      const unsigned long long j = base + (unsigned long long)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+      unsigned long long t, hi;
+      if (order != nullptr) { // interleaved positions of the order
+        t = (unsigned long long)qk + kFastQueues * j;
+        hi = n_mine;
+      } else { // a contiguous slice of the batch
+        const unsigned long long lo = B * (unsigned long long)qk / kFastQueues;
+        t = lo + j;
+        hi = B * (unsigned long long)(qk + 1) / kFastQueues;
+      }
       if (mine && t < hi) {
-        idx = t; active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+        idx = order != nullptr ? (unsigned long long)order[split + t] : t;
+        active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
 #pragma unroll
         for (int e = 0; e < 14; e++) {
           if (MODE == 0) x[e] = q_in[idx * 14 + e];
@@ -282,7 +299,8 @@ __global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
     const ccmp_consts K_arg, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
-    const unsigned long long *__restrict__ pool_count, int wrap_output)
+    const unsigned long long *__restrict__ pool_count, int wrap_output, const unsigned int *__restrict__ order,
+    const unsigned int *__restrict__ split_ptr)
 {
   __shared__ double ktab[kConstsDoubles + 1];
   __shared__ double lds[rGroups * rRec];
@@ -299,7 +317,8 @@ __global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
   double *rec = lds + (live ? g : 0) * rRec; // idle lanes alias group 0 for reads, never write
   const int arm = r < 3 ? 0 : 1, row = r < 3 ? r : r - 3;
   const double d_lane = K.base_R[arm][4 * row], bp_lane = K.base_p[arm][row];
-  const unsigned long long total = (SRC == 2) ? *pool_count : B;
+  // SRC 0 / 1 with a processing order: the first *split_ptr positions of it (the samples predicted longest)
+  const unsigned long long total = (SRC == 2) ? *pool_count : ((order != nullptr && split_ptr != nullptr) ? (unsigned long long)*split_ptr : B);
 
   unsigned long long idx = 0;
   int iter = 0, updates = 0;
@@ -325,7 +344,8 @@ __global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
             norm2 = ent[17];
             for (int e = r; e < 14; e += rGroup) rec[rX + e] = ent[e];
           } else {
-            idx = t; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+            idx = order != nullptr ? (unsigned long long)order[t] : t;
+            iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
             for (int e = r; e < 14; e += rGroup) {
               double v;
               if (SRC == 0) v = q_in[idx * 14 + e];
@@ -468,20 +488,39 @@ __global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
 
 // One-lane kernel (+ hand-over of the samples past cap_iter iterations to the rows kernel when pool != NULL), or the
 // rows kernel alone (lane_blocks == 0).  queue: kFastQueues words for the one-lane kernel, then one word for the rows
-// kernel's tickets and one for the pool's fill count.
+// kernel's tickets, one for the pool's fill count and one for the rows kernel's tickets of a split launch.
+//
+// Split launch (order != NULL): the batch is processed in `order` (longest predicted first); its first *split_ptr
+// positions — the samples predicted longest — run on the six-lane kernel on stream `side` WHILE the one-lane kernel takes
+// the rest on `st`, longest first; what the one-lane kernel still hands over past cap_iter (mispredictions) is finished
+// by a second pass of the six-lane kernel behind both.  fork / join order the two streams (no host synchronisation).
 extern "C" hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out,
                                                uint8_t *ok, uint16_t *iters, double *q_ambient, size_t B,
                                                unsigned long long *queue, unsigned long long seed,
                                                unsigned long long first, int lane_blocks, int rows_blocks, double *pool,
-                                               int cap_iter, hipStream_t st)
+                                               int cap_iter, const unsigned int *order, const unsigned int *split_ptr,
+                                               int front_blocks, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipStream_t st)
 {
-  hipError_t e = hipMemsetAsync(queue, 0, (kFastQueues + 2) * sizeof(unsigned long long), st);
+  hipError_t e = hipMemsetAsync(queue, 0, (kFastQueues + 3) * sizeof(unsigned long long), st);
   if (e != hipSuccess) return e;
-  unsigned long long *rows_queue = queue + kFastQueues, *pool_count = queue + kFastQueues + 1;
+  unsigned long long *rows_queue = queue + kFastQueues, *pool_count = queue + kFastQueues + 1, *front_queue = queue + kFastQueues + 2;
+  const bool split = order != nullptr && split_ptr != nullptr && front_blocks > 0 && lane_blocks > 0;
+  if (split) {
+    if ((e = hipEventRecord(fork, st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return e;
+    if (mode == 0)
+      hipLaunchKernelGGL((project_fast_rows_kernel<0>), dim3(front_blocks), dim3(64), 0, side, *K, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, front_queue, seed, first, pool, pool_count, mode, order, split_ptr);
+    else
+      hipLaunchKernelGGL((project_fast_rows_kernel<1>), dim3(front_blocks), dim3(64), 0, side, *K, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, front_queue, seed, first, pool, pool_count, mode, order, split_ptr);
+    if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
+  }
+  const unsigned int *lane_order = split ? order : nullptr, *lane_split = split ? split_ptr : nullptr;
   if (lane_blocks > 0) {
 #define CCMP_LAUNCH_FAST(MODE, STOCK)                                                                                                \
   hipLaunchKernelGGL((project_fast_kernel<MODE, STOCK>), dim3(lane_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
-                     (unsigned long long)B, queue, seed, first, pool, pool_count, cap_iter)
+                     (unsigned long long)B, queue, seed, first, pool, pool_count, cap_iter, lane_order, lane_split)
     if (mode == 0) {
       if (K->stock) CCMP_LAUNCH_FAST(0, true);
       else CCMP_LAUNCH_FAST(0, false);
@@ -490,16 +529,17 @@ extern "C" hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, c
       else CCMP_LAUNCH_FAST(1, false);
     }
 #undef CCMP_LAUNCH_FAST
+    if (split && (e = hipStreamWaitEvent(st, join, 0)) != hipSuccess) return e;
     if (pool != nullptr && rows_blocks > 0) // the pool's fill count is read on the device: surplus waves exit at once
       hipLaunchKernelGGL((project_fast_rows_kernel<2>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode);
+                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode, nullptr, nullptr);
   } else {
     if (mode == 0)
       hipLaunchKernelGGL((project_fast_rows_kernel<0>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode);
+                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode, nullptr, nullptr);
     else
       hipLaunchKernelGGL((project_fast_rows_kernel<1>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode);
+                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode, nullptr, nullptr);
   }
   return hipGetLastError();
 }

@@ -342,7 +342,23 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint16_t *__restrict
     if (key[k] != 0xffffffffu) order[base[key[k]] + atomicAdd(&cnt[key[k]], 1u)] = (unsigned int)(i0 + k);
 }
 
+// after scatter_kernel the cursor array holds, at k, the number of samples predicted >= k iterations: the front of
+// the order that a split launch gives to the latency kernel = those predicted >= pred_min, at most `limit`
+__global__ void split_kernel(const unsigned int *__restrict__ hist, int pred_min, unsigned int limit, unsigned int *__restrict__ out)
+{
+  if (threadIdx.x == 0) {
+    const unsigned int n = hist[pred_min < kBins ? pred_min : kBins - 1];
+    *out = n < limit ? n : limit;
+  }
+}
+
 } // namespace
+
+extern "C" hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st)
+{
+  hipLaunchKernelGGL(split_kernel, dim3(1), dim3(64), 0, st, hist, pred_min, limit, out);
+  return hipGetLastError();
+}
 
 extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                               unsigned int *hist, unsigned int *order, unsigned long long *queue,

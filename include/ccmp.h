@@ -125,7 +125,10 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
  * same bits, fewer operations (default); 0 = always the general kernels); analytic mode: "analytic_small_batch" (at or below:
  * the six-lanes-per-sample kernel alone; default 16384), "analytic_cap" (samples past this many iterations are handed from
  * the one-lane kernel to it; default 96, 0 = never), "analytic_handover_max" (hand-over for batches up to this size;
- * default 131072); proxy clearance: "clearance_per_state_max" (batches up to this many states run one block per state,
+ * default 131072), "analytic_split" (1 = batches of analytic_split_min..analytic_split_max samples, default 100000..300000,
+ * are ordered longest-predicted-first by the FP32 scout and the samples predicted past "analytic_split_pred" iterations
+ * (default 90) run on "analytic_split_front" wavefronts (default 128) of the six-lane kernel on a side stream BESIDE the
+ * one-lane kernel, which hands over past "analytic_split_cap" iterations (default 160); 0 = off); proxy clearance: "clearance_per_state_max" (batches up to this many states run one block per state,
  * larger ones 64-state tiles; default 8192).  CCMP_EINVAL for unknown names. */
 int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
 /* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index

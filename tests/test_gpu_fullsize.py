@@ -156,3 +156,23 @@ def test_default_policy_at_mid_sizes_is_bitwise_the_oracle(gpu_ctx, oracle_det, 
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
+
+
+@pytest.mark.parametrize("obj,n", [("Wine_Bottle", 262144), ("stefan", 131072), ("Wine_Bottle", 70000)])
+def test_analytic_default_policy_at_full_size_is_bitwise_the_oracle(gpu_ctx, oracle_det, obj, n):
+    """analytic mode under its default policy at the sizes where the split launch is on (100 000 .. 300 000 samples: scout
+    order, six-lane kernel on the side stream beside the one-lane kernel, hand-over pass behind both) and just below it
+    (hand-over only) — every sample against the oracle's analytic mode, bit for bit, twice (the second launch reuses
+    the queues, the pool and the events of the first)"""
+    import torch
+
+    c = _constraint(obj, gpu_ctx, mode=1)
+    P = _oracle_problem(oracle_det, c)
+    q = c.ambient_uniform_batch(0xA11 + n, 0, n)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q.cpu().numpy(), NCPU)
+    for rep in range(2):
+        out = torch.full_like(q, 777.0)
+        _, ok, it = c.project_batch(q, out=out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64)), rep
+        assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu), rep

@@ -265,11 +265,14 @@ def test_analytic_mode_bitwise(gpu_ctx, oracle_det, obj, B):
     assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
 
 
-@pytest.mark.parametrize("cap,small", [(0, 0), (20, 0), (64, 0), (96, 1 << 30)])
-def test_analytic_schedules_are_bitwise_identical(gpu_ctx, oracle_det, cap, small):
+@pytest.mark.parametrize("cap,small,split_pred", [(0, 0, 0), (20, 0, 0), (64, 0, 0), (96, 1 << 30, 0), (96, 0, 90), (40, 0, 25), (96, 0, 1)])
+def test_analytic_schedules_are_bitwise_identical(gpu_ctx, oracle_det, cap, small, split_pred):
     """analytic mode's kernels: the one-lane kernel alone / with hand-over of the samples past `cap` iterations to the
     six-lanes-per-sample kernel (lanes hand over at different times: the refill after a hand-over is what once lost
-    samples) / the six-lane kernel alone with several samples per group — all bit-identical to the oracle's analytic mode"""
+    samples) / the six-lane kernel alone with several samples per group / the split launch (scout order, the samples
+    predicted past `split_pred` iterations on the six-lane kernel on the side stream beside the one-lane kernel, which
+    takes the rest longest first and still hands over past `cap`; split_pred 1 = the front kernel is offered everything
+    and takes its capacity) — all bit-identical to the oracle's analytic mode"""
     import torch
 
     c = _constraint("stefan", gpu_ctx, mode=1)
@@ -279,16 +282,32 @@ def test_analytic_schedules_are_bitwise_identical(gpu_ctx, oracle_det, cap, smal
     q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q.cpu().numpy(), NCPU)
     gpu_ctx.set_option("analytic_cap", cap)
     gpu_ctx.set_option("analytic_small_batch", small)
+    gpu_ctx.set_option("analytic_split", 1 if split_pred else 0)
+    gpu_ctx.set_option("analytic_split_min", 0)
+    if split_pred:
+        gpu_ctx.set_option("analytic_split_pred", split_pred)
+        gpu_ctx.set_option("analytic_split_cap", cap)  # 40 with split_pred 25: the one-lane kernel of the split launch hands over too
     try:
         out = torch.full_like(q, 777.0)
         _, ok, it = c.project_batch(q, out=out)
         torch.cuda.synchronize()
+        if split_pred:  # the fused sampler through the same launch shape
+            qs, oks, its, _ = c.sample_project_batch(0xA8, 5, 30000)
+            torch.cuda.synchronize()
     finally:
         gpu_ctx.set_option("analytic_cap", 96)
         gpu_ctx.set_option("analytic_small_batch", 16384)
+        gpu_ctx.set_option("analytic_split", 1)
+        gpu_ctx.set_option("analytic_split_min", 100000)
+        gpu_ctx.set_option("analytic_split_pred", 90)
+        gpu_ctx.set_option("analytic_split_cap", 160)
     assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
     assert it_cpu.max() == 250 and (it_cpu < 20).any()
+    if split_pred:
+        e_q, e_ok, e_it = oracle_det.sample_project_batch(P, 0xA8, 5, 30000, NCPU)
+        assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
+        assert np.array_equal(its.cpu().numpy().astype(np.int32), e_it)
 
 
 def test_analytic_mode_statistics(gpu_ctx, oracle_det):

@@ -133,6 +133,38 @@ def analytic(argv):
             print("analytic %s B=%-8d " % (obj, B) + "  ".join(res) + "  DEFAULT %7.3f ms (%.3e/s)" % (ms, B / ms * 1e3), flush=True)
 
 
+def split(argv):
+    """analytic mode, large batches: the split launch (scout order, six-lane kernel beside the one-lane kernel) against the
+    one-lane kernel alone / with hand-over, for several split thresholds"""
+    ctx = Context(0)
+    for obj in ("Wine_Bottle", "stefan"):
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        c.setJacobianMode(1)
+        for B in (131072, 262144, 393216):
+            q = c.ambient_uniform_batch(0xC3, 0, B)
+            out = torch.empty_like(q)
+            ctx.set_option("analytic_split_min", 0)
+            ctx.set_option("analytic_split_max", 1 << 40)
+            ctx.set_option("analytic_handover_max", 1 << 40)
+            ctx.set_option("analytic_small_batch", 0)
+            res = []
+            ctx.set_option("analytic_split", 0)
+            for cap in (0, 96):
+                ctx.set_option("analytic_cap", cap)
+                res.append("nosplit cap%d %.3f" % (cap, timed(lambda: c.project_batch(q, out=out), reps=5)))
+            ctx.set_option("analytic_split", 1)
+            for pred, cap, front in ((90, 128, 64), (90, 128, 96), (90, 128, 128), (90, 128, 192), (80, 128, 128), (90, 160, 128), (96, 128, 128)):
+                ctx.set_option("analytic_split_pred", pred)
+                ctx.set_option("analytic_split_cap", cap)
+                ctx.set_option("analytic_split_front", front)
+                res.append("split p%d cap%d f%d %.3f" % (pred, cap, front, timed(lambda: c.project_batch(q, out=out), reps=5)))
+            print("%s B=%-8d " % (obj, B) + "  ".join(res), flush=True)
+    for name, v in (("analytic_split_min", 100000), ("analytic_split_max", 300000), ("analytic_handover_max", 131072),
+                    ("analytic_small_batch", 16384), ("analytic_cap", 96), ("analytic_split_pred", 90), ("analytic_split_front", 128),
+                    ("analytic_split_cap", 160)):
+        ctx.set_option(name, v)
+
+
 def host(argv):
     ctx = Context(0)
     L = _lib.lib()
@@ -262,7 +294,7 @@ def run(argv):
 
 
 if __name__ == "__main__":
-    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, host, sampler, soak, scout, clearance, run)}
+    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sampler, soak, scout, clearance, run)}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
     cmds[sys.argv[1]](sys.argv[2:])
