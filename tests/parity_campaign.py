@@ -24,10 +24,13 @@ NCPU = bench.usable_cores()[0]
 build_oracle()
 orc = Oracle("det")
 ctx = Context(0)
-cases = [("Wine_Bottle", None, 0xA1, 0), ("stefan", None, 0xA2, 0), ("dumbbell", None, 0xA3, 0), ("stefan", (5e-4, 2.5e-3), 0xA4, 0),
-         ("Wine_Bottle", None, 0xA5, 1)]  # last: the analytic mode against the oracle's analytic mode
+# (object, tolerances, seed, jacobian mode, samples); the analytic mode (its own extension) against the oracle's analytic
+# mode: above and inside the batch sizes of its split launch (100 000 .. 300 000 samples)
+cases = [("Wine_Bottle", None, 0xA1, 0, N), ("stefan", None, 0xA2, 0, N), ("dumbbell", None, 0xA3, 0, N), ("stefan", (5e-4, 2.5e-3), 0xA4, 0, N),
+         ("Wine_Bottle", None, 0xA5, 1, N), ("Wine_Bottle", None, 0xA6, 1, min(N, 250000)), ("stefan", None, 0xA7, 1, min(N, 250000))]
 report = {"samples_per_case": N, "host_threads": NCPU, "cases": []}
-for obj, tol, seed, mode in cases:
+from closed_chain_motion_planner_amd.scene import ProxyValidityChecker  # noqa: E402
+for obj, tol, seed, mode, N in cases:
     c = KinematicChainConstraint.from_yaml(os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml"), ctx=ctx)
     c.setJacobianMode(mode)
     if tol:
@@ -72,6 +75,23 @@ for obj, tol, seed, mode in cases:
             m = min(int(nst[e]), maxs)
             same_edges += int(nst[e] == nc[e] and gok[e] == okc[e] and gits[e] == itc[e]
                               and np.array_equal(st[e, :m].view(np.uint64), sc[e, :m].view(np.uint64)))
+    # proxy clearance (the pre-filter ahead of the host's validity test) on the projected states: default scene, both
+    # kernels (64-state tiles for the whole batch, one block per state for its first 4096 states)
+    if mode == 0:
+        scn = ProxyValidityChecker(c).scene
+        clr, pair, _ = scn.clearance_batch(out)
+        clr1, pair1, _ = scn.clearance_batch(out[:4096].contiguous())
+        t0 = time.time()
+        clr_cpu, pair_cpu = orc.clearance_batch(P, scn.spheres, scn.boxes, scn.allowed, out_h)
+        clr_h, pair_h = clr.cpu().numpy(), pair.cpu().numpy()
+        same = (clr_h.view(np.uint64) == clr_cpu.view(np.uint64)) | (np.isnan(clr_h) & np.isnan(clr_cpu))
+        entry["clearance_states"] = N
+        entry["clearance_bit_identical"] = int((same & (pair_h == pair_cpu)).sum())
+        entry["clearance_small_batch_bit_identical"] = int(((clr1.cpu().numpy().view(np.uint64) == clr_cpu[:4096].view(np.uint64))
+                                                            & (pair1.cpu().numpy() == pair_cpu[:4096])).sum())
+        entry["clearance_pairs_per_state"] = scn.num_pairs
+        entry["clearance_oracle_seconds"] = round(time.time() - t0, 1)
+        assert entry["clearance_bit_identical"] == N and entry["clearance_small_batch_bit_identical"] == min(N, 4096)
     entry["geodesic_edges"] = ne
     entry["geodesic_edges_bit_identical"] = int(same_edges)
     entry["geodesic_mean_states"] = float(nst.mean())
