@@ -26,7 +26,8 @@ ARCH = "gfx950"
 _UNITS = [
     # -disable-machine-licm: LLVM's machine LICM hoists ~35 FP64 polynomial/literal constants out of the Newton
     # loop into VGPR pairs and then spills them to scratch (168 VGPRs + 30 spilled dwords); without it the
-    # throughput kernel needs 133 VGPRs and no scratch (measured +3.3 %, in-process A/B).  The wave kernels are
+    # throughput kernel needed 133 VGPRs and no scratch (measured +3.3 %, in-process A/B; today's kernel: 167, no scratch,
+    # three wavefronts per SIMD).  The wave kernels are
     # 2.7 % slower with the option, hence their own unit.
     ("ccmp_kernels_fd.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
      + os.environ.get("CCMP_FD_EXTRA_FLAGS", "").split()),
