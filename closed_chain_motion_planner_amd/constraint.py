@@ -51,7 +51,9 @@ class Context:
         check(_lib.lib().ccmp_ctx_set_schedule(self._h, int(wave_kernel), sb), "ccmp_ctx_set_schedule")
 
     def set_option(self, name, value):
-        """tuning knobs: "handover_threshold" (-1 auto, 0..10), "flat_kernel" (0/1), "stock_kernels" (0/1); results never change"""
+        """tuning knobs of include/ccmp.h (ccmp_ctx_set_option): "handover_threshold", "flat_kernel", "stock_kernels",
+        "analytic_cap" / "analytic_small_batch" / "analytic_handover_max", "analytic_split" (+ "_min", "_max", "_pred",
+        "_front", "_cap"), "clearance_per_state_max"; results never change"""
         check(_lib.lib().ccmp_ctx_set_option(self._h, name.encode(), int(value)), "ccmp_ctx_set_option(%s)" % name)
 
     def set_lpt(self, mode=1, min_batch=None):
