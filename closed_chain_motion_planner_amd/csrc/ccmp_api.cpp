@@ -36,6 +36,7 @@ int ensure_stage(ccmp_ctx *ctx, size_t bytes)
 }  // namespace ccmp_host
 
 extern "C" {
+hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st);
 hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                      uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                      unsigned long long seed, unsigned long long first, int nblocks, double *pool,
@@ -486,7 +487,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   const FdPlan pl = plan_fd_batch(ctx, B, ctx->order != nullptr);
   // queue[0]: sample queue of the throughput kernel; queue[1]: pool fill count; queue[2]: read head of the latency kernel
   unsigned long long *const q_group = ctx->queue, *const q_pool_count = ctx->queue + 1, *const q_latency = ctx->queue + 2;
-  if (!pl.latency_static) HIP_TRY(hipMemsetAsync(ctx->queue, 0, 4 * sizeof(unsigned long long), st));
+  if (!pl.latency_static) HIP_TRY(ccmp_launch_clear_words(ctx->queue, 8, st)); // four 64-bit words
 
   if (pl.group_blocks == 0) { // small batches and single states
     if (ctx->flat_kernel) {
@@ -666,7 +667,7 @@ int ccmp_compact_valid_capped(ccmp_ctx *ctx, const double *q, const uint8_t *ok,
   if (!guard.ok) return CCMP_ENODEV;
   hipStream_t st = (hipStream_t)hip_stream;
   if (B == 0) {
-    HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint64_t), st));
+    HIP_TRY(ccmp_launch_clear_words(count_dev, 2, st));
     return CCMP_OK;
   }
   if (!q || !ok || !q_valid) return CCMP_EINVAL;

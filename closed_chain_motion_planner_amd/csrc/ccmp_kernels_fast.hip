@@ -486,6 +486,8 @@ __global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
 
 } // namespace
 
+extern "C" hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st); // ccmp_kernels_fd.hip
+
 // One-lane kernel (+ hand-over of the samples past cap_iter iterations to the rows kernel when pool != NULL), or the
 // rows kernel alone (lane_blocks == 0).  queue: kFastQueues words for the one-lane kernel, then one word for the rows
 // kernel's tickets, one for the pool's fill count and one for the rows kernel's tickets of a split launch.
@@ -501,7 +503,7 @@ extern "C" hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, c
                                                int cap_iter, const unsigned int *order, const unsigned int *split_ptr,
                                                int front_blocks, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipStream_t st)
 {
-  hipError_t e = hipMemsetAsync(queue, 0, (kFastQueues + 3) * sizeof(unsigned long long), st);
+  hipError_t e = ccmp_launch_clear_words(queue, (kFastQueues + 3) * 2, st); // a kernel, so that a stream capture replays it
   if (e != hipSuccess) return e;
   unsigned long long *rows_queue = queue + kFastQueues, *pool_count = queue + kFastQueues + 1, *front_queue = queue + kFastQueues + 2;
   const bool split = order != nullptr && split_ptr != nullptr && front_blocks > 0 && lane_blocks > 0;

@@ -562,6 +562,15 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
 }
 
 
+// Workspace words (queue heads, counters, the scout's histogram) are cleared by a kernel, not by hipMemsetAsync: a kernel
+// node is what a stream capture records and every replay of the graph executes (with hipMemsetAsync the first replay of a
+// captured call worked and every later one found the queues exhausted and the histogram still full).
+__global__ void clear_words_kernel(unsigned int *__restrict__ w, unsigned int n)
+{
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = 0u;
+}
+
 // ---- simple per-lane kernels (one sample per lane; all bit-identical to the oracle) -------------
 // publish the completion word of a single-state call behind its result (pinned host memory, polled by the host)
 __device__ __forceinline__ void publish_done(unsigned int *done_flag, unsigned int done_seq)
@@ -747,6 +756,12 @@ __global__ void compact_scatter_kernel(const double *__restrict__ q, const uint8
 
 // ---- launchers (called from ccmp_api.cpp) --------------------------------------------------------
 extern "C" {
+
+hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st)
+{
+  hipLaunchKernelGGL(clear_words_kernel, dim3((unsigned)((n_u32 + 255) / 256)), dim3(256), 0, st, (unsigned int *)words, (unsigned int)n_u32);
+  return hipGetLastError();
+}
 
 hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                      uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,

@@ -354,6 +354,8 @@ __global__ void split_kernel(const unsigned int *__restrict__ hist, int pred_min
 
 } // namespace
 
+extern "C" hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st); // ccmp_kernels_fd.hip
+
 extern "C" hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st)
 {
   hipLaunchKernelGGL(split_kernel, dim3(1), dim3(64), 0, st, hist, pred_min, limit, out);
@@ -375,9 +377,9 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
   for (int k = 0; k < 4; k++) F.init_q[k] = (float)K->init_q[k];
   F.tol_pos = (float)K->tol_pos; F.tol_rot = (float)K->tol_rot; F.step = (float)K->step;
   F.max_iter = K->max_iter < kScoutCap ? K->max_iter : kScoutCap;
-  hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+  hipError_t e = ccmp_launch_clear_words(queue, 2, st); // kernels, so that a stream capture replays them
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(hist, 0, kBins * sizeof(unsigned int), st);
+  e = ccmp_launch_clear_words(hist, kBins, st);
   if (e != hipSuccess) return e;
   // does the model look like the stock Panda to single precision?  (axes on coordinate axes, the expected zero offsets,
   // block-diagonal tool rotation, diagonal base rotation)  Only the prediction depends on it.

@@ -1,0 +1,83 @@
+"""The *_batch entry points are asynchronous on the caller's stream and keep no host-side state per call, so a planner can
+record a launch-bound step (sample -> project -> pre-filter -> compact, or a handful of extend edges) into a HIP graph once
+and replay it.  Every replay must redo ALL of the work — the queue heads, counters and the scout's histogram are cleared by
+kernels for that reason (a captured hipMemsetAsync left later replays with exhausted queues) — and produce the eager
+results, bit for bit."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _constraint
+
+pytestmark = pytest.mark.gpu
+
+
+def _capture_and_replay(work, replays=3):
+    import torch
+
+    ref = [t.clone() for t in work()]  # eager, default stream: also grows the context's workspaces before any capture
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # the same call on a non-default stream
+        on_side = work()
+        side.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(ref, on_side))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = work()
+    for rep in range(replays):
+        for t in outs:
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, outs)), "replay %d differs from the eager call" % rep
+    return ref
+
+
+@pytest.mark.parametrize("mode,B", [(0, 1), (0, 4096), (0, 40000), (0, 70000), (1, 30000), (1, 120000)])
+def test_projector_calls_replay_from_a_graph(gpu_ctx, mode, B):
+    """single state, latency kernel with its queue, scout + throughput kernel + hand-over (occupancy-driven and at once),
+    analytic mode with hand-over and with the split launch on the side stream"""
+    c = _constraint("Wine_Bottle", gpu_ctx, mode=mode)
+
+    def work():
+        q, ok, it, _ = c.sample_project_batch(0x6A + B, 7, B)
+        return q, ok, it
+
+    ref = _capture_and_replay(work)
+    assert int(ref[1].sum().item()) > 0 or B == 1
+
+
+def test_sample_filter_compact_and_extend_replay_from_a_graph(gpu_ctx):
+    """a planner step: sampleUniform x 8192 -> proxy pre-filter chained behind the projector's flags -> compaction of the
+    survivors; and growTree-shaped extend edges (checkMotion in one launch)"""
+    import torch
+    from closed_chain_motion_planner_amd.scene import ProxyValidityChecker
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    scene = ProxyValidityChecker(c).scene
+    kept = torch.empty((8192, 14), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def step():
+        q, ok, _, _ = c.sample_project_batch(0x57E9, 0, 8192, want_iters=False)
+        clr, pair, free = scene.clearance_batch(q, 0.0, ok=ok)
+        kept.zero_()  # rows past the count are not written by the compaction
+        c.compact_valid(q, free, out=kept, cnt=cnt)
+        return q, ok, clr, pair, free, kept, cnt
+
+    ref = _capture_and_replay(step)
+    n = int(ref[6].item())
+    assert 0 < n == int(ref[4].sum().item())
+    frm = ref[5][:64].contiguous()
+    to = c.sample_near_project_batch(0x57EA, 0, frm, 0.5, 64, want_iters=False)[0]
+
+    slot = torch.arange(32, device="cuda")[None, :, None]
+
+    def extend():
+        st, ns, ok, its = c.discrete_geodesic_batch(frm, to, 32, check_target=True)
+        return torch.where(slot < ns[:, None, None], st, 0.0), ns, ok, its  # the list past n_states is not written
+
+    st, ns, ok, its = _capture_and_replay(extend)
+    assert int(ok.sum().item()) > 0 and int(ns.max().item()) > 1
