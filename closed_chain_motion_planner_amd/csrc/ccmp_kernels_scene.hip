@@ -43,14 +43,28 @@ __device__ __forceinline__ void place_spheres(const ccmp_consts &K, const scene_
   }
 }
 
-// signed distance of one sphere-sphere pair of the tile (stored indices in ij, rsum = r_i + r_j)
-__device__ __forceinline__ double sphere_pair(const double *cen, int lane, unsigned ij, double rsum)
+// squared distance between the centres of one sphere-sphere pair of the tile (stored indices in ij)
+__device__ __forceinline__ double sphere_pair_d2(const double *cen, int lane, unsigned ij)
 {
   const int i = (int)(ij & 0xffu), j = (int)(ij >> 8);
   const double d0 = cen[(i * 3 + 0) * kTile + lane] - cen[(j * 3 + 0) * kTile + lane];
   const double d1 = cen[(i * 3 + 1) * kTile + lane] - cen[(j * 3 + 1) * kTile + lane];
   const double d2 = cen[(i * 3 + 2) * kTile + lane] - cen[(j * 3 + 2) * kTile + lane];
-  return ccmp_sqrt(dot3(d0, d0, d1, d1, d2, d2)) - rsum;
+  return dot3(d0, d0, d1, d1, d2, d2);
+}
+// One pair against the running minimum.  The signed distance sqrt(d2) - rsum can only become the minimum (ties keep
+// the earlier pair) if sqrt(d2) < best + rsum; a pair that is further than that by a nanometre is dropped on its
+// squared distance — the margin is 1e6 times the rounding of the four operations involved — and the square root, ten
+// dependent operations, runs only when some lane of the wavefront still needs it: after the first few pairs of a state
+// almost never.  Pairs that do run are computed exactly as before, so the result is unchanged bit for bit.
+__device__ __forceinline__ void consider_pair(double d2, double rsum, int p, double &best, int &bestp)
+{
+  const double t = (best + rsum) + 1e-9;
+  const bool need = !(t <= 0.0 || d2 > t * t); // also true for a NaN (never the case for finite states)
+  if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+    const double clr = ccmp_sqrt(d2) - rsum;
+    if (clr < best) { best = clr; bestp = p; }
+  }
 }
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
@@ -140,9 +154,9 @@ __global__ __launch_bounds__(kTileThreads) void clearance_kernel(const ccmp_cons
     }
     __syncthreads();
     // ---- phase 2: this wavefront's quarter of the pair list ------------------------------------------------------------
-    // Sphere-sphere pairs four at a time: one pair is a chain of ~20 dependent FP64 operations (the square root alone
-    // is ten), and with the two or three wavefronts per SIMD that the LDS footprint allows nothing else would fill the
-    // pipeline.  The minimum is taken in list order, so the result does not depend on the grouping.
+    // Sphere-sphere pairs four at a time (their LDS reads and squared distances in flight together: with the two or three
+    // wavefronts per SIMD that the LDS footprint allows nothing else would fill the pipeline); the minimum is taken in
+    // list order, so the result does not depend on the grouping.
     double best = __builtin_inf();
     int bestp = 0x7fffffff;
 #pragma unroll
@@ -152,18 +166,18 @@ __global__ __launch_bounds__(kTileThreads) void clearance_kernel(const ccmp_cons
       const int end = np_w - base > 64 ? 64 : np_w - base; // <= 0 past the table: nothing runs
       int l = 0;
       for (; l + 3 < ss_end; l += 4) {
-        double clr[4];
+        double d2[4], rs[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-          clr[u] = sphere_pair(cen, lane, (unsigned)__builtin_amdgcn_readlane((int)my_ij[k], l + u), readlane_f64(my_rs[k], l + u));
+        for (int u = 0; u < 4; u++) {
+          d2[u] = sphere_pair_d2(cen, lane, (unsigned)__builtin_amdgcn_readlane((int)my_ij[k], l + u));
+          rs[u] = readlane_f64(my_rs[k], l + u);
+        }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (clr[u] < best) { best = clr[u]; bestp = w + kTileWaves * (base + l + u); }
+        for (int u = 0; u < 4; u++) consider_pair(d2[u], rs[u], w + kTileWaves * (base + l + u), best, bestp);
       }
-      for (; l < ss_end; l++) {
-        const double clr = sphere_pair(cen, lane, (unsigned)__builtin_amdgcn_readlane((int)my_ij[k], l), readlane_f64(my_rs[k], l));
-        if (clr < best) { best = clr; bestp = w + kTileWaves * (base + l); }
-      }
+      for (; l < ss_end; l++)
+        consider_pair(sphere_pair_d2(cen, lane, (unsigned)__builtin_amdgcn_readlane((int)my_ij[k], l)), readlane_f64(my_rs[k], l),
+                      w + kTileWaves * (base + l), best, bestp);
       for (; l < end; l++) { // sphere-box pairs
         const unsigned ij = (unsigned)__builtin_amdgcn_readlane((int)my_ij[k], l);
         const int i = (int)(ij & 0xffu), b = (int)(ij >> 8) - CCMP_MAX_SPHERES;
@@ -176,8 +190,7 @@ __global__ __launch_bounds__(kTileThreads) void clearance_kernel(const ccmp_cons
           const double a = ccmp_abs(lb[c]) - S->box_half[b][c];
           e[c] = a > 0.0 ? a : 0.0;
         }
-        const double clr = ccmp_sqrt(dot3(e[0], e[0], e[1], e[1], e[2], e[2])) - readlane_f64(my_rs[k], l);
-        if (clr < best) { best = clr; bestp = w + kTileWaves * (base + l); }
+        consider_pair(dot3(e[0], e[0], e[1], e[1], e[2], e[2]), readlane_f64(my_rs[k], l), w + kTileWaves * (base + l), best, bestp);
       }
     }
     red[w * kTile + lane] = best;
