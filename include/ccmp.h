@@ -12,7 +12,7 @@
  *   - all pointers are caller-owned; *_batch calls take DEVICE pointers and are asynchronous on
  *     the caller's HIP stream (NULL = the HIP default stream, as in every HIP API); *_host calls
  *     take host pointers, run on the ctx's own stream and are synchronous; a *_batch call may be recorded into a HIP
- *     graph by stream capture and replayed (tests/test_gpu_graph.py) — after one eager call at that size, which grows
+ *     graph by stream capture and replayed (tests/test_gpu_usage_modes.py) — after one eager call at that size, which grows
  *     the context's workspaces
  *   - state layout everywhere: row-major double q[B][14]; first 7 = the alphabetically first arm
  *     name, next 7 = the second (std::map order, src/base/constraints/ConstrainedPlanningCommon.cpp:89-91)

@@ -1,4 +1,7 @@
-"""The *_batch entry points are asynchronous on the caller's stream and keep no host-side state per call, so a planner can
+"""Ways of calling the library beyond "one call, default stream, wait": non-default streams, HIP graphs, two contexts
+side by side.
+
+The *_batch entry points are asynchronous on the caller's stream and keep no host-side state per call, so a planner can
 record a launch-bound step (sample -> project -> pre-filter -> compact, or a handful of extend edges) into a HIP graph once
 and replay it.  Every replay must redo ALL of the work — the queue heads, counters and the scout's histogram are cleared by
 kernels for that reason (a captured hipMemsetAsync left later replays with exhausted queues) — and produce the eager
@@ -81,3 +84,30 @@ def test_sample_filter_compact_and_extend_replay_from_a_graph(gpu_ctx):
 
     st, ns, ok, its = _capture_and_replay(extend)
     assert int(ok.sum().item()) > 0 and int(ns.max().item()) > 1
+
+
+def test_two_contexts_on_two_streams_run_side_by_side(gpu_ctx):
+    """"use one context per stream for concurrency" (include/ccmp.h): two contexts of one device, each on its own stream,
+    launched back to back without synchronising in between — reference arithmetic with scout and hand-over on one, the
+    analytic split launch (which brings its own side stream) on the other — give what they give alone"""
+    import torch
+    from closed_chain_motion_planner_amd import Context
+
+    ctx2 = Context(0)
+    a = _constraint("Wine_Bottle", gpu_ctx, mode=0)
+    b = _constraint("stefan", ctx2, mode=1)
+    qa = a.ambient_uniform_batch(0x2C0, 0, 50000)
+    qb = b.ambient_uniform_batch(0x2C1, 0, 120000)
+    ref_a = [t.clone() for t in a.project_batch(qa)]
+    ref_b = [t.clone() for t in b.project_batch(qb)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            out_a = a.project_batch(qa)
+        with torch.cuda.stream(s2):
+            out_b = b.project_batch(qb)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(ref_a, out_a)), rep
+        assert all(torch.equal(x, y) for x, y in zip(ref_b, out_b)), rep
+    ctx2.close()
