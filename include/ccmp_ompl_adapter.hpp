@@ -282,6 +282,55 @@ inline bool discreteGeodesic(const Projector &proj, const double *from14, const 
   return good;
 }
 
+// The same for E edges in ONE launch: growTree tries its (up to five) nearest neighbours one after the other
+// (src/planner/stefanBiPRM.cpp:307-351, each a discreteGeodesic(neighbour, new vertex, false, &states)); handed over
+// together they cost the longest edge's serial chain instead of the sum.  from / to: E x 14, row-major.  The validity
+// checker sees the same states in the same order as in the reference's loop — edge by edge, state by state, an edge
+// stopping at its first rejected state.  reached[e] is the bool of edge e, (*geodesics)[e] its list.
+template <class ValidFn>
+inline void discreteGeodesicBatch(const Projector &proj, const double *from, const double *to, size_t E, bool interpolate, ValidFn valid,
+                                  std::vector<std::vector<std::vector<double>>> *geodesics, std::vector<char> *reached, int max_states = 64,
+                                  bool check_target = false)
+{
+  if (reached) reached->assign(E, 0);
+  if (geodesics) geodesics->assign(E, {});
+  if (E == 0) return;
+  std::vector<double> states(E * (size_t)max_states * 14);
+  std::vector<int32_t> n(E);
+  std::vector<uint8_t> ok(E);
+  {
+    std::lock_guard<std::mutex> hold(proj.mutex());
+    check((check_target ? ccmp_check_motion_host : ccmp_geodesic_host)(proj.ctx(), &proj.problem(), from, to, E, max_states, states.data(),
+                                                                       n.data(), ok.data()),
+          "ccmp_geodesic_host");
+  }
+  for (size_t e = 0; e < E; ++e) {
+    std::vector<std::vector<double>> list;
+    bool good;
+    if (n[e] > max_states) { // did not fit: this edge alone again, with room (validity included)
+      good = discreteGeodesic(proj, from + 14 * e, to + 14 * e, interpolate, valid, &list, 4 * max_states, check_target);
+    } else {
+      const double *st = &states[e * (size_t)max_states * 14];
+      good = ok[e] != 0;
+      int keep = n[e];
+      if (!interpolate) {
+        for (int k = 1; k < n[e]; ++k)
+          if (!valid(st + (size_t)k * 14)) {
+            keep = k;
+            double d = 0;
+            for (int i = 0; i < 14; ++i) { const double df = st[(size_t)(k - 1) * 14 + i] - to[14 * e + i]; d += df * df; }
+            good = std::sqrt(d) <= proj.problem().delta;
+            break;
+          }
+      }
+      if (geodesics)
+        for (int k = 0; k < keep; ++k) list.emplace_back(st + (size_t)k * 14, st + (size_t)k * 14 + 14);
+    }
+    if (reached) (*reached)[e] = good ? 1 : 0;
+    if (geodesics) (*geodesics)[e] = std::move(list);
+  }
+}
+
 // One planner process, several GPUs (the reference's shape: src/main.cpp is one process): one context per device and an
 // RCCL communicator over them.  sampleProjectSharded / projectSharded spread a batch over the GPUs in contiguous shards,
 // every GPU compacts its valid states into a fixed-capacity block and ONE all-gather brings them together; the valid
@@ -609,6 +658,45 @@ public:
   }
   // checkMotion's two tests — isSatisfied(s2) && discreteGeodesic(s1, s2, false) — in one GPU launch
   bool checkMotion(const ompl::base::State *s1, const ompl::base::State *s2) const { return traverse(s1, s2, false, nullptr, true); }
+
+  // growTree's neighbour loop (src/planner/stefanBiPRM.cpp:307-351) in one launch: discreteGeodesic(from[e], to, interpolate,
+  // &(*geodesics)[e]) for every e; reached[e] is the bool the reference's call returns.  The StateValidityChecker is asked
+  // about the same states in the same order as by that loop.
+  void discreteGeodesics(const std::vector<const ompl::base::State *> &from, const ompl::base::State *to, bool interpolate,
+                         std::vector<std::vector<ompl::base::State *>> *geodesics, std::vector<char> *reached) const
+  {
+    const size_t E = from.size();
+    std::vector<double> a(E * 14), b(E * 14);
+    const auto &tb = *to->as<StateType>();
+    for (size_t e = 0; e < E; ++e) {
+      const auto &fa = *from[e]->as<StateType>();
+      for (int i = 0; i < 14; ++i) { a[14 * e + i] = fa[i]; b[14 * e + i] = tb[i]; }
+    }
+    ccmp::Projector &proj = chain_->impl();
+    proj.problem().delta = delta_;
+    proj.problem().lambda = lambda_;
+    auto &&svc = si_->getStateValidityChecker();
+    std::vector<std::vector<std::vector<double>>> lists;
+    ompl::base::State *scratch = allocState();
+    ccmp::discreteGeodesicBatch(proj, a.data(), b.data(), E, interpolate,
+                                [&](const double *q) {
+                                  auto &x = *scratch->as<StateType>();
+                                  for (int i = 0; i < 14; ++i) x[i] = q[i];
+                                  return svc->isValid(scratch);
+                                },
+                                geodesics ? &lists : nullptr, reached);
+    freeState(scratch);
+    if (geodesics) {
+      geodesics->assign(E, {});
+      for (size_t e = 0; e < E; ++e)
+        for (const auto &st : lists[e]) {
+          ompl::base::State *s = allocState();
+          auto &x = *s->as<StateType>();
+          for (int i = 0; i < 14; ++i) x[i] = st[i];
+          (*geodesics)[e].push_back(s);
+        }
+    }
+  }
 
 private:
   bool traverse(const ompl::base::State *from, const ompl::base::State *to, bool interpolate, std::vector<ompl::base::State *> *geodesic,

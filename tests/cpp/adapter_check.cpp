@@ -69,6 +69,24 @@ int main(int argc, char **argv)
       // a buffer that is too small must not cut the list: the adapter re-runs the edge with room for all of it
       bool g3 = ccmp::discreteGeodesic(P, &out[0], &out[14], true, [](const double *) { return true; }, &geo, 1);
       std::printf("geodesic_small_buffer ok %d n %zu\n", g3 ? 1 : 0, geo.size());
+      // growTree's neighbour loop in one launch: edges 0->1, 1->0 and 0->0 (closer than delta: only `from`), nothing rejected
+      {
+        std::vector<double> fr, tt;
+        const int pairs[3][2] = {{0, 1}, {1, 0}, {0, 0}};
+        for (auto &pr : pairs) {
+          fr.insert(fr.end(), &out[14 * pr[0]], &out[14 * pr[0]] + 14);
+          tt.insert(tt.end(), &out[14 * pr[1]], &out[14 * pr[1]] + 14);
+        }
+        std::vector<std::vector<std::vector<double>>> lists;
+        std::vector<char> reached;
+        int calls = 0;
+        ccmp::discreteGeodesicBatch(P, fr.data(), tt.data(), 3, false, [&](const double *) { calls++; return true; }, &lists, &reached, 64);
+        for (int e = 0; e < 3; e++) {
+          std::printf("gbatch %d ok %d n %zu\n", e, (int)reached[e], lists[e].size());
+          print_hex(lists[e].back().data(), 14);
+        }
+        std::printf("gbatch checker_calls %d\n", calls);
+      }
       // sampleUniformNear / sampleGaussian around the first projected state through the look-ahead buffers
       ccmp::RefSampleBuffer nb(P, 42, ccmp::RefSampleBuffer::Near, 4), gb(P, 42, ccmp::RefSampleBuffer::Gaussian, 4);
       for (int i = 0; i < 6; i++) {  // 6 > look-ahead: the second refill continues the stream

@@ -136,6 +136,18 @@ int main(int argc, char **argv)
         space->freeState(s);
       }
     }
+    // growTree's neighbour loop through discreteGeodesics: edges a->b and b->b in one launch, checker accepting everything
+    {
+      auto svc = std::make_shared<CountingChecker>(1000000);
+      si.setStateValidityChecker(svc);
+      std::vector<std::vector<ob::State *>> lists;
+      std::vector<char> reached;
+      space->discreteGeodesics({a, b}, b, false, &lists, &reached);
+      std::printf("geodesics ok %d %d n %zu %zu checker_calls %d\n", (int)reached[0], (int)reached[1], lists[0].size(), lists[1].size(), svc->calls_);
+      print_hex("gl", lists[0].back()->as<ob::ConstrainedStateSpace::StateType>()->values, 14);
+      for (auto &l : lists)
+        for (ob::State *st : l) space->freeState(st);
+    }
     si.setStateValidityChecker(std::make_shared<CountingChecker>(1000000));
     jy_MotionValidator mv(si_ptr);
     std::printf("checkMotion %d %d\n", mv.checkMotion(a, b) ? 1 : 0, mv.checkMotion(b, a) ? 1 : 0);

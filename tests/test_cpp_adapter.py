@@ -78,6 +78,17 @@ def test_adapter_matches_oracle(ccmp_built, oracle_det, tmp_path):
     assert out[k] == "geodesic_small_buffer ok %d n %d" % (int(ok_g), len(st_g))  # re-run, not cut
     k += 1
 
+    calls = 0
+    for e, (i0, i1) in enumerate(((0, 1), (1, 0), (0, 0))):  # ccmp::discreteGeodesicBatch: three edges in one launch
+        ok_e, st_e, _ = oracle_det.discrete_geodesic(P, proj[i0], proj[i1], interpolate=True, max_states=256)
+        assert out[k] == "gbatch %d ok %d n %d" % (e, int(ok_e), len(st_e))
+        x = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in out[k + 1].split()])
+        assert np.array_equal(x.view(np.uint64), st_e[-1].view(np.uint64))
+        calls += len(st_e) - 1
+        k += 2
+    assert out[k] == "gbatch checker_calls %d" % calls  # every state but `from`, edge by edge
+    k += 1
+
     def around(kind, salt, index, param):
         amb = oracle_det.ambient_ref_batch(P, kind, 42 ^ salt, index, proj[0], param, 1)
         _, x, _ = oracle_det.project(P, amb[0])
@@ -192,6 +203,9 @@ def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
         d = float(np.sqrt(((st_g[2] - xn) ** 2).sum()))
         assert int(hdr[4]) == int(d <= 0.25)
     k += 1 + n_cut
+    assert out[k] == "geodesics ok %d 1 n %d 1 checker_calls %d" % (int(ok_g), n_full, n_full - 1)  # a->b, and b->b: only `from`
+    assert np.array_equal(_hex_row(out[k + 1], "gl").view(np.uint64), st_g[-1].view(np.uint64))
+    k += 2
     ok_back, _, _ = oracle_det.discrete_geodesic(P, xn, xa, interpolate=True, max_states=256)
     assert out[k] == "checkMotion %d %d" % (int(oracle_det.is_satisfied(P, xn) and ok_g), int(oracle_det.is_satisfied(P, xa) and ok_back))
     assert out[k + 1] == "geodesic_interpolate ok %d" % int(ok_g)
