@@ -66,18 +66,26 @@ def build_library(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     hipcc = hipcc_path()
     headers = [os.path.join(CSRC, h) for h in _HEADERS]
-    objs = []
+    objs, jobs = [], []
     relink = force
     for src, flags in _UNITS:
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + headers):
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags + ["-c", sp, "-o", op]
+            jobs.append([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags + ["-c", sp, "-o", op])
+    if jobs:  # the units are independent: compile them side by side (hipcc is one process per unit)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
-            relink = True
+
+        workers = max(1, min(len(jobs), int(os.environ.get("CCMP_BUILD_JOBS", "0")) or min(4, os.cpu_count() or 1)))
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(run, jobs))
+        relink = True
     if relink or _stale(LIBPATH, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIBPATH] + objs
         if verbose:
