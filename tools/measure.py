@@ -206,6 +206,19 @@ def soak(argv):
         ref = c.project_batch(q)
         bad = sum(not all(torch.equal(a, b) for a, b in zip(c.project_batch(q), ref)) for _ in range(25))
         print(obj, B, "repeats differing from the first run:", bad, flush=True)
+    # the analytic mode's split launch (two streams, scout order) and the proxy clearance, the same way
+    from closed_chain_motion_planner_amd.scene import ProxyValidityChecker
+
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    c.setJacobianMode(1)
+    q = c.ambient_uniform_batch(0x50B, 0, 200000)
+    ref = c.project_batch(q)
+    bad = sum(not all(torch.equal(a, b) for a, b in zip(c.project_batch(q), ref)) for _ in range(25))
+    print("Wine_Bottle analytic 200000 (split launch) repeats differing:", bad, flush=True)
+    sc = ProxyValidityChecker(c).scene
+    refc = sc.clearance_batch(ref[0])
+    bad = sum(not all(torch.equal(a, b) for a, b in zip(sc.clearance_batch(ref[0]), refc)) for _ in range(25))
+    print("proxy clearance 200000 repeats differing:", bad, flush=True)
 
 
 def scout(argv):
