@@ -47,6 +47,17 @@ int orc_is_detmath(void)
 }
 size_t orc_problem_sizeof(void) { return sizeof(orc_problem); }
 
+/* ---- deliberately WRONG variants (all zero = the restatement; never set outside tests/test_oracle_golden.py) --------
+ * Used for one purpose: to measure which choices of the un-vendored third-party arithmetic (OMPL's stencil, Eigen's
+ * solve and angularDistance) the reference's recorded artefacts can tell apart and which they cannot
+ * (test_recorded_paths_resolving_power).  Process-global, not thread-safe: set, run single-threaded, reset. */
+static int g_variant[ORC_VAR_COUNT];
+void orc_set_variant(int which, int value)
+{
+  if (which >= 0 && which < ORC_VAR_COUNT) g_variant[which] = value;
+}
+int orc_get_variant(int which) { return which >= 0 && which < ORC_VAR_COUNT ? g_variant[which] : -1; }
+
 /* ---- tiny fixed-size linear algebra, explicit evaluation order ---------------------------- */
 static void m3_mul(const double A[9], const double B[9], double C[9])
 {
@@ -241,6 +252,10 @@ static void residual_of_chain(const orc_problem *P, const double Rc[9], const do
   double dz = FMA(-ay, bx, FMA(ax, by, FMA(az, bw, aw * bz)));
   double vn = sqrt(DOT3(dx, dx, dy, dy, dz, dz));
   f[1] = 2.0 * ORC_ATAN2_NN(vn, fabs(dw)); /* angularDistance, Eigen >= 3.3 */
+  if (g_variant[ORC_VAR_ANGLE] == 1) { /* variant: Eigen 3.2's angularDistance, 2*acos(|a.b|) */
+    double dd = fabs(FMA(qc[3], q0[3], DOT3(qc[0], q0[0], qc[1], q0[1], qc[2], q0[2])));
+    f[1] = dd >= 1.0 ? 0.0 : 2.0 * acos(dd);
+  }
   double e0 = pc[0] - P->init_p[0], e1 = pc[1] - P->init_p[1], e2 = pc[2] - P->init_p[2];
   f[0] = sqrt(DOT3(e0, e0, e1, e1, e2, e2));
   if (dquat) { dquat[0] = dx; dquat[1] = dy; dquat[2] = dz; dquat[3] = dw; }
@@ -318,7 +333,8 @@ void orc_jacobian_fd(const orc_problem *P, const double x[14], double J[28])
   memcpy(y2, x, sizeof y2);
   for (int j = 0; j < 14; j++) {
     const double ax = fabs(x[j]);
-    const double h = 1.4901161193847656e-08 /* sqrt(DBL_EPSILON) = 2^-26 */ * (ax >= 1 ? ax : 1);
+    double h = 1.4901161193847656e-08 /* sqrt(DBL_EPSILON) = 2^-26 */ * (ax >= 1 ? ax : 1);
+    if (g_variant[ORC_VAR_H] == 1) h = 1e-6 * (ax >= 1 ? ax : 1); /* variant: a coarser step */
     double m[3][2];
     for (int s = 0; s < 3; s++) {
       y1[j] += h;
@@ -330,6 +346,8 @@ void orc_jacobian_fd(const orc_problem *P, const double x[14], double J[28])
       m[s][1] = (t1[1] - t2[1]) / den;
     }
     for (int r = 0; r < 2; r++) J[r * 14 + j] = FMA(0.1, m[2][r], FMA(-0.6, m[1][r], 1.5 * m[0][r]));
+    if (g_variant[ORC_VAR_STENCIL] == 1) /* variant: plain 3-point central difference */
+      for (int r = 0; r < 2; r++) J[r * 14 + j] = m[0][r];
     y1[j] = y2[j] = x[j];
   }
 }
@@ -465,6 +483,15 @@ void orc_jacobian_analytic(const orc_problem *P, const double x[14], double J[28
  * is a polish — which keeps kappa*eps accuracy without forming (J J^T)^-1 explicitly. */
 void orc_solve_minnorm(const double J[28], const double f[2], double dx[14])
 {
+  if (g_variant[ORC_VAR_SOLVE]) { /* variants: 1 = normal equations J^T (J J^T)^-1 f, 2 = the same damped by 1e-4 I */
+    double a = 0, d = 0, b = 0;
+    for (int j = 0; j < 14; j++) { a += J[j] * J[j]; d += J[14 + j] * J[14 + j]; b += J[j] * J[14 + j]; }
+    if (g_variant[ORC_VAR_SOLVE] == 2) { a += 1e-4; d += 1e-4; }
+    const double det = a * d - b * b;
+    const double y0 = (d * f[0] - b * f[1]) / det, y1 = (a * f[1] - b * f[0]) / det;
+    for (int j = 0; j < 14; j++) dx[j] = J[j] * y0 + J[14 + j] * y1;
+    return;
+  }
   double r0[14], r1[14], g0 = f[0], g1 = f[1];
   memcpy(r0, J, sizeof r0);
   memcpy(r1, J + 14, sizeof r1);
@@ -536,6 +563,8 @@ int orc_project(const orc_problem *P, double x[14], int32_t *iters)
     updates++;
   }
   if (iters) *iters = updates;
+  if (g_variant[ORC_VAR_RETURN] == 1) /* variant: the test a reader expects — both residuals, non-strict */
+    return orc_joint_valid(P, x) && f[0] <= P->tol_pos && f[1] <= P->tol_rot;
   return orc_joint_valid(P, x) && (norm1 < P->tol_pos) && (norm2 < P->tol_rot);
 }
 

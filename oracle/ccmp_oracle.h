@@ -26,10 +26,17 @@
  * precision (Wine_Bottle, delta 0.25: 4 segments / 25 states, max 8.4e-6 rad; dumbbell, recorded with delta 0.5:
  * 2 segments / 6 states, max 1.3e-4 rad, inside the spread that endpoints consistent with the printed digits
  * produce) — tests/test_oracle_golden.py::test_recorded_paths_are_reproduced; a Newton step of 0.25 / 0.35, other
- * tolerances or another delta miss by > 1e-4 (::test_recorded_path_rejects_a_wrong_projector).  That pins project()
- * as a whole (FK, residual, FD stencil, min-norm solve, 0.30 step, stop rule, quirks), interpolate and the break
- * tests of discreteGeodesic against the real RBDL / Eigen / OMPL build.  Also pinned: start_joint rows (f ~ 1e-6),
- * the dumped roadmaps (tests/golden/roadmaps/), an independent 50-digit mpmath FK/residual (tests/golden/mp_vectors.json).
+ * tolerances or another delta miss by > 1e-4 (::test_recorded_path_rejects_a_wrong_projector).  WHAT THAT RESOLVES
+ * (::test_recorded_paths_resolving_power, measured): FK, the residual definition, both tolerances, the 0.30 step, the
+ * stop rule, interpolate, the break tests of discreteGeodesic and delta — to the 6 printed digits (~1e-5 rad), against
+ * the real RBDL / Eigen / OMPL build.  WHAT IT DOES NOT RESOLVE: which Jacobian (OMPL's 7-point stencil, a 3-point
+ * stencil, h = 1e-6, or the exact derivative), which linear solve (thresholded SVD or plain normal equations), which
+ * angle formula (2 atan2 of Eigen >= 3.3 or 2 acos of Eigen 3.2) and the strictness of the return test: every such
+ * variant (ORC_VAR_* below) reproduces the recorded rows exactly as well as this restatement (8.37e-6 rad either way).
+ * Rows a3 / a4 of SURVEY.md §8 (OMPL Constraint::jacobian, Eigen JacobiSVD::solve; call sites ConstraintFunction.h:70-71)
+ * are therefore pinned by restating the published upstream algorithms, not by any artefact of the reference.
+ * Also pinned: start_joint rows (f ~ 1e-6), the dumped roadmaps (tests/golden/roadmaps/), an independent 50-digit
+ * mpmath FK/residual (tests/golden/mp_vectors.json).
  * Not pinned by any reference artefact: projections from uniform random samples (30+ Newton iterations) — there the
  * iteration amplifies last-bit differences past 1e-6 rad whatever the implementation, and the samplers'
  * random streams (OMPL's RNG is replaced by a counter-based generator).
@@ -81,6 +88,19 @@ typedef struct orc_problem {
 } orc_problem;
 
 enum { ORC_JAC_FD = 0, ORC_JAC_ANALYTIC = 1 };
+
+/* Deliberately wrong variants of the third-party arithmetic, for measuring what the reference's recorded artefacts can
+ * and cannot resolve (tests/test_oracle_golden.py::test_recorded_paths_resolving_power).  All zero = the restatement. */
+enum {
+  ORC_VAR_STENCIL = 0, /* 1: 3-point central difference instead of OMPL's 7-point stencil            */
+  ORC_VAR_H = 1,       /* 1: h = 1e-6 max(1,|x|) instead of sqrt(eps) max(1,|x|)                      */
+  ORC_VAR_SOLVE = 2,   /* 1: J^T (J J^T)^-1 f by normal equations; 2: the same damped (J J^T + 1e-4 I) */
+  ORC_VAR_ANGLE = 3,   /* 1: Eigen 3.2 angularDistance 2 acos|a.b| instead of 2 atan2(|vec|, |w|)      */
+  ORC_VAR_RETURN = 4,  /* 1: return f0 <= tol1 && f1 <= tol2 instead of the quirk's norm1 / norm2 test  */
+  ORC_VAR_COUNT = 5
+};
+void orc_set_variant(int which, int value);
+int orc_get_variant(int which);
 
 /* --- setup ------------------------------------------------------------------------------- */
 /* Panda constants from the modified-DH tables (panda_rbdl.cpp:73-148); dh_off may be NULL

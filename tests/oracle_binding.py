@@ -136,6 +136,9 @@ class Oracle:
         lib.orc_atan2_nn.restype = C.c_double
         lib.orc_is_detmath.restype = C.c_int
         lib.orc_problem_sizeof.restype = C.c_size_t
+        lib.orc_set_variant.argtypes = [C.c_int, C.c_int]
+        lib.orc_get_variant.argtypes = [C.c_int]
+        lib.orc_get_variant.restype = C.c_int
 
     # -- setup ------------------------------------------------------------------------------
     def problem(self, cfg):
@@ -235,6 +238,22 @@ class Oracle:
             r = ref if ref.ndim == 1 else np.ascontiguousarray(ref[i])
             fn(C.byref(P), seed, first + i, _dptr(r), float(param), _dptr(out[i]))
         return out
+
+    VARIANTS = {"stencil": 0, "h": 1, "solve": 2, "angle": 3, "return": 4}
+
+    def variant(self, name, value):
+        """context manager: one deliberately wrong variant of the third-party arithmetic (oracle/ccmp_oracle.h ORC_VAR_*),
+        reset to the restatement on exit; process-global — single-threaded use only"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.lib.orc_set_variant(self.VARIANTS[name], int(value))
+            try:
+                yield self
+            finally:
+                self.lib.orc_set_variant(self.VARIANTS[name], 0)
+        return cm()
 
     def discrete_geodesic(self, P, a, b, interpolate=False, max_states=256):
         a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
