@@ -67,7 +67,7 @@ EXPORTS = [
     "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_set_schedule", "ccmp_ctx_set_option", "ccmp_ctx_set_lpt", "ccmp_ctx_device", "ccmp_ctx_num_cus",
     "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
     "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
-    "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_check_motion_batch", "ccmp_check_motion_host", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid", "ccmp_compact_valid_capped",
+    "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_check_motion_batch", "ccmp_geodesic_batch_ex", "ccmp_geodesic_host_ex", "ccmp_check_motion_host", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid", "ccmp_compact_valid_capped",
     "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_sample_project_host", "ccmp_sample_ref_project_host", "ccmp_geodesic_host", "ccmp_project_sharded_host", "ccmp_sample_project_sharded_host",
     "ccmp_comm_create", "ccmp_comm_destroy", "ccmp_project_sharded", "ccmp_sample_project_sharded", "ccmp_ctx_set_order_experimental",
     "ccmp_scene_create", "ccmp_scene_destroy", "ccmp_scene_num_pairs", "ccmp_clearance_batch", "ccmp_clearance_host",
@@ -126,6 +126,8 @@ def lib():
         "ccmp_compute_t_wo_batch": ([vp, pp, vp, C.c_int, vp, C.c_size_t, vp], C.c_int),
         "ccmp_geodesic_batch": ([vp, pp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "ccmp_check_motion_batch": ([vp, pp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp], C.c_int),
+        "ccmp_geodesic_batch_ex": ([vp, pp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp], C.c_int),
+        "ccmp_geodesic_host_ex": ([vp, pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32), u8p, dp, dp, C.c_int], C.c_int),
         "ccmp_check_motion_host": ([vp, pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32), u8p], C.c_int),
         "ccmp_ambient_uniform_batch": ([vp, pp, C.c_uint64, C.c_uint64, vp, C.c_size_t, vp], C.c_int),
         "ccmp_enforce_bounds_batch": ([vp, vp, C.c_size_t, vp], C.c_int),

@@ -203,6 +203,10 @@ class KinematicChainConstraint:
     def _need_problem(self):
         if self.problem is None:
             raise RuntimeError("call setArmModels()/from_yaml() first")
+        if not 0 <= self.problem.max_iter <= 32767:
+            # the C side reports uint16 iteration counts and this mirror holds them in int16 tensors: a cap the tensors
+            # cannot represent is refused here instead of wrapping silently (the reference's cap is 250)
+            raise ValueError("problem.max_iter = %d: this binding supports 0..32767" % self.problem.max_iter)
 
     # -- batched API (CUDA tensors) -------------------------------------------------------------
     def _check_q(self, q):
@@ -231,10 +235,8 @@ class KinematicChainConstraint:
         return out, ok, self._iters(it)
 
     def _iters(self, it):
-        """the C side writes uint16 counts into an int16 tensor (torch's uint16 has few kernels): identical up to the
-        reference's cap of 250; widen when a caller raised max_iter past 32767"""
-        if it is not None and self.problem.max_iter > 32767:
-            return it.to(_torch().int32) & 0xFFFF
+        """the C side writes uint16 counts into an int16 tensor (torch's uint16 has few kernels): identical for every
+        cap `_need_problem` lets through (<= 32767; the reference's is 250)"""
         return it
 
     def sample_project_batch(self, seed, first_index, B, want_iters=True, want_ambient=False, stream=None):
@@ -294,11 +296,14 @@ class KinematicChainConstraint:
                                                  out.data_ptr(), q.shape[0], _stream_handle(stream)), "ccmp_compute_t_wo_batch")
         return out
 
-    def discrete_geodesic_batch(self, frm, to, max_states=64, stream=None, check_target=False):
+    def discrete_geodesic_batch(self, frm, to, max_states=64, stream=None, check_target=False, carry_in=None, want_carry=False):
         """`jy_ProjectedStateSpace::discreteGeodesic` for E edges (jy_ProjectedStateSpace.cpp:32-96), run as with
-        interpolate == true.  Returns (states (E,max_states,14), n_states (E,), ok (E,), newton_iters (E,)).
+        interpolate == true.  Returns (states (E,max_states,14), n_states (E,), ok (E,), newton_iters (E,)) and, with
+        want_carry, a fifth tensor carry (E,2).
         check_target: `checkMotion` in one launch — isSatisfied(to) && discreteGeodesic(from, to)
-        (src/planner/stefanBiPRM.cpp:397-398); an edge whose target is not satisfied reports ok = 0, n_states = 1."""
+        (src/planner/stefanBiPRM.cpp:397-398); an edge whose target is not satisfied reports ok = 0, n_states = 1.
+        An edge with n_states == max_states + 1 did not fit: continue it with frm = its last stored state, the same to and
+        carry_in = its carry row (ccmp_geodesic_batch_ex) — `continue_geodesics` below does that until every list is whole."""
         self._need_problem()
         self._check_q(frm)
         self._check_q(to)
@@ -308,11 +313,52 @@ class KinematicChainConstraint:
         n = torch.empty(E, dtype=torch.int32, device=frm.device)
         ok = torch.empty(E, dtype=torch.uint8, device=frm.device)
         its = torch.empty(E, dtype=torch.int32, device=frm.device)
-        fn = _lib.lib().ccmp_check_motion_batch if check_target else _lib.lib().ccmp_geodesic_batch
-        check(fn(self.ctx.handle, C.byref(self.problem), frm.data_ptr(), to.data_ptr(), E, int(max_states), states.data_ptr(),
-                 n.data_ptr(), ok.data_ptr(), its.data_ptr(), _stream_handle(stream)),
-              "ccmp_check_motion_batch" if check_target else "ccmp_geodesic_batch")
-        return states, n, ok, its
+        if carry_in is not None and not (isinstance(carry_in, torch.Tensor) and carry_in.is_cuda and carry_in.dtype == torch.float64
+                                         and carry_in.is_contiguous() and tuple(carry_in.shape) == (E, 2)):
+            raise ValueError("carry_in: contiguous (E,2) float64 CUDA tensor")
+        carry = torch.empty((E, 2), dtype=torch.float64, device=frm.device) if want_carry else None
+        check(_lib.lib().ccmp_geodesic_batch_ex(self.ctx.handle, C.byref(self.problem), frm.data_ptr(), to.data_ptr(), E, int(max_states),
+                                                states.data_ptr(), n.data_ptr(), ok.data_ptr(), its.data_ptr(),
+                                                carry_in.data_ptr() if carry_in is not None else None,
+                                                carry.data_ptr() if carry is not None else None, 1 if check_target else 0,
+                                                _stream_handle(stream)), "ccmp_geodesic_batch_ex")
+        return (states, n, ok, its, carry) if want_carry else (states, n, ok, its)
+
+    def continue_geodesics(self, to, states, n, ok, its, carry, max_states, max_rounds=1 << 20):
+        """Finishes the edges of a `discrete_geodesic_batch(..., want_carry=True)` result that did not fit
+        (n == max_states + 1), each from its last stored state.  Returns {edge index: (states (m,14) numpy, ok, newton
+        iterations)} with the complete list of every such edge — what one uninterrupted traversal produces, bit for bit."""
+        torch = _torch()
+        long = torch.nonzero(n > max_states).flatten()
+        out = {}
+        if long.numel() == 0:
+            return out
+        parts = {int(e): [states[e, :max_states].cpu().numpy()] for e in long.tolist()}
+        total_its = {int(e): int(its[e]) for e in long.tolist()}
+        cur_from = states[long, max_states - 1].contiguous()
+        cur_to = to[long].contiguous()
+        cur_carry = carry[long].contiguous()
+        idx = long.tolist()
+        for _ in range(max_rounds):
+            s2, n2, ok2, it2, c2 = self.discrete_geodesic_batch(cur_from, cur_to, max_states, carry_in=cur_carry, want_carry=True)
+            n2c, ok2c, it2c = n2.cpu().numpy(), ok2.cpu().numpy(), it2.cpu().numpy()
+            again = []
+            for k, e in enumerate(idx):
+                m = min(int(n2c[k]), max_states)
+                parts[e].append(s2[k, 1:m].cpu().numpy())  # row 0 repeats the state the continuation started from
+                total_its[e] += int(it2c[k])
+                if n2c[k] > max_states:
+                    again.append(k)
+                else:
+                    out[e] = (np.concatenate(parts[e], axis=0), int(ok2c[k]), total_its[e])
+            if not again:
+                break
+            sel = torch.as_tensor(again, device=to.device)
+            cur_from = s2[sel, max_states - 1].contiguous()
+            cur_to = cur_to[sel].contiguous()
+            cur_carry = c2[sel].contiguous()
+            idx = [idx[k] for k in again]
+        return out
 
     def ambient_uniform_batch(self, seed, first_index, B, stream=None):
         self._need_problem()

@@ -73,7 +73,10 @@ hipError_t ccmp_launch_ambient_ref(const ccmp_consts *K, int kind, unsigned long
 hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride, double *out, size_t B, hipStream_t st);
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
-                                int check_target, int nblocks, hipStream_t st);
+                                int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
+                                const double *carry_in, double *carry_out, hipStream_t st);
+hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
+                                      unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st);
 hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, size_t capacity,
                                unsigned int *block_counts, unsigned long long *total, hipStream_t st);
@@ -96,7 +99,10 @@ struct HostIO {
   char *host = nullptr; // pinned alias (small calls) or nullptr
   struct Out { void *dst; size_t off, n; } outs[4];
   int n_outs = 0;
-  explicit HostIO(ccmp_ctx *c) : ctx(c) {}
+  // every *_host call starts with the completion-word machinery off: a flag left over from a call that returned early
+  // (an argument error behind want_done = true) must never make a later launch arm, or a later finish() poll, a word
+  // that its own kernel does not publish last
+  explicit HostIO(ccmp_ctx *c) : ctx(c) { ctx->want_done = ctx->done_armed = false; }
   int begin(size_t bytes)
   {
     if (bytes <= kPinData) {
@@ -306,6 +312,15 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "clearance_per_state_max")) { // proxy clearance: one block per state up to this many states
     if (value < 0) return CCMP_EINVAL;
     ctx->clearance_per_state_max = (size_t)value;
+  } else if (!strcmp(name, "geodesic_order")) { // extend step: long edges first when a batch exceeds the resident blocks (0/1)
+    if (value != 0 && value != 1) return CCMP_EINVAL;
+    ctx->geodesic_order = (int)value;
+  } else if (!strcmp(name, "geodesic_order_min")) { // ... from this many edges on
+    if (value < 0) return CCMP_EINVAL;
+    ctx->geodesic_order_min = (size_t)value;
+  } else if (!strcmp(name, "geodesic_long_steps")) { // ... an edge is long when |to - from| exceeds this many delta
+    if (value < 0) return CCMP_EINVAL;
+    ctx->geodesic_long_steps = (double)value;
   } else if (!strcmp(name, "handover_threshold")) { // -1 = automatic, 0..10 = hand a wave over once <= this many groups are busy
     if (value < -1 || value > 110) return CCMP_EINVAL; // 11..110: occupancy-driven, hand over below (value - 10) % of the group slots
     ctx->dump_threshold = (int)value;
@@ -584,31 +599,58 @@ int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *
 }
 
 static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
-                           double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, int check_target, void *hip_stream)
+                           double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, const double *carry_in,
+                           double *carry_out, int check_target, void *hip_stream)
 {
   CCMP_PROLOGUE();
   if (E == 0) return CCMP_OK;
   if (!from || !to || !states || !n_states || !ok || max_states < 1) return CCMP_EINVAL;
   if (!(p->delta > 0) || !(p->lambda > 0)) return CCMP_EINVAL;
   if (p->jacobian_mode != CCMP_JAC_FD) return CCMP_EINVAL; // the extend step exists in reference arithmetic only
-  // one 128-thread block per edge; the hardware dispatcher balances edges of different length (the kernel strides
-  // over the edges if the grid is capped)
-  const size_t nb = E < ((size_t)1 << 20) ? E : ((size_t)1 << 20);
+  if (carry_in && check_target) return CCMP_EINVAL;        // a continuation's target was tested by the call it continues
+  // One 128-thread block per edge.  Up to the resident capacity (8 blocks per CU) every edge has its block at once and
+  // the hardware dispatcher is the queue.  Beyond it the blocks are persistent and take tickets from an atomic word,
+  // handed out through a long-edges-first order when the batch is large enough for the ordering pass to pay: the
+  // launch then ends on short edges (16384 near-neighbour edges, 16-state lists: 3.15 -> 2.1 ms).
+  const size_t resident = (size_t)ctx->num_cus * 8;
+  size_t nb = E;
+  unsigned long long *queue = nullptr;
+  const unsigned int *order = nullptr;
+  if (E > resident) {
+    nb = resident;
+    queue = ctx->queue + 3; // word 3: ticket; word 4: the two counters of the ordering pass
+    HIP_TRY(ccmp_launch_clear_words(queue, 4, st));
+    if (ctx->geodesic_order && E >= ctx->geodesic_order_min && E < 0xffffffffull) {
+      int rc = ensure_lpt_buffers(ctx, E);
+      if (rc != CCMP_OK) return rc;
+      unsigned int *ord = (unsigned int *)((char *)ctx->lpt_buf + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255) + 4096);
+      HIP_TRY(ccmp_launch_geodesic_order(from, to, E, ctx->geodesic_long_steps * p->delta, (unsigned int *)(ctx->queue + 4), ord, st));
+      order = ord;
+    }
+  }
   HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target, (int)nb,
-                               st));
+                               queue, order, carry_in, carry_out, st));
   return CCMP_OK;
 }
 
 int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                         double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream)
 {
-  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, 0, hip_stream);
+  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, nullptr, nullptr, 0, hip_stream);
 }
 
 int ccmp_check_motion_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                             double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream)
 {
-  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, 1, hip_stream);
+  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, nullptr, nullptr, 1, hip_stream);
+}
+
+int ccmp_geodesic_batch_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                           double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, const double *carry_in,
+                           double *carry_out, int check_target, void *hip_stream)
+{
+  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, carry_in, carry_out, check_target,
+                         hip_stream);
 }
 
 int ccmp_is_satisfied_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B, void *hip_stream)
@@ -736,7 +778,7 @@ int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, do
   if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
   ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_function_batch(ctx, p, (const double *)io.dev, (double *)(io.dev + off_f), B, ctx->stream);
-  if (rc != CCMP_OK) return rc;
+  if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
   if ((rc = io.out(f, off_f, B * 2 * sizeof(double))) != CCMP_OK) return rc;
   return io.finish();
 }
@@ -756,7 +798,7 @@ int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
   if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
   ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_is_satisfied_batch(ctx, p, (const double *)io.dev, (uint8_t *)(io.dev + off_ok), B, ctx->stream);
-  if (rc != CCMP_OK) return rc;
+  if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
   if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
   return io.finish();
 }
@@ -776,7 +818,7 @@ int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q,
   if ((rc = io.in(0, q, qb)) != CCMP_OK) return rc;
   ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_joint_valid_batch(ctx, p, (const double *)io.dev, (uint8_t *)(io.dev + off_ok), B, ctx->stream);
-  if (rc != CCMP_OK) return rc;
+  if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
   if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
   return io.finish();
 }
@@ -850,7 +892,7 @@ int ccmp_clearance_host(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *
   ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_clearance_batch(ctx, p, scene, (const double *)io.dev, nullptr, B, margin, (double *)(io.dev + off_c),
                             (int32_t *)(io.dev + off_p), (uint8_t *)(io.dev + off_f), ctx->stream);
-  if (rc != CCMP_OK) return rc;
+  if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
   if ((rc = io.out(clearance, off_c, B * sizeof(double))) != CCMP_OK) return rc;
   if (pair && (rc = io.out(pair, off_p, B * sizeof(int32_t))) != CCMP_OK) return rc;
   if (free_out && (rc = io.out(free_out, off_f, B)) != CCMP_OK) return rc;
@@ -858,7 +900,8 @@ int ccmp_clearance_host(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *
 }
 
 static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
-                                double *states, int32_t *n_states, uint8_t *ok, int check_target)
+                                double *states, int32_t *n_states, uint8_t *ok, const double *carry_in, double *carry_out,
+                                int check_target)
 {
   if (!ctx || !p) return CCMP_EINVAL;
   if (E == 0) return CCMP_OK;
@@ -867,34 +910,48 @@ static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const doub
   if (!guard.ok) return CCMP_ENODEV;
   const size_t eb = E * 14 * sizeof(double);
   const size_t sb = E * (size_t)max_states * 14 * sizeof(double);
+  const size_t cb = E * 2 * sizeof(double);
   const size_t off_to = (eb + 255) & ~(size_t)255;
   const size_t off_st = (off_to + eb + 255) & ~(size_t)255;
   const size_t off_n = (off_st + sb + 255) & ~(size_t)255;
   const size_t off_ok = (off_n + E * sizeof(int32_t) + 255) & ~(size_t)255;
+  const size_t off_ci = (off_ok + E + 255) & ~(size_t)255;
+  const size_t off_co = (off_ci + cb + 255) & ~(size_t)255;
   HostIO io(ctx);
-  int rc = io.begin(off_ok + E);
+  int rc = io.begin(off_co + cb);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.in(0, from, eb)) != CCMP_OK) return rc;
   if ((rc = io.in(off_to, to, eb)) != CCMP_OK) return rc;
+  if (carry_in && (rc = io.in(off_ci, carry_in, cb)) != CCMP_OK) return rc;
   rc = geodesic_common(ctx, p, (const double *)io.dev, (const double *)(io.dev + off_to), E, max_states, (double *)(io.dev + off_st),
-                       (int32_t *)(io.dev + off_n), (uint8_t *)(io.dev + off_ok), nullptr, check_target, ctx->stream);
+                       (int32_t *)(io.dev + off_n), (uint8_t *)(io.dev + off_ok), nullptr,
+                       carry_in ? (const double *)(io.dev + off_ci) : nullptr, carry_out ? (double *)(io.dev + off_co) : nullptr,
+                       check_target, ctx->stream);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.out(states, off_st, sb)) != CCMP_OK) return rc;
   if ((rc = io.out(n_states, off_n, E * sizeof(int32_t))) != CCMP_OK) return rc;
   if ((rc = io.out(ok, off_ok, E)) != CCMP_OK) return rc;
+  if (carry_out && (rc = io.out(carry_out, off_co, cb)) != CCMP_OK) return rc;
   return io.finish();
 }
 
 int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                        double *states, int32_t *n_states, uint8_t *ok)
 {
-  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, 0);
+  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, nullptr, nullptr, 0);
 }
 
 int ccmp_check_motion_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                            double *states, int32_t *n_states, uint8_t *ok)
 {
-  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, 1);
+  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, nullptr, nullptr, 1);
+}
+
+int ccmp_geodesic_host_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                          double *states, int32_t *n_states, uint8_t *ok, const double *carry_in, double *carry_out, int check_target)
+{
+  if (carry_in && check_target) return CCMP_EINVAL;
+  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, carry_in, carry_out, check_target);
 }
 
 static int sharded_common(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, int mode, const double *q_in, double *q_out,

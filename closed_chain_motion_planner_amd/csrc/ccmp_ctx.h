@@ -60,7 +60,7 @@ struct ccmp_ctx {
   int num_cus = 0;
   int waves_per_cu = 0;
   hipStream_t stream = nullptr;
-  unsigned long long *queue = nullptr; // work-queue heads of the projector kernels (4 words)
+  unsigned long long *queue = nullptr; // work-queue heads: words 0-2 projector kernels, 3-4 extend step, 5 scout, 8.. analytic kernels
   double *pool = nullptr;              // straggler hand-over records (group kernel -> wave kernel)
   size_t pool_cap = 0;                 // in records
   int wave_kernel = 1;                 // 0: group kernel only, 1: group + wave-per-sample (default), 2: wave only
@@ -81,6 +81,9 @@ struct ccmp_ctx {
   int analytic_split_pred = 90;          // predicted iterations from which a sample goes to the six-lane kernel
   hipStream_t side = nullptr;            // side stream of split launches
   hipEvent_t fork = nullptr, join = nullptr;
+  int geodesic_order = 1;                // extend step: batches beyond the resident blocks run long edges first
+  size_t geodesic_order_min = 4096;      // ... from this many edges on (the ordering pass is one more launch)
+  double geodesic_long_steps = 12.0;     // ... "long" = further than this many delta apart (median near-neighbour edge: 4)
   size_t clearance_per_state_max = 8192; // proxy clearance: up to here one block per state, above 64-state tiles
   int dump_threshold = -1;             // hand a wave's samples over once the queue is dry and <= this many groups are busy; -1 = auto
   size_t small_batch = kDefaultSmallBatch;    // at or below: latency kernel on everything

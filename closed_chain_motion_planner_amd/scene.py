@@ -64,14 +64,22 @@ def default_allowed(adjacency=3):
     return allowed
 
 
+# reject threshold that goes with the default skeleton spheres (see skeleton_spheres): they are not inscribed in the links
+DEFAULT_SKELETON_MARGIN = -0.03
+
+
 def skeleton_spheres(problem, radius=0.055, spacing=0.08, hand_extent=0.09, hand_radius=0.035):
     """Spheres strung along the joint-to-joint skeleton of both arms, built from the problem's own chain constants
     (joint offsets of panda_rbdl.cpp:128-130, the hand offset of :124-126): one at every joint origin, more every
-    `spacing` metres along each segment, attached to the body that carries the segment; group = frame code.  A radius
-    at or below the physical link radius (~0.055 m for the Panda's arm links) makes them INSCRIBED proxies: a negative
-    clearance then proves a collision; the hand's spheres are thinner (two hands hold one object a few centimetres
-    apart).  They are a coarse default, not the robot's meshes: every state the reference itself validated with MoveIt —
-    its recorded paths and roadmap vertices — keeps a positive clearance with them (tests/test_scene.py)."""
+    `spacing` metres along each segment, attached to the body that carries the segment; group = frame code.  The radius is
+    about the physical radius of the Panda's arm links (~0.055 m); the hand's spheres are thinner (two hands hold one
+    object a few centimetres apart).  They are a COARSE default, not the robot's meshes and NOT provably inscribed: the
+    straight joint-to-joint segments cut corners of the real links (the forearm's (-0.0825, 0, 0.384) diagonal leaves the
+    L-shaped link by centimetres), so a slightly negative clearance does not prove a collision.  ProxyValidityChecker
+    therefore rejects with these spheres only below DEFAULT_SKELETON_MARGIN (an overlap deeper than 3 cm); strict
+    "negative clearance = collision" semantics are for inscribed proxies the caller supplies.  What is checked: every
+    state the reference itself validated with MoveIt — its recorded paths and roadmap vertices — keeps a positive
+    clearance with them (tests/test_scene.py)."""
     off = np.ctypeslib.as_array(problem.offset).reshape(2, 7, 3)
     ee = np.ctypeslib.as_array(problem.ee).reshape(2, 3)
     out = []
@@ -192,21 +200,23 @@ class ProxyValidityChecker:
 
         chk = ProxyValidityChecker(constraint)             # both arms' skeleton spheres + sub_table
         chk.attachObject(points_in_object_frame, radius)   # optional: the grasped object as spheres
-        chk.isValid(x)                                     # False = the proxies overlap (margin 0)
+        chk.isValid(x)                                     # False = clearance <= margin
         chk.filter_batch(q, ok)                            # device flags for a whole batch
 
-    `inner` (optional) is the exact checker to ask when the proxies do NOT overlap (MoveIt in the reference's build):
-    with inscribed proxies the pre-filter only ever rejects states that really collide."""
+    `inner` (optional) is the exact checker to ask when the proxies do NOT refuse the state (MoveIt in the reference's
+    build).  `margin` None = 0 for proxies the caller supplies (with INSCRIBED proxies the pre-filter then only ever
+    rejects states that really collide) and DEFAULT_SKELETON_MARGIN = -3 cm for the default skeleton spheres, which are
+    not inscribed: the pre-filter must not refuse states MoveIt would accept — that would change the planner's answers."""
 
     SUB_TABLE = (GROUP_ENVIRONMENT, (0.65, 0.0, 1.1), np.eye(3), (0.325, 0.5, 0.1))  # addBox(dim (0.65, 1.0, 0.2), pose)
 
-    def __init__(self, constraint, spheres=None, boxes=None, allowed=None, margin=0.0, inner=None):
+    def __init__(self, constraint, spheres=None, boxes=None, allowed=None, margin=None, inner=None):
         self.constraint = constraint
         constraint._need_problem()
         self._spheres = list(skeleton_spheres(constraint.problem) if spheres is None else spheres)
         self._boxes = [self.SUB_TABLE] if boxes is None else list(boxes)
         self._allowed = list(default_allowed() if allowed is None else allowed)
-        self.margin = float(margin)
+        self.margin = float((DEFAULT_SKELETON_MARGIN if spheres is None else 0.0) if margin is None else margin)
         self.inner = inner
         self._scene = None
 

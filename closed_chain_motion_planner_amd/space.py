@@ -144,25 +144,16 @@ class jy_ProjectedStateSpace:
         dev = "cuda:%d" % self.constraint_.ctx.device
         f = torch.as_tensor(np.ascontiguousarray(frm, dtype=np.float64)).to(dev)
         t = torch.as_tensor(np.ascontiguousarray(to, dtype=np.float64)).to(dev)
-        states, n, ok, _ = self.constraint_.discrete_geodesic_batch(f, t, self.max_states, check_target=check_target)
+        states, n, ok, its, carry = self.constraint_.discrete_geodesic_batch(f, t, self.max_states, check_target=check_target,
+                                                                             want_carry=True)
+        # n_states == max_states + 1: these lists did not fit and the traversal stopped there.  Continue them from
+        # their last stored state until they are whole (ccmp_geodesic_batch_ex: the same states as one uninterrupted
+        # traversal) — a cut list must never reach the validity test or the caller as if it were complete.
+        whole = self.constraint_.continue_geodesics(t, states, n, ok, its, carry, self.max_states)
         n, ok = n.cpu().numpy(), ok.cpu().numpy()
         rows = [None] * len(n)
-        long, cap = np.nonzero(n > self.max_states)[0], self.max_states
-        while len(long):
-            # n_states == max_states + 1: these lists did not fit and the traversal stopped there.  Run them again with
-            # four times the room — a cut list must never reach the validity test or the caller as if it were complete.
-            cap *= 4
-            idx = torch.as_tensor(long, device=f.device)
-            s2, n2, ok2, _ = self.constraint_.discrete_geodesic_batch(f[idx].contiguous(), t[idx].contiguous(), cap,
-                                                                      check_target=check_target)
-            s2, n2, ok2 = s2.cpu().numpy(), n2.cpu().numpy(), ok2.cpu().numpy()
-            again = []
-            for k, e in enumerate(long):
-                if n2[k] > cap:
-                    again.append(e)
-                else:
-                    rows[e], n[e], ok[e] = s2[k, : n2[k]], n2[k], ok2[k]
-            long = np.array(again, dtype=np.int64)
+        for e, (st_e, ok_e, _) in whole.items():
+            rows[e], n[e], ok[e] = st_e, st_e.shape[0], ok_e
         states = states.cpu().numpy()
         delta = self.constraint_.problem.delta
         out = []

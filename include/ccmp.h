@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CCMP_VERSION 210
+#define CCMP_VERSION 300
 
 enum {
   CCMP_OK = 0,
@@ -189,6 +189,16 @@ int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *
  * interpolate == false the host truncates at the first state its StateValidityChecker rejects. */
 int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                         double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream);
+/* The same, resumable.  carry_out (nullable, [E][2]) receives what a continuation of an edge that did not fit needs — the
+ * running length before the step that found the list full and the bound lambda * dist(from, to).  A later call with
+ * from[e] = the edge's last stored state (states[e][max_states - 1]), the same to[e] and carry_in[e] = that carry_out[e]
+ * goes on where the first one stopped: its list starts with that state again (drop it when joining the lists) and
+ * first call + continuations give the states, flags and Newton counts of one uninterrupted traversal, bit for bit — the
+ * 952-state creeping edge costs its own serial chain once instead of a re-run per enlargement.  check_target as in
+ * ccmp_check_motion_batch (not together with carry_in: the target was tested by the call being continued). */
+int ccmp_geodesic_batch_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                           double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, const double *carry_in,
+                           double *carry_out, int check_target, void *hip_stream);
 /* OMPL ConstrainedMotionValidator::checkMotion as the reference's planner calls it (src/planner/stefanBiPRM.cpp:397-398,
  * 463-464; jy_MotionValidator, jy_ProjectedStateSpace.h:57-69): isSatisfied(to) && discreteGeodesic(from, to) in ONE
  * launch — same outputs as ccmp_geodesic_batch, except that an edge whose target fails isSatisfied reports ok = 0 and
@@ -226,6 +236,8 @@ int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from,
                        double *states, int32_t *n_states, uint8_t *ok);
 int ccmp_check_motion_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                            double *states, int32_t *n_states, uint8_t *ok);
+int ccmp_geodesic_host_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
+                          double *states, int32_t *n_states, uint8_t *ok, const double *carry_in, double *carry_out, int check_target);
 
 /* ---- one process, several GPUs (the reference's planner is a single process) ------------------------- */
 /* Contiguous shards of the batch go to the n contexts (1 <= n <= 64, one per device; the same device may appear twice),

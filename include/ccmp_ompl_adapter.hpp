@@ -235,100 +235,101 @@ private:
   std::vector<uint8_t> ok_;
 };
 
-// jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96) for one edge on raw
-// buffers.  `valid` (nullable) is the host StateValidityChecker; it is consulted only when !interpolate,
-// in order, and the list is cut at the first rejected state — where the reference's loop breaks.  The traversal on the
-// GPU stops when max_states states are listed (edges of the reference's roadmaps have 3-7 states; the work spent beyond a
-// state the checker rejects is bounded by this) and an edge that needs more is run again with four times the room.
+// jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96) for E edges in ONE launch on raw
+// buffers (from / to: E x 14, row-major): growTree tries its (up to five) nearest neighbours one after the other
+// (src/planner/stefanBiPRM.cpp:307-351, each a discreteGeodesic(neighbour, new vertex, false, &states)); handed over
+// together they cost the longest edge's serial chain instead of the sum.  `valid` is the host StateValidityChecker; it is
+// consulted only when !interpolate, and it sees the same states in the same order as in the reference's loop — edge by
+// edge, state by state, an edge stopping at its first rejected state, where the reference's loop breaks.  reached[e] is
+// the bool of edge e, (*geodesics)[e] its list.
+// The traversal on the GPU lists max_states states per call (edges of the reference's roadmaps have 3-7; the work spent
+// beyond a state the checker rejects is bounded by this).  An edge that needs more is CONTINUED from its last stored
+// state (ccmp_geodesic_host_ex: the states of one uninterrupted traversal, bit for bit) — after the checker has passed
+// what is there, so that a long or creeping edge the checker cuts early costs nothing more.  A cut list never reaches
+// the caller as if it were complete.
 // check_target: ConstrainedMotionValidator::checkMotion in one launch — isSatisfied(to) is tested first and an edge whose
 // target fails it returns false with only `from` in the list (src/planner/stefanBiPRM.cpp:397-398).
-template <class ValidFn>
-inline bool discreteGeodesic(const Projector &proj, const double *from14, const double *to14, bool interpolate, ValidFn valid,
-                             std::vector<std::vector<double>> *geodesic, int max_states = 64, bool check_target = false)
-{
-  std::vector<double> states;
-  int32_t n = 0;
-  uint8_t ok = 0;
-  for (;;) {
-    states.resize((size_t)max_states * 14);
-    {
-      std::lock_guard<std::mutex> hold(proj.mutex());
-      check((check_target ? ccmp_check_motion_host : ccmp_geodesic_host)(proj.ctx(), &proj.problem(), from14, to14, 1, max_states,
-                                                                         states.data(), &n, &ok),
-            "ccmp_geodesic_host");
-    }
-    if (n <= max_states) break;
-    // n == max_states + 1: the list did not fit and the traversal stopped there (small delta, long or creeping edge).
-    // A cut list must never reach the validity test or the caller as if it were complete — run the edge again with
-    // four times the room.
-    max_states *= 4;
-  }
-  bool good = ok != 0;
-  int keep = n;
-  if (!interpolate) {
-    for (int k = 1; k < n; ++k)
-      if (!valid(&states[(size_t)k * 14])) {
-        keep = k;
-        double d = 0;
-        for (int i = 0; i < 14; ++i) { const double df = states[(size_t)(k - 1) * 14 + i] - to14[i]; d += df * df; }
-        good = std::sqrt(d) <= proj.problem().delta;
-        break;
-      }
-  }
-  if (geodesic) {
-    geodesic->clear();
-    for (int k = 0; k < keep; ++k) geodesic->emplace_back(&states[(size_t)k * 14], &states[(size_t)k * 14] + 14);
-  }
-  return good;
-}
-
-// The same for E edges in ONE launch: growTree tries its (up to five) nearest neighbours one after the other
-// (src/planner/stefanBiPRM.cpp:307-351, each a discreteGeodesic(neighbour, new vertex, false, &states)); handed over
-// together they cost the longest edge's serial chain instead of the sum.  from / to: E x 14, row-major.  The validity
-// checker sees the same states in the same order as in the reference's loop — edge by edge, state by state, an edge
-// stopping at its first rejected state.  reached[e] is the bool of edge e, (*geodesics)[e] its list.
+// delta / lambda > 0 override the problem's values for this call (the space's setDelta / setLambda) through a per-call
+// copy of the problem: nothing shared is written, whichever thread calls.
 template <class ValidFn>
 inline void discreteGeodesicBatch(const Projector &proj, const double *from, const double *to, size_t E, bool interpolate, ValidFn valid,
                                   std::vector<std::vector<std::vector<double>>> *geodesics, std::vector<char> *reached, int max_states = 64,
-                                  bool check_target = false)
+                                  bool check_target = false, double delta = -1.0, double lambda = -1.0)
 {
   if (reached) reached->assign(E, 0);
   if (geodesics) geodesics->assign(E, {});
   if (E == 0) return;
-  std::vector<double> states(E * (size_t)max_states * 14);
+  if (max_states < 2) max_states = 2; // a continuation starts from a stored state other than `from`
+  ccmp_problem pb;
+  std::vector<double> states(E * (size_t)max_states * 14), carry(E * 2);
   std::vector<int32_t> n(E);
   std::vector<uint8_t> ok(E);
   {
     std::lock_guard<std::mutex> hold(proj.mutex());
-    check((check_target ? ccmp_check_motion_host : ccmp_geodesic_host)(proj.ctx(), &proj.problem(), from, to, E, max_states, states.data(),
-                                                                       n.data(), ok.data()),
-          "ccmp_geodesic_host");
+    pb = proj.problem();
+    if (delta > 0) pb.delta = delta;
+    if (lambda > 0) pb.lambda = lambda;
+    check(ccmp_geodesic_host_ex(proj.ctx(), &pb, from, to, E, max_states, states.data(), n.data(), ok.data(), nullptr, carry.data(),
+                                check_target ? 1 : 0),
+          "ccmp_geodesic_host_ex");
   }
+  std::vector<double> more((size_t)max_states * 14);
   for (size_t e = 0; e < E; ++e) {
     std::vector<std::vector<double>> list;
-    bool good;
-    if (n[e] > max_states) { // did not fit: this edge alone again, with room (validity included)
-      good = discreteGeodesic(proj, from + 14 * e, to + 14 * e, interpolate, valid, &list, 4 * max_states, check_target);
-    } else {
-      const double *st = &states[e * (size_t)max_states * 14];
-      good = ok[e] != 0;
-      int keep = n[e];
-      if (!interpolate) {
-        for (int k = 1; k < n[e]; ++k)
-          if (!valid(st + (size_t)k * 14)) {
-            keep = k;
-            double d = 0;
-            for (int i = 0; i < 14; ++i) { const double df = st[(size_t)(k - 1) * 14 + i] - to[14 * e + i]; d += df * df; }
-            good = std::sqrt(d) <= proj.problem().delta;
-            break;
-          }
+    const double *st = &states[e * (size_t)max_states * 14];
+    const double *to_e = to + 14 * e;
+    double cr[2] = {carry[2 * e], carry[2 * e + 1]};
+    int32_t ne = n[e];
+    uint8_t oke = ok[e];
+    bool good = false, cut = false;
+    std::vector<double> last(14);
+    int first = 0; // a continuation's row 0 repeats the state it started from
+    for (;;) {
+      const int have = ne > max_states ? max_states : ne;
+      for (int k = first; k < have && !cut; ++k) {
+        const double *row = st + (size_t)k * 14;
+        if (!interpolate && !(list.empty() && k == 0) && !valid(row)) {
+          // the reference's loop breaks here, before `dist` is updated: the answer is about the last accepted state
+          double d = 0;
+          for (int i = 0; i < 14; ++i) { const double df = last[i] - to_e[i]; d += df * df; }
+          good = std::sqrt(d) <= pb.delta;
+          cut = true;
+          break;
+        }
+        last.assign(row, row + 14);
+        list.emplace_back(row, row + 14);
       }
-      if (geodesics)
-        for (int k = 0; k < keep; ++k) list.emplace_back(st + (size_t)k * 14, st + (size_t)k * 14 + 14);
+      if (cut) break;
+      if (ne <= max_states) { good = oke != 0; break; }
+      // ne == max_states + 1: the list was full and the traversal stopped there — go on from its last state
+      double cr_out[2];
+      {
+        std::lock_guard<std::mutex> hold(proj.mutex());
+        check(ccmp_geodesic_host_ex(proj.ctx(), &pb, last.data(), to_e, 1, max_states, more.data(), &ne, &oke, cr, cr_out, 0),
+              "ccmp_geodesic_host_ex(continue)");
+      }
+      cr[0] = cr_out[0];
+      cr[1] = cr_out[1];
+      st = more.data();
+      first = 1;
     }
     if (reached) (*reached)[e] = good ? 1 : 0;
     if (geodesics) (*geodesics)[e] = std::move(list);
   }
+}
+
+// one edge
+template <class ValidFn>
+inline bool discreteGeodesic(const Projector &proj, const double *from14, const double *to14, bool interpolate, ValidFn valid,
+                             std::vector<std::vector<double>> *geodesic, int max_states = 64, bool check_target = false,
+                             double delta = -1.0, double lambda = -1.0)
+{
+  std::vector<std::vector<std::vector<double>>> lists;
+  std::vector<char> reached;
+  discreteGeodesicBatch(proj, from14, to14, 1, interpolate, valid, geodesic ? &lists : nullptr, &reached, max_states, check_target, delta,
+                        lambda);
+  if (geodesic) *geodesic = std::move(lists[0]);
+  return reached[0] != 0;
 }
 
 // One planner process, several GPUs (the reference's shape: src/main.cpp is one process): one context per device and an
@@ -673,8 +674,6 @@ public:
       for (int i = 0; i < 14; ++i) { a[14 * e + i] = fa[i]; b[14 * e + i] = tb[i]; }
     }
     ccmp::Projector &proj = chain_->impl();
-    proj.problem().delta = delta_;
-    proj.problem().lambda = lambda_;
     auto &&svc = si_->getStateValidityChecker();
     std::vector<std::vector<std::vector<double>>> lists;
     ompl::base::State *scratch = allocState();
@@ -684,7 +683,7 @@ public:
                                   for (int i = 0; i < 14; ++i) x[i] = q[i];
                                   return svc->isValid(scratch);
                                 },
-                                geodesics ? &lists : nullptr, reached);
+                                geodesics ? &lists : nullptr, reached, 64, false, delta_, lambda_); // setDelta / setLambda of the base class
     freeState(scratch);
     if (geodesics) {
       geodesics->assign(E, {});
@@ -707,8 +706,6 @@ private:
     const auto &tb = *to->as<StateType>();
     for (int i = 0; i < 14; ++i) { a[i] = fa[i]; b[i] = tb[i]; }
     ccmp::Projector &proj = chain_->impl();
-    proj.problem().delta = delta_;   // setDelta / setLambda of the base class stay the source of truth
-    proj.problem().lambda = lambda_;
     auto &&svc = si_->getStateValidityChecker();
     std::vector<std::vector<double>> states;
     ompl::base::State *scratch = allocState();
@@ -718,7 +715,8 @@ private:
                                              for (int i = 0; i < 14; ++i) x[i] = q[i];
                                              return svc->isValid(scratch);
                                            },
-                                           geodesic ? &states : nullptr, 64, check_target);
+                                           geodesic ? &states : nullptr, 64, check_target, delta_,
+                                           lambda_);  // setDelta / setLambda of the base class stay the source of truth
     freeState(scratch);
     if (geodesic) {
       geodesic->clear();

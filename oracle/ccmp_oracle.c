@@ -679,24 +679,31 @@ int orc_sample_uniform(const orc_problem *P, uint64_t seed, uint64_t index, doub
   return ok;
 }
 
-/* ---- jy_ProjectedStateSpace::discreteGeodesic, jy_ProjectedStateSpace.cpp:32-96 -------------- */
-int orc_discrete_geodesic(const orc_problem *P, const double from[14], const double to[14],
-                          int interpolate, orc_valid_fn valid, void *user, double *out,
-                          int max_states, int *n_states, int64_t *newton_iters)
+/* ---- jy_ProjectedStateSpace::discreteGeodesic, jy_ProjectedStateSpace.cpp:32-96 --------------
+ * carry_in / carry_out (nullable) are this project's resumable form (include/ccmp.h: ccmp_geodesic_batch_ex): an edge
+ * whose list is full stops, and a continuation re-enters the reference's do-while from the last stored state with the
+ * running length it had before the step that did not fit and the bound lambda * dist(from, to) of the first call. */
+int orc_discrete_geodesic_ex(const orc_problem *P, const double from[14], const double to[14],
+                             int interpolate, orc_valid_fn valid, void *user, double *out,
+                             int max_states, int *n_states, int64_t *newton_iters, const double carry_in[2],
+                             double carry_out[2])
 {
   /* when an accepted state finds the list full the traversal stops and reports max_states + 1 states (and false):
-   * the caller re-runs the edge with a larger buffer — a creeping edge must not run on unbounded */
+   * the caller continues the edge (or re-runs it with a larger buffer) — a creeping edge must not run on unbounded */
   int n = 1;
   int64_t its = 0;
   if (out && max_states > 0) memcpy(out, from, 14 * sizeof(double));
   const double tolerance = P->delta;
   double dist, step = 0, total = 0;
-  if ((dist = orc_distance(from, to)) <= tolerance) {
+  dist = orc_distance(from, to);
+  double max = dist * P->lambda;
+  if (carry_in) { total = carry_in[0]; max = carry_in[1]; }
+  if (carry_out) { carry_out[0] = total; carry_out[1] = max; }
+  if (carry_in ? !(dist >= tolerance) : dist <= tolerance) {
     if (n_states) *n_states = n;
     if (newton_iters) *newton_iters = 0;
-    return 1;
+    return dist <= tolerance;
   }
-  const double max = dist * P->lambda;
   double previous[14], scratch[14];
   memcpy(previous, from, sizeof previous);
   do {
@@ -707,13 +714,15 @@ int orc_discrete_geodesic(const orc_problem *P, const double from[14], const dou
     if (!proj || !(interpolate || !valid || valid(scratch, user)) ||
         (step = orc_distance(previous, scratch)) > P->lambda * P->delta)
       break;
+    const double total_before = total;
     total += step;
     if (total > max) break;
     const double newDist = orc_distance(scratch, to);
     if (newDist >= dist) break;
     if (out && n >= max_states) {
       if (n_states) *n_states = max_states + 1;
-      if (newton_iters) *newton_iters = its;
+      if (newton_iters) *newton_iters = its - it; /* the state that did not fit is projected again by the continuation */
+      if (carry_out) { carry_out[0] = total_before; carry_out[1] = max; }
       return 0;
     }
     dist = newDist;
@@ -723,7 +732,15 @@ int orc_discrete_geodesic(const orc_problem *P, const double from[14], const dou
   } while (dist >= tolerance);
   if (n_states) *n_states = n;
   if (newton_iters) *newton_iters = its;
+  if (carry_out) { carry_out[0] = total; carry_out[1] = max; }
   return dist <= tolerance;
+}
+
+int orc_discrete_geodesic(const orc_problem *P, const double from[14], const double to[14],
+                          int interpolate, orc_valid_fn valid, void *user, double *out,
+                          int max_states, int *n_states, int64_t *newton_iters)
+{
+  return orc_discrete_geodesic_ex(P, from, to, interpolate, valid, user, out, max_states, n_states, newton_iters, NULL, NULL);
 }
 
 /* IKTask::compute_t_wo, ik_task.cpp:10-14: t_wb * FK(q_left) * t_o7.inverse() for panda_left

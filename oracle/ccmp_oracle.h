@@ -149,6 +149,11 @@ typedef int (*orc_valid_fn)(const double q[14], void *user);
 int orc_discrete_geodesic(const orc_problem *P, const double from[14], const double to[14],
                           int interpolate, orc_valid_fn valid, void *user, double *out,
                           int max_states, int *n_states, int64_t *newton_iters);
+/* resumable form (include/ccmp.h: ccmp_geodesic_batch_ex): carry = {running length, lambda * dist(from, to)} */
+int orc_discrete_geodesic_ex(const orc_problem *P, const double from[14], const double to[14],
+                             int interpolate, orc_valid_fn valid, void *user, double *out,
+                             int max_states, int *n_states, int64_t *newton_iters, const double carry_in[2],
+                             double carry_out[2]);
 void orc_compute_t_wo(const orc_problem *P, const double q_left[7], double R[9], double p[3]);
 
 /* --- proxy-geometry clearance (the product's pre-filter in front of the MoveIt validity test; include/ccmp.h) ----------

@@ -7,6 +7,23 @@
 #include <cstdlib>
 #include <cstring>
 
+// exactly what INTEGRATION.md §2's replacement ConstraintFunction.h consists of: the original header's includes
+// (include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:3-17), its `using namespace std;` (:20),
+// then the adapter in place of the class body
+#include <iostream>
+#include <vector>
+#include <string>
+#include <fstream>
+#include <memory>
+
+#include <ompl/base/Constraint.h>
+#include <ompl/base/ConstrainedSpaceInformation.h>
+#include <ompl/base/spaces/constraint/ConstrainedStateSpace.h>
+#include <ompl/base/spaces/constraint/ProjectedStateSpace.h>
+
+#include <closed_chain_motion_planner/kinematics/panda_rbdl.h>
+
+using namespace std;
 #define CCMP_WITH_OMPL
 #include "ccmp_ompl_adapter.hpp"
 
@@ -167,6 +184,38 @@ int main(int argc, char **argv)
       const bool v = pre.isValid(a);
       std::printf("prefilter radius %.2f valid %d exact_calls %d rejected %llu\n", radius, v ? 1 : 0, exact->calls_,
                   (unsigned long long)pre.rejectedByProxies());
+    }
+    // the reference's configuration, in its order (ConstrainedProblem::setConstrainedOptions,
+    // src/base/constraints/ConstrainedPlanningCommon.cpp:116-131): setArmModels -> setInitialPosition -> setTolerance ->
+    // setMaxIterations(c_opt.tries = 1000) on the constraint, then setDelta / setLambda on the space — written the way an
+    // includer of the original header writes it (unqualified shared_ptr / make_shared through `using namespace std;`)
+    {
+      struct { double delta = 0.25, lambda = 2.0, tolerance1 = 0.001, tolerance2 = 0.005; int tries = 1000; } c_opt;
+      shared_ptr<KinematicChainConstraint> constraint2 = make_shared<KinematicChainConstraint>(14);
+      auto css = make_shared<jy_ProjectedStateSpace>(ambient, constraint2);
+      constraint2->setArmModels(arm1, arm2);
+      constraint2->setInitialPosition(start);
+      constraint2->setTolerance(c_opt.tolerance1, c_opt.tolerance2);
+      constraint2->setMaxIterations(c_opt.tries);
+      css->setDelta(c_opt.delta);
+      css->setLambda(c_opt.lambda);
+      // setMaxIterations reaches OMPL's base-class field only; project() keeps the cap of ConstraintFunction.h:26,68
+      std::printf("replay cap %d delta %.2f lambda %.1f tol %.3g %.3g\n", (int)constraint2->impl().problem().max_iter, css->getDelta(),
+                  css->getLambda(), constraint2->impl().problem().tol_pos, constraint2->impl().problem().tol_rot);
+      ob::State *c2 = css->allocState();
+      auto &xc = *c2->as<ob::ConstrainedStateSpace::StateType>();
+      for (int i = 0; i < 14; i++) xc[i] = start[i] + 0.05 * ((i % 3) - 1);
+      const bool okc = constraint2->project(c2);
+      std::printf("replay project %d\n", okc ? 1 : 0);
+      print_hex("xc", xc.values, 14);
+      css->freeState(c2);
+    }
+    // jy_ProjectedStateSampler's two-argument constructor (jy_ProjectedStateSpace.h:21), as user code may call it directly:
+    // the third sampler of `space`, with its own stream
+    {
+      jy_ProjectedStateSampler direct(space.get(), ambient->allocDefaultStateSampler());
+      direct.sampleUniform(b);
+      print_hex("uniform3", xb.values, 14);
     }
     space->freeState(a);
     space->freeState(b);

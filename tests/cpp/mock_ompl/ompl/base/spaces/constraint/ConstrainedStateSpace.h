@@ -59,6 +59,8 @@ public:
   void setSpaceInformation(SpaceInformation *si) { si_ = si; }
   void setDelta(double d) { delta_ = d; }
   void setLambda(double l) { lambda_ = l; }
+  double getDelta() const { return delta_; }
+  double getLambda() const { return lambda_; }
   void enforceBounds(State *state) const override { space_->enforceBounds(state); }
   State *allocState() const override { return new StateType(); }
   virtual bool discreteGeodesic(const State *from, const State *to, bool interpolate = false, std::vector<State *> *geodesic = nullptr) const = 0;

@@ -118,6 +118,9 @@ class Oracle:
         lib.orc_discrete_geodesic.argtypes = [pp, dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, C.c_int,
                                               C.POINTER(C.c_int), C.POINTER(C.c_int64)]
         lib.orc_discrete_geodesic.restype = C.c_int
+        lib.orc_discrete_geodesic_ex.argtypes = [pp, dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, C.c_int,
+                                                 C.POINTER(C.c_int), C.POINTER(C.c_int64), dp, dp]
+        lib.orc_discrete_geodesic_ex.restype = C.c_int
         lib.orc_compute_t_wo.argtypes = [pp, dp, dp, dp]
         lib.orc_function_batch.argtypes = [pp, dp, dp, C.c_size_t, C.c_int]
         lib.orc_project_batch.argtypes = [pp, dp, dp, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_size_t, C.c_int]
@@ -264,6 +267,17 @@ class Oracle:
         if n.value > max_states:  # the list did not fit (max_states + 1): run the edge again with room
             return self.discrete_geodesic(P, a, b, interpolate, max_states=4 * max_states)
         return bool(ok), out[: n.value].copy(), its.value
+
+    def discrete_geodesic_ex(self, P, a, b, max_states, carry_in=None):
+        """one bounded call of the resumable form: (ok, states (min(n, max_states),14), n, its, carry (2,))"""
+        a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.zeros((max_states, 14))
+        n = C.c_int(0); its = C.c_int64(0)
+        cin = None if carry_in is None else np.ascontiguousarray(carry_in, dtype=np.float64)
+        cout = np.zeros(2)
+        ok = self.lib.orc_discrete_geodesic_ex(C.byref(P), _dptr(a), _dptr(b), 1, None, None, _dptr(out), max_states,
+                                               C.byref(n), C.byref(its), _dptr(cin) if cin is not None else None, _dptr(cout))
+        return bool(ok), out[: min(n.value, max_states)].copy(), n.value, its.value, cout
 
     def compute_t_wo(self, P, q7):
         q = np.ascontiguousarray(q7, dtype=np.float64)

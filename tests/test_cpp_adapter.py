@@ -218,3 +218,10 @@ def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
         free = clr > 0.0
         assert line == "prefilter radius %.2f valid %d exact_calls %d rejected %d" % (radius, int(free), int(free), int(not free))
     assert out[k + 2].split()[4] == "0" and out[k + 3].split()[4] == "1"
+    # the reference's configuration call order on a second constraint: same problem, cap still 250, same projection
+    assert out[k + 4] == "replay cap 250 delta 0.25 lambda 2.0 tol 0.001 0.005"
+    assert out[k + 5] == "replay project %d" % int(ok_a)
+    assert np.array_equal(_hex_row(out[k + 6], "xc").view(np.uint64), xa.view(np.uint64))
+    # the sampler's two-argument constructor: third sampler of the space, its own stream
+    exp3, _, _ = oracle_det.sample_project_batch(P, splitmix64(space_seed + 2), 0, 1, 1)
+    assert np.array_equal(_hex_row(out[k + 7], "uniform3").view(np.uint64), exp3[0].view(np.uint64))

@@ -352,3 +352,71 @@ def test_check_motion_and_geodesic_interpolate(gpu_ctx, oracle_det):
     acc = np.concatenate([[0], np.cumsum(d)])
     i = int(np.searchsorted(acc, 0.5 * d.sum()) - 1)
     assert abs(np.linalg.norm(mid - st[i]) + acc[i] - 0.5 * d.sum()) < 1e-12
+
+
+def test_geodesic_continuation_is_the_uninterrupted_traversal(gpu_ctx, oracle_det):
+    """ccmp_geodesic_batch_ex: lists of 3 states, every edge that did not fit continued from its last stored state until it
+    is whole — states, flag and Newton count of the oracle's uninterrupted traversal, bit for bit (the host mirror and the
+    C++ adapter finish long or creeping edges this way instead of running them again with more room)"""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    frm, to = _edges(oracle_det, P, 40, 0x6E7)
+    rows = load_path_rows("Wine_Bottle")
+    frm[0], to[0] = rows[14], rows[21]
+    frm[1], to[1] = rows[2], rows[2] + 0.01
+    cap = 3
+    f, t = torch.as_tensor(frm).cuda(), torch.as_tensor(to).cuda()
+    st, n, ok, its, carry = c.discrete_geodesic_batch(f, t, cap, want_carry=True)
+    whole = c.continue_geodesics(t, st, n, ok, its, carry, cap)
+    st, n, ok, its = st.cpu().numpy(), n.cpu().numpy(), ok.cpu().numpy(), its.cpu().numpy()
+    assert len(whole) >= 20 and set(whole) == set(np.nonzero(n > cap)[0].tolist())
+    for e in range(len(frm)):
+        ok_cpu, st_cpu, its_cpu = oracle_det.discrete_geodesic(P, frm[e], to[e], interpolate=True, max_states=512)
+        if e in whole:
+            got, ok_e, its_e = whole[e]
+        else:
+            got, ok_e, its_e = st[e, : n[e]], int(ok[e]), int(its[e])
+        assert got.shape == st_cpu.shape and np.array_equal(np.ascontiguousarray(got).view(np.uint64), st_cpu.view(np.uint64)), e
+        assert bool(ok_e) == ok_cpu and its_e == its_cpu, e
+    with pytest.raises(Exception):  # a continuation's target was tested by the call it continues
+        c.discrete_geodesic_batch(f, t, cap, check_target=True, carry_in=carry)
+
+
+def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):
+    """more edges than resident blocks (8 per CU): persistent blocks + ticket queue, with and without the long-edges-first
+    order — the same bits as the one-block-per-edge launches of the same edges, and as the oracle on a slice"""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    E = 8 * gpu_ctx.num_cus + 1500
+    q, ok, _, _ = c.sample_project_batch(0x6E9, 0, 8 * E, want_iters=False)
+    frm = q[ok == 1][:E].contiguous()
+    assert frm.shape[0] == E
+    to, _, _, _ = c.sample_near_project_batch(0x6EA, 0, frm, 0.6, E, want_iters=False)
+    cap = 12
+    ref = [torch.cat([c.discrete_geodesic_batch(frm[a:a + 1024].contiguous(), to[a:a + 1024].contiguous(), cap)[k] for a in range(0, E, 1024)])
+           for k in range(4)]
+    try:
+        for order, order_min, long_steps in ((0, 0, 12), (1, 0, 12), (1, 0, 3), (1, 0, 0), (1, 1 << 30, 12)):
+            gpu_ctx.set_option("geodesic_order", order)
+            gpu_ctx.set_option("geodesic_order_min", order_min)
+            gpu_ctx.set_option("geodesic_long_steps", long_steps)
+            got = c.discrete_geodesic_batch(frm, to, cap)
+            n = ref[1].clamp(max=cap)
+            assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3]), (order, long_steps)
+            live = torch.arange(cap, device=frm.device)[None, :] < n[:, None]
+            assert torch.equal(got[0][live], ref[0][live]), (order, long_steps)
+    finally:
+        gpu_ctx.set_option("geodesic_order", 1)
+        gpu_ctx.set_option("geodesic_order_min", 4096)
+        gpu_ctx.set_option("geodesic_long_steps", 12)
+    sl = slice(E - 192, E)
+    s_cpu, n_cpu, ok_cpu, it_cpu = oracle_det.discrete_geodesic_batch(P, frm[sl].cpu().numpy(), to[sl].cpu().numpy(), cap, NCPU)
+    assert np.array_equal(got[1][sl].cpu().numpy(), n_cpu) and np.array_equal(got[2][sl].cpu().numpy(), ok_cpu)
+    assert np.array_equal(got[3][sl].cpu().numpy(), it_cpu)
+    for k in range(192):
+        m = min(int(n_cpu[k]), cap)
+        assert np.array_equal(got[0][E - 192 + k, :m].cpu().numpy().view(np.uint64), s_cpu[k, :m].view(np.uint64))

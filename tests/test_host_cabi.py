@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(L, ccmp_built):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ccmp_version() == 210
+    assert L.ccmp_version() == 300
 
 
 def test_library_does_not_link_rccl(ccmp_built):

@@ -475,3 +475,31 @@ def test_geodesic_reports_a_list_that_does_not_fit(oracle_det):
     assert n[0] == 7 and bool(ok[0]) == full_ok and np.array_equal(st[0], full)
     ok2, st2, _ = oracle_det.discrete_geodesic(P, rows[14], rows[21], interpolate=True, max_states=2)  # binding re-runs
     assert ok2 == full_ok and np.array_equal(st2, full)
+
+
+def test_a_continued_geodesic_is_the_uninterrupted_one(oracle_det):
+    """the resumable form (ccmp_geodesic_batch_ex / orc_discrete_geodesic_ex): a traversal cut into lists of 2, 3 or 5
+    states and continued from each list's last state gives the states, flag and Newton count of the uninterrupted
+    traversal, bit for bit — on every recorded segment and on every directed edge of the dumped Wine_Bottle roadmap"""
+    from conftest import load_roadmap
+
+    cfg = load_cfg("Wine_Bottle")
+    P = oracle_det.problem(cfg)
+    rows = load_path_rows("Wine_Bottle")
+    nodes, edges = load_roadmap("Wine_Bottle")
+    pairs = [(rows[a], rows[b]) for a, b in RECORDED_SEGMENTS["Wine_Bottle"][1]] + [(nodes[a], nodes[b]) for a, b in edges]
+    cuts = 0
+    for frm, to in pairs:
+        full_ok, full, full_its = oracle_det.discrete_geodesic(P, frm, to, interpolate=True)
+        for cap in (2, 3, 5):
+            ok, st, n, its, carry = oracle_det.discrete_geodesic_ex(P, frm, to, cap)
+            parts, total_its = [st], its
+            while n > cap:
+                cuts += 1
+                ok, st, n, its, carry = oracle_det.discrete_geodesic_ex(P, parts[-1][-1], to, cap, carry_in=carry)
+                parts.append(st[1:])
+                total_its += its
+            got = np.concatenate(parts, axis=0)
+            assert got.shape == full.shape and np.array_equal(got.view(np.uint64), full.view(np.uint64))
+            assert ok == full_ok and total_its == full_its
+    assert cuts > 50
