@@ -79,24 +79,42 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", CCMP_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    rc = 0
+    # rank 0's line is collected by a reader thread; the parent polls EVERY child: the first rank that dies (build, device
+    # initialisation, rendezvous) takes the others down with it instead of leaving them in a collective until torch's
+    # own timeout, and the whole job has a deadline
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("CCMP_BENCH_TIMEOUT", "2400"))
+    rc, why = 0, ""
     try:
-        out0, _ = procs[0].communicate()
-        for p in procs:
-            rc = rc or p.wait()
-    except BaseException:
-        for p in procs:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc, why = (bad[0][1] if bad[0][1] > 0 else 1), "rank %d exited with code %d" % bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                rc, why = 124, "deadline (CCMP_BENCH_TIMEOUT) passed"
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # only the children started above, by handle
             if p.poll() is None:
                 p.kill()
-        raise
-    if rc != 0:
         for p in procs:
-            if p.poll() is None:
-                p.kill()
-        sys.stdout.write(out0 or "")
-        sys.exit(rc if rc > 0 else 1)
-    sys.stdout.write(out0)
+            p.wait()
+    reader.join(timeout=10)
+    text = out0[0] if out0 else ""
+    sys.stdout.write(text or "")
     sys.stdout.flush()
+    if rc != 0:
+        print("bench.py: %s; the other ranks were stopped" % why, file=sys.stderr)
+        sys.exit(rc)
 
 
 # ---- host cores -----------------------------------------------------------------------------------------------------------
@@ -160,7 +178,7 @@ def cpu_baseline(obj, seed, gpu_check=None):
         cores, how = max(1, cores // 2), "scaling probe (detected count did not scale)"
     sample = int(max(1024, min(131072, per_core * cores * 15.0)))  # ~15 s of CPU work
     q = O.ambient_uniform_batch(P, seed, 0, sample)
-    value, (_, ok, it) = rate(q, cores)
+    value, (q_libm, ok, it) = rate(q, cores)
     # the same algorithm with the analytic Jacobian on the CPU (fair algorithmic comparison for the fast mode)
     Pa = O.problem(cfg)
     Pa.jacobian_mode = 1
@@ -168,9 +186,22 @@ def cpu_baseline(obj, seed, gpu_check=None):
     O.project_batch(Pa, q, cores)
     wall_a = time.perf_counter() - t0
     # in-run parity evidence: the det build of the oracle vs the GPU on the first 2048 samples of the batch
-    parity = None
+    parity, vs_libm = None, None
     if gpu_check is not None:
-        parity = det_parity(gpu_check["problem_bytes"], gpu_check["q_in"], gpu_check["q_out"], gpu_check["ok"], gpu_check["iters"], cores)
+        m = 2048
+        parity = det_parity(gpu_check["problem_bytes"], gpu_check["q_in"][:m], gpu_check["q_out"][:m], gpu_check["ok"][:m],
+                            gpu_check["iters"][:m], cores)
+        # how far the GPU's results are from what the reference's libm gives — the glibc build timed
+        # above, on the same leading samples of the batch.  (The GPU is bit-identical to the det build; this is the
+        # distance between the two rounding models through ~33 Newton iterations)
+        import numpy as np
+
+        m = min(sample, len(gpu_check["q_out"]))
+        d = np.abs(q_libm[:m] - gpu_check["q_out"][:m]).max(axis=1)
+        di = it[:m].astype(np.int64) - gpu_check["iters"][:m].astype(np.int64)
+        vs_libm = {"samples": int(m), "max_abs_dq": float(d.max()), "median_abs_dq": float(np.median(d)), "n_gt_1e-6": int((d > 1e-6).sum()),
+                   "iteration_flips_pm1": int((np.abs(di) == 1).sum()), "iteration_diffs_gt1": int((np.abs(di) > 1).sum()),
+                   "ok_mismatches": int((ok[:m] != gpu_check["ok"][:m]).sum())}
     return {
         "value": value, "unit": "projections/s", "cores": cores, "kind": "port",
         "sample": "first %d samples of the bench batch, FD-faithful C oracle (glibc libm, -O2), %d threads taking samples "
@@ -178,6 +209,7 @@ def cpu_baseline(obj, seed, gpu_check=None):
         "cores_reported_by_os": reported, "cores_found_by": how, "scaling_probes": probes,
         "single_thread_value": per_core, "parallel_efficiency": value / (cores * per_core),
         "analytic_jacobian_value": sample / wall_a, "mean_iters": float(it.mean()), "parity_gpu_vs_det_oracle": parity,
+        "parity_gpu_vs_libm_oracle": vs_libm,
     }
 
 
@@ -195,6 +227,26 @@ def det_parity(problem_bytes, q_in, q_out, ok, iters, threads):
     return {"samples": len(q_in), "max_abs_dq": float(d.max()), "n_gt_1e-6": int((d > 1e-6).sum()),
             "bit_identical": bool(np.array_equal(qd.view(np.uint64), q_out.view(np.uint64))),
             "ok_mismatches": int((okd != ok).sum()), "iteration_mismatches": int((itd != iters).sum())}
+
+
+def gather_probe(c, vg, rank, world, torch, dist, n=4096, seed=0xC5):
+    """single-GPU and G-GPU outputs must be bit-identical.  After the timed region every rank projects
+    its contiguous shard of an n-sample probe (sampler on the GLOBAL index), the shards' valid states are all-gathered
+    through the bench's own blocks, and rank 0 compares them — count for count, bit for bit — with the compacted valid
+    states of the whole probe projected by itself alone."""
+    from closed_chain_motion_planner_amd.distributed import shard_range
+
+    lo, hi = shard_range(n, rank, world)
+    q, ok, _, _ = c.sample_project_batch(seed, lo, hi - lo, want_iters=False)
+    c.compact_valid(q, ok, out=vg.rows, cnt=vg.count)
+    vg.launch()
+    states, counts = vg.unpack()
+    res = {"samples": n, "valid_states": int(sum(counts)), "valid_per_rank": [int(v) for v in counts]}
+    if rank == 0:
+        qa, oka, _, _ = c.sample_project_batch(seed, 0, n, want_iters=False)
+        alone = qa[oka == 1]
+        res["bit_identical_to_one_gpu"] = bool(alone.shape == states.shape and torch.equal(alone.view(torch.int64), states.view(torch.int64)))
+    return res
 
 
 def main():
@@ -305,13 +357,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ok, it = step(True)
+    e_done = torch.cuda.Event(enable_timing=True)
     if vg is not None:
         vg.wait()  # every step's all-gather belongs to the timed region
+    e_done.record()  # behind the last collective on this stream: when the gathered states are there
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -324,8 +379,21 @@ def main():
     if vg is not None:
         counts = vg.counts()  # after the timed region: what the host tree would read when it consumes the states
         n_valid = counts[rank]
+        # what a first multi-GPU run is diagnosed by: every rank's own kernel time and wall clock, and how long the last
+        # step's collective ran past the last projector kernel (one small all-gather, after the timed region)
+        mine = torch.tensor([kms, local_elapsed * 1e3 / args.steps, kernel_ms[-1][1].elapsed_time(e_done)], dtype=torch.float64, device="cuda")
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank = torch.stack(per_rank).cpu()
         gathered = {"valid_states_all_ranks": int(sum(counts)), "capacity_rows_per_rank": vg.capacity,
-                    "overflow": bool(max(counts) > vg.capacity), "bytes_sent_per_rank": int((vg.capacity + 1) * 14 * 8)}
+                    "overflow": bool(max(counts) > vg.capacity), "bytes_sent_per_rank": int((vg.capacity + 1) * 14 * 8),
+                    "bytes_received_per_rank": int(world * (vg.capacity + 1) * 14 * 8),
+                    "kernel_ms_per_rank": [float(v) for v in per_rank[:, 0]],
+                    "kernel_ms_min": float(per_rank[:, 0].min()), "kernel_ms_max": float(per_rank[:, 0].max()),
+                    "step_ms_per_rank": [float(v) for v in per_rank[:, 1]],
+                    "last_kernel_to_gather_done_ms_per_rank": [float(v) for v in per_rank[:, 2]],
+                    "last_kernel_to_gather_done_ms_max": float(per_rank[:, 2].max()),
+                    "probe": gather_probe(c, vg, rank, world, torch, dist)}
     else:
         n_valid = int(cnt.item())
     rccl_ranks = dist.get_world_size() if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)
@@ -393,8 +461,9 @@ def main():
         try:
             gpu_check = None
             if args.mode == "fd" and not args.tol:
-                gpu_check = {"problem_bytes": bytes(c.problem), "q_in": q_in[:2048].cpu().numpy(), "q_out": q_out[:2048].cpu().numpy(),
-                             "ok": ok[:2048].cpu().numpy(), "iters": it[:2048].cpu().numpy().astype("int32")}
+                m = min(B, 131072)  # the CPU leg's sample is at most this long
+                gpu_check = {"problem_bytes": bytes(c.problem), "q_in": q_in[:m].cpu().numpy(), "q_out": q_out[:m].cpu().numpy(),
+                             "ok": ok[:m].cpu().numpy(), "iters": it[:m].cpu().numpy().astype("int32")}
             line["cpu_baseline"] = cpu_baseline(args.obj, seed, gpu_check)
         except Exception as e:  # the oracle is a checker; its absence must not fail the GPU bench
             line["cpu_baseline"] = {"error": repr(e)}
@@ -452,18 +521,47 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts[4:]) * 1e6)
 
-    def geodesic(n_edges=16384):
+    def geodesic(n_edges=16384, first_pass=16):
         # growTree-shaped edges (src/planner/stefanBiPRM.cpp:307-351: a milestone towards a near neighbour): from a valid
-        # projected state to a projected sampleUniformNear state within 0.6 rad per joint (about 1.3 rad apart, ~5 states
-        # per edge like the reference's recorded roadmap edges)
+        # projected state to a projected sampleUniformNear state within 0.6 rad per joint (about 1.0 rad apart, ~4 states
+        # per edge like the reference's recorded roadmap edges).  What is timed: the call with lists of
+        # `first_pass` states — `edges_per_s` counts only the edges that are COMPLETE after it, `overflowed_edges` says how
+        # many were not — and the whole operation (`complete_*`): the same call plus the continuation of every edge that
+        # did not fit, from its last stored state, until each list is whole (one edge in 16384 creeps for 952 states:
+        # a serial chain of ~11 000 Newton rounds that the reference pays as well).
         c.setJacobianMode(CCMP_JAC_FD)
         q, ok, _, _ = c.sample_project_batch(0x6E0, 0, 8 * n_edges, want_iters=False)
         frm = q[ok == 1][:n_edges].contiguous()
         to, _, _, _ = c.sample_near_project_batch(0x6E1, 0, frm, 0.6, n_edges, want_iters=False)
-        sec = timed(lambda: c.discrete_geodesic_batch(frm, to, 64), 3)
-        st, n, gok, its = c.discrete_geodesic_batch(frm, to, 64)
-        res = {"edges_per_s": n_edges / sec, "ms": sec * 1e3, "edges": n_edges, "mean_states_per_edge": float(n.to(torch.float64).mean().item()),
-               "mean_newton_iters_per_edge": float(its.to(torch.float64).mean().item()), "reached_fraction": float(gok.to(torch.float64).mean().item())}
+        sec = timed(lambda: c.discrete_geodesic_batch(frm, to, first_pass), 5)
+        sec64 = timed(lambda: c.discrete_geodesic_batch(frm, to, 64), 3)
+        st, n, gok, its, carry = c.discrete_geodesic_batch(frm, to, first_pass, want_carry=True)
+        over = int((n > first_pass).sum().item())
+
+        def complete():
+            r = c.discrete_geodesic_batch(frm, to, first_pass, want_carry=True)
+            return r, c.continue_geodesics(to, r[0], r[1], r[2], r[3], r[4], first_pass)
+
+        complete()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, whole = complete()
+        torch.cuda.synchronize()
+        sec_all = time.perf_counter() - t0
+        nn = n.clone()
+        for e, (st_e, _, _) in whole.items():
+            nn[e] = st_e.shape[0]
+        # the planner's neighbour loop: five edges in one call (lists of 64 states, as the adapter asks for)
+        f5, t5 = frm[:5].contiguous(), to[:5].contiguous()
+        sec5 = timed(lambda: c.discrete_geodesic_batch(f5, t5, 64), 20)
+        res = {"edges_per_s": (n_edges - over) / sec, "ms": sec * 1e3, "edges": n_edges, "max_states_first_pass": first_pass,
+               "overflowed_edges": over, "complete_ms": sec_all * 1e3, "complete_edges_per_s": n_edges / sec_all,
+               "longest_edge_states": int(nn.max().item()), "ms_lists_of_64": sec64 * 1e3,
+               "edges_per_s_lists_of_64": (n_edges - int((nn > 64).sum().item())) / sec64,
+               "growtree_5_edges_ms": sec5 * 1e3,
+               "mean_states_per_edge": float(nn.to(torch.float64).mean().item()),
+               "mean_newton_iters_per_edge_first_pass": float(its.to(torch.float64).mean().item()),
+               "reached_fraction_first_pass": float(gok.to(torch.float64).mean().item())}
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle_binding import Oracle
@@ -471,12 +569,81 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             Od = Oracle("det")
             Pd = Od.problem_from_bytes(bytes(c.problem))
             m = 1024
-            sc, nc, okc, itc = Od.discrete_geodesic_batch(Pd, frm[:m].cpu().numpy(), to[:m].cpu().numpy(), 64, threads)
+            sc, nc, okc, itc = Od.discrete_geodesic_batch(Pd, frm[:m].cpu().numpy(), to[:m].cpu().numpy(), first_pass, threads)
             sg, ng = st[:m].cpu().numpy(), n[:m].cpu().numpy()
-            same = all(np.array_equal(sg[e, : min(ng[e], 64)].view(np.uint64), sc[e, : min(nc[e], 64)].view(np.uint64)) for e in range(m))
+            same = all(np.array_equal(sg[e, : min(ng[e], first_pass)].view(np.uint64), sc[e, : min(nc[e], first_pass)].view(np.uint64))
+                       for e in range(m))
             res["parity_vs_det_oracle"] = {"edges": m, "bit_identical": bool(same and np.array_equal(ng, nc)),
                                            "flag_mismatches": int((gok[:m].cpu().numpy() != okc).sum()),
                                            "iteration_mismatches": int((its[:m].cpu().numpy() != itc).sum())}
+            # a continued edge against the oracle's uninterrupted traversal (the longest one that is not the creeper)
+            cand = sorted(whole, key=lambda e: whole[e][0].shape[0])
+            cand = [e for e in cand if whole[e][0].shape[0] <= 256]
+            if cand:
+                e = cand[-1]
+                okf, stf, itf = Od.discrete_geodesic(Pd, frm[e].cpu().numpy(), to[e].cpu().numpy(), interpolate=True, max_states=512)
+                res["parity_vs_det_oracle"]["continued_edge"] = {
+                    "states": int(stf.shape[0]), "bit_identical": bool(stf.shape == whole[e][0].shape and np.array_equal(
+                        np.ascontiguousarray(whole[e][0]).view(np.uint64), stf.view(np.uint64)) and bool(whole[e][1]) == okf and whole[e][2] == itf)}
+        except Exception as e:
+            res["parity_vs_det_oracle"] = {"error": repr(e)}
+        return res
+
+    def host_buffer():
+        # SURVEY.md §8d "report both": the reference's entry is host memory (an Eigen::Ref over the OMPL state's values,
+        # src/base/jy_ProjectedStateSpace.cpp:10-15) — ccmp_project_host on the bench batch: upload, project, download.
+        # Never `value`.
+        import ctypes as C
+        from closed_chain_motion_planner_amd import _lib
+
+        c.setJacobianMode(main_mode)
+        L = _lib.lib()
+        qh = c.ambient_uniform_batch(SEEDS.get(B, 0xC3), 0, B).cpu()
+        res = {"samples": B}
+        for name, pin in (("pageable", False), ("pinned", True)):
+            mk = (lambda t: t.pin_memory()) if pin else (lambda t: t)
+            qi, qo = mk(qh.clone()), mk(torch.empty_like(qh))
+            okh, ith = mk(torch.empty(B, dtype=torch.uint8)), mk(torch.empty(B, dtype=torch.int16))
+            ts = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                rc = L.ccmp_project_host(ctx.handle, C.byref(c.problem), C.cast(qi.data_ptr(), C.POINTER(C.c_double)),
+                                         C.cast(qo.data_ptr(), C.POINTER(C.c_double)), C.cast(okh.data_ptr(), C.POINTER(C.c_uint8)),
+                                         C.cast(ith.data_ptr(), C.POINTER(C.c_uint16)), B)
+                ts.append(time.perf_counter() - t0)
+                if rc != 0:
+                    raise RuntimeError("ccmp_project_host: %d" % rc)
+            sec = float(np.median(ts[1:]))
+            res[name] = {"projections_per_s": B / sec, "ms": sec * 1e3}
+        return res
+
+    def c1_dumbbell(b=1024, seed=0xC1):
+        # BASELINE configs[0]: config/dumbbell.yaml on a single CPU thread (plumbing: YAML -> problem -> oracle), with the
+        # GPU beside it on the same 1024 samples, bit for bit against the det oracle
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import yaml
+        from oracle_binding import Oracle
+
+        db = KinematicChainConstraint.from_yaml(cfg_path("dumbbell"), ctx=ctx)
+        db.setJacobianMode(CCMP_JAC_FD)
+        Ol = Oracle("libm")
+        Pl = Ol.problem(yaml.safe_load(open(cfg_path("dumbbell"))))
+        qi = db.ambient_uniform_batch(seed, 0, b)
+        qn = qi.cpu().numpy()  # the CPU projects the very samples the GPU does
+        Ol.project_batch(Pl, qn[:32], 1)
+        t0 = time.perf_counter()
+        _, okl, itl = Ol.project_batch(Pl, qn, 1)
+        cpu_sec = time.perf_counter() - t0
+        qo = torch.empty_like(qi)
+        sec = timed(lambda: db.project_batch(qi, out=qo), 10)
+        _, okg, itg = db.project_batch(qi, out=qo)
+        res = {"samples": b, "cpu_single_thread_projections_per_s": b / cpu_sec, "cpu_threads": 1, "cpu_kind": "port (glibc build of the oracle)",
+               "cpu_mean_newton_iters": float(itl.mean()), "cpu_ok_fraction": float(okl.mean()),
+               "gpu_projections_per_s": b / sec, "gpu_ms": sec * 1e3, "same_ambient_samples_on_both_sides": True,
+               "gpu_ok_fraction": float(okg.to(torch.float64).mean().item())}
+        try:
+            res["parity_vs_det_oracle"] = det_parity(bytes(db.problem), qi.cpu().numpy(), qo.cpu().numpy(), okg.cpu().numpy(),
+                                                     itg.cpu().numpy().astype("int32"), threads)
         except Exception as e:
             res["parity_vs_det_oracle"] = {"error": repr(e)}
         return res
@@ -487,12 +654,13 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         from closed_chain_motion_planner_amd.scene import ProxyValidityChecker
 
         c.setJacobianMode(CCMP_JAC_FD)
-        sc = ProxyValidityChecker(c).scene
+        chk = ProxyValidityChecker(c)
+        sc = chk.scene
         q, ok, _, _ = c.sample_project_batch(0xC1EA, 0, B, want_iters=False)
-        sec = timed(lambda: sc.clearance_batch(q, 0.0, ok=ok, want_pair=True), 10)
-        clr, pair, free = sc.clearance_batch(q, 0.0, ok=ok)
+        sec = timed(lambda: sc.clearance_batch(q, chk.margin, ok=ok, want_pair=True), 10)
+        clr, pair, free = sc.clearance_batch(q, chk.margin, ok=ok)
         res = {"states_per_s": B / sec, "ms": sec * 1e3, "states": B, "spheres": len(sc.spheres), "boxes": len(sc.boxes),
-               "pairs_per_state": sc.num_pairs, "pair_tests_per_s": B * sc.num_pairs / sec,
+               "pairs_per_state": sc.num_pairs, "pair_tests_per_s": B * sc.num_pairs / sec, "reject_below_m": chk.margin,
                "kept_fraction_of_valid": float(free.to(torch.float64).sum().item() / max(1.0, ok.to(torch.float64).sum().item()))}
         xs = q[:3].cpu().numpy()
         ts = []
@@ -532,6 +700,11 @@ def secondary(args, c, ctx, B, torch, cfg_path):
     out["stefan_batch%d_tol_5e-4_2.5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True)
     out["discrete_geodesic"] = geodesic()
     out["proxy_clearance"] = proxy_clearance()
+    for name, fn in (("host_buffer", host_buffer), ("c1_dumbbell", c1_dumbbell)):
+        try:
+            out[name] = fn()
+        except Exception as e:  # secondaries must not take the headline line down
+            out[name] = {"error": repr(e)}
     c.setJacobianMode(main_mode)
     return out
 

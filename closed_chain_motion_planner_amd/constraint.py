@@ -88,6 +88,13 @@ class Communicator:
     def handle(self):
         return self._h
 
+    def last_timing(self):
+        """(kernel_ms, gather_ms) per GPU of the last sharded call, on each GPU's own stream (ccmp_comm_last_timing)"""
+        n = len(self.contexts)
+        k, g = (C.c_double * n)(), (C.c_double * n)()
+        check(_lib.lib().ccmp_comm_last_timing(self._h, k, g), "ccmp_comm_last_timing")
+        return list(k), list(g)
+
     def close(self):
         if self._h:
             _lib.lib().ccmp_comm_destroy(self._h)

@@ -77,6 +77,9 @@ hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambd
                                 const double *carry_in, double *carry_out, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
+hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
+                                            int max_states, int round_cap, uint16_t *pred, unsigned int *hist, unsigned int *order,
+                                            hipStream_t st);
 hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st);
 hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, size_t capacity,
                                unsigned int *block_counts, unsigned long long *total, hipStream_t st);
@@ -312,9 +315,15 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "clearance_per_state_max")) { // proxy clearance: one block per state up to this many states
     if (value < 0) return CCMP_EINVAL;
     ctx->clearance_per_state_max = (size_t)value;
-  } else if (!strcmp(name, "geodesic_order")) { // extend step: long edges first when a batch exceeds the resident blocks (0/1)
-    if (value != 0 && value != 1) return CCMP_EINVAL;
+  } else if (!strcmp(name, "geodesic_order")) { // extend step, batches beyond the resident blocks: 0 = index order, 1 = far-apart
+    if (value < 0 || value > 2) return CCMP_EINVAL; // edges first, 2 = FP32 scout + longest-predicted-first (falls back to 1 below geodesic_scout_min)
     ctx->geodesic_order = (int)value;
+  } else if (!strcmp(name, "geodesic_scout_min")) {
+    if (value < 0) return CCMP_EINVAL;
+    ctx->geodesic_scout_min = (size_t)value;
+  } else if (!strcmp(name, "geodesic_scout_rounds")) { // the scout stops an edge after this many Newton rounds ("long")
+    if (value < 1 || value > 1023) return CCMP_EINVAL;
+    ctx->geodesic_scout_rounds = (int)value;
   } else if (!strcmp(name, "geodesic_order_min")) { // ... from this many edges on
     if (value < 0) return CCMP_EINVAL;
     ctx->geodesic_order_min = (size_t)value;
@@ -623,8 +632,17 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     if (ctx->geodesic_order && E >= ctx->geodesic_order_min && E < 0xffffffffull) {
       int rc = ensure_lpt_buffers(ctx, E);
       if (rc != CCMP_OK) return rc;
-      unsigned int *ord = (unsigned int *)((char *)ctx->lpt_buf + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255) + 4096);
-      HIP_TRY(ccmp_launch_geodesic_order(from, to, E, ctx->geodesic_long_steps * p->delta, (unsigned int *)(ctx->queue + 4), ord, st));
+      char *base = (char *)ctx->lpt_buf;
+      unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
+      unsigned int *ord = (unsigned int *)((char *)hist + 4096);
+      if (ctx->geodesic_order == 2 && E >= ctx->geodesic_scout_min && !carry_in) {
+        // FP32 scout of every edge (the traversal in single precision with the exact Jacobian, one edge per lane, rounds
+        // capped) -> predicted Newton rounds -> descending counting sort: longest-predicted-first
+        HIP_TRY(ccmp_launch_geodesic_scout_order(&K, from, to, E, p->delta, p->lambda, max_states, ctx->geodesic_scout_rounds,
+                                                 (uint16_t *)base, hist, ord, st));
+      } else {
+        HIP_TRY(ccmp_launch_geodesic_order(from, to, E, ctx->geodesic_long_steps * p->delta, (unsigned int *)(ctx->queue + 4), ord, st));
+      }
       order = ord;
     }
   }

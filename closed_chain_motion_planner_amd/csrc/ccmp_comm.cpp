@@ -80,6 +80,10 @@ struct ccmp_comm {
   size_t cap = 0;                   // rows per block
   double *host_recv = nullptr;      // pinned staging of GPU 0's gathered blocks
   size_t host_cap = 0;
+  // timing of the last sharded call, per GPU, on that GPU's stream: [start -> shard projected and compacted] and
+  // [-> all-gather complete] (ccmp_comm_last_timing; what a first multi-GPU run is diagnosed by)
+  std::vector<hipEvent_t> ev; // 3 per GPU
+  std::vector<float> kernel_ms, gather_ms;
 };
 
 int ccmp_comm_create(ccmp_ctx *const *ctxs, int n, ccmp_comm **out)
@@ -107,7 +111,22 @@ int ccmp_comm_create(ccmp_ctx *const *ctxs, int n, ccmp_comm **out)
   c->recv.assign(n, nullptr);
   ncclResult_t r = rccl().CommInitAll(c->comms.data(), n, devs.data());
   if (r != ncclSuccess) { delete c; return rccl_fail(r, "ncclCommInitAll"); }
+  c->ev.assign(3 * (size_t)n, nullptr);
+  c->kernel_ms.assign(n, -1.0f);
+  c->gather_ms.assign(n, -1.0f);
+  for (int g = 0; g < n; g++) {
+    DeviceGuard guard(devs[g]);
+    for (int k = 0; k < 3; k++)
+      if (hipEventCreate(&c->ev[3 * g + k]) != hipSuccess) c->ev[3 * g + k] = nullptr; // timing is optional: the call works without
+  }
   *out = c;
+  return CCMP_OK;
+}
+
+int ccmp_comm_last_timing(const ccmp_comm *c, double *kernel_ms, double *gather_ms)
+{
+  if (!c || !kernel_ms || !gather_ms) return CCMP_EINVAL;
+  for (int g = 0; g < c->n; g++) { kernel_ms[g] = c->kernel_ms[g]; gather_ms[g] = c->gather_ms[g]; }
   return CCMP_OK;
 }
 
@@ -118,6 +137,8 @@ void ccmp_comm_destroy(ccmp_comm *c)
     DeviceGuard guard(c->ctxs[g]->device);
     (void)hipStreamSynchronize(c->ctxs[g]->stream);
     if (c->comms[g]) (void)rccl().CommDestroy(c->comms[g]);
+    for (int k = 0; k < 3; k++)
+      if (!c->ev.empty() && c->ev[3 * g + k]) (void)hipEventDestroy(c->ev[3 * g + k]);
     if (c->send[g]) (void)hipFree(c->send[g]);
     if (c->recv[g]) (void)hipFree(c->recv[g]);
   }
@@ -171,6 +192,7 @@ static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, co
     const size_t nb = sh[g].nb, qb = nb * 14 * sizeof(double);
     sh[g].off_ok = (qb + 255) & ~(size_t)255;
     sh[g].off_it = (sh[g].off_ok + nb + 255) & ~(size_t)255;
+    if (c->ev[3 * g]) (void)hipEventRecord(c->ev[3 * g], ctx->stream);
     hipError_t e = hipMemsetAsync(c->send[g], 0, 14 * sizeof(double), ctx->stream); // row 0: count 0 for an empty shard
     if (e != hipSuccess) { rc = hip_fail(e, "hipMemsetAsync(send block)"); break; }
     if (nb == 0) continue;
@@ -189,6 +211,10 @@ static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, co
     rc = ccmp_compact_valid_capped(ctx, (const double *)stage, (const uint8_t *)(stage + sh[g].off_ok), nb, c->send[g] + 14, cap,
                                    (uint64_t *)c->send[g], ctx->stream);
   }
+  for (int g = 0; g < n && rc == CCMP_OK; g++) {
+    DeviceGuard guard(c->ctxs[g]->device);
+    if (c->ev[3 * g + 1]) (void)hipEventRecord(c->ev[3 * g + 1], c->ctxs[g]->stream);
+  }
   // phase 2: ONE all-gather of the fixed-capacity blocks over the n devices (grouped: one call per rank of this process)
   if (rc == CCMP_OK) {
     ncclResult_t r = rccl().GroupStart();
@@ -196,6 +222,10 @@ static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, co
       r = rccl().AllGather(c->send[g], c->recv[g], block_doubles, ncclDouble, c->comms[g], c->ctxs[g]->stream);
     ncclResult_t r2 = rccl().GroupEnd();
     if (r != ncclSuccess || r2 != ncclSuccess) rc = rccl_fail(r != ncclSuccess ? r : r2, "ncclAllGather");
+    for (int g = 0; g < n && rc == CCMP_OK; g++) {
+      DeviceGuard guard(c->ctxs[g]->device);
+      if (c->ev[3 * g + 2]) (void)hipEventRecord(c->ev[3 * g + 2], c->ctxs[g]->stream);
+    }
   }
   // phase 3: GPU 0 returns the gathered blocks; every GPU returns its shard's full results if the caller wants them
   if (rc == CCMP_OK) {
@@ -222,6 +252,13 @@ static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, co
     if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize(shard)");
   }
   if (rc != CCMP_OK) return rc;
+  for (int g = 0; g < n; g++) {
+    c->kernel_ms[g] = c->gather_ms[g] = -1.0f;
+    if (!c->ev[3 * g] || !c->ev[3 * g + 1] || !c->ev[3 * g + 2]) continue;
+    DeviceGuard guard(c->ctxs[g]->device);
+    (void)hipEventElapsedTime(&c->kernel_ms[g], c->ev[3 * g], c->ev[3 * g + 1]);
+    (void)hipEventElapsedTime(&c->gather_ms[g], c->ev[3 * g + 1], c->ev[3 * g + 2]);
+  }
   // unpack in rank order = global sample order for contiguous shards
   size_t total = 0;
   bool overflow = false;

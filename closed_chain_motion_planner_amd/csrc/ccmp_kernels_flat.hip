@@ -10,6 +10,9 @@ using namespace ccmp;
 namespace {
 
 constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
+#ifndef CCMP_FLAT_MIN_WAVES
+#define CCMP_FLAT_MIN_WAVES 4 // waves per SIMD the register budget must allow (A/B: -DCCMP_FLAT_MIN_WAVES=2)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // "Flat" Newton: one sample per 128-thread block, every evaluation of an iteration in ONE round.
@@ -288,7 +291,7 @@ __device__ __forceinline__ bool flat_joint_valid(const ccmp_consts &KL, double *
 // SRC 0: q_in, SRC 1: ambient sampler, SRC 2: straggler pool.  queue == nullptr: static striding (one block per
 // sample launches need no queue reset).
 template <int SRC, bool STOCK>
-__global__ __launch_bounds__(128, 4) void project_fd_flat_kernel(
+__global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kernel(
     const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
@@ -393,7 +396,7 @@ __device__ __forceinline__ double lds_distance(const double *a, const double *b)
 }
 
 template <bool STOCK>
-__global__ __launch_bounds__(128, 4) void geodesic_flat_kernel(
+__global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel(
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,

@@ -22,6 +22,7 @@ struct consts_f {
   float init_p[3], init_q[4];
   float tol_pos, tol_rot, step;
   int max_iter; // scout cap: min(problem cap, kScoutCap) — samples still unconverged there are all "long"
+  float lbe[7], ube[7]; // joint limits with the margin (extend-step scout: project() must return true for a state to count)
 };
 constexpr int kScoutCap = 96;
 
@@ -179,6 +180,78 @@ __device__ __forceinline__ void chain_sel(const consts_f &K, const int arm, cons
   else chain_f<PASS>(K, arm, q, Rw, pw, al, bl, pl, sgn, J0, J1);
 }
 
+// One Newton round of the scout on the lane's iterate: residual, the reference's loop test (without its precedence quirk: a
+// prediction does not need it), and — if any lane of the wave goes on — the analytic step.  Returns whether THIS lane
+// updated x; `resid` = the residual is still above tolerance.
+template <bool STOCK>
+__device__ __forceinline__ bool scout_round(const consts_f &K, float *x, bool active, int iter, bool &resid)
+{
+    float Rw0[9], pw0[3], Rw1[9], pw1[3];
+  chain_sel<0, STOCK>(K, 0, x, Rw0, pw0, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
+  chain_sel<0, STOCK>(K, 1, x + 7, Rw1, pw1, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
+  // chain = T2^-1 T1, residual against the initial chain
+  float Rc[9], pc[3], qc[4];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) Rc[3 * i + j] = Rw1[i] * Rw0[j] + Rw1[3 + i] * Rw0[3 + j] + Rw1[6 + i] * Rw0[6 + j];
+  {
+    const float d0 = pw0[0] - pw1[0], d1 = pw0[1] - pw1[1], d2 = pw0[2] - pw1[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) pc[i] = Rw1[i] * d0 + Rw1[3 + i] * d1 + Rw1[6 + i] * d2;
+  }
+  quatf(Rc, qc);
+  const float bx = -K.init_q[0], by = -K.init_q[1], bz = -K.init_q[2], bw = K.init_q[3];
+  const float dw = qc[3] * bw - qc[0] * bx - qc[1] * by - qc[2] * bz;
+  const float dx = qc[3] * bx + qc[0] * bw + qc[1] * bz - qc[2] * by;
+  const float dy = qc[3] * by + qc[1] * bw + qc[2] * bx - qc[0] * bz;
+  const float dz = qc[3] * bz + qc[2] * bw + qc[0] * by - qc[1] * bx;
+  const float vn = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float f1 = 2.0f * atan2f(vn, fabsf(dw));
+  const float e0 = pc[0] - K.init_p[0], e1 = pc[1] - K.init_p[1], e2 = pc[2] - K.init_p[2];
+  const float f0 = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+
+  resid = (f0 > K.tol_pos) || (f1 > K.tol_rot);
+  const bool cont = active && resid && iter < K.max_iter;
+  if (__builtin_amdgcn_ballot_w64(cont) == 0ull) return false;
+
+    // analytic 2x14 Jacobian (SURVEY.md §7.3) and the minimum-norm step through the 2x2 Gram matrix
+  float u[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+  if (f0 > 0.0f) { const float inv = 1.0f / f0; u[0] = e0 * inv; u[1] = e1 * inv; u[2] = e2 * inv; }
+  if (vn > 0.0f) { const float sg = (dw < 0.0f ? -1.0f : 1.0f) / vn; n[0] = dx * sg; n[1] = dy * sg; n[2] = dz * sg; }
+  float aw[3], bwv[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    aw[k] = Rw1[3 * k] * u[0] + Rw1[3 * k + 1] * u[1] + Rw1[3 * k + 2] * u[2];
+    bwv[k] = Rw1[3 * k] * n[0] + Rw1[3 * k + 1] * n[1] + Rw1[3 * k + 2] * n[2];
+  }
+  float J0[14], J1[14];
+#pragma unroll
+  for (int arm = 0; arm < 2; arm++) {
+    float al[3], bl[3], pl[3];
+    const float *Bm = K.base_R[arm];
+    const float q0 = pw0[0] - K.base_p[arm][0], q1 = pw0[1] - K.base_p[arm][1], q2 = pw0[2] - K.base_p[arm][2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      al[k] = Bm[k] * aw[0] + Bm[3 + k] * aw[1] + Bm[6 + k] * aw[2];
+      bl[k] = Bm[k] * bwv[0] + Bm[3 + k] * bwv[1] + Bm[6 + k] * bwv[2];
+      pl[k] = Bm[k] * q0 + Bm[3 + k] * q1 + Bm[6 + k] * q2;
+    }
+    chain_sel<1, STOCK>(K, arm, x + 7 * arm, nullptr, nullptr, al, bl, pl, arm == 0 ? 1.0f : -1.0f, J0 + 7 * arm, J1 + 7 * arm);
+  }
+  float ga = 0, gd = 0, gb = 0;
+#pragma unroll
+  for (int e = 0; e < 14; e++) { ga += J0[e] * J0[e]; gd += J1[e] * J1[e]; gb += J0[e] * J1[e]; }
+  const float det = ga * gd - gb * gb;
+  float y0 = 0.0f, y1 = 0.0f;
+  if (det > 1e-30f) { const float inv = 1.0f / det; y0 = (gd * f0 - gb * f1) * inv; y1 = (ga * f1 - gb * f0) * inv; }
+  if (cont) {
+#pragma unroll
+    for (int e = 0; e < 14; e++) x[e] -= K.step * (J0[e] * y0 + J1[e] * y1);
+  }
+  return cont;
+}
+
 template <int MODE, bool STOCK>
 __global__ __launch_bounds__(256) void scout_kernel(const consts_f K, const ccmp_consts KD, const double *__restrict__ q_in,
                                                     uint16_t *__restrict__ pred, unsigned long long B,
@@ -208,77 +281,106 @@ __global__ __launch_bounds__(256) void scout_kernel(const consts_f K, const ccmp
       } else drained = true;
     }
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-
-    float Rw0[9], pw0[3], Rw1[9], pw1[3];
-    chain_sel<0, STOCK>(K, 0, x, Rw0, pw0, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
-    chain_sel<0, STOCK>(K, 1, x + 7, Rw1, pw1, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr);
-    // chain = T2^-1 T1, residual against the initial chain
-    float Rc[9], pc[3], qc[4];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) Rc[3 * i + j] = Rw1[i] * Rw0[j] + Rw1[3 + i] * Rw0[3 + j] + Rw1[6 + i] * Rw0[6 + j];
-    {
-      const float d0 = pw0[0] - pw1[0], d1 = pw0[1] - pw1[1], d2 = pw0[2] - pw1[2];
-#pragma unroll
-      for (int i = 0; i < 3; i++) pc[i] = Rw1[i] * d0 + Rw1[3 + i] * d1 + Rw1[6 + i] * d2;
-    }
-    quatf(Rc, qc);
-    const float bx = -K.init_q[0], by = -K.init_q[1], bz = -K.init_q[2], bw = K.init_q[3];
-    const float dw = qc[3] * bw - qc[0] * bx - qc[1] * by - qc[2] * bz;
-    const float dx = qc[3] * bx + qc[0] * bw + qc[1] * bz - qc[2] * by;
-    const float dy = qc[3] * by + qc[1] * bw + qc[2] * bx - qc[0] * bz;
-    const float dz = qc[3] * bz + qc[2] * bw + qc[0] * by - qc[1] * bx;
-    const float vn = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float f1 = 2.0f * atan2f(vn, fabsf(dw));
-    const float e0 = pc[0] - K.init_p[0], e1 = pc[1] - K.init_p[1], e2 = pc[2] - K.init_p[2];
-    const float f0 = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
-
-    bool cont = false;
-    if (active) {
-      const bool resid = (f0 > K.tol_pos) || (f1 > K.tol_rot);
-      if (resid) cont = iter < K.max_iter;
-    }
+    bool resid;
+    const bool cont = scout_round<STOCK>(K, x, active, iter, resid);
     if (active && !cont) {
       pred[idx] = (uint16_t)iter;
       active = false;
     }
-    if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue;
+    if (cont) iter++;
+  }
+}
 
-    // analytic 2x14 Jacobian (SURVEY.md §7.3) and the minimum-norm step through the 2x2 Gram matrix
-    float u[3] = {0, 0, 0}, n[3] = {0, 0, 0};
-    if (f0 > 0.0f) { const float inv = 1.0f / f0; u[0] = e0 * inv; u[1] = e1 * inv; u[2] = e2 * inv; }
-    if (vn > 0.0f) { const float sg = (dw < 0.0f ? -1.0f : 1.0f) / vn; n[0] = dx * sg; n[1] = dy * sg; n[2] = dz * sg; }
-    float aw[3], bwv[3];
+// ---- extend-step scout: jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96) in single
+// precision, one edge per lane, with the scout's Newton round as project().  Its only output is the number of Newton
+// rounds (evaluations of the Jacobian-and-residual round of the latency kernel: updates + 1 per projected state) each
+// edge needs, capped at `round_cap` — every edge at the cap is simply "long".  The real kernel then takes the edges
+// longest-predicted-first, so that a launch of many more edges than resident blocks ends on short edges instead of on
+// a 200-round edge that happened to start last (the number of rounds is not predictable from the endpoints' distance:
+// it is the conditioning of the projections along the way that makes an edge long).
+__device__ __forceinline__ float distf(const float *a, const float *b)
+{
+  float d = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      aw[k] = Rw1[3 * k] * u[0] + Rw1[3 * k + 1] * u[1] + Rw1[3 * k + 2] * u[2];
-      bwv[k] = Rw1[3 * k] * n[0] + Rw1[3 * k + 1] * n[1] + Rw1[3 * k + 2] * n[2];
+  for (int i = 0; i < 14; i++) { const float v = a[i] - b[i]; d += v * v; }
+  return sqrtf(d);
+}
+__device__ __forceinline__ void interpolatef(const float *from, const float *to, float t, float *out)
+{
+  const float pi = 3.14159265358979f;
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    float diff = to[i] - from[i], v;
+    if (fabsf(diff) <= pi) v = from[i] + diff * t;
+    else {
+      diff = diff > 0.f ? 2.f * pi - diff : -2.f * pi - diff;
+      v = from[i] - diff * t;
+      if (v > pi) v -= 2.f * pi;
+      else if (v < -pi) v += 2.f * pi;
     }
-    float J0[14], J1[14];
+    out[i] = v;
+  }
+}
+
+template <bool STOCK>
+__global__ __launch_bounds__(64) void scout_geodesic_kernel(const consts_f K, const double *__restrict__ from, const double *__restrict__ to,
+                                                            unsigned long long E, float delta, float lambda, int max_states, int round_cap,
+                                                            uint16_t *__restrict__ pred)
+{
+  float x[14], prev[14], tgt[14];
+  unsigned long long idx = 0, next = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int iter = 0, rounds = 0, n = 1;
+  float dist = 0.f, total = 0.f, maxd = 0.f;
+  bool active = false, drained = false;
+  for (;;) {
+    if (!active && !drained) {
+      const unsigned long long t = next;
+      next += (unsigned long long)gridDim.x * blockDim.x;
+      if (t < E) {
+        idx = t;
 #pragma unroll
-    for (int arm = 0; arm < 2; arm++) {
-      float al[3], bl[3], pl[3];
-      const float *Bm = K.base_R[arm];
-      const float q0 = pw0[0] - K.base_p[arm][0], q1 = pw0[1] - K.base_p[arm][1], q2 = pw0[2] - K.base_p[arm][2];
+        for (int e = 0; e < 14; e++) { prev[e] = (float)from[idx * 14 + e]; tgt[e] = (float)to[idx * 14 + e]; }
+        dist = distf(prev, tgt);
+        if (dist > delta) {
+          active = true; iter = 0; rounds = 0; n = 1; total = 0.f; maxd = dist * lambda;
+          interpolatef(prev, tgt, delta / dist, x);
+        } else {
+          pred[idx] = 0; // already there (or not a number): nothing to traverse
+        }
+      } else drained = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
+      if (__builtin_amdgcn_ballot_w64(!drained) == 0ull) break;
+      continue;
+    }
+    bool resid;
+    const bool cont = scout_round<STOCK>(K, x, active, iter, resid);
+    if (!active) continue;
+    rounds++;
+    if (cont) iter++;
+    bool done = rounds >= round_cap;
+    if (!cont && !done) { // project() of this state has returned: the reference's break tests, then the next state
+      bool ok = !resid;
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        al[k] = Bm[k] * aw[0] + Bm[3 + k] * aw[1] + Bm[6 + k] * aw[2];
-        bl[k] = Bm[k] * bwv[0] + Bm[3 + k] * bwv[1] + Bm[6 + k] * bwv[2];
-        pl[k] = Bm[k] * q0 + Bm[3 + k] * q1 + Bm[6 + k] * q2;
+      for (int e = 0; e < 14; e++) ok = ok && x[e] >= K.lbe[e % 7] && x[e] <= K.ube[e % 7];
+      done = !ok;
+      if (!done) {
+        const float step = distf(prev, x);
+        total += step;
+        const float nd = distf(x, tgt);
+        done = step > lambda * delta || total > maxd || nd >= dist || ++n > max_states || !(nd >= delta);
+        if (!done) {
+          dist = nd;
+#pragma unroll
+          for (int e = 0; e < 14; e++) prev[e] = x[e];
+          interpolatef(prev, tgt, delta / dist, x);
+          iter = 0;
+        }
       }
-      chain_sel<1, STOCK>(K, arm, x + 7 * arm, nullptr, nullptr, al, bl, pl, arm == 0 ? 1.0f : -1.0f, J0 + 7 * arm, J1 + 7 * arm);
     }
-    float ga = 0, gd = 0, gb = 0;
-#pragma unroll
-    for (int e = 0; e < 14; e++) { ga += J0[e] * J0[e]; gd += J1[e] * J1[e]; gb += J0[e] * J1[e]; }
-    const float det = ga * gd - gb * gb;
-    float y0 = 0.0f, y1 = 0.0f;
-    if (det > 1e-30f) { const float inv = 1.0f / det; y0 = (gd * f0 - gb * f1) * inv; y1 = (ga * f1 - gb * f0) * inv; }
-    if (cont) {
-#pragma unroll
-      for (int e = 0; e < 14; e++) x[e] -= K.step * (J0[e] * y0 + J1[e] * y1);
-      iter++;
+    if (done) {
+      pred[idx] = (uint16_t)rounds;
+      active = false;
     }
   }
 }
@@ -301,11 +403,11 @@ __global__ void hist_kernel(const uint16_t *__restrict__ pred, unsigned long lon
 }
 
 // exclusive scan in DESCENDING key order: base[k] = number of samples predicted longer than k
-__global__ void scan_desc_kernel(unsigned int *__restrict__ hist /* in: counts, out: running cursor = base */)
+__global__ void scan_desc_kernel(unsigned int *__restrict__ hist /* in: counts, out: running cursor = base */, int nbins)
 {
   if (threadIdx.x == 0) {
     unsigned int run = 0;
-    for (int k = kBins - 1; k >= 0; k--) { const unsigned int c = hist[k]; hist[k] = run; run += c; }
+    for (int k = nbins - 1; k >= 0; k--) { const unsigned int c = hist[k]; hist[k] = run; run += c; }
   }
 }
 
@@ -362,11 +464,11 @@ extern "C" hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred
   return hipGetLastError();
 }
 
-extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
-                                              unsigned int *hist, unsigned int *order, unsigned long long *queue,
-                                              unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st)
+// single-precision copy of the kernel constants; *stock = the model looks like the stock Panda to single precision (axes
+// on coordinate axes, the expected zero offsets, block-diagonal tool rotation, diagonal base rotation) — only the
+// prediction depends on it
+static void make_consts_f(const ccmp_consts *K, consts_f &F, bool *stock_out)
 {
-  consts_f F;
   for (int a = 0; a < 2; a++) {
     for (int i = 0; i < 7; i++)
       for (int k = 0; k < 3; k++) { F.axis[a][i][k] = (float)K->axis[a][i][k]; F.offset[a][i][k] = (float)K->offset[a][i][k]; }
@@ -377,10 +479,7 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
   for (int k = 0; k < 4; k++) F.init_q[k] = (float)K->init_q[k];
   F.tol_pos = (float)K->tol_pos; F.tol_rot = (float)K->tol_rot; F.step = (float)K->step;
   F.max_iter = K->max_iter < kScoutCap ? K->max_iter : kScoutCap;
-  hipError_t e = ccmp_launch_clear_words(queue, 2, st); // kernels, so that a stream capture replays them
-  if (e != hipSuccess) return e;
-  e = ccmp_launch_clear_words(hist, kBins, st);
-  if (e != hipSuccess) return e;
+  for (int i = 0; i < 7; i++) { F.lbe[i] = (float)K->lbe[i]; F.ube[i] = (float)K->ube[i]; }
   // does the model look like the stock Panda to single precision?  (axes on coordinate axes, the expected zero offsets,
   // block-diagonal tool rotation, diagonal base rotation)  Only the prediction depends on it.
   bool stock = true;
@@ -400,6 +499,20 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
     for (int k = 0; k < 9; k++)
       if (k % 4 != 0 && !(fabsf(F.base_R[a][k]) < tol)) stock = false;
   }
+  *stock_out = stock;
+}
+
+extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
+                                              unsigned int *hist, unsigned int *order, unsigned long long *queue,
+                                              unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st)
+{
+  consts_f F;
+  bool stock;
+  make_consts_f(K, F, &stock);
+  hipError_t e = ccmp_launch_clear_words(queue, 2, st); // kernels, so that a stream capture replays them
+  if (e != hipSuccess) return e;
+  e = ccmp_launch_clear_words(hist, kBins, st);
+  if (e != hipSuccess) return e;
 #define CCMP_LAUNCH_SCOUT(MODE, STOCK) \
   hipLaunchKernelGGL((scout_kernel<MODE, STOCK>), dim3(nblocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, queue, seed, first)
   if (mode == 0) {
@@ -411,8 +524,35 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
   }
 #undef CCMP_LAUNCH_SCOUT
   hipLaunchKernelGGL(hist_kernel, dim3(256), dim3(256), 0, st, pred, (unsigned long long)B, hist);
-  hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist);
+  hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist, kBins);
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((B + 256 * kScatterPerThread - 1) / (256 * kScatterPerThread))), dim3(256), 0, st, pred,
                      (unsigned long long)B, hist, order);
+  return hipGetLastError();
+}
+
+// extend-step order: FP32 scout of every edge (rounds capped at round_cap < 1024), then the descending counting sort
+extern "C" hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta,
+                                                        double lambda, int max_states, int round_cap, uint16_t *pred, unsigned int *hist,
+                                                        unsigned int *order, hipStream_t st)
+{
+  consts_f F;
+  bool stock;
+  make_consts_f(K, F, &stock);
+  if (round_cap > kBins - 1) round_cap = kBins - 1;
+  F.max_iter = K->max_iter < round_cap ? K->max_iter : round_cap;
+  const int nbins = round_cap + 1;
+  hipError_t e = ccmp_launch_clear_words(hist, (size_t)nbins, st);
+  if (e != hipSuccess) return e;
+  const unsigned blocks = (unsigned)((E + 63) / 64);
+  if (stock)
+    hipLaunchKernelGGL(scout_geodesic_kernel<true>, dim3(blocks), dim3(64), 0, st, F, from, to, (unsigned long long)E, (float)delta,
+                       (float)lambda, max_states, round_cap, pred);
+  else
+    hipLaunchKernelGGL(scout_geodesic_kernel<false>, dim3(blocks), dim3(64), 0, st, F, from, to, (unsigned long long)E, (float)delta,
+                       (float)lambda, max_states, round_cap, pred);
+  hipLaunchKernelGGL(hist_kernel, dim3(64), dim3(256), 0, st, pred, (unsigned long long)E, hist);
+  hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist, nbins);
+  hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((E + 256 * kScatterPerThread - 1) / (256 * kScatterPerThread))), dim3(256), 0, st, pred,
+                     (unsigned long long)E, hist, order);
   return hipGetLastError();
 }

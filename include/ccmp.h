@@ -257,6 +257,10 @@ int ccmp_sample_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_pr
 typedef struct ccmp_comm ccmp_comm;
 int ccmp_comm_create(ccmp_ctx *const *ctxs, int n, ccmp_comm **out);
 void ccmp_comm_destroy(ccmp_comm *comm);
+/* per GPU (n values each), measured on that GPU's stream during the last ccmp_*_sharded call: milliseconds from the start
+ * of its shard to the end of its projection + compaction, and from there to the completion of the all-gather (-1: no
+ * call yet).  What a multi-GPU run is diagnosed by: stragglers show in kernel_ms, a slow collective in gather_ms. */
+int ccmp_comm_last_timing(const ccmp_comm *comm, double *kernel_ms, double *gather_ms);
 /* project(x) x B (host buffers), contiguous shards over the communicator's GPUs; every GPU compacts its VALID states
  * into a block of block_rows rows (+ one leading row that carries its count) and ONE ncclAllGather brings all blocks
  * to every GPU; GPU 0 hands them to the host: valid_out[0..*n_valid) (capacity valid_capacity rows) = the valid

@@ -40,7 +40,21 @@ def test_bench_line_contract():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1
     assert cb["parity_gpu_vs_det_oracle"]["bit_identical"] is True
+    # SURVEY.md §8d's in-run classification against the glibc build (what the reference's libm gives), >= 4096 samples
+    pl = cb["parity_gpu_vs_libm_oracle"]
+    assert pl["samples"] >= 4096 and set(pl) >= {"n_gt_1e-6", "iteration_flips_pm1", "ok_mismatches", "max_abs_dq"}
+    assert 0 < pl["n_gt_1e-6"] < 0.5 * pl["samples"] and pl["ok_mismatches"] < 0.05 * pl["samples"]  # ~20 % / ~0.5 %
     assert j["value"] > 1e6  # the north star's floor, even at this small batch
+    sec = j["secondary"]
+    hb = sec["host_buffer"]  # §8d "report both": the host-buffer (PCIe-inclusive) rate, never `value`
+    assert hb["pageable"]["projections_per_s"] > 1e5 and hb["pinned"]["projections_per_s"] > 1e5
+    c1 = sec["c1_dumbbell"]  # BASELINE configs[0]
+    assert c1["samples"] == 1024 and c1["cpu_threads"] == 1 and c1["cpu_single_thread_projections_per_s"] > 50
+    assert c1["parity_vs_det_oracle"]["bit_identical"] is True and c1["same_ambient_samples_on_both_sides"] is True
+    g = sec["discrete_geodesic"]  # the complete operation is timed, overflowing edges are counted
+    assert set(g) >= {"edges_per_s", "overflowed_edges", "complete_ms", "complete_edges_per_s", "growtree_5_edges_ms", "max_states_first_pass"}
+    assert g["parity_vs_det_oracle"]["bit_identical"] is True and g["overflowed_edges"] < 0.01 * g["edges"]
+    assert g["parity_vs_det_oracle"].get("continued_edge", {"bit_identical": True})["bit_identical"] is True
 
 
 def _run_bench(*argv, env=None, timeout=600):
@@ -79,3 +93,10 @@ def test_bench_two_ranks_from_the_bare_command():
     g = j["stats"]["gather"]
     assert g["overflow"] is False and 0.15 * 65536 < g["valid_states_all_ranks"] < 0.3 * 65536
     assert g["capacity_rows_per_rank"] == 16384 and j["value"] > 5e4  # gloo moves the blocks through the host: a rehearsal, not a rate
+    # what a first multi-GPU run is diagnosed by: per-rank kernel and step times, the collective's tail, bytes moved, and
+    # the §8e identity — gathered valid states of a 4096-sample probe == those of the same probe on one GPU, bit for bit
+    assert len(g["kernel_ms_per_rank"]) == 2 and g["kernel_ms_min"] <= g["kernel_ms_max"] and len(g["step_ms_per_rank"]) == 2
+    assert len(g["last_kernel_to_gather_done_ms_per_rank"]) == 2 and g["bytes_sent_per_rank"] == 16385 * 112
+    assert g["bytes_received_per_rank"] == 2 * g["bytes_sent_per_rank"]
+    pr = g["probe"]
+    assert pr["samples"] == 4096 and pr["bit_identical_to_one_gpu"] is True and sum(pr["valid_per_rank"]) == pr["valid_states"] > 500

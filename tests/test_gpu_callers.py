@@ -297,6 +297,8 @@ def test_single_process_rccl_all_gather(gpu_ctx, oracle_det):
     v2, c2, _ = c.sample_project_sharded(0x5B, 0, B, comm, block_rows=1000, want_full=False)
     e_q, e_ok, _ = oracle_det.sample_project_batch(P, 0x5B, 0, B, NCPU)
     assert c2 == [int(e_ok.sum())] and np.array_equal(v2.view(np.uint64), e_q[e_ok == 1].view(np.uint64))
+    k_ms, g_ms = comm.last_timing()  # per-GPU stream times of the last call: shard kernels, then the all-gather behind them
+    assert len(k_ms) == 1 and 0.0 < k_ms[0] < 1000.0 and 0.0 <= g_ms[0] < 1000.0
     with pytest.raises(OverflowError):  # a block too small for the shard's valid states is reported, never cut silently
         c.sample_project_sharded(0x5B, 0, B, comm, block_rows=100, want_full=False)
     comm.close()
@@ -400,19 +402,25 @@ def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):
     ref = [torch.cat([c.discrete_geodesic_batch(frm[a:a + 1024].contiguous(), to[a:a + 1024].contiguous(), cap)[k] for a in range(0, E, 1024)])
            for k in range(4)]
     try:
-        for order, order_min, long_steps in ((0, 0, 12), (1, 0, 12), (1, 0, 3), (1, 0, 0), (1, 1 << 30, 12)):
+        # index order | far-apart edges first (three thresholds) | order switched off by size | FP32 scout order (two caps)
+        for order, order_min, long_steps, scout_rounds in ((0, 0, 12, 48), (1, 0, 12, 48), (1, 0, 3, 48), (1, 0, 0, 48), (1, 1 << 30, 12, 48),
+                                                           (2, 0, 12, 48), (2, 0, 12, 7)):
             gpu_ctx.set_option("geodesic_order", order)
             gpu_ctx.set_option("geodesic_order_min", order_min)
             gpu_ctx.set_option("geodesic_long_steps", long_steps)
+            gpu_ctx.set_option("geodesic_scout_min", 0)
+            gpu_ctx.set_option("geodesic_scout_rounds", scout_rounds)
             got = c.discrete_geodesic_batch(frm, to, cap)
             n = ref[1].clamp(max=cap)
             assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3]), (order, long_steps)
             live = torch.arange(cap, device=frm.device)[None, :] < n[:, None]
             assert torch.equal(got[0][live], ref[0][live]), (order, long_steps)
     finally:
-        gpu_ctx.set_option("geodesic_order", 1)
+        gpu_ctx.set_option("geodesic_order", 2)
         gpu_ctx.set_option("geodesic_order_min", 4096)
         gpu_ctx.set_option("geodesic_long_steps", 12)
+        gpu_ctx.set_option("geodesic_scout_min", 8192)
+        gpu_ctx.set_option("geodesic_scout_rounds", 48)
     sl = slice(E - 192, E)
     s_cpu, n_cpu, ok_cpu, it_cpu = oracle_det.discrete_geodesic_batch(P, frm[sl].cpu().numpy(), to[sl].cpu().numpy(), cap, NCPU)
     assert np.array_equal(got[1][sl].cpu().numpy(), n_cpu) and np.array_equal(got[2][sl].cpu().numpy(), ok_cpu)

@@ -156,7 +156,10 @@ def test_host_entry_and_checker_mirror(gpu_ctx, oracle_det, kernel_choice):
     n = int(cnt.item())
     qh, okh = qp.cpu().numpy(), ok.cpu().numpy()
     clr_o, _ = oracle_det.clearance_batch(P, sc.spheres, sc.boxes, sc.allowed, qh)
-    expect = qh[(okh != 0) & (clr_o > 0.0)]
+    # the default skeleton spheres are not inscribed in the links: the checker refuses only overlaps deeper than 3 cm
+    # (a caller's own proxies keep the strict threshold 0)
+    assert chk.margin == S.DEFAULT_SKELETON_MARGIN == -0.03 and S.ProxyValidityChecker(c, spheres=sc.spheres).margin == 0.0
+    expect = qh[(okh != 0) & (clr_o > chk.margin)]
     assert n == len(expect) and np.array_equal(kept[:n].cpu().numpy().view(np.uint64), expect.view(np.uint64))
     print("pipeline: %d sampled, %d on the manifold and within limits, %d also clear of proxy contact" % (len(qh), int(okh.sum()), n))
 

@@ -74,5 +74,135 @@ def geo_stats():
     print("space.discreteGeodesicBatch 5 edges host->host: median %.1f us" % (np.median(ts[5:]) * 1e6))
 
 
+
+
+def geo_order():
+    """extend step, 16384 edges, lists of 16: index order / far-apart first / FP32 scout order with several round caps"""
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    frm, to = near_edges(c, 16384)
+    ref = c.discrete_geodesic_batch(frm, to, 16)
+    for E in (16384, 8192, 65536):
+        if E != 16384:
+            frm, to = near_edges(c, E)
+            ref = c.discrete_geodesic_batch(frm, to, 16)
+        for name, order, rounds in (("index", 0, 48), ("far-first", 1, 48), ("scout32", 2, 32), ("scout48", 2, 48), ("scout64", 2, 64), ("scout96", 2, 96)):
+            ctx.set_option("geodesic_order", order)
+            ctx.set_option("geodesic_scout_min", 0)
+            ctx.set_option("geodesic_scout_rounds", rounds)
+            ms = min(timed(lambda: c.discrete_geodesic_batch(frm, to, 16), reps=5) for _ in range(2))
+            got = c.discrete_geodesic_batch(frm, to, 16)
+            same = all(torch.equal(a, b) for a, b in zip(got[1:], ref[1:]))
+            print("E=%d %-10s %.3f ms  %.2f M edges/s  same counts/flags/iterations %s" % (E, name, ms, E / ms / 1e3, same), flush=True)
+    L = _lib.lib()
+    L.ccmp_ctx_debug_lpt_pred.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    frm, to = near_edges(c, 16384)
+    ctx.set_option("geodesic_scout_rounds", 255)
+    st, n, ok, its = c.discrete_geodesic_batch(frm, to, 16)
+    pred = np.zeros(16384, dtype=np.uint16)
+    assert L.ccmp_ctx_debug_lpt_pred(ctx.handle, pred.ctypes.data, 16384) == 0
+    rounds = (its + n.clamp(max=16) - 1).cpu().numpy()
+    p = pred.astype(np.int64)
+    print("scout vs true rounds (cap 255): corr %.3f, |d|<=2: %.3f, of the %d edges with > 60 true rounds the scout says > 40 for %.3f"
+          % (np.corrcoef(p, rounds)[0, 1], (np.abs(p - rounds) <= 2).mean(), (rounds > 60).sum(), (p[rounds > 60] > 40).mean()))
+
+
+def phases():
+    """cycle counters per phase of the latency kernel's Newton round (variant B built with -DCCMP_FLAT_TIMING for the flat unit)"""
+    import os
+    LIBB = os.path.join("closed_chain_motion_planner_amd", "lib", "libccmp_B.so")
+    from closed_chain_motion_planner_amd import load_config
+    LB = C.CDLL(LIBB)
+    P = load_config(CFG % "Wine_Bottle")
+    h = C.c_void_p()
+    LB.ccmp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    assert LB.ccmp_ctx_create(0, C.byref(h)) == 0
+    LB.ccmp_project_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    LB.ccmp_ambient_uniform_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]
+    LB.ccmp_debug_flat_timing.argtypes = [C.c_void_p, C.c_int]
+    q = torch.empty((64, 14), dtype=torch.float64, device="cuda")
+    LB.ccmp_ambient_uniform_batch(h, C.byref(P), 0xC1, 0, q.data_ptr(), 64, None)
+    out = torch.empty_like(q)
+    ok = torch.empty(64, dtype=torch.uint8, device="cuda")
+    it = torch.empty(64, dtype=torch.int16, device="cuda")
+    t = (C.c_ulonglong * 8)()
+    LB.ccmp_debug_flat_timing(t, 1)
+    iters = 0
+    for i in range(64):
+        assert LB.ccmp_project_batch(h, C.byref(P), q[i:i + 1].data_ptr(), out[i:i + 1].data_ptr(), ok[i:i + 1].data_ptr(), it[i:i + 1].data_ptr(), 1, None) == 0
+    torch.cuda.synchronize()
+    iters = int(it.to(torch.int32).sum())
+    LB.ccmp_debug_flat_timing(t, 0)
+    tot = sum(t)
+    names = ["A angles", "B chain", "C residual + stencil", "(3)", "E solve + update", "", "", ""]
+    rounds = iters + 64
+    print("64 single-state projections, %d Newton updates, %d rounds" % (iters, rounds))
+    for k in range(5):
+        print("  %-22s %8.0f cycles per round  %5.1f %%" % (names[k], t[k] / rounds, 100.0 * t[k] / tot))
+    print("  total %.0f cycles per round (100 MHz-ish counter? s_memrealtime vs clock: compare with the wall-clock per round)" % (tot / rounds))
+
+
+
+
+def ab_latency():
+    """A (libccmp.so) against B (libccmp_B.so), interleaved: single-state project, 5-edge and 16384-edge extend steps, 4096 batch"""
+    import os, statistics
+    from closed_chain_motion_planner_amd import load_config
+    LA = _lib.lib()
+    LB = C.CDLL(os.path.join("closed_chain_motion_planner_amd", "lib", "libccmp_B.so"))
+    P = load_config(CFG % "Wine_Bottle")
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    frm, to = near_edges(c, 16384)
+    vp = C.c_void_p
+    H = {}
+    for name, L in (("A", LA), ("B", LB)):
+        h = C.c_void_p()
+        L.ccmp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        assert L.ccmp_ctx_create(0, C.byref(h)) == 0
+        L.ccmp_project_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+        L.ccmp_geodesic_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp]
+        L.ccmp_project_host.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t]
+        H[name] = (L, h)
+    s = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for E, cap in ((5, 64), (1024, 64), (16384, 16), (16384, 64)):
+        f, t = frm[:E].contiguous(), to[:E].contiguous()
+        states = {n: torch.empty((E, cap, 14), dtype=torch.float64, device=f.device) for n in H}
+        nn = torch.empty(E, dtype=torch.int32, device=f.device)
+        ok = torch.empty(E, dtype=torch.uint8, device=f.device)
+        it = torch.empty(E, dtype=torch.int32, device=f.device)
+        ts = {n: [] for n in H}
+        for rep in range(8):
+            for n, (L, h) in H.items():
+                fn = lambda: L.ccmp_geodesic_batch(h, C.byref(P), f.data_ptr(), t.data_ptr(), E, cap, states[n].data_ptr(), nn.data_ptr(), ok.data_ptr(), it.data_ptr(), s)
+                ts[n].append(timed(fn, reps=1))
+        same = torch.equal(states["A"][:, :4], states["B"][:, :4])
+        print("geodesic E=%d cap=%d: A %.3f ms  B %.3f ms  (B/A %.3f) same %s" % (E, cap, statistics.median(ts["A"]), statistics.median(ts["B"]),
+              statistics.median(ts["B"]) / statistics.median(ts["A"]), same), flush=True)
+    for B in (1, 256, 4096, 16384):
+        q = c.ambient_uniform_batch(0xC2, 0, B)
+        out = {n: torch.empty_like(q) for n in H}
+        ok = torch.empty(B, dtype=torch.uint8, device=q.device)
+        it = torch.empty(B, dtype=torch.int16, device=q.device)
+        ts = {n: [] for n in H}
+        for rep in range(8):
+            for n, (L, h) in H.items():
+                fn = lambda: L.ccmp_project_batch(h, C.byref(P), q.data_ptr(), out[n].data_ptr(), ok.data_ptr(), it.data_ptr(), B, s)
+                ts[n].append(timed(fn, reps=1))
+        print("project B=%d: A %.4f ms  B %.4f ms  (B/A %.3f) same %s" % (B, statistics.median(ts["A"]), statistics.median(ts["B"]),
+              statistics.median(ts["B"]) / statistics.median(ts["A"]), torch.equal(out["A"], out["B"])), flush=True)
+    x = c.ambient_uniform_batch(0xC1, 0, 64).cpu().numpy()
+    for n, (L, h) in H.items():
+        ts = []
+        for i in range(64):
+            xi, xo = x[i].copy(), np.zeros(14)
+            okb = (C.c_uint8 * 1)()
+            t0 = time.perf_counter()
+            L.ccmp_project_host(h, C.byref(P), xi.ctypes.data, xo.ctypes.data, okb, None, 1)
+            ts.append(time.perf_counter() - t0)
+        print("%s single project_host: median %.1f us" % (n, np.median(ts[8:]) * 1e6))
+
+
 if __name__ == "__main__":
     globals()[sys.argv[1]]()

@@ -7,6 +7,7 @@
     python tools/measure.py geodesic [E ...]                batched discreteGeodesic (near-neighbour edges)
     python tools/measure.py analytic                        analytic mode against batch size and waves per CU
     python tools/measure.py host                            PCIe-inclusive rate of ccmp_project_host (pageable / pinned)
+    python tools/measure.py sharded [n_gpus [B]]            one process, n GPUs, RCCL all-gather inside the C ABI: per-GPU stream times
     python tools/measure.py sampler                         project_batch vs the fused sampler
     python tools/measure.py soak                            25 repeats of the default policy, outputs compared bit for bit
     python tools/measure.py scout                           FP32 scout's predictions against the true iteration counts
@@ -97,14 +98,27 @@ def single(argv):
 
 
 def geodesic(argv):
+    """batched extend step: the call with lists of 16 and of 64 states, the edges that did not fit, and the complete
+    operation (continuation of those edges until every list is whole)"""
     ctx = Context(0)
     c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
     for E in [int(a) for a in argv] or [5, 64, 1024, 16384]:
         frm, to = near_edges(c, E)
-        ms = timed(lambda: c.discrete_geodesic_batch(frm, to, 64), reps=3)
-        st, n, okg, its = c.discrete_geodesic_batch(frm, to, 64)
-        print("E=%-6d %8.3f ms  %.3e edges/s  mean states %.2f  reached %.3f  Newton iterations per edge %.1f"
-              % (E, ms, E / ms * 1e3, n.float().mean().item(), okg.float().mean().item(), its.float().mean().item()), flush=True)
+        row = []
+        for cap in (16, 64):
+            ms = timed(lambda: c.discrete_geodesic_batch(frm, to, cap), reps=3)
+            st, n, okg, its, carry = c.discrete_geodesic_batch(frm, to, cap, want_carry=True)
+            over = int((n > cap).sum())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = c.discrete_geodesic_batch(frm, to, cap, want_carry=True)
+            whole = c.continue_geodesics(to, r[0], r[1], r[2], r[3], r[4], cap)
+            torch.cuda.synchronize()
+            ms_all = (time.perf_counter() - t0) * 1e3
+            row.append("lists of %d: %.3f ms, %d edges did not fit, %.3e complete edges/s; everything continued to the end: %.2f ms"
+                       % (cap, ms, over, (E - over) / ms * 1e3, ms_all))
+        print("E=%-6d %s | mean states %.2f (first %d), reached %.3f, Newton iterations per edge %.1f"
+              % (E, "; ".join(row), n.clamp(max=cap).float().mean().item(), cap, okg.float().mean().item(), its.float().mean().item()), flush=True)
 
 
 def analytic(argv):
@@ -185,6 +199,36 @@ def host(argv):
             assert rc == 0
         ms = np.median(ts[1:]) * 1e3
         print("%-9s host buffers: %.2f ms per 262144 -> %.2e projections/s (device-resident: bench.py)" % (name, ms, B / ms * 1e3))
+
+
+def sharded(argv):
+    """one process, every visible GPU (ccmp_comm_* + ccmp_sample_project_sharded: the reference's shape, RCCL inside the C
+    ABI): wall time per call, per-GPU stream time of the shard's kernels and of the all-gather behind them, and the
+    identity of the gathered valid states with those of the same samples on GPU 0 alone"""
+    from closed_chain_motion_planner_amd import Communicator
+
+    n = int(argv[0]) if argv else torch.cuda.device_count()
+    B = int(argv[1]) if len(argv) > 1 else 262144 * n
+    ctxs = [Context(g) for g in range(n)]
+    comm = Communicator(ctxs)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctxs[0])
+    c.sample_project_sharded(0xC5, 0, B, comm, want_full=False)  # communicator and workspaces
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        valid, counts, _ = c.sample_project_sharded(0xC5, 0, B, comm, want_full=False)
+        ts.append(time.perf_counter() - t0)
+    k, g = comm.last_timing()
+    print("%d GPUs, %d samples: %.2f ms per call (host wall, upload-free sampler form) -> %.3e projections/s" % (n, B, min(ts) * 1e3, B / min(ts)))
+    print("  per-GPU kernel ms:", " ".join("%.2f" % v for v in k), "| all-gather ms behind them:", " ".join("%.3f" % v for v in g))
+    print("  valid states per GPU:", counts)
+    probe = 4096
+    vp, cp, _ = c.sample_project_sharded(0xC5, 0, probe, comm, want_full=False)
+    q, ok, _, _ = c.sample_project_batch(0xC5, 0, probe, want_iters=False)
+    alone = q[ok == 1].cpu().numpy()
+    print("  4096-sample probe: gathered == one GPU alone, bit for bit: %s (%d valid)"
+          % (bool(alone.shape == np.asarray(vp).shape and np.array_equal(alone.view(np.uint64), np.asarray(vp).view(np.uint64))), len(alone)))
+    comm.close()
 
 
 def sampler(argv):
@@ -284,7 +328,7 @@ def run(argv):
         fn = lambda: [c.project(x[i].copy()) for i in range(64)]
     elif what == "geodesic":
         frm, to = near_edges(c, 16384)
-        fn = lambda: c.discrete_geodesic_batch(frm, to, 64)
+        fn = lambda: c.discrete_geodesic_batch(frm, to, 16)  # bench.py's first pass: lists of 16 states
     elif what == "analytic":
         c.setJacobianMode(1)
         q = c.ambient_uniform_batch(0xC3, 0, 262144)
@@ -307,7 +351,7 @@ def run(argv):
 
 
 if __name__ == "__main__":
-    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sampler, soak, scout, clearance, run)}
+    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sharded, sampler, soak, scout, clearance, run)}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
     cmds[sys.argv[1]](sys.argv[2:])
