@@ -82,8 +82,10 @@ struct ccmp_ctx {
   hipStream_t side = nullptr;            // side stream of split launches
   hipEvent_t fork = nullptr, join = nullptr;
   int geodesic_order = 2;                // extend step, batches beyond the resident blocks: 1 = far-apart edges first, 2 = FP32 scout order
-  size_t geodesic_scout_min = 8192;      // ... the scout from this many edges on (below: the two-class order by distance)
-  int geodesic_scout_rounds = 48;        // ... the scout stops an edge after this many Newton rounds (all such edges are "long")
+  size_t geodesic_scout_min = 6144;      // ... the scout from this many edges on (below: the two-class order by distance)
+  int geodesic_scout_rounds = 64;        // ... the scout stops an edge after this many Newton rounds (all such edges are "long");
+                                         // 16384 near-neighbour edges, lists of 16, ms: index order 2.90, far-apart first 2.43,
+                                         // scout capped at 32 / 48 / 64 / 96 rounds 2.40 / 2.54 / 2.18 / 2.25 (8192 edges: 1.20 / 1.14 / 0.98 at 64)
   size_t geodesic_order_min = 4096;      // ... from this many edges on (the ordering pass is one more launch)
   double geodesic_long_steps = 12.0;     // ... "long" = further than this many delta apart (median near-neighbour edge: 4)
   size_t clearance_per_state_max = 8192; // proxy clearance: up to here one block per state, above 64-state tiles

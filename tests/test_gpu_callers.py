@@ -419,8 +419,8 @@ def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):
         gpu_ctx.set_option("geodesic_order", 2)
         gpu_ctx.set_option("geodesic_order_min", 4096)
         gpu_ctx.set_option("geodesic_long_steps", 12)
-        gpu_ctx.set_option("geodesic_scout_min", 8192)
-        gpu_ctx.set_option("geodesic_scout_rounds", 48)
+        gpu_ctx.set_option("geodesic_scout_min", 6144)
+        gpu_ctx.set_option("geodesic_scout_rounds", 64)
     sl = slice(E - 192, E)
     s_cpu, n_cpu, ok_cpu, it_cpu = oracle_det.discrete_geodesic_batch(P, frm[sl].cpu().numpy(), to[sl].cpu().numpy(), cap, NCPU)
     assert np.array_equal(got[1][sl].cpu().numpy(), n_cpu) and np.array_equal(got[2][sl].cpu().numpy(), ok_cpu)
