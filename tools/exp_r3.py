@@ -204,5 +204,31 @@ def ab_latency():
         print("%s single project_host: median %.1f us" % (n, np.median(ts[8:]) * 1e6))
 
 
+
+
+def handover():
+    """mid-size batches: occupancy threshold of the hand-over (throughput kernel -> latency kernel), scout on/off"""
+    ctx = Context(0)
+    for obj in ("Wine_Bottle", "stefan"):
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        for B in (12288, 16384, 24576, 32768, 49152, 65536):
+            q = c.ambient_uniform_batch(0xC3, 0, B)
+            out = torch.empty_like(q)
+            row = []
+            ctx.set_schedule(2, 0)
+            row.append("flat-only %.3f" % timed(lambda: c.project_batch(q, out=out), reps=5))
+            ctx.set_schedule(1)
+            for lpt_min in (0, 1 << 30):
+                ctx.set_lpt(1, lpt_min)
+                for thr in (-1, 60, 70, 80, 90, 100):
+                    ctx.set_option("handover_threshold", thr if thr < 0 else 10 + thr)
+                    row.append("%s%s %.3f" % ("scout " if lpt_min == 0 else "", "auto" if thr < 0 else "%d%%" % thr, timed(lambda: c.project_batch(q, out=out), reps=5)))
+            ctx.set_option("handover_threshold", -1)
+            ctx.set_lpt(1)
+            print("%s B=%d: %s" % (obj, B, " | ".join(row)), flush=True)
+
+
+
+
 if __name__ == "__main__":
     globals()[sys.argv[1]]()
