@@ -68,8 +68,20 @@ for obj, tol, seed, mode, N in cases:
         frm = good[:ne].contiguous()
         to, _, _, _ = c.sample_near_project_batch(seed + 0x200, 0, frm, 0.6, ne, want_iters=False)
         maxs = 32
-        st, nst, gok, gits = c.discrete_geodesic_batch(frm, to, maxs)
-        st, nst, gok, gits = st.cpu().numpy(), nst.cpu().numpy(), gok.cpu().numpy(), gits.cpu().numpy()
+        st_d, nst_d, gok_d, gits_d, carry_d = c.discrete_geodesic_batch(frm, to, maxs, want_carry=True)
+        # every edge that did not fit, continued from its last stored state until it is whole, against the oracle's
+        # uninterrupted traversal (round 3: ccmp_geodesic_batch_ex)
+        whole = c.continue_geodesics(to, st_d, nst_d, gok_d, gits_d, carry_d, maxs)
+        cont_same = 0
+        for e, (st_e, ok_e, its_e) in whole.items():
+            okf, stf, itf = orc.discrete_geodesic(P, frm[e].cpu().numpy(), to[e].cpu().numpy(), interpolate=True, max_states=8192)
+            cont_same += int(stf.shape == st_e.shape and np.array_equal(np.ascontiguousarray(st_e).view(np.uint64), stf.view(np.uint64))
+                             and bool(ok_e) == okf and its_e == itf)
+        entry["geodesic_edges_continued"] = len(whole)
+        entry["geodesic_edges_continued_bit_identical"] = cont_same
+        entry["geodesic_longest_edge_states"] = max([v[0].shape[0] for v in whole.values()], default=int(nst_d.max()))
+        assert cont_same == len(whole)
+        st, nst, gok, gits = st_d.cpu().numpy(), nst_d.cpu().numpy(), gok_d.cpu().numpy(), gits_d.cpu().numpy()
         sc, nc, okc, itc = orc.discrete_geodesic_batch(P, frm.cpu().numpy(), to.cpu().numpy(), maxs, NCPU)
         for e in range(ne):
             m = min(int(nst[e]), maxs)
@@ -101,6 +113,8 @@ for obj, tol, seed, mode, N in cases:
     assert same_q == N and entry["ok_mismatches"] == 0 and entry["iteration_mismatches"] == 0
     assert entry["sampler_rows_bit_identical"] == n2 and entry["sampler_ok_mismatches"] == 0
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-with open(os.path.join(ROOT, "profiles", "parity_campaign.json"), "w") as f:
-    json.dump(report, f, indent=1)
+for path in (os.path.join(ROOT, "profiles", "parity_campaign.json"), os.path.join(ROOT, "gpurun_out", "parity_campaign.json")):
+    os.makedirs(os.path.dirname(path), exist_ok=True)  # gpurun_out/ is what travels back from the GPU box
+    with open(path, "w") as f:
+        json.dump(report, f, indent=1)
 print("all cases bit-identical")
