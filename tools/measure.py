@@ -259,6 +259,17 @@ def soak(argv):
     ref = c.project_batch(q)
     bad = sum(not all(torch.equal(a, b) for a, b in zip(c.project_batch(q), ref)) for _ in range(25))
     print("Wine_Bottle analytic 200000 (split launch) repeats differing:", bad, flush=True)
+    # the extend step beyond the resident blocks: ticket queue + FP32 scout order (atomics decide who takes which edge,
+    # the sort's ties fall as they fall) — counts, flags, Newton counts and every listed state, the same 25 times over
+    cg = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    frm, to = near_edges(cg, 16384)
+    rg = cg.discrete_geodesic_batch(frm, to, 16)
+    live = torch.arange(16, device=frm.device)[None, :] < rg[1].clamp(max=16)[:, None]
+    bad = 0
+    for _ in range(25):
+        g = cg.discrete_geodesic_batch(frm, to, 16)
+        bad += not (all(torch.equal(a, b) for a, b in zip(g[1:], rg[1:])) and torch.equal(g[0][live], rg[0][live]))
+    print("Wine_Bottle extend step, 16384 edges, scout order: repeats differing:", bad, flush=True)
     sc = ProxyValidityChecker(c).scene
     refc = sc.clearance_batch(ref[0])
     bad = sum(not all(torch.equal(a, b) for a, b in zip(sc.clearance_batch(ref[0]), refc)) for _ in range(25))
