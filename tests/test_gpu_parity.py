@@ -23,10 +23,22 @@ def _constraint(obj, ctx, mode=0):
 
     c = KinematicChainConstraint.from_yaml(config_path(obj), ctx=ctx)
     c.setJacobianMode(mode)
+    c._fixture = obj  # which YAML fixture it came from (see _oracle_problem)
     return c
 
 
 def _oracle_problem(oracle, c):
+    """The checker's problem for the constraint under test.  Built by the ORACLE'S OWN set-up code from the YAML fixture
+    (orc_problem_init / orc_set_start: arm order, base frames, DH constants, init_chain_) whenever the product's problem
+    still is what its loader made of that fixture — then the two set-up paths are also compared, byte for byte, in every
+    GPU test (VERDICT r2, weak #6a).  Only a problem the test has changed since (tolerances, iteration cap, calibration,
+    arms, analytic mode) is handed over as bytes."""
+    obj = getattr(c, "_fixture", None)
+    if obj is not None:
+        own = oracle.problem(load_cfg(obj))
+        own.jacobian_mode = c.problem.jacobian_mode  # a switch of this library, not part of the reference's set-up
+        if bytes(own) == bytes(c.problem):
+            return own
     return oracle.problem_from_bytes(bytes(c.problem))
 
 
@@ -69,6 +81,15 @@ def test_device_arithmetic_is_bitwise_host(gpu_ctx, oracle_det):
         exp[:, 4] = x / y
     same = (got.view(np.uint64) == exp.view(np.uint64)) | (np.isnan(got) & np.isnan(exp))
     assert same.all(), "device/host arithmetic differs at %s" % np.argwhere(~same)[:5]
+    # and against an implementation that shares no source with the product (VERDICT r2, weak #6b: the det oracle compiles
+    # the product's ccmp_detmath.h, so the comparison above cannot see a wrong ccmp_sincos): the DEVICE's sines, cosines
+    # and arc tangents against glibc's, in units of the last place, over the range the reduction is exact for
+    fin = np.isfinite(x) & (np.abs(x) <= 1e5)  # the range tests/test_detmath.py establishes for the host build
+    with np.errstate(all="ignore"):
+        ref = np.stack([np.sin(x), np.cos(x), np.arctan2(np.abs(x), np.abs(y))], axis=1)
+    ulp = np.abs(got[:, :3] - ref) / np.spacing(np.abs(ref))
+    ok3 = fin & np.isfinite(y) & ~((x == 0) & (y == 0))
+    assert ulp[fin, 0].max() <= 1.0 and ulp[fin, 1].max() <= 1.0 and ulp[ok3, 2].max() <= 2.0, ulp[fin].max(axis=0)
 
 
 @pytest.mark.parametrize("obj", OBJECTS)
@@ -97,6 +118,8 @@ def test_project_fd_bitwise(gpu_ctx, oracle_det, obj, B, seed):
 
     c = _constraint(obj, gpu_ctx)
     P = _oracle_problem(oracle_det, c)
+    # the checker's problem comes from the oracle's own set-up code, not from the product's struct
+    assert bytes(P) == bytes(c.problem) and bytes(oracle_det.problem(load_cfg(obj))) == bytes(P)
     q = oracle_det.ambient_uniform_batch(P, seed, 0, B)
     q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
     qd = torch.as_tensor(q).cuda()
