@@ -221,6 +221,9 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
     // owning column c.  A second wave repeating it would only take issue slots from other blocks; wave 1 waits at the
     // barrier below.
     if (w == 0) {
+#ifdef CCMP_FLAT_SOLVE_PRIO
+      __builtin_amdgcn_s_setprio(CCMP_FLAT_SOLVE_PRIO); // the serial solve is every block's critical path: first in line on its SIMD
+#endif
       double2 P[14];
       load_rows(rec, P);
       const int me = lane < 14 ? lane : 13;
@@ -263,6 +266,9 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
       const double k1 = s1 > thr ? g1 / d : 0.0;
       const double dxm = CCMP_FMA(k1, mine.y, k0 * mine.x);
       if (lane < 14) rec[fX + lane] = CCMP_FMA(-K.step, dxm, rec[fX + lane]);
+#ifdef CCMP_FLAT_SOLVE_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     updates++;
     __syncthreads();
