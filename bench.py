@@ -521,26 +521,31 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts[4:]) * 1e6)
 
-    def geodesic(n_edges=16384, first_pass=16):
+    def geodesic(n_edges=16384, first_pass=16, budget=128):
         # growTree-shaped edges (src/planner/stefanBiPRM.cpp:307-351: a milestone towards a near neighbour): from a valid
         # projected state to a projected sampleUniformNear state within 0.6 rad per joint (about 1.0 rad apart, ~4 states
         # per edge like the reference's recorded roadmap edges).  What is timed: the call with lists of
-        # `first_pass` states — `edges_per_s` counts only the edges that are COMPLETE after it, `overflowed_edges` says how
-        # many were not — and the whole operation (`complete_*`): the same call plus the continuation of every edge that
-        # did not fit, from its last stored state, until each list is whole (one edge in 16384 creeps for 952 states:
-        # a serial chain of ~11 000 Newton rounds that the reference pays as well).
+        # `first_pass` states and a budget of `budget` Newton rounds per edge — `edges_per_s` counts only the edges that are
+        # COMPLETE after it, `overflowed_edges` says how many were not (list full or budget spent) — and the whole operation
+        # (`complete_*`): the same call plus the continuation of every such edge, from its last stored state, until each
+        # list is whole (one edge in 16384 creeps for 952 states: a serial chain of ~12 000 Newton rounds that the
+        # reference pays as well).  `ms_unbounded_rounds` is the same call without the round budget: it lasts as long as
+        # that one edge needs for its first 15 states (545 rounds).
         c.setJacobianMode(CCMP_JAC_FD)
         q, ok, _, _ = c.sample_project_batch(0x6E0, 0, 8 * n_edges, want_iters=False)
         frm = q[ok == 1][:n_edges].contiguous()
         to, _, _, _ = c.sample_near_project_batch(0x6E1, 0, frm, 0.6, n_edges, want_iters=False)
-        sec = timed(lambda: c.discrete_geodesic_batch(frm, to, first_pass), 5)
+        call = lambda: c.discrete_geodesic_batch(frm, to, first_pass, want_carry=True, round_budget=budget)
+        sec = timed(call, 5)
+        sec_nb = timed(lambda: c.discrete_geodesic_batch(frm, to, first_pass), 3)
         sec64 = timed(lambda: c.discrete_geodesic_batch(frm, to, 64), 3)
-        st, n, gok, its, carry = c.discrete_geodesic_batch(frm, to, first_pass, want_carry=True)
-        over = int((n > first_pass).sum().item())
+        st, n, gok, its, carry = call()
+        unfinished = (n > first_pass) | (gok == 2)
+        over = int(unfinished.sum().item())
 
         def complete():
-            r = c.discrete_geodesic_batch(frm, to, first_pass, want_carry=True)
-            return r, c.continue_geodesics(to, r[0], r[1], r[2], r[3], r[4], first_pass)
+            r = call()
+            return r, c.continue_geodesics(to, r[0], r[1], r[2], r[3], r[4], first_pass, round_budget=budget)
 
         complete()
         torch.cuda.synchronize()
@@ -554,14 +559,17 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         # the planner's neighbour loop: five edges in one call (lists of 64 states, as the adapter asks for)
         f5, t5 = frm[:5].contiguous(), to[:5].contiguous()
         sec5 = timed(lambda: c.discrete_geodesic_batch(f5, t5, 64), 20)
+        done = ~unfinished
         res = {"edges_per_s": (n_edges - over) / sec, "ms": sec * 1e3, "edges": n_edges, "max_states_first_pass": first_pass,
-               "overflowed_edges": over, "complete_ms": sec_all * 1e3, "complete_edges_per_s": n_edges / sec_all,
-               "longest_edge_states": int(nn.max().item()), "ms_lists_of_64": sec64 * 1e3,
+               "newton_round_budget_per_edge": budget, "overflowed_edges": over,
+               "overflowed_list_full": int((n > first_pass).sum().item()), "overflowed_budget_spent": int((gok == 2).sum().item()),
+               "complete_ms": sec_all * 1e3, "complete_edges_per_s": n_edges / sec_all,
+               "longest_edge_states": int(nn.max().item()), "ms_unbounded_rounds": sec_nb * 1e3, "ms_lists_of_64": sec64 * 1e3,
                "edges_per_s_lists_of_64": (n_edges - int((nn > 64).sum().item())) / sec64,
                "growtree_5_edges_ms": sec5 * 1e3,
                "mean_states_per_edge": float(nn.to(torch.float64).mean().item()),
                "mean_newton_iters_per_edge_first_pass": float(its.to(torch.float64).mean().item()),
-               "reached_fraction_first_pass": float(gok.to(torch.float64).mean().item())}
+               "reached_fraction_of_complete_edges": float((gok[done] == 1).to(torch.float64).mean().item())}
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle_binding import Oracle
@@ -570,21 +578,21 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             Pd = Od.problem_from_bytes(bytes(c.problem))
             m = 1024
             sc, nc, okc, itc = Od.discrete_geodesic_batch(Pd, frm[:m].cpu().numpy(), to[:m].cpu().numpy(), first_pass, threads)
-            sg, ng = st[:m].cpu().numpy(), n[:m].cpu().numpy()
+            sg, ng, og, ig = st[:m].cpu().numpy(), n[:m].cpu().numpy(), gok[:m].cpu().numpy(), its[:m].cpu().numpy()
+            live = og != 2  # an edge suspended by the budget is compared through its continuation below
             same = all(np.array_equal(sg[e, : min(ng[e], first_pass)].view(np.uint64), sc[e, : min(nc[e], first_pass)].view(np.uint64))
-                       for e in range(m))
-            res["parity_vs_det_oracle"] = {"edges": m, "bit_identical": bool(same and np.array_equal(ng, nc)),
-                                           "flag_mismatches": int((gok[:m].cpu().numpy() != okc).sum()),
-                                           "iteration_mismatches": int((its[:m].cpu().numpy() != itc).sum())}
-            # a continued edge against the oracle's uninterrupted traversal (the longest one that is not the creeper)
-            cand = sorted(whole, key=lambda e: whole[e][0].shape[0])
-            cand = [e for e in cand if whole[e][0].shape[0] <= 256]
-            if cand:
-                e = cand[-1]
+                       for e in range(m) if live[e])
+            res["parity_vs_det_oracle"] = {"edges": int(live.sum()), "bit_identical": bool(same and np.array_equal(ng[live], nc[live])),
+                                           "flag_mismatches": int((og[live] != okc[live]).sum()),
+                                           "iteration_mismatches": int((ig[live] != itc[live]).sum())}
+            # continued edges against the oracle's uninterrupted traversal (all but the creeper: <= 256 states)
+            cand = [e for e in whole if whole[e][0].shape[0] <= 256]
+            okc_all = True
+            for e in cand:
                 okf, stf, itf = Od.discrete_geodesic(Pd, frm[e].cpu().numpy(), to[e].cpu().numpy(), interpolate=True, max_states=512)
-                res["parity_vs_det_oracle"]["continued_edge"] = {
-                    "states": int(stf.shape[0]), "bit_identical": bool(stf.shape == whole[e][0].shape and np.array_equal(
-                        np.ascontiguousarray(whole[e][0]).view(np.uint64), stf.view(np.uint64)) and bool(whole[e][1]) == okf and whole[e][2] == itf)}
+                okc_all = okc_all and bool(stf.shape == whole[e][0].shape and np.array_equal(
+                    np.ascontiguousarray(whole[e][0]).view(np.uint64), stf.view(np.uint64)) and bool(whole[e][1]) == okf and whole[e][2] == itf)
+            res["parity_vs_det_oracle"]["continued_edges"] = {"edges": len(cand), "bit_identical": bool(okc_all)}
         except Exception as e:
             res["parity_vs_det_oracle"] = {"error": repr(e)}
         return res

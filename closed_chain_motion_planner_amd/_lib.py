@@ -126,8 +126,8 @@ def lib():
         "ccmp_compute_t_wo_batch": ([vp, pp, vp, C.c_int, vp, C.c_size_t, vp], C.c_int),
         "ccmp_geodesic_batch": ([vp, pp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp], C.c_int),
         "ccmp_check_motion_batch": ([vp, pp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp], C.c_int),
-        "ccmp_geodesic_batch_ex": ([vp, pp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp], C.c_int),
-        "ccmp_geodesic_host_ex": ([vp, pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32), u8p, dp, dp, C.c_int], C.c_int),
+        "ccmp_geodesic_batch_ex": ([vp, pp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp], C.c_int),
+        "ccmp_geodesic_host_ex": ([vp, pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32), u8p, dp, dp, C.c_int, C.c_int], C.c_int),
         "ccmp_check_motion_host": ([vp, pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32), u8p], C.c_int),
         "ccmp_ambient_uniform_batch": ([vp, pp, C.c_uint64, C.c_uint64, vp, C.c_size_t, vp], C.c_int),
         "ccmp_enforce_bounds_batch": ([vp, vp, C.c_size_t, vp], C.c_int),

@@ -303,14 +303,17 @@ class KinematicChainConstraint:
                                                  out.data_ptr(), q.shape[0], _stream_handle(stream)), "ccmp_compute_t_wo_batch")
         return out
 
-    def discrete_geodesic_batch(self, frm, to, max_states=64, stream=None, check_target=False, carry_in=None, want_carry=False):
+    def discrete_geodesic_batch(self, frm, to, max_states=64, stream=None, check_target=False, carry_in=None, want_carry=False,
+                                round_budget=0):
         """`jy_ProjectedStateSpace::discreteGeodesic` for E edges (jy_ProjectedStateSpace.cpp:32-96), run as with
         interpolate == true.  Returns (states (E,max_states,14), n_states (E,), ok (E,), newton_iters (E,)) and, with
         want_carry, a fifth tensor carry (E,2).
         check_target: `checkMotion` in one launch — isSatisfied(to) && discreteGeodesic(from, to)
         (src/planner/stefanBiPRM.cpp:397-398); an edge whose target is not satisfied reports ok = 0, n_states = 1.
-        An edge with n_states == max_states + 1 did not fit: continue it with frm = its last stored state, the same to and
-        carry_in = its carry row (ccmp_geodesic_batch_ex) — `continue_geodesics` below does that until every list is whole."""
+        An edge did not reach its end when n_states == max_states + 1 (its list is full) or — with round_budget > 0, the
+        bound on the Newton rounds this call spends on one edge — when ok == 2: continue it with frm = its last stored
+        state, the same to and carry_in = its carry row (ccmp_geodesic_batch_ex); `continue_geodesics` below does that
+        until every list is whole."""
         self._need_problem()
         self._check_q(frm)
         self._check_q(to)
@@ -323,45 +326,56 @@ class KinematicChainConstraint:
         if carry_in is not None and not (isinstance(carry_in, torch.Tensor) and carry_in.is_cuda and carry_in.dtype == torch.float64
                                          and carry_in.is_contiguous() and tuple(carry_in.shape) == (E, 2)):
             raise ValueError("carry_in: contiguous (E,2) float64 CUDA tensor")
+        if round_budget and not want_carry:
+            raise ValueError("round_budget needs want_carry=True: a suspended edge is continued from its carry")
         carry = torch.empty((E, 2), dtype=torch.float64, device=frm.device) if want_carry else None
         check(_lib.lib().ccmp_geodesic_batch_ex(self.ctx.handle, C.byref(self.problem), frm.data_ptr(), to.data_ptr(), E, int(max_states),
                                                 states.data_ptr(), n.data_ptr(), ok.data_ptr(), its.data_ptr(),
                                                 carry_in.data_ptr() if carry_in is not None else None,
-                                                carry.data_ptr() if carry is not None else None, 1 if check_target else 0,
-                                                _stream_handle(stream)), "ccmp_geodesic_batch_ex")
+                                                carry.data_ptr() if carry is not None else None, int(round_budget),
+                                                1 if check_target else 0, _stream_handle(stream)), "ccmp_geodesic_batch_ex")
         return (states, n, ok, its, carry) if want_carry else (states, n, ok, its)
 
-    def continue_geodesics(self, to, states, n, ok, its, carry, max_states, max_rounds=1 << 20):
-        """Finishes the edges of a `discrete_geodesic_batch(..., want_carry=True)` result that did not fit
-        (n == max_states + 1), each from its last stored state.  Returns {edge index: (states (m,14) numpy, ok, newton
-        iterations)} with the complete list of every such edge — what one uninterrupted traversal produces, bit for bit."""
+    def continue_geodesics(self, to, states, n, ok, its, carry, max_states, round_budget=0, max_calls=1 << 20):
+        """Finishes the edges of a `discrete_geodesic_batch(..., want_carry=True)` result that did not reach their end
+        (list full: n == max_states + 1; round budget spent: ok == 2), each from its last stored state.  Returns {edge index:
+        (states (m,14) numpy, ok, newton iterations)} with the complete list of every such edge — what one uninterrupted
+        traversal produces, bit for bit."""
         torch = _torch()
-        long = torch.nonzero(n > max_states).flatten()
+        if max_states < 2:
+            raise ValueError("a continuation starts from a stored state other than `from`: max_states >= 2")
+        long = torch.nonzero((n > max_states) | (ok == 2)).flatten()
         out = {}
         if long.numel() == 0:
             return out
-        parts = {int(e): [states[e, :max_states].cpu().numpy()] for e in long.tolist()}
-        total_its = {int(e): int(its[e]) for e in long.tolist()}
-        cur_from = states[long, max_states - 1].contiguous()
+        stored = n.clamp(max=max_states)[long]  # states each of them holds
+        idx = long.tolist()
+        st_h, stored_h = states[long].cpu().numpy(), stored.cpu().tolist()
+        parts = {e: [st_h[k, : stored_h[k]]] for k, e in enumerate(idx)}
+        total_its = {e: int(v) for e, v in zip(idx, its[long].cpu().tolist())}
+        rows = torch.arange(len(idx), device=to.device)
+        cur_from = states[long][rows, (stored - 1).long()].contiguous()
         cur_to = to[long].contiguous()
         cur_carry = carry[long].contiguous()
-        idx = long.tolist()
-        for _ in range(max_rounds):
-            s2, n2, ok2, it2, c2 = self.discrete_geodesic_batch(cur_from, cur_to, max_states, carry_in=cur_carry, want_carry=True)
+        for _ in range(max_calls):
+            s2, n2, ok2, it2, c2 = self.discrete_geodesic_batch(cur_from, cur_to, max_states, carry_in=cur_carry, want_carry=True,
+                                                                round_budget=round_budget)
             n2c, ok2c, it2c = n2.cpu().numpy(), ok2.cpu().numpy(), it2.cpu().numpy()
+            s2h = s2.cpu().numpy()
             again = []
             for k, e in enumerate(idx):
                 m = min(int(n2c[k]), max_states)
-                parts[e].append(s2[k, 1:m].cpu().numpy())  # row 0 repeats the state the continuation started from
+                parts[e].append(s2h[k, 1:m])  # row 0 repeats the state the continuation started from
                 total_its[e] += int(it2c[k])
-                if n2c[k] > max_states:
+                if n2c[k] > max_states or ok2c[k] == 2:
                     again.append(k)
                 else:
                     out[e] = (np.concatenate(parts[e], axis=0), int(ok2c[k]), total_its[e])
             if not again:
                 break
             sel = torch.as_tensor(again, device=to.device)
-            cur_from = s2[sel, max_states - 1].contiguous()
+            last = (n2.clamp(max=max_states)[sel] - 1).long()
+            cur_from = s2[sel, last].contiguous()
             cur_to = cur_to[sel].contiguous()
             cur_carry = c2[sel].contiguous()
             idx = [idx[k] for k in again]

@@ -74,7 +74,7 @@ hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride,
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, hipStream_t st);
+                                const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -315,6 +315,9 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "clearance_per_state_max")) { // proxy clearance: one block per state up to this many states
     if (value < 0) return CCMP_EINVAL;
     ctx->clearance_per_state_max = (size_t)value;
+  } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the latency kernel / extend step per CU (8 resident)
+    if (value < 1 || value > 32) return CCMP_EINVAL;
+    ctx->latency_blocks_per_cu = (int)value;
   } else if (!strcmp(name, "geodesic_order")) { // extend step, batches beyond the resident blocks: 0 = index order, 1 = far-apart
     if (value < 0 || value > 2) return CCMP_EINVAL; // edges first, 2 = FP32 scout + longest-predicted-first (falls back to 1 below geodesic_scout_min)
     ctx->geodesic_order = (int)value;
@@ -402,7 +405,7 @@ static FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order)
   FdPlan pl;
   const int wpc = ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12;
   // latency kernels: the flat kernel runs 8 blocks of 128 threads per CU (16 waves), the one-wave kernel wpc waves
-  const size_t lat_cap = ctx->flat_kernel ? (size_t)ctx->num_cus * 8 : (size_t)ctx->num_cus * (size_t)wpc;
+  const size_t lat_cap = ctx->flat_kernel ? (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu : (size_t)ctx->num_cus * (size_t)wpc;
   const bool latency_only = ctx->wave_kernel == 2 || (ctx->wave_kernel == 1 && B <= ctx->small_batch);
   if (latency_only) {
     pl.latency_blocks = (int)(B < lat_cap ? B : lat_cap);
@@ -609,19 +612,20 @@ int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *
 
 static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                            double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, const double *carry_in,
-                           double *carry_out, int check_target, void *hip_stream)
+                           double *carry_out, int round_budget, int check_target, void *hip_stream)
 {
   CCMP_PROLOGUE();
   if (E == 0) return CCMP_OK;
-  if (!from || !to || !states || !n_states || !ok || max_states < 1) return CCMP_EINVAL;
+  if (!from || !to || !states || !n_states || !ok || max_states < 1 || round_budget < 0) return CCMP_EINVAL;
   if (!(p->delta > 0) || !(p->lambda > 0)) return CCMP_EINVAL;
   if (p->jacobian_mode != CCMP_JAC_FD) return CCMP_EINVAL; // the extend step exists in reference arithmetic only
   if (carry_in && check_target) return CCMP_EINVAL;        // a continuation's target was tested by the call it continues
+  if (round_budget > 0 && !carry_out) return CCMP_EINVAL;  // a suspended edge is useless without what its continuation needs
   // One 128-thread block per edge.  Up to the resident capacity (8 blocks per CU) every edge has its block at once and
   // the hardware dispatcher is the queue.  Beyond it the blocks are persistent and take tickets from an atomic word,
   // handed out through a long-edges-first order when the batch is large enough for the ordering pass to pay: the
   // launch then ends on short edges (16384 near-neighbour edges, 16-state lists: 3.15 -> 2.1 ms).
-  const size_t resident = (size_t)ctx->num_cus * 8;
+  const size_t resident = (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
   size_t nb = E;
   unsigned long long *queue = nullptr;
   const unsigned int *order = nullptr;
@@ -647,28 +651,28 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     }
   }
   HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target, (int)nb,
-                               queue, order, carry_in, carry_out, st));
+                               queue, order, carry_in, carry_out, round_budget, st));
   return CCMP_OK;
 }
 
 int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                         double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream)
 {
-  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, nullptr, nullptr, 0, hip_stream);
+  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, nullptr, nullptr, 0, 0, hip_stream);
 }
 
 int ccmp_check_motion_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                             double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream)
 {
-  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, nullptr, nullptr, 1, hip_stream);
+  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, nullptr, nullptr, 0, 1, hip_stream);
 }
 
 int ccmp_geodesic_batch_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                            double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, const double *carry_in,
-                           double *carry_out, int check_target, void *hip_stream)
+                           double *carry_out, int round_budget, int check_target, void *hip_stream)
 {
-  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, carry_in, carry_out, check_target,
-                         hip_stream);
+  return geodesic_common(ctx, p, from, to, E, max_states, states, n_states, ok, newton_iters, carry_in, carry_out, round_budget,
+                         check_target, hip_stream);
 }
 
 int ccmp_is_satisfied_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, uint8_t *ok, size_t B, void *hip_stream)
@@ -919,7 +923,7 @@ int ccmp_clearance_host(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *
 
 static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                                 double *states, int32_t *n_states, uint8_t *ok, const double *carry_in, double *carry_out,
-                                int check_target)
+                                int round_budget, int check_target)
 {
   if (!ctx || !p) return CCMP_EINVAL;
   if (E == 0) return CCMP_OK;
@@ -944,7 +948,7 @@ static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const doub
   rc = geodesic_common(ctx, p, (const double *)io.dev, (const double *)(io.dev + off_to), E, max_states, (double *)(io.dev + off_st),
                        (int32_t *)(io.dev + off_n), (uint8_t *)(io.dev + off_ok), nullptr,
                        carry_in ? (const double *)(io.dev + off_ci) : nullptr, carry_out ? (double *)(io.dev + off_co) : nullptr,
-                       check_target, ctx->stream);
+                       round_budget, check_target, ctx->stream);
   if (rc != CCMP_OK) return rc;
   if ((rc = io.out(states, off_st, sb)) != CCMP_OK) return rc;
   if ((rc = io.out(n_states, off_n, E * sizeof(int32_t))) != CCMP_OK) return rc;
@@ -956,20 +960,22 @@ static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const doub
 int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                        double *states, int32_t *n_states, uint8_t *ok)
 {
-  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, nullptr, nullptr, 0);
+  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, nullptr, nullptr, 0, 0);
 }
 
 int ccmp_check_motion_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                            double *states, int32_t *n_states, uint8_t *ok)
 {
-  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, nullptr, nullptr, 1);
+  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, nullptr, nullptr, 0, 1);
 }
 
 int ccmp_geodesic_host_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
-                          double *states, int32_t *n_states, uint8_t *ok, const double *carry_in, double *carry_out, int check_target)
+                          double *states, int32_t *n_states, uint8_t *ok, const double *carry_in, double *carry_out, int round_budget,
+                          int check_target)
 {
   if (carry_in && check_target) return CCMP_EINVAL;
-  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, carry_in, carry_out, check_target);
+  if (round_budget > 0 && !carry_out) return CCMP_EINVAL; // a suspended edge is useless without what its continuation needs
+  return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, carry_in, carry_out, round_budget, check_target);
 }
 
 static int sharded_common(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, int mode, const double *q_in, double *q_out,

@@ -81,6 +81,7 @@ struct ccmp_ctx {
   int analytic_split_pred = 90;          // predicted iterations from which a sample goes to the six-lane kernel
   hipStream_t side = nullptr;            // side stream of split launches
   hipEvent_t fork = nullptr, join = nullptr;
+  int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the latency kernel and the extend step per CU
   int geodesic_order = 2;                // extend step, batches beyond the resident blocks: 1 = far-apart edges first, 2 = FP32 scout order
   size_t geodesic_scout_min = 6144;      // ... the scout from this many edges on (below: the two-class order by distance)
   int geodesic_scout_rounds = 64;        // ... the scout stops an edge after this many Newton rounds (all such edges are "long");

@@ -270,6 +270,22 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
       __builtin_amdgcn_s_setprio(0);
 #endif
     }
+#ifdef CCMP_FLAT_PROBE_DUMMY
+    // probe (never in the product): wave 1 burns CCMP_FLAT_PROBE_DUMMY dependent-free FP64 instructions while it would wait
+    // for the solve — issue load without any effect on the block's critical path.  If the loaded throughput falls, the
+    // kernel is bound by issue slots; if it does not, by the latency of the rounds.
+    else {
+      // eight independent accumulators, multiplier and addend in registers: nothing but v_fma_f64, 4 cycles each
+      double a0 = f0, a1 = f1, a2 = f0 + 1.0, a3 = f1 + 1.0, a4 = f0 + 2.0, a5 = f1 + 2.0, a6 = f0 + 3.0, a7 = f1 + 3.0;
+      const double m = 1.0 + f0 * 1e-9, c0 = f1 * 1e-9;
+#pragma unroll
+      for (int k = 0; k < CCMP_FLAT_PROBE_DUMMY / 8; k++) {
+        a0 = CCMP_FMA(a0, m, c0); a1 = CCMP_FMA(a1, m, c0); a2 = CCMP_FMA(a2, m, c0); a3 = CCMP_FMA(a3, m, c0);
+        a4 = CCMP_FMA(a4, m, c0); a5 = CCMP_FMA(a5, m, c0); a6 = CCMP_FMA(a6, m, c0); a7 = CCMP_FMA(a7, m, c0);
+      }
+      if (((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) == 12345.678) rec[fV] = a0; // keeps the chain alive; never true
+    }
+#endif
     updates++;
     __syncthreads();
     FLAT_TICK(4);
@@ -387,6 +403,11 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
 // is then the distance of that state to the target, recomputed from the same operands as the value the first call held,
 // so first call + continuation produce the states, flags and counts of one uninterrupted traversal bit for bit.
 constexpr int gPrev = fRec, gTo = fRec + 14, gRec = fRec + 28;
+#ifdef CCMP_GEO_TRACE
+// per-edge timeline of one launch (tools/exp_r3.py geo_trace; never defined in the product build): start, end (100 MHz
+// wall clock), block
+__device__ unsigned long long g_geo_trace[3 * 65536];
+#endif
 
 // RealVectorStateSpace::distance over the 14 joints (plain Euclidean, KinematicChainSpace does not override it),
 // summed serially in the canonical order; every thread computes it from LDS.
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,
     unsigned long long *queue, const unsigned int *__restrict__ order, const double *__restrict__ carry_in,
-    double *__restrict__ carry_out)
+    double *__restrict__ carry_out, int round_budget)
 {
   __shared__ __attribute__((aligned(16))) double lds[gRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -433,6 +454,9 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     }
     if (tk >= E) break;
     const unsigned long long t = order ? (unsigned long long)order[tk] : tk;
+#ifdef CCMP_GEO_TRACE
+    if (tid == 0 && t < 65536) { g_geo_trace[3 * t] = wall_clock64(); g_geo_trace[3 * t + 2] = ((unsigned long long)blockIdx.x << 32) | tk; }
+#endif
     double *out = states + t * (unsigned long long)max_states * 14ull;
     if (tid < 14) {
       const double a = from[t * 14 + tid];
@@ -441,7 +465,8 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
       if (max_states > 0) out[tid] = a; // geodesic->push_back(cloneState(from))
     }
     __syncthreads();
-    int n = 1, its = 0;
+    int n = 1, its = 0, rounds = 0;
+    bool suspended = false; // the edge used up the call's budget of Newton rounds: it stops between two states (ok = 2)
     bool fits = true; // false: an accepted state found the list full — the edge stops there and reports max_states + 1
     bool target_ok = true;
     if (check_target) {
@@ -468,11 +493,19 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
       enter = dist >= delta;
     }
     if (target_ok && enter) {
+      // Between two projections every thread does the reference's bookkeeping for itself, in ONE pass over the 14 joints
+      // and without a barrier (round 3; before: jointValid through a ballot and two barriers, then the distances one
+      // after the other — per state about as long as a Newton round): jointValid(x), step = |previous - x| and
+      // newDist = |x - to| are accumulated side by side (two independent serial sums, the canonical order each), the
+      // tests then run in the reference's order.  The joints' owners (tid < 14) keep x, previous and to in registers and
+      // write the next interpolated state themselves: two block barriers per state instead of five.
+      double x_own = 0.0, to_own = 0.0; // this thread's joint of the accepted state / of the target (tid < 14)
+      if (tid < 14) { x_own = rec[gPrev + tid]; to_own = rec[gTo + tid]; }
       for (int guard = 0; guard < 1000000; guard++) { // the reference loop ends by itself; guard bounds a non-finite input
         if (tid < 14) { // WrapperStateSpace::interpolate(previous, to, delta_ / dist, scratch)
           const double tt = delta / dist;
-          const double fr = rec[gPrev + tid];
-          double diff = rec[gTo + tid] - fr, v;
+          const double fr = x_own;
+          double diff = to_own - fr, v;
           if (ccmp_abs(diff) <= pi) v = CCMP_FMA(diff, tt, fr);
           else {
             if (diff > 0.0) diff = 2.0 * pi - diff;
@@ -482,42 +515,63 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
             else if (v < -pi) v += 2.0 * pi;
           }
           rec[fX + tid] = v;
+          rec[gPrev + tid] = fr; // previous := the accepted state (unchanged on the first pass)
         }
         __syncthreads();
         int iter = 0, updates = 0;
         double norm1 = 0.0, norm2 = 0.0;
         const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2, K.max_iter);
-        const bool jv = flat_joint_valid(KL, rec, tid);
         its += updates;
+        rounds += updates + 1;
+        // flat_newton leaves through a block barrier behind which nobody writes x any more: every thread reads the final
+        // iterate, previous and the target straight from LDS
+        bool jv = true;
+        double s_acc = 0.0, d_acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+          const double xi = rec[fX + i];
+          const int jj = i < 7 ? i : i - 7;
+          if (xi < K.lbe[jj]) jv = false; // KinematicChainConstraint::jointValid (ConstraintFunction.h:43-55)
+          if (xi > K.ube[jj]) jv = false;
+          const double ds = rec[gPrev + i] - xi, dd = xi - rec[gTo + i];
+          s_acc = CCMP_FMA(ds, ds, s_acc); // distance(previous, scratch)
+          d_acc = CCMP_FMA(dd, dd, d_acc); // distance(scratch, to)
+        }
         if (!(conv && jv)) break;                        // not on manifold
-        const double step = lds_distance(rec + gPrev, rec + fX);
+        const double step = ccmp_sqrt(s_acc), newDist = ccmp_sqrt(d_acc);
         if (step > lambda * delta) break;                // deviated
         total_before = total;
         total += step;
         if (total > maxd) break;                         // wandered too far
-        const double newDist = lds_distance(rec + fX, rec + gTo);
         if (newDist >= dist) break;                      // no closer than before
         // an edge that creeps (hundreds of accepted states, each a hair closer: seen at 1 in 16384 near-neighbour edges,
         // 952 states) must not hold the whole launch: when the list is full the edge stops and says so
         // (its running length and Newton count go back to what they were before this state: a continuation projects it again)
         if (n >= max_states) { fits = false; n = max_states + 1; total = total_before; its -= updates; break; }
         dist = newDist;
-        __syncthreads();
         if (tid < 14) {
-          const double v = rec[fX + tid];
-          rec[gPrev + tid] = v;
-          out[(unsigned long long)n * 14ull + tid] = v;
+          x_own = rec[fX + tid];
+          out[(unsigned long long)n * 14ull + tid] = x_own;
         }
         n++;
-        __syncthreads();
         if (!(dist >= delta)) break;
+        // A call bounds the serial work it spends on one edge: past round_budget Newton rounds the edge stops HERE — between
+        // two states, where the reference's do-while has just found dist >= delta — and reports ok = 2; a continuation
+        // from its last stored state with carry_out goes on exactly where this one stops (nothing is projected twice).
+        // 16 384 near-neighbour edges, lists of 16: everything but one edge is through after 1.46 ms, that one creeping
+        // edge needs 545 rounds for its 15 states and held the launch until 2.1 ms (profiles/r03_extend_timeline.log).
+        if (round_budget > 0 && rounds >= round_budget) { suspended = true; break; }
+        __syncthreads(); // everybody has read x and previous: their owners may overwrite them (top of the loop)
       }
     }
     if (tid == 0) {
       n_states[t] = n;
-      ok_out[t] = (uint8_t)(target_ok && fits && dist <= delta);
+      ok_out[t] = suspended ? (uint8_t)2 : (uint8_t)(target_ok && fits && dist <= delta);
       if (newton_iters) newton_iters[t] = its;
       if (carry_out) { carry_out[2 * t] = total; carry_out[2 * t + 1] = maxd; }
+#ifdef CCMP_GEO_TRACE
+      if (t < 65536) g_geo_trace[3 * t + 1] = wall_clock64();
+#endif
     }
     __syncthreads();
     if (!queue) tk += gridDim.x;
@@ -588,14 +642,14 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, hipStream_t st)
+                                const double *carry_in, double *carry_out, int round_budget, hipStream_t st)
 {
   if (K->stock)
     hipLaunchKernelGGL(geodesic_flat_kernel<true>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget);
   else
     hipLaunchKernelGGL(geodesic_flat_kernel<false>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget);
   return hipGetLastError();
 }
 
@@ -607,6 +661,13 @@ hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size
                      long_dist * long_dist, counters, order);
   return hipGetLastError();
 }
+
+#ifdef CCMP_GEO_TRACE
+hipError_t ccmp_debug_geo_trace(unsigned long long *out, size_t n_edges)
+{
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_geo_trace), 3 * n_edges * sizeof(unsigned long long));
+}
+#endif
 
 #ifdef CCMP_FLAT_TIMING
 hipError_t ccmp_debug_flat_timing(unsigned long long *out8, int reset)

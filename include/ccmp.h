@@ -189,16 +189,21 @@ int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *
  * interpolate == false the host truncates at the first state its StateValidityChecker rejects. */
 int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                         double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream);
-/* The same, resumable.  carry_out (nullable, [E][2]) receives what a continuation of an edge that did not fit needs — the
- * running length before the step that found the list full and the bound lambda * dist(from, to).  A later call with
- * from[e] = the edge's last stored state (states[e][max_states - 1]), the same to[e] and carry_in[e] = that carry_out[e]
- * goes on where the first one stopped: its list starts with that state again (drop it when joining the lists) and
- * first call + continuations give the states, flags and Newton counts of one uninterrupted traversal, bit for bit — the
- * 952-state creeping edge costs its own serial chain once instead of a re-run per enlargement.  check_target as in
- * ccmp_check_motion_batch (not together with carry_in: the target was tested by the call being continued). */
+/* The same, resumable.  carry_out (nullable, [E][2]) receives what a continuation needs: the running length and the
+ * bound lambda * dist(from, to).  An edge can stop short of its end in two ways, and either way a later call with
+ * from[e] = its last stored state, the same to[e] and carry_in[e] = that carry_out[e] goes on where it stopped (its list
+ * starts with that state again: drop it when joining the lists); first call + continuations give the states, flags and
+ * Newton counts of ONE uninterrupted traversal, bit for bit:
+ *   - its list is full: n_states[e] = max_states + 1, ok[e] = 0, last stored state = states[e][max_states - 1];
+ *   - round_budget > 0 and the edge has spent that many Newton rounds (Jacobian evaluations) in this call: it stops between
+ *     two states, ok[e] = 2, n_states[e] = the states stored so far (last stored state = states[e][n_states[e] - 1]).
+ * A call thereby bounds the serial work it spends on any one edge — one edge in 16 384 near-neighbour edges creeps (952
+ * states, 12 379 Newton rounds) and two dozen need more than 128 rounds; without a bound a launch lasts as long as its
+ * longest edge.  round_budget = 0: no bound (ok is 0 / 1 only).  check_target as in ccmp_check_motion_batch (not together
+ * with carry_in: the target was tested by the call being continued). */
 int ccmp_geodesic_batch_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                            double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, const double *carry_in,
-                           double *carry_out, int check_target, void *hip_stream);
+                           double *carry_out, int round_budget, int check_target, void *hip_stream);
 /* OMPL ConstrainedMotionValidator::checkMotion as the reference's planner calls it (src/planner/stefanBiPRM.cpp:397-398,
  * 463-464; jy_MotionValidator, jy_ProjectedStateSpace.h:57-69): isSatisfied(to) && discreteGeodesic(from, to) in ONE
  * launch — same outputs as ccmp_geodesic_batch, except that an edge whose target fails isSatisfied reports ok = 0 and
@@ -237,7 +242,8 @@ int ccmp_geodesic_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from,
 int ccmp_check_motion_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                            double *states, int32_t *n_states, uint8_t *ok);
 int ccmp_geodesic_host_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
-                          double *states, int32_t *n_states, uint8_t *ok, const double *carry_in, double *carry_out, int check_target);
+                          double *states, int32_t *n_states, uint8_t *ok, const double *carry_in, double *carry_out, int round_budget,
+                          int check_target);
 
 /* ---- one process, several GPUs (the reference's planner is a single process) ------------------------- */
 /* Contiguous shards of the batch go to the n contexts (1 <= n <= 64, one per device; the same device may appear twice),

@@ -269,7 +269,7 @@ inline void discreteGeodesicBatch(const Projector &proj, const double *from, con
     pb = proj.problem();
     if (delta > 0) pb.delta = delta;
     if (lambda > 0) pb.lambda = lambda;
-    check(ccmp_geodesic_host_ex(proj.ctx(), &pb, from, to, E, max_states, states.data(), n.data(), ok.data(), nullptr, carry.data(),
+    check(ccmp_geodesic_host_ex(proj.ctx(), &pb, from, to, E, max_states, states.data(), n.data(), ok.data(), nullptr, carry.data(), 0,
                                 check_target ? 1 : 0),
           "ccmp_geodesic_host_ex");
   }
@@ -305,7 +305,7 @@ inline void discreteGeodesicBatch(const Projector &proj, const double *from, con
       double cr_out[2];
       {
         std::lock_guard<std::mutex> hold(proj.mutex());
-        check(ccmp_geodesic_host_ex(proj.ctx(), &pb, last.data(), to_e, 1, max_states, more.data(), &ne, &oke, cr, cr_out, 0),
+        check(ccmp_geodesic_host_ex(proj.ctx(), &pb, last.data(), to_e, 1, max_states, more.data(), &ne, &oke, cr, cr_out, 0, 0),
               "ccmp_geodesic_host_ex(continue)");
       }
       cr[0] = cr_out[0];

@@ -54,7 +54,8 @@ def test_bench_line_contract():
     g = sec["discrete_geodesic"]  # the complete operation is timed, overflowing edges are counted
     assert set(g) >= {"edges_per_s", "overflowed_edges", "complete_ms", "complete_edges_per_s", "growtree_5_edges_ms", "max_states_first_pass"}
     assert g["parity_vs_det_oracle"]["bit_identical"] is True and g["overflowed_edges"] < 0.01 * g["edges"]
-    assert g["parity_vs_det_oracle"].get("continued_edge", {"bit_identical": True})["bit_identical"] is True
+    assert g["parity_vs_det_oracle"]["continued_edges"]["bit_identical"] is True and g["parity_vs_det_oracle"]["continued_edges"]["edges"] >= 1
+    assert g["overflowed_edges"] == g["overflowed_list_full"] + g["overflowed_budget_spent"] and g["ms_unbounded_rounds"] > 0
 
 
 def _run_bench(*argv, env=None, timeout=600):

@@ -384,6 +384,21 @@ def test_geodesic_continuation_is_the_uninterrupted_traversal(gpu_ctx, oracle_de
         assert bool(ok_e) == ok_cpu and its_e == its_cpu, e
     with pytest.raises(Exception):  # a continuation's target was tested by the call it continues
         c.discrete_geodesic_batch(f, t, cap, check_target=True, carry_in=carry)
+    # the other way an edge stops short: the call's budget of Newton rounds (ok == 2, between two states) — lists of 8,
+    # 12 rounds per call; suspended and overflowing edges continued under the same budget until they are whole
+    cap, budget = 8, 12
+    st, n, ok, its, carry = c.discrete_geodesic_batch(f, t, cap, want_carry=True, round_budget=budget)
+    assert int((ok == 2).sum()) >= 10 and int(((ok == 2) & (n > cap)).sum()) == 0  # a suspended list is never also "full"
+    whole = c.continue_geodesics(t, st, n, ok, its, carry, cap, round_budget=budget)
+    st, n, ok, its = st.cpu().numpy(), n.cpu().numpy(), ok.cpu().numpy(), its.cpu().numpy()
+    assert set(whole) == set(np.nonzero((n > cap) | (ok == 2))[0].tolist())
+    for e in range(len(frm)):
+        ok_cpu, st_cpu, its_cpu = oracle_det.discrete_geodesic(P, frm[e], to[e], interpolate=True, max_states=512)
+        got, ok_e, its_e = whole[e] if e in whole else (st[e, : n[e]], int(ok[e]), int(its[e]))
+        assert got.shape == st_cpu.shape and np.array_equal(np.ascontiguousarray(got).view(np.uint64), st_cpu.view(np.uint64)), e
+        assert ok_e in (0, 1) and bool(ok_e) == ok_cpu and its_e == its_cpu, e
+    with pytest.raises(Exception):  # a budget without the carry a continuation needs
+        c.discrete_geodesic_batch(f, t, cap, round_budget=budget)
 
 
 def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):

@@ -230,5 +230,73 @@ def handover():
 
 
 
+
+
+def blocks_per_cu():
+    """persistent blocks of the latency kernel per CU: extend step and projector at loaded sizes"""
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    frm, to = near_edges(c, 16384)
+    q4, q16 = c.ambient_uniform_batch(0xC2, 0, 4096), c.ambient_uniform_batch(0xC2, 0, 10240)
+    o4, o16 = torch.empty_like(q4), torch.empty_like(q16)
+    for k in (2, 3, 4, 5, 6, 7, 8, 10, 12, 16):
+        ctx.set_option("latency_blocks_per_cu", k)
+        g = min(timed(lambda: c.discrete_geodesic_batch(frm, to, 16), reps=5) for _ in range(2))
+        a = min(timed(lambda: c.project_batch(q4, out=o4), reps=5) for _ in range(2))
+        b = min(timed(lambda: c.project_batch(q16, out=o16), reps=5) for _ in range(2))
+        print("blocks per CU %2d: 16384 edges %.3f ms | 4096 samples %.3f ms | 10240 samples %.3f ms" % (k, g, a, b), flush=True)
+    ctx.set_option("latency_blocks_per_cu", 8)
+
+
+
+
+
+
+def geo_trace():
+    """timeline of a 16384-edge extend-step launch (variant B built with -DCCMP_GEO_TRACE for the flat unit)"""
+    import os
+    from closed_chain_motion_planner_amd import load_config
+    LB = C.CDLL(os.path.join("closed_chain_motion_planner_amd", "lib", "libccmp_B.so"))
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    vp = C.c_void_p
+    h = C.c_void_p()
+    LB.ccmp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    assert LB.ccmp_ctx_create(0, C.byref(h)) == 0
+    LB.ccmp_geodesic_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp]
+    LB.ccmp_debug_geo_trace.argtypes = [vp, C.c_size_t]
+    LB.ccmp_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    P = c.problem
+    for E, cap in ((16384, 16), (16384, 64)):
+        frm, to = near_edges(c, E)
+        states = torch.empty((E, cap, 14), dtype=torch.float64, device=frm.device)
+        nn = torch.empty(E, dtype=torch.int32, device=frm.device)
+        ok = torch.empty(E, dtype=torch.uint8, device=frm.device)
+        it = torch.empty(E, dtype=torch.int32, device=frm.device)
+        s = torch.cuda.current_stream().cuda_stream
+        for order in (2, 0):
+            LB.ccmp_ctx_set_option(h, b"geodesic_order", order)
+            for _ in range(3):
+                assert LB.ccmp_geodesic_batch(h, C.byref(P), frm.data_ptr(), to.data_ptr(), E, cap, states.data_ptr(), nn.data_ptr(), ok.data_ptr(), it.data_ptr(), s) == 0
+            torch.cuda.synchronize()
+            tr = np.zeros(3 * E, dtype=np.uint64)
+            assert LB.ccmp_debug_geo_trace(tr.ctypes.data, E) == 0
+            tr = tr.reshape(E, 3)
+            t0 = tr[:, 0].min()
+            start, end = (tr[:, 0] - t0).astype(np.float64) / 100.0, (tr[:, 1] - t0).astype(np.float64) / 100.0  # us
+            rounds = (it + nn.clamp(max=cap) - 1).cpu().numpy().astype(np.float64)
+            dur = end - start
+            last = np.argsort(-end)[:12]
+            print("E=%d lists of %d order %d: launch spans %.0f us; edges finishing last:" % (E, cap, order, end.max()))
+            for e in last:
+                print("   edge %5d ticket %5d block %4d start %7.1f end %7.1f us rounds %4d -> %.2f us per round" % (e, int(tr[e, 2] & 0xffffffff), int(tr[e, 2] >> 32), start[e], end[e], rounds[e], dur[e] / max(1.0, rounds[e])))
+            for lo, hi in ((0, 200), (200, 500), (500, 1000), (1000, 1500), (1500, 2000), (2000, 3000), (3000, 1e9)):
+                m = (start >= lo) & (start < hi)
+                busy = ((start < hi) & (end > lo)).sum()
+                if m.sum() or busy:
+                    rr = dur[m] / np.maximum(1.0, rounds[m]) if m.sum() else np.zeros(1)
+                    print("   window %5.0f-%5.0f us: %5d edges start, %5d in flight at some point, median us per round of those starting %.2f" % (lo, min(hi, end.max()), m.sum(), busy, np.median(rr)))
+
+
 if __name__ == "__main__":
     globals()[sys.argv[1]]()
