@@ -163,6 +163,9 @@ def ab_latency():
         L.ccmp_project_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         L.ccmp_geodesic_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp]
         L.ccmp_project_host.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t]
+        L.ccmp_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+        if name == "B" and os.environ.get("AB_B_BLOCKS"):  # variant B with another number of persistent blocks per CU
+            assert L.ccmp_ctx_set_option(h, b"latency_blocks_per_cu", int(os.environ["AB_B_BLOCKS"])) == 0
         H[name] = (L, h)
     s = torch.cuda.current_stream().cuda_stream
     res = {}
@@ -180,7 +183,7 @@ def ab_latency():
         same = torch.equal(states["A"][:, :4], states["B"][:, :4])
         print("geodesic E=%d cap=%d: A %.3f ms  B %.3f ms  (B/A %.3f) same %s" % (E, cap, statistics.median(ts["A"]), statistics.median(ts["B"]),
               statistics.median(ts["B"]) / statistics.median(ts["A"]), same), flush=True)
-    for B in (1, 256, 4096, 16384):
+    for B in (1, 256, 4096, 10240, 16384, 32768):
         q = c.ambient_uniform_batch(0xC2, 0, B)
         out = {n: torch.empty_like(q) for n in H}
         ok = torch.empty(B, dtype=torch.uint8, device=q.device)

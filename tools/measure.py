@@ -12,7 +12,7 @@
     python tools/measure.py soak                            25 repeats of the default policy, outputs compared bit for bit
     python tools/measure.py scout                           FP32 scout's predictions against the true iteration counts
     python tools/measure.py run <workload> [reps]           a fixed workload for rocprofv3 (tools/profile.sh):
-                                                           c3 | flat4096 | flat1 | geodesic | analytic | stefan | clearance
+                                                           c3 | flat4096 | mid<B> | flat1 | geodesic | analytic | stefan | clearance
 """
 import ctypes as C
 import sys
@@ -334,6 +334,9 @@ def run(argv):
         fn = lambda: c.project_batch(q)
     elif what == "flat4096":
         q = c.ambient_uniform_batch(0xC2, 0, 4096)
+        fn = lambda: c.project_batch(q)
+    elif what.startswith("mid"):  # mid32768, mid65536 ...: scout + throughput kernel + hand-over to the latency kernel
+        q = c.ambient_uniform_batch(0xC3, 0, int(what[3:]))
         fn = lambda: c.project_batch(q)
     elif what == "flat1":
         x = c.ambient_uniform_batch(0xC1, 0, 64).cpu().numpy()
