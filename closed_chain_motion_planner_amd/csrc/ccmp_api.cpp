@@ -40,7 +40,8 @@ hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st);
 hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                      uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                      unsigned long long seed, unsigned long long first, int nblocks, double *pool,
-                                     int dump_threshold, const unsigned int *order, hipStream_t st);
+                                     int dump_threshold, const unsigned int *order, const uint16_t *pred, int long_remaining,
+                                     size_t pool_records, hipStream_t st);
 hipError_t ccmp_launch_project_wave(const ccmp_consts *K, int src, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
@@ -49,7 +50,7 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
-                                    unsigned int done_seq, hipStream_t st);
+                                    unsigned int done_seq, size_t pool_records, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
@@ -318,6 +319,9 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the latency kernel / extend step per CU (8 resident)
     if (value < 1 || value > 32) return CCMP_EINVAL;
     ctx->latency_blocks_per_cu = (int)value;
+  } else if (!strcmp(name, "pool_long_remaining")) { // hand-over: samples predicted to need this many more iterations go first (0 = one class)
+    if (value < 0 || value > 1000) return CCMP_EINVAL;
+    ctx->pool_long_remaining = (int)value;
   } else if (!strcmp(name, "geodesic_order")) { // extend step, batches beyond the resident blocks: 0 = index order, 1 = far-apart
     if (value < 0 || value > 2) return CCMP_EINVAL; // edges first, 2 = FP32 scout + longest-predicted-first (falls back to 1 below geodesic_scout_min)
     ctx->geodesic_order = (int)value;
@@ -514,13 +518,13 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   const FdPlan pl = plan_fd_batch(ctx, B, ctx->order != nullptr);
   // queue[0]: sample queue of the throughput kernel; queue[1]: pool fill count; queue[2]: read head of the latency kernel
   unsigned long long *const q_group = ctx->queue, *const q_pool_count = ctx->queue + 1, *const q_latency = ctx->queue + 2;
-  if (!pl.latency_static) HIP_TRY(ccmp_launch_clear_words(ctx->queue, 8, st)); // four 64-bit words
+  if (!pl.latency_static) HIP_TRY(ccmp_launch_clear_words(ctx->queue, 16, st)); // the eight 64-bit words of this path (6: pool count from the back)
 
   if (pl.group_blocks == 0) { // small batches and single states
     if (ctx->flat_kernel) {
       unsigned int *flag = arm_done_word(ctx, B);
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
-                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, st));
+                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, st));
     }
     else
       HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count,
@@ -544,12 +548,17 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     int rc = ensure_pool(ctx, (size_t)pl.group_blocks * 10);
     if (rc != CCMP_OK) return rc;
   }
+  // hand-over in two classes (scout's prediction minus the iterations done): the pool is filled from both ends and the
+  // latency kernel takes the long samples first; only with the scout's predictions and the default latency kernel
+  const uint16_t *pred = (pl.scout && pl.handover && ctx->flat_kernel && ctx->pool_long_remaining > 0) ? (const uint16_t *)ctx->lpt_buf : nullptr;
+  const size_t pool_records = pred ? (size_t)pl.group_blocks * 10 : 0;
   HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_group, seed, first, pl.group_blocks,
-                                    pl.handover ? ctx->pool : nullptr, pl.dump_threshold, order, st));
+                                    pl.handover ? ctx->pool : nullptr, pl.dump_threshold, order, pred, ctx->pool_long_remaining, pool_records,
+                                    st));
   if (pl.handover) { // the pool's fill count is read on the device: the latency kernel's surplus blocks exit at once
     if (ctx->flat_kernel)
       HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
-                                       pl.latency_blocks, nullptr, 0, st));
+                                       pl.latency_blocks, nullptr, 0, pool_records, st));
     else
       HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
                                        pl.latency_blocks, st));

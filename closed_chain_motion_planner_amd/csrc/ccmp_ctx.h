@@ -81,6 +81,10 @@ struct ccmp_ctx {
   int analytic_split_pred = 90;          // predicted iterations from which a sample goes to the six-lane kernel
   hipStream_t side = nullptr;            // side stream of split launches
   hipEvent_t fork = nullptr, join = nullptr;
+  int pool_long_remaining = 24;          // hand-over with scout predictions: samples with >= this many predicted iterations left go to the
+                                         // front of the pool and are taken first by the latency kernel (0 = one class).  Wine_Bottle, ms,
+                                         // one class | 16 | 24 | 32 | 48 | 64: 28672: 2.83 | 2.62 | 2.42 | 2.41 | 2.44 | 2.78; 32768: 3.18 |
+                                         // 2.88 | 2.71 | 2.73 | 2.74 | 3.01; 40960: 3.44 | 3.31 | 3.28 | 3.27 | 3.38 | 3.47; >= 49152 and stefan: +-2 %
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the latency kernel and the extend step per CU
   int geodesic_order = 2;                // extend step, batches beyond the resident blocks: 1 = far-apart edges first, 2 = FP32 scout order
   size_t geodesic_scout_min = 6144;      // ... the scout from this many edges on (below: the two-class order by distance)

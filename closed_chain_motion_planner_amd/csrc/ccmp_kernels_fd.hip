@@ -334,7 +334,8 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, double *__restrict__ pool, unsigned long long *pool_count,
-    int dump_threshold, const unsigned int *__restrict__ order)
+    int dump_threshold, const unsigned int *__restrict__ order, const uint16_t *__restrict__ pred, int long_remaining,
+    unsigned long long pool_records)
 {
   __shared__ double lds[kGroupsPerWave * kRec];
   const int lane = threadIdx.x;
@@ -425,9 +426,25 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     }
     if (pool != nullptr && dry &&
         __builtin_popcountll(__builtin_amdgcn_ballot_w64(active && r == 0)) <= dump_threshold) {
-      unsigned long long slot = 0;
-      if (active && r == 0) slot = atomicAdd(pool_count, 1ull);
-      slot = shfl_u64(slot, leader);
+      // Two classes (round 3): samples the scout predicts to need long_remaining or more further iterations fill the pool
+      // from the front, the others from the back, and the latency kernel takes the front first — the hand-over's longest
+      // samples start at once instead of wherever the order of the dumps put them (a 200-round sample that started one
+      // millisecond into the latency kernel's two was the end of a 32768-sample batch).  One reservation per wavefront
+      // and class.  pool_records == 0: one class, filled from the front.
+      bool is_long = true;
+      if (pool_records != 0ull) is_long = active && pred != nullptr && (int)pred[idx] - iter >= long_remaining;
+      const unsigned long long mL = __builtin_amdgcn_ballot_w64(active && r == 0 && is_long);
+      const unsigned long long mS = __builtin_amdgcn_ballot_w64(active && r == 0 && !is_long);
+      unsigned long long bL = 0, bS = 0;
+      if (lane == 0) {
+        if (mL) bL = atomicAdd(pool_count, (unsigned long long)__builtin_popcountll(mL));
+        if (mS) bS = atomicAdd(pool_count + 5, (unsigned long long)__builtin_popcountll(mS));
+      }
+      bL = shfl_u64(bL, 0);
+      bS = shfl_u64(bS, 0);
+      const unsigned long long below = (1ull << leader) - 1ull;
+      const unsigned long long slot = is_long ? bL + (unsigned long long)__builtin_popcountll(mL & below)
+                                              : pool_records - 1ull - (bS + (unsigned long long)__builtin_popcountll(mS & below));
       if (active) {
         double *ent = pool + slot * kPoolEntry;
         for (int e = r; e < 14; e += kGroup) ent[e] = rec[kX + e];
@@ -766,12 +783,14 @@ hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st)
 hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                      uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
                                      unsigned long long seed, unsigned long long first, int nblocks, double *pool,
-                                     int dump_threshold, const unsigned int *order, hipStream_t st)
+                                     int dump_threshold, const unsigned int *order, const uint16_t *pred, int long_remaining,
+                                     size_t pool_records, hipStream_t st)
 {
-  // queue[0]: sample queue of this kernel; queue[1]: pool fill count
+  // queue[0]: sample queue of this kernel; queue[1]: pool fill count (front); queue[6]: pool fill count from the back
 #define CCMP_LAUNCH_GROUP(MODE, STOCK)                                                                                        \
   hipLaunchKernelGGL((project_fd_kernel<MODE, STOCK>), dim3(nblocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
-                     (unsigned long long)B, queue, seed, first, pool, queue + 1, dump_threshold, order)
+                     (unsigned long long)B, queue, seed, first, pool, queue + 1, dump_threshold, order, pred, long_remaining, \
+                     (unsigned long long)pool_records)
   if (mode == 0) {
     if (K->stock && K->twin_arms) CCMP_LAUNCH_GROUP(0, true);
     else CCMP_LAUNCH_GROUP(0, false);

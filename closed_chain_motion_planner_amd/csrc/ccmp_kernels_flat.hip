@@ -10,6 +10,11 @@ using namespace ccmp;
 namespace {
 
 constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
+#ifdef CCMP_GEO_TRACE
+// per-edge / per-sample timeline of one launch (tools/exp_r3.py geo_trace, flat_trace; never defined in the product build):
+// start, end (100 MHz wall clock), block << 32 | ticket
+__device__ unsigned long long g_geo_trace[3 * 65536];
+#endif
 #ifndef CCMP_FLAT_MIN_WAVES
 #define CCMP_FLAT_MIN_WAVES 4 // waves per SIMD the register budget must allow (A/B: -DCCMP_FLAT_MIN_WAVES=2)
 #endif
@@ -317,7 +322,8 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
     const ccmp_consts K, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
-    const unsigned long long *__restrict__ pool_count, int wrap_output, unsigned int *done_flag, unsigned int done_seq)
+    const unsigned long long *__restrict__ pool_count, int wrap_output, unsigned int *done_flag, unsigned int done_seq,
+    unsigned long long pool_records)
 {
   __shared__ __attribute__((aligned(16))) double lds[fRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -332,7 +338,10 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
   __syncthreads();
   const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
   double *rec = lds;
-  const unsigned long long total = (SRC == 2) ? *pool_count : B;
+  // the pool is filled from both ends (ccmp_kernels_fd.hip): pool_count[0] records predicted long at the front — taken
+  // first — and pool_count[5] others from the back (pool_records == 0: front only)
+  const unsigned long long n_front = (SRC == 2) ? pool_count[0] : 0ull;
+  const unsigned long long total = (SRC == 2) ? n_front + (pool_records ? pool_count[5] : 0ull) : B;
   unsigned long long t = blockIdx.x;
 
   for (;;) {
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
     int iter = 0, updates = 0;
     double norm1 = 0.0, norm2 = 0.0;
     if (SRC == 2) {
-      const double *ent = pool + t * kPoolEntry;
+      const double *ent = pool + (t < n_front ? t : pool_records - 1ull - (t - n_front)) * kPoolEntry;
       idx = (unsigned long long)__double_as_longlong(ent[14]);
       iter = __double2hiint(ent[15]);
       updates = __double2loint(ent[15]);
@@ -366,7 +375,14 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
       }
     }
     __syncthreads();
+#ifdef CCMP_GEO_TRACE
+    const int updates_in = updates;
+    if (tid == 0 && t < 65536) { g_geo_trace[3 * t] = wall_clock64(); g_geo_trace[3 * t + 2] = ((unsigned long long)blockIdx.x << 32) | (unsigned)updates_in; }
+#endif
     const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2, K.max_iter);
+#ifdef CCMP_GEO_TRACE
+    if (tid == 0 && t < 65536) { g_geo_trace[3 * t + 1] = wall_clock64(); g_geo_trace[3 * t + 2] |= (unsigned long long)(unsigned)(updates - updates_in) << 16; }
+#endif
     const bool jv = flat_joint_valid(KL, rec, tid);
     if (tid < 14) {
       const double v = rec[fX + tid];
@@ -403,11 +419,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
 // is then the distance of that state to the target, recomputed from the same operands as the value the first call held,
 // so first call + continuation produce the states, flags and counts of one uninterrupted traversal bit for bit.
 constexpr int gPrev = fRec, gTo = fRec + 14, gRec = fRec + 28;
-#ifdef CCMP_GEO_TRACE
-// per-edge timeline of one launch (tools/exp_r3.py geo_trace; never defined in the product build): start, end (100 MHz
-// wall clock), block
-__device__ unsigned long long g_geo_trace[3 * 65536];
-#endif
+
 
 // RealVectorStateSpace::distance over the 14 joints (plain Euclidean, KinematicChainSpace does not override it),
 // summed serially in the canonical order; every thread computes it from LDS.
@@ -619,12 +631,13 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
-                                    unsigned int done_seq, hipStream_t st)
+                                    unsigned int done_seq, size_t pool_records, hipStream_t st)
 {
   if (nblocks != 1) done_flag = nullptr; // the completion word is written by the one block of a single-state call
 #define CCMP_LAUNCH_FLAT(SRC, STOCK)                                                                                             \
   hipLaunchKernelGGL((project_fd_flat_kernel<SRC, STOCK>), dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
-                     (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output, done_flag, done_seq)
+                     (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output, done_flag, done_seq, \
+                     (unsigned long long)pool_records)
   if (src == 0) {
     if (K->stock) CCMP_LAUNCH_FLAT(0, true);
     else CCMP_LAUNCH_FLAT(0, false);

@@ -301,5 +301,98 @@ def geo_trace():
                     print("   window %5.0f-%5.0f us: %5d edges start, %5d in flight at some point, median us per round of those starting %.2f" % (lo, min(hi, end.max()), m.sum(), busy, np.median(rr)))
 
 
+
+
+def flat_trace():
+    """timeline of the latency kernel's part of a mid-size projection (variant B built with -DCCMP_GEO_TRACE): per pool
+    ticket start / end and the rounds it ran"""
+    import os
+    LB = C.CDLL(os.path.join("closed_chain_motion_planner_amd", "lib", "libccmp_B.so"))
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    vp = C.c_void_p
+    h = C.c_void_p()
+    LB.ccmp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    assert LB.ccmp_ctx_create(0, C.byref(h)) == 0
+    LB.ccmp_project_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    LB.ccmp_debug_geo_trace.argtypes = [vp, C.c_size_t]
+    P = c.problem
+    for B in (32768, 65536, 4096, 10240):
+        q = c.ambient_uniform_batch(0xC3 if B > 16384 else 0xC2, 0, B)
+        out = torch.empty_like(q)
+        ok = torch.empty(B, dtype=torch.uint8, device=q.device)
+        it = torch.empty(B, dtype=torch.int16, device=q.device)
+        s = torch.cuda.current_stream().cuda_stream
+        n = min(B, 65536)
+        z = np.zeros(3 * 65536, dtype=np.uint64)
+        for _ in range(3):
+            assert LB.ccmp_project_batch(h, C.byref(P), q.data_ptr(), out.data_ptr(), ok.data_ptr(), it.data_ptr(), B, s) == 0
+        torch.cuda.synchronize()
+        tr = np.zeros(3 * 65536, dtype=np.uint64)
+        assert LB.ccmp_debug_geo_trace(tr.ctypes.data, 65536) == 0
+        tr = tr.reshape(65536, 3)
+        used = tr[:, 1] > 0
+        # stale entries of earlier launches have older time stamps: keep those of the last launch (start within 50 ms of the latest end)
+        tmax = tr[used, 1].max()
+        used &= tr[:, 0] + 5000000 > tmax
+        tr = tr[used]
+        t0 = tr[:, 0].min()
+        start, end = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0
+        rounds = ((tr[:, 2] >> 16) & 0xffff).astype(np.float64) + 1
+        done_before = (tr[:, 2] & 0xffff).astype(np.float64)
+        print("B=%d: latency kernel ran %d samples, %.0f rounds, spans %.0f us -> %.0f rounds/us; iterations already done at hand-over: mean %.1f"
+              % (B, len(tr), rounds.sum(), end.max(), rounds.sum() / end.max(), done_before.mean()))
+        last = np.argsort(-end)[:8]
+        for e in last:
+            print("   start %7.1f end %7.1f us rounds %4d (%.2f us per round), %d iterations before the hand-over" % (start[e], end[e], rounds[e], (end[e] - start[e]) / rounds[e], done_before[e]))
+        T = end.max()
+        for lo in np.arange(0, T, T / 8):
+            hi = lo + T / 8
+            busy = ((start < hi) & (end > lo)).sum()
+            print("   %6.0f-%6.0f us: %5d samples in flight, %5d start" % (lo, hi, busy, ((start >= lo) & (start < hi)).sum()))
+
+
+
+
+def lpt_min():
+    """from which batch size the scout (order + two-class hand-over) pays"""
+    ctx = Context(0)
+    for obj in ("Wine_Bottle", "stefan"):
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        for B in (12288, 14336, 16384, 18432, 20480, 22528, 24576, 26624):
+            q = c.ambient_uniform_batch(0xC3, 0, B)
+            out = torch.empty_like(q)
+            row = []
+            for name, mn in (("no scout", 1 << 30), ("scout", 0)):
+                ctx.set_lpt(1, mn)
+                row.append("%s %.3f" % (name, min(timed(lambda: c.project_batch(q, out=out), reps=5) for _ in range(2))))
+            ctx.set_schedule(2, 0)
+            row.append("latency kernel alone %.3f" % min(timed(lambda: c.project_batch(q, out=out), reps=5) for _ in range(2)))
+            ctx.set_schedule(1)
+            ctx.set_lpt(1)
+            print("%s B=%d  %s" % (obj, B, " | ".join(row)), flush=True)
+
+
+def pool_classes():
+    """hand-over in two classes: threshold on the predicted remaining iterations"""
+    ctx = Context(0)
+    for obj in ("Wine_Bottle", "stefan"):
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        for B in (28672, 32768, 40960, 49152, 65536, 98304):
+            q = c.ambient_uniform_batch(0xC3, 0, B)
+            out = torch.empty_like(q)
+            ctx.set_option("pool_long_remaining", 0)
+            ref = c.project_batch(q)
+            row = []
+            for thr in (0, 8, 16, 24, 32, 48, 64, 96):
+                ctx.set_option("pool_long_remaining", thr)
+                ms = min(timed(lambda: c.project_batch(q, out=out), reps=5) for _ in range(2))
+                got = c.project_batch(q)
+                same = all(torch.equal(a, b) for a, b in zip(got, ref))
+                row.append("%d: %.3f%s" % (thr, ms, "" if same else " DIFFERENT"))
+            print("%s B=%d  %s" % (obj, B, " | ".join(row)), flush=True)
+    ctx.set_option("pool_long_remaining", 24)
+
+
 if __name__ == "__main__":
     globals()[sys.argv[1]]()
