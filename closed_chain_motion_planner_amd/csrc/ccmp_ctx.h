@@ -52,7 +52,9 @@ struct DeviceGuard {
 //   32768    4.24 / 7.10            3.44 / 5.69                      3.43 / 5.38                        3.09 / 4.88
 // (from 49152 on the scout with immediate hand-over is best or equal; from 120000 on no hand-over at all)
 constexpr size_t kDefaultSmallBatch = 10240;   // up to here the latency kernel alone is quickest
-constexpr size_t kDefaultLptMinBatch = 26624;  // from here on the longest-first order pays for the scout pass
+constexpr size_t kDefaultLptMinBatch = 16384;  // from here on the scout pays (round 3: its predictions also sort the hand-over into two classes
+                                               // and its sort lost 0.09 ms; Wine_Bottle / stefan, ms without | with: 16384: 1.99 | 1.92 / 3.16 | 3.15;
+                                               // 20480: 2.37 | 2.16 / 3.60 | 3.43; 26624: 2.72 | 2.38 / 4.40 | 3.94; 14336: 1.85 | 1.87 / 2.91 | 2.98)
 constexpr size_t kOccupancyHandoverBelow = 40960; // smaller batches: keep the throughput kernel going while >= 80 % of its slots are busy
 
 struct ccmp_ctx {
