@@ -20,7 +20,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIBPATH = os.path.join(LIBDIR, "libccmp.so")
+# CCMP_LIBRARY: another build of the same library (tools/sanitize_cpu.py: host code under ASan/UBSan); never set in production
+LIBPATH = os.environ.get("CCMP_LIBRARY") or os.path.join(LIBDIR, "libccmp.so")
 ARCH = "gfx950"
 
 _UNITS = [

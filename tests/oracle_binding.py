@@ -82,7 +82,8 @@ class Oracle:
     """One build (libm or det) of the oracle."""
 
     def __init__(self, kind="det"):
-        path = os.path.join(ORACLE_DIR, "build", "libccmp_oracle_%s.so" % kind)
+        # CCMP_ORACLE_BUILD: a sanitized build of the same sources (tools/sanitize_cpu.py)
+        path = os.path.join(os.environ.get("CCMP_ORACLE_BUILD") or os.path.join(ORACLE_DIR, "build"), "libccmp_oracle_%s.so" % kind)
         if not os.path.exists(path):
             build_oracle()
         self.kind = kind

@@ -1,0 +1,58 @@
+"""AddressSanitizer + UBSan over everything that runs on the CPU (GPU sanitizers are not available on this pool):
+the host side of libccmp.so (problem set-up, YAML loader, scene validation, C-ABI argument checks, launch plans —
+built with `-Xarch_host -fsanitize=address,undefined`, device code unchanged) and both builds of the oracle, driven
+by the CPU test suite (`-m "not gpu"`).  Nothing of the normal build is touched: the sanitized libraries go to
+/tmp and are picked up through CCMP_LIBRARY / CCMP_ORACLE_BUILD.
+
+  python tools/sanitize_cpu.py            # exit code 0 = suite green and no sanitizer report
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+
+
+def main():
+    from closed_chain_motion_planner_amd import build as b
+
+    b.build_library()  # the device objects are reused as they are
+    out = tempfile.mkdtemp(prefix="ccmp_asan_")
+    hipcc, objs = b.hipcc_path(), []
+    for src, flags in b._UNITS:
+        if src.endswith(".hip"):
+            objs.append(os.path.join(b.HERE, "build", src + ".o"))
+            continue
+        op = os.path.join(out, src + ".o")
+        host = [x for f in SAN for x in ("-Xarch_host", f)]
+        subprocess.run([hipcc, "--offload-arch=" + b.ARCH, "-fPIC", "-std=c++17", "-g"] + flags + host +
+                       ["-c", os.path.join(b.CSRC, src), "-o", op], check=True)
+        objs.append(op)
+    lib = os.path.join(out, "libccmp.so")
+    subprocess.run([hipcc, "--offload-arch=" + b.ARCH, "-shared", "-fPIC"] + SAN + ["-o", lib] + objs, check=True)
+    orc = os.path.join(out, "oracle")
+    clang = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin", "clang")
+    # one sanitizer runtime per process: the oracle is built with the same clang as the library's host code
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "OUT=" + orc, "CC=" + clang,
+                    "CFLAGS=-O1 -g -std=c99 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function " + " ".join(SAN)], check=True)
+    rt = subprocess.run([clang, "--print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=rt, CCMP_LIBRARY=lib, CCMP_ORACLE_BUILD=orc,
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    # the two adapter tests link a plain C++ program against the library: a sanitized library needs a sanitized link
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-m", "not gpu", "-s", "-p", "no:cacheprovider",
+                          "-k", "not cxx14 and not type_checks"], env=env, capture_output=True, text=True, cwd=ROOT)
+    text = run.stdout + run.stderr
+    reports = re.findall(r".*(?:AddressSanitizer|runtime error).*", text)
+    print("\n".join(text.strip().splitlines()[-3:]))
+    print("sanitizer reports: %d" % len(reports))
+    for r in reports[:20]:
+        print("  " + r)
+    return 1 if (run.returncode != 0 or reports) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
