@@ -26,15 +26,38 @@ orc = Oracle("det")
 ctx = Context(0)
 # (object, tolerances, seed, jacobian mode, samples); the analytic mode (its own extension) against the oracle's analytic
 # mode: above and inside the batch sizes of its split launch (100 000 .. 300 000 samples)
-cases = [("Wine_Bottle", None, 0xA1, 0, N), ("stefan", None, 0xA2, 0, N), ("dumbbell", None, 0xA3, 0, N), ("stefan", (5e-4, 2.5e-3), 0xA4, 0, N),
-         ("Wine_Bottle", None, 0xA5, 1, N), ("Wine_Bottle", None, 0xA6, 1, min(N, 250000)), ("stefan", None, 0xA7, 1, min(N, 250000))]
+# variants (the general kernel instantiations at scale — every shipped configuration takes the stock-structure ones):
+# "calibrated" = DH calibration offsets, different for the two arms (ccmp_set_calibration: axes tilt, offsets fill in, the
+# arms stop being twins); "tilted" = arm 2 on a base rotated about two axes and arm 1 on a 1-ulp-off identity (tool_pose's
+# full product instead of the diag(+-1) shortcut)
+cases = [("Wine_Bottle", None, 0xA1, 0, N, None), ("stefan", None, 0xA2, 0, N, None), ("dumbbell", None, 0xA3, 0, N, None),
+         ("stefan", (5e-4, 2.5e-3), 0xA4, 0, N, None),
+         ("Wine_Bottle", None, 0xA8, 0, N // 2, "calibrated"), ("stefan", None, 0xA9, 0, N // 2, "tilted"),
+         ("Wine_Bottle", None, 0xA5, 1, N, None), ("Wine_Bottle", None, 0xA6, 1, min(N, 250000), None), ("stefan", None, 0xA7, 1, min(N, 250000), None),
+         ("Wine_Bottle", None, 0xAA, 1, N // 2, "calibrated")]
 report = {"samples_per_case": N, "host_threads": NCPU, "cases": []}
 from closed_chain_motion_planner_amd.scene import ProxyValidityChecker  # noqa: E402
-for obj, tol, seed, mode, N in cases:
+for obj, tol, seed, mode, N, variant in cases:
     c = KinematicChainConstraint.from_yaml(os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml"), ctx=ctx)
     c.setJacobianMode(mode)
     if tol:
         c.setTolerance(*tol)
+    if variant == "calibrated":
+        import ctypes as C
+        from closed_chain_motion_planner_amd import _lib
+        for arm in (0, 1):
+            dh = (C.c_double * 28)(*[1e-3 * ((7 * i + 3 * arm) % 5 - 2) for i in range(28)])
+            assert _lib.lib().ccmp_set_calibration(C.byref(c.problem), arm, dh) == 0
+        c.setInitialPosition(np.array(c.problem.start_joint[:]))
+    elif variant == "tilted":
+        a, b = 0.3, -0.7
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Rz = np.array([[np.cos(b), -np.sin(b), 0], [np.sin(b), np.cos(b), 0], [0, 0, 1]])
+        tilt = (Rz @ Rx).reshape(-1)
+        for k in range(9):
+            c.problem.base_R[9 + k] = float(tilt[k])
+        c.problem.base_R[0] = float(np.nextafter(1.0, 0.0))
+        c.setInitialPosition(np.array(c.problem.start_joint[:]))
     P = orc.problem_from_bytes(bytes(c.problem))
     # projector on resident inputs
     q = c.ambient_uniform_batch(seed, 0, N)
@@ -46,7 +69,7 @@ for obj, tol, seed, mode, N in cases:
     out_h, ok_h, it_h = out.cpu().numpy(), ok.cpu().numpy(), it.cpu().numpy().astype(np.int32)
     same_q = int((out_h.view(np.uint64) == q_cpu.view(np.uint64)).all(axis=1).sum())
     entry = {
-        "object": obj, "jacobian_mode": "analytic" if mode else "finite-difference (reference arithmetic)",
+        "object": obj, "variant": variant or "shipped configuration", "jacobian_mode": "analytic" if mode else "finite-difference (reference arithmetic)",
         "tolerance": list(tol) if tol else [1e-3, 5e-3], "seed": seed, "samples": N,
         "rows_bit_identical": same_q, "ok_mismatches": int((ok_h != ok_cpu).sum()), "iteration_mismatches": int((it_h != it_cpu).sum()),
         "max_abs_dq": float(np.nanmax(np.abs(out_h - q_cpu))), "ok_fraction": float(ok_cpu.mean()), "mean_iterations": float(it_cpu.mean()),
