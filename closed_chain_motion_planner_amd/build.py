@@ -5,6 +5,9 @@ Translation units with deliberately different flags:
                          -DCCMP_LEAN_SQRT: ccmp_detmath.h's wave-uniform fast path of the IEEE square root (same bits, -1.9 %)
   ccmp_kernels_wave.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one-wave-per-sample kernels
   ccmp_kernels_flat.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one 128-thread block per sample (latency kernel)
+  ccmp_kernels_geo.hip   -ffp-contract=off -DCCMP_USE_FMA   the extend step on the same Newton routine (ccmp_flat_newton.h), built twice:
+                         like the flat unit (throughput flavour) and -DCCMP_GEO_LATENCY with machine LICM and a 256-register
+                         budget (latency flavour)
   ccmp_problem.cpp       -ffp-contract=off -DCCMP_USE_FMA   host set-up (problem, constants) in the same rounding model
   ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   context, scheduling, launches
   ccmp_comm.cpp                                             one process / several GPUs: RCCL communicator and sharded entry points
@@ -35,6 +38,13 @@ _UNITS = [
     ("ccmp_kernels_wave.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
     # max-ilp scheduling: -0.6 % (throughput kernel) ... -1.5 % (latency kernel, single state), in-process A/B
     ("ccmp_kernels_flat.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+    # the extend step, built twice from one source.  Throughput flavour (the projector's latency kernel's flags: eight blocks
+    # per CU) for calls that bound the Newton rounds per edge; latency flavour (machine LICM on, 256-register budget, four
+    # blocks per CU: the ~60 FP64 literals of a Newton round stay in registers instead of being re-materialised every
+    # round) for calls whose end is one edge's serial chain: 16 384 edges without a round budget -16 %, with one +23 %.
+    ("ccmp_kernels_geo.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+    ("ccmp_kernels_geo.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_GEO_LATENCY", "-DCCMP_FLAT_MIN_WAVES=2", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+     "ccmp_kernels_geo_lat.hip.o"),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_problem.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
@@ -43,7 +53,7 @@ _UNITS = [
     ("ccmp_kernels_scene.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT"]),
     ("ccmp_scene.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]
-_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_flat_newton.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
 
 
 def hipcc_path():
@@ -69,9 +79,9 @@ def build_library(force=False, verbose=False):
     headers = [os.path.join(CSRC, h) for h in _HEADERS]
     objs, jobs = [], []
     relink = force
-    for src, flags in _UNITS:
+    for src, flags, *obj in _UNITS:  # optional third entry: object name (a source built twice)
         sp = os.path.join(CSRC, src)
-        op = os.path.join(objdir, src + ".o")
+        op = os.path.join(objdir, obj[0] if obj else src + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + headers):
             jobs.append([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags + ["-c", sp, "-o", op])

@@ -76,6 +76,10 @@ hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambd
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
                                 const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
+hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
+                                    size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
+                                    int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
+                                    const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -316,9 +320,15 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "clearance_per_state_max")) { // proxy clearance: one block per state up to this many states
     if (value < 0) return CCMP_EINVAL;
     ctx->clearance_per_state_max = (size_t)value;
-  } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the latency kernel / extend step per CU (8 resident)
+  } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the projector's latency kernel per CU (8 resident)
     if (value < 1 || value > 32) return CCMP_EINVAL;
     ctx->latency_blocks_per_cu = (int)value;
+  } else if (!strcmp(name, "geodesic_blocks_per_cu")) { // persistent blocks of the extend step's latency flavour per CU (4 resident)
+    if (value < 1 || value > 32) return CCMP_EINVAL;
+    ctx->geodesic_blocks_per_cu = (int)value;
+  } else if (!strcmp(name, "geodesic_flavour")) { // 0: by call shape, 1: throughput build always, 2: latency build always (both: same bits)
+    if (value < 0 || value > 2) return CCMP_EINVAL;
+    ctx->geodesic_flavour = (int)value;
   } else if (!strcmp(name, "pool_long_remaining")) { // hand-over: samples predicted to need this many more iterations go first (0 = one class)
     if (value < 0 || value > 1000) return CCMP_EINVAL;
     ctx->pool_long_remaining = (int)value;
@@ -630,11 +640,17 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   if (p->jacobian_mode != CCMP_JAC_FD) return CCMP_EINVAL; // the extend step exists in reference arithmetic only
   if (carry_in && check_target) return CCMP_EINVAL;        // a continuation's target was tested by the call it continues
   if (round_budget > 0 && !carry_out) return CCMP_EINVAL;  // a suspended edge is useless without what its continuation needs
-  // One 128-thread block per edge.  Up to the resident capacity (8 blocks per CU) every edge has its block at once and
+  // One 128-thread block per edge.  Up to the resident capacity every edge has its block at once and
   // the hardware dispatcher is the queue.  Beyond it the blocks are persistent and take tickets from an atomic word,
   // handed out through a long-edges-first order when the batch is large enough for the ordering pass to pay: the
   // launch then ends on short edges (16384 near-neighbour edges, 16-state lists: 3.15 -> 2.1 ms).
-  const size_t resident = (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
+  // Two builds of the kernel (ccmp_kernels_geo.hip): a call that bounds the rounds per edge is bound by the chip's turnover
+  // of Newton rounds and takes the throughput flavour (8 blocks per CU); a call that ends on one edge's serial chain — no
+  // round budget, or no more edges than the latency flavour has blocks — takes the latency flavour (4 blocks per CU,
+  // fewer instructions per round).
+  const size_t lat_resident = (size_t)ctx->num_cus * (size_t)ctx->geodesic_blocks_per_cu;
+  const bool latency_flavour = ctx->geodesic_flavour == 2 || (ctx->geodesic_flavour == 0 && (round_budget == 0 || E <= lat_resident));
+  const size_t resident = latency_flavour ? lat_resident : (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
   size_t nb = E;
   unsigned long long *queue = nullptr;
   const unsigned int *order = nullptr;
@@ -659,8 +675,9 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
       order = ord;
     }
   }
-  HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target, (int)nb,
-                               queue, order, carry_in, carry_out, round_budget, st));
+  HIP_TRY((latency_flavour ? ccmp_launch_geodesic_lat : ccmp_launch_geodesic)(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok,
+                                                                             newton_iters, check_target, (int)nb, queue, order, carry_in, carry_out,
+                                                                             round_budget, st));
   return CCMP_OK;
 }
 

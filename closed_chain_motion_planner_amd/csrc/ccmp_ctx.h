@@ -87,7 +87,9 @@ struct ccmp_ctx {
                                          // front of the pool and are taken first by the latency kernel (0 = one class).  Wine_Bottle, ms,
                                          // one class | 16 | 24 | 32 | 48 | 64: 28672: 2.83 | 2.62 | 2.42 | 2.41 | 2.44 | 2.78; 32768: 3.18 |
                                          // 2.88 | 2.71 | 2.73 | 2.74 | 3.01; 40960: 3.44 | 3.31 | 3.28 | 3.27 | 3.38 | 3.47; >= 49152 and stefan: +-2 %
-  int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the latency kernel and the extend step per CU
+  int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
+  int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
+  int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency
   int geodesic_order = 2;                // extend step, batches beyond the resident blocks: 1 = far-apart edges first, 2 = FP32 scout order
   size_t geodesic_scout_min = 6144;      // ... the scout from this many edges on (below: the two-class order by distance)
   int geodesic_scout_rounds = 64;        // ... the scout stops an edge after this many Newton rounds (all such edges are "long");

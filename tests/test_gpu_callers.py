@@ -401,6 +401,49 @@ def test_geodesic_continuation_is_the_uninterrupted_traversal(gpu_ctx, oracle_de
         c.discrete_geodesic_batch(f, t, cap, round_budget=budget)
 
 
+def test_geodesic_flavours_are_bitwise_identical(gpu_ctx, oracle_det):
+    """the extend step is built twice from one source (ccmp_kernels_geo.hip): a throughput flavour (128 registers, eight
+    blocks per CU) and a latency flavour (machine LICM on, 256 registers, four blocks per CU); the library picks by call
+    shape.  Forced either way, with and without a round budget, above and below the resident capacity: the same states,
+    counts, flags, Newton counts and carries; a slice against the oracle."""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    E = 4 * gpu_ctx.num_cus + 700
+    q, ok, _, _ = c.sample_project_batch(0x6F1, 0, 8 * E, want_iters=False)
+    frm = q[ok == 1][:E].contiguous()
+    to, _, _, _ = c.sample_near_project_batch(0x6F2, 0, frm, 0.6, E, want_iters=False)
+    cap = 10
+    res = {}
+    try:
+        for flavour in (1, 2, 0):
+            gpu_ctx.set_option("geodesic_flavour", flavour)
+            for n_e, budget in ((E, 0), (E, 40), (300, 0), (300, 40)):
+                out = c.discrete_geodesic_batch(frm[:n_e].contiguous(), to[:n_e].contiguous(), cap, want_carry=True, round_budget=budget)
+                torch.cuda.synchronize()
+                res[(flavour, n_e, budget)] = out
+    finally:
+        gpu_ctx.set_option("geodesic_flavour", 0)
+    for n_e, budget in ((E, 0), (E, 40), (300, 0), (300, 40)):
+        a = res[(1, n_e, budget)]
+        live = torch.arange(cap, device=frm.device)[None, :] < a[1].clamp(max=cap)[:, None]
+        for flavour in (2, 0):
+            b = res[(flavour, n_e, budget)]
+            assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), (flavour, n_e, budget)
+            assert torch.equal(a[0][live], b[0][live]) and torch.equal(a[4], b[4]), (flavour, n_e, budget)
+        if budget:
+            assert int((a[2] == 2).sum()) > 0  # some edges did run out of rounds
+    got = res[(2, E, 0)]
+    sl = slice(E - 128, E)
+    s_cpu, n_cpu, ok_cpu, it_cpu = oracle_det.discrete_geodesic_batch(P, frm[sl].cpu().numpy(), to[sl].cpu().numpy(), cap, NCPU)
+    assert np.array_equal(got[1][sl].cpu().numpy(), n_cpu) and np.array_equal(got[2][sl].cpu().numpy(), ok_cpu)
+    assert np.array_equal(got[3][sl].cpu().numpy(), it_cpu)
+    for k in range(128):
+        m = min(int(n_cpu[k]), cap)
+        assert np.array_equal(got[0][E - 128 + k, :m].cpu().numpy().view(np.uint64), s_cpu[k, :m].view(np.uint64))
+
+
 def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):
     """more edges than resident blocks (8 per CU): persistent blocks + ticket queue, with and without the long-edges-first
     order — the same bits as the one-block-per-edge launches of the same edges, and as the oracle on a slice"""

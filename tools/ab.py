@@ -22,9 +22,17 @@ def build(flags):
     objdir = os.path.join(b.HERE, "build_B")
     os.makedirs(objdir, exist_ok=True)
     objs = []
-    for src, fl in b._UNITS:
-        op = os.path.join(objdir, src + ".o")
-        extra = flags.split() if src == os.environ.get("AB_UNIT", "ccmp_kernels_fd.hip") else []
+    for src, fl, *obj in b._UNITS:
+        op = os.path.join(objdir, obj[0] if obj else src + ".o")
+        # AB_UNIT names a source, or the object of a source that is built twice (ccmp_kernels_geo_lat.hip.o)
+        hit = os.environ.get("AB_UNIT", "ccmp_kernels_fd.hip") in (src if not obj else None, os.path.basename(op))
+        extra = flags.split() if hit else []
+        if hit:
+            # AB_DROP="-disable-machine-licm": flags of the unit that variant B is built WITHOUT (an -mllvm option goes with its "-mllvm")
+            for d in os.environ.get("AB_DROP", "").split():
+                while d in fl:
+                    k = fl.index(d)
+                    fl = fl[:k - 1] + fl[k + 1:] if k > 0 and fl[k - 1] == "-mllvm" else fl[:k] + fl[k + 1:]
         subprocess.run([b.hipcc_path(), "--offload-arch=" + b.ARCH, "-fPIC", "-std=c++17"] + fl + extra +
                        ["-c", os.path.join(b.CSRC, src), "-o", op], check=True)
         objs.append(op)

@@ -166,6 +166,9 @@ def ab_latency():
         L.ccmp_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
         if name == "B" and os.environ.get("AB_B_BLOCKS"):  # variant B with another number of persistent blocks per CU
             assert L.ccmp_ctx_set_option(h, b"latency_blocks_per_cu", int(os.environ["AB_B_BLOCKS"])) == 0
+        if name == "B" and os.environ.get("AB_B_GEO_BLOCKS"):
+            assert L.ccmp_ctx_set_option(h, b"geodesic_blocks_per_cu", int(os.environ["AB_B_GEO_BLOCKS"])) == 0
+        L.ccmp_geodesic_batch_ex.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
         H[name] = (L, h)
     s = torch.cuda.current_stream().cuda_stream
     res = {}
@@ -183,6 +186,21 @@ def ab_latency():
         same = torch.equal(states["A"][:, :4], states["B"][:, :4])
         print("geodesic E=%d cap=%d: A %.3f ms  B %.3f ms  (B/A %.3f) same %s" % (E, cap, statistics.median(ts["A"]), statistics.median(ts["B"]),
               statistics.median(ts["B"]) / statistics.median(ts["A"]), same), flush=True)
+    # the bench's shape: lists of 16, 128 Newton rounds per edge and call
+    E, cap = 16384, 16
+    states = {n: torch.zeros((E, cap, 14), dtype=torch.float64, device=frm.device) for n in H}
+    nn = {n: torch.zeros(E, dtype=torch.int32, device=frm.device) for n in H}
+    ok = torch.empty(E, dtype=torch.uint8, device=frm.device)
+    it = torch.empty(E, dtype=torch.int32, device=frm.device)
+    carry = torch.empty((E, 2), dtype=torch.float64, device=frm.device)
+    ts = {n: [] for n in H}
+    for rep in range(10):
+        for n, (L, h) in H.items():
+            fn = lambda: L.ccmp_geodesic_batch_ex(h, C.byref(P), frm.data_ptr(), to.data_ptr(), E, cap, states[n].data_ptr(), nn[n].data_ptr(), ok.data_ptr(),
+                                                  it.data_ptr(), None, carry.data_ptr(), 128, 0, s)
+            ts[n].append(timed(fn, reps=1))
+    print("geodesic E=16384 cap=16 budget=128: A %.3f ms  B %.3f ms  (B/A %.3f) same counts %s" % (statistics.median(ts["A"]), statistics.median(ts["B"]),
+          statistics.median(ts["B"]) / statistics.median(ts["A"]), torch.equal(nn["A"], nn["B"])), flush=True)
     for B in (1, 256, 4096, 10240, 16384, 32768):
         q = c.ambient_uniform_batch(0xC2, 0, B)
         out = {n: torch.empty_like(q) for n in H}
@@ -244,11 +262,16 @@ def blocks_per_cu():
     o4, o16 = torch.empty_like(q4), torch.empty_like(q16)
     for k in (2, 3, 4, 5, 6, 7, 8, 10, 12, 16):
         ctx.set_option("latency_blocks_per_cu", k)
+        ctx.set_option("geodesic_blocks_per_cu", k)
         g = min(timed(lambda: c.discrete_geodesic_batch(frm, to, 16), reps=5) for _ in range(2))
+        g2 = min(timed(lambda: c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128), reps=5) for _ in range(2))
+        g3 = min(timed(lambda: c.discrete_geodesic_batch(frm[:2048], to[:2048], 16), reps=5) for _ in range(2))
+        print("blocks per CU %2d: 16384 edges, 128 rounds %.3f ms | 2048 edges %.3f ms" % (k, g2, g3))
         a = min(timed(lambda: c.project_batch(q4, out=o4), reps=5) for _ in range(2))
         b = min(timed(lambda: c.project_batch(q16, out=o16), reps=5) for _ in range(2))
         print("blocks per CU %2d: 16384 edges %.3f ms | 4096 samples %.3f ms | 10240 samples %.3f ms" % (k, g, a, b), flush=True)
     ctx.set_option("latency_blocks_per_cu", 8)
+    ctx.set_option("geodesic_blocks_per_cu", 4)
 
 
 
@@ -315,7 +338,7 @@ def flat_trace():
     LB.ccmp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     assert LB.ccmp_ctx_create(0, C.byref(h)) == 0
     LB.ccmp_project_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
-    LB.ccmp_debug_geo_trace.argtypes = [vp, C.c_size_t]
+    LB.ccmp_debug_flat_trace.argtypes = [vp, C.c_size_t]
     P = c.problem
     for B in (32768, 65536, 4096, 10240):
         q = c.ambient_uniform_batch(0xC3 if B > 16384 else 0xC2, 0, B)
@@ -329,7 +352,7 @@ def flat_trace():
             assert LB.ccmp_project_batch(h, C.byref(P), q.data_ptr(), out.data_ptr(), ok.data_ptr(), it.data_ptr(), B, s) == 0
         torch.cuda.synchronize()
         tr = np.zeros(3 * 65536, dtype=np.uint64)
-        assert LB.ccmp_debug_geo_trace(tr.ctypes.data, 65536) == 0
+        assert LB.ccmp_debug_flat_trace(tr.ctypes.data, 65536) == 0
         tr = tr.reshape(65536, 3)
         used = tr[:, 1] > 0
         # stale entries of earlier launches have older time stamps: keep those of the last launch (start within 50 ms of the latest end)

@@ -23,9 +23,9 @@ def main():
     b.build_library()  # the device objects are reused as they are
     out = tempfile.mkdtemp(prefix="ccmp_asan_")
     hipcc, objs = b.hipcc_path(), []
-    for src, flags in b._UNITS:
+    for src, flags, *obj in b._UNITS:
         if src.endswith(".hip"):
-            objs.append(os.path.join(b.HERE, "build", src + ".o"))
+            objs.append(os.path.join(b.HERE, "build", obj[0] if obj else src + ".o"))
             continue
         op = os.path.join(out, src + ".o")
         host = [x for f in SAN for x in ("-Xarch_host", f)]
