@@ -279,7 +279,8 @@ def blocks_per_cu():
 
 
 def geo_trace():
-    """timeline of a 16384-edge extend-step launch (variant B built with -DCCMP_GEO_TRACE for the flat unit)"""
+    """timeline of a 16384-edge extend-step launch (variant B built with -DCCMP_GEO_TRACE, AB_UNIT=ccmp_kernels_geo.hip: the
+    throughput flavour, which the traced context is pinned to)"""
     import os
     from closed_chain_motion_planner_amd import load_config
     LB = C.CDLL(os.path.join("closed_chain_motion_planner_amd", "lib", "libccmp_B.so"))
@@ -292,6 +293,7 @@ def geo_trace():
     LB.ccmp_geodesic_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp, vp, vp, vp]
     LB.ccmp_debug_geo_trace.argtypes = [vp, C.c_size_t]
     LB.ccmp_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    assert LB.ccmp_ctx_set_option(h, b"geodesic_flavour", 1) == 0
     P = c.problem
     for E, cap in ((16384, 16), (16384, 64)):
         frm, to = near_edges(c, E)
