@@ -41,6 +41,15 @@
 #define CCMP_FMA(a, b, c) ((a) * (b) + (c))
 #endif
 
+/* CCMP_K(i, v): the i-th FP64 literal of the elementary functions below.  By default the literal itself.  A device
+ * translation unit may define CCMP_K before including this header to fetch the constant from a table instead —
+ * ccmp_flat_newton.h keeps one in LDS, filled by ccmp_fill_ktab() below, because a lone wavefront pays two move
+ * instructions per FP64 literal and use, and a 16-byte LDS read brings two constants for one.  Same values either way. */
+#ifndef CCMP_K
+#define CCMP_K(i, v) (v)
+#endif
+#define CCMP_K_COUNT 36
+
 /* Largest |x| the pi/2 reduction is exact for (2^20 * pi/2).  Beyond it sincos returns NaN:
  * a Newton iterate that large is a diverged sample, never a valid projection. */
 #define CCMP_SINCOS_MAX 1647099.0
@@ -79,9 +88,9 @@ CCMP_HD double ccmp_abs(double x) { return __builtin_fabs(x); }
 /* sin(x+y) and cos(x+y), |x| <= pi/4 (+ a hair), y the tail of the reduced argument. */
 CCMP_HD double ccmp_kernel_sin(double x, double y)
 {
-  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double S1 = CCMP_K(4, -1.66666666666666324348e-01), S2 = CCMP_K(5, 8.33333333332248946124e-03),
+               S3 = CCMP_K(6, -1.98412698298579493134e-04), S4 = CCMP_K(7, 2.75573137070700676789e-06),
+               S5 = CCMP_K(8, -2.50507602534068634195e-08), S6 = CCMP_K(9, 1.58969099521155010221e-10);
   double z = x * x;
   double w = z * z;
   double p1 = CCMP_FMA(z, S4, S3);
@@ -97,9 +106,9 @@ CCMP_HD double ccmp_kernel_sin(double x, double y)
 
 CCMP_HD double ccmp_kernel_cos(double x, double y)
 {
-  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double C1 = CCMP_K(10, 4.16666666666666019037e-02), C2 = CCMP_K(11, -1.38888888888741095749e-03),
+               C3 = CCMP_K(12, 2.48015872894767294178e-05), C4 = CCMP_K(13, -2.75573143513906633035e-07),
+               C5 = CCMP_K(14, 2.08757232129817482790e-09), C6 = CCMP_K(15, -1.13596475577881948265e-11);
   double z = x * x;
   double w = z * z;
   double q1 = CCMP_FMA(z, C3, C2);
@@ -116,17 +125,15 @@ CCMP_HD double ccmp_kernel_cos(double x, double y)
 /* Simultaneous sine and cosine.  NaN for non-finite or |x| >= CCMP_SINCOS_MAX. */
 CCMP_HD void ccmp_sincos(double x, double *s_out, double *c_out)
 {
-  const double invpio2 = 6.36619772367581382433e-01;
-  const double pio2_1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
-  const double pio2_2 = 6.07710050630396597660e-11;  /* second 33 bits */
-  const double pio2_2t = 2.02226624879595063154e-21; /* pi/2 - (pio2_1 + pio2_2) */
+  const double invpio2 = CCMP_K(0, 6.36619772367581382433e-01);
+  const double pio2_1 = CCMP_K(1, 1.57079632673412561417e+00);  /* first 33 bits of pi/2 */
+  const double pio2_2 = CCMP_K(2, 6.07710050630396597660e-11);  /* second 33 bits */
+  const double pio2_2t = CCMP_K(3, 2.02226624879595063154e-21); /* pi/2 - (pio2_1 + pio2_2) */
   double t = ccmp_abs(x);
-  if (!(t < CCMP_SINCOS_MAX)) {
-    double nan = (x - x) / (x - x); /* NaN for inf, NaN and out-of-range finite x alike */
-    *s_out = nan;
-    *c_out = nan;
-    return;
-  }
+  /* out of range (or not finite): the reduction below runs on zero instead and its result is replaced at the end —
+   * one rarely-taken region instead of an if/else around the whole function */
+  const int bad = !(t < CCMP_SINCOS_MAX);
+  if (bad) t = 0.0;
   /* n = nearest multiple of pi/2; fn*pio2_1 is exact (33 + 20 bits) */
   int n = (int)CCMP_FMA(t, invpio2, 0.5);
   double fn = (double)n;
@@ -144,23 +151,29 @@ CCMP_HD void ccmp_sincos(double x, double *s_out, double *c_out)
   double c = (n & 1) ? ks : kc;
   if (n & 2) s = -s;
   if ((n + 1) & 2) c = -c;
-  *s_out = x < 0.0 ? -s : s;
+  s = x < 0.0 ? -s : s;
+  if (bad) {
+    double nan = (x - x) / (x - x); /* NaN for inf, NaN and out-of-range finite x alike */
+    s = nan;
+    c = nan;
+  }
+  *s_out = s;
   *c_out = c;
 }
 
 /* atan(x) for any double (NaN propagates). */
 CCMP_HD double ccmp_atan(double x)
 {
-  const double hi0 = 4.63647609000806093515e-01, lo0 = 2.26987774529616870924e-17; /* atan(0.5) */
-  const double hi1 = 7.85398163397448278999e-01, lo1 = 3.06161699786838301793e-17; /* atan(1)   */
-  const double hi2 = 9.82793723247329054082e-01, lo2 = 1.39033110312309984516e-17; /* atan(1.5) */
-  const double hi3 = 1.57079632679489655800e+00, lo3 = 6.12323399573676603587e-17; /* atan(inf) */
-  const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01,
-               a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
-               a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02,
-               a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
-               a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02,
-               a10 = 1.62858201153657823623e-02;
+  const double hi0 = CCMP_K(16, 4.63647609000806093515e-01), lo0 = CCMP_K(17, 2.26987774529616870924e-17); /* atan(0.5) */
+  const double hi1 = CCMP_K(18, 7.85398163397448278999e-01), lo1 = CCMP_K(19, 3.06161699786838301793e-17); /* atan(1)   */
+  const double hi2 = CCMP_K(20, 9.82793723247329054082e-01), lo2 = CCMP_K(21, 1.39033110312309984516e-17); /* atan(1.5) */
+  const double hi3 = CCMP_K(22, 1.57079632679489655800e+00), lo3 = CCMP_K(23, 6.12323399573676603587e-17); /* atan(inf) */
+  const double a0 = CCMP_K(24, 3.33333333333329318027e-01), a1 = CCMP_K(25, -1.99999999998764832476e-01),
+               a2 = CCMP_K(26, 1.42857142725034663711e-01), a3 = CCMP_K(27, -1.11111104054623557880e-01),
+               a4 = CCMP_K(28, 9.09088713343650656196e-02), a5 = CCMP_K(29, -7.69187620504482999495e-02),
+               a6 = CCMP_K(30, 6.66107313738753120669e-02), a7 = CCMP_K(31, -5.83357013379057348645e-02),
+               a8 = CCMP_K(32, 4.97687799461593236017e-02), a9 = CCMP_K(33, -3.65315727442169155270e-02),
+               a10 = CCMP_K(34, 1.62858201153657823623e-02);
   int neg = x < 0.0;
   double ax = ccmp_abs(x);
   if (ax >= 7.378697629483821e19) { /* 2^66: atan saturates (also catches +-inf) */
@@ -201,6 +214,47 @@ CCMP_HD double ccmp_atan(double x)
   else
     res = hi - (CCMP_FMA(t, s1 + s2, -lo) - t);
   return neg ? -res : res;
+}
+
+/* the table CCMP_K may be redirected to: entry i = the literal CCMP_K(i, .) names */
+CCMP_HD void ccmp_fill_ktab(double *t)
+{
+  t[0] = 6.36619772367581382433e-01; /* invpio2 */
+  t[1] = 1.57079632673412561417e+00; /* pio2_1 */
+  t[2] = 6.07710050630396597660e-11; /* pio2_2 */
+  t[3] = 2.02226624879595063154e-21; /* pio2_2t */
+  t[4] = -1.66666666666666324348e-01; /* S1 */
+  t[5] = 8.33333333332248946124e-03; /* S2 */
+  t[6] = -1.98412698298579493134e-04; /* S3 */
+  t[7] = 2.75573137070700676789e-06; /* S4 */
+  t[8] = -2.50507602534068634195e-08; /* S5 */
+  t[9] = 1.58969099521155010221e-10; /* S6 */
+  t[10] = 4.16666666666666019037e-02; /* C1 */
+  t[11] = -1.38888888888741095749e-03; /* C2 */
+  t[12] = 2.48015872894767294178e-05; /* C3 */
+  t[13] = -2.75573143513906633035e-07; /* C4 */
+  t[14] = 2.08757232129817482790e-09; /* C5 */
+  t[15] = -1.13596475577881948265e-11; /* C6 */
+  t[16] = 4.63647609000806093515e-01; /* hi0 */
+  t[17] = 2.26987774529616870924e-17; /* lo0 */
+  t[18] = 7.85398163397448278999e-01; /* hi1 */
+  t[19] = 3.06161699786838301793e-17; /* lo1 */
+  t[20] = 9.82793723247329054082e-01; /* hi2 */
+  t[21] = 1.39033110312309984516e-17; /* lo2 */
+  t[22] = 1.57079632679489655800e+00; /* hi3 */
+  t[23] = 6.12323399573676603587e-17; /* lo3 */
+  t[24] = 3.33333333333329318027e-01; /* a0 */
+  t[25] = -1.99999999998764832476e-01; /* a1 */
+  t[26] = 1.42857142725034663711e-01; /* a2 */
+  t[27] = -1.11111104054623557880e-01; /* a3 */
+  t[28] = 9.09088713343650656196e-02; /* a4 */
+  t[29] = -7.69187620504482999495e-02; /* a5 */
+  t[30] = 6.66107313738753120669e-02; /* a6 */
+  t[31] = -5.83357013379057348645e-02; /* a7 */
+  t[32] = 4.97687799461593236017e-02; /* a8 */
+  t[33] = -3.65315727442169155270e-02; /* a9 */
+  t[34] = 1.62858201153657823623e-02; /* a10 */
+  t[35] = 0.0;
 }
 
 /* atan2(y, x) restricted to y >= 0, x >= 0 — the only quadrant the residual's

@@ -5,6 +5,14 @@
 // model: both units are built -ffp-contract=off -DCCMP_USE_FMA like ccmp_kernels_fd.hip.
 #ifndef CCMP_FLAT_NEWTON_H
 #define CCMP_FLAT_NEWTON_H
+// The FP64 literals of sine/cosine and arctangent come from an LDS table in these units (ccmp_detmath.h: CCMP_K): the
+// compiler re-materialises a literal with two move instructions per use (machine LICM is off here, and hoisting them
+// costs the registers that eight blocks per CU live on), one 16-byte LDS read brings two.  -DCCMP_FLAT_LITERALS: as before.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CCMP_FLAT_LITERALS)
+__shared__ __attribute__((aligned(16))) double ccmp_ktab[36];
+#define CCMP_K(i, v) (ccmp_ktab[i])
+#define CCMP_KTAB_IN_LDS 1
+#endif
 #include "ccmp_fd_common.h"
 
 using namespace ccmp;
@@ -56,8 +64,9 @@ __device__ __forceinline__ void flat_tick(int k, unsigned long long &prev)
 #define FLAT_TICK(k) do { } while (0)
 #endif
 
-// record of one sample in LDS (doubles): x 14 | sin,cos 28 | tool poses at x 24 | f(x) 2 | J as [column][row] 28 | flag
-constexpr int fX = 0, fSC = 14, fEE = 42, fF = 66, fJ = 68, fV = 96, fRec = 98;
+// record of one sample in LDS (doubles): x 14 | sin,cos 28 | tool poses at x 24 | f(x) 2 | J as [column][row] 28 | flag |
+// one (sin, cos) slot per thread: the sine and cosine of the lane's own perturbed angle
+constexpr int fX = 0, fSC = 14, fEE = 42, fF = 66, fJ = 68, fV = 96, fOwn = 98, fRec = fOwn + 2 * 128;
 constexpr int kXLane = 54, kScLane0 = 55; // chain at x; first sine/cosine lane
 
 // value of the lane CTRL says: 0x100 + n = row_shl:n (lane i takes lane i + n of its 16-lane row)
@@ -84,6 +93,9 @@ constexpr int kStepDoubles = 12, kStepTab = 2 * 7 * kStepDoubles;
 
 __device__ __forceinline__ void stage_step_table(const ccmp_consts &K, double *tab, int tid)
 {
+#ifdef CCMP_KTAB_IN_LDS
+  if (tid == 64) ccmp_fill_ktab(ccmp_ktab); // one thread of wave 1; the caller's barrier publishes it
+#endif
   for (int k = tid; k < kStepTab; k += 128) {
     const int a = k / (7 * kStepDoubles), r = k - a * 7 * kStepDoubles, i = r / kStepDoubles, c = r - i * kStepDoubles;
     tab[k] = c < 3 ? K.offset[a][i][c] : (c < 6 ? K.axis[a][i][c - 3] : K.aprod[a][i][c - 6]);
@@ -91,34 +103,34 @@ __device__ __forceinline__ void stage_step_table(const ccmp_consts &K, double *t
 }
 
 // joints I..6 of the chain of arm W with compile-time joint indices (STOCK: the exact-zero structure of the uncalibrated
-// Panda is known to the compiler, ccmp_kin.h); the constants of joint I+1 are read while joint I is computed
+// Panda is known to the compiler, ccmp_kin.h); the constants of joint I+1 are read while joint I is computed.  A lane
+// finds joint I's (sin, cos) at rec[sc_at(I)]: the arm's table at x, or — for the lane's own perturbed joint — the
+// lane's slot (an address select per joint instead of four register selects).
 template <int W, bool STOCK, int I>
-__device__ __forceinline__ void flat_chain_from(const double2 *tab, const double2 *sct, int j, double s, double c, const double2 *cur,
-                                                double2 sc_cur, double *R, double *o)
+__device__ __forceinline__ void flat_chain_from(const double2 *tab, const double *rec, int j, int own, const double2 *cur, double2 sc_cur,
+                                                double *R, double *o)
 {
   if constexpr (I < 7) {
     double2 nxt[6], sc_nxt = sc_cur;
     if constexpr (I < 6) {
 #pragma unroll
       for (int k = 0; k < 6; k++) nxt[k] = tab[6 * (I + 1) + k];
-      sc_nxt = sct[I + 1];
+      sc_nxt = *reinterpret_cast<const double2 *>(rec + ((I + 1 == j) ? own : fSC + 2 * (W * 7 + I + 1)));
     }
     double Rn[9];
-    const double si = (I == j) ? s : sc_cur.x;
-    const double ci = (I == j) ? c : sc_cur.y;
     const double off[3] = {cur[0].x, cur[0].y, cur[1].x};
     const double ax[3] = {cur[1].y, cur[2].x, cur[2].y};
     const double ap[6] = {cur[3].x, cur[3].y, cur[4].x, cur[4].y, cur[5].x, cur[5].y};
-    chain_step<I, STOCK>(off, ax, ap, si, ci, R, Rn, o);
+    chain_step<I, STOCK>(off, ax, ap, sc_cur.x, sc_cur.y, R, Rn, o);
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = Rn[k];
-    flat_chain_from<W, STOCK, I + 1>(tab, sct, j, s, c, nxt, sc_nxt, R, o);
+    flat_chain_from<W, STOCK, I + 1>(tab, rec, j, own, nxt, sc_nxt, R, o);
   }
 }
 
 template <int W, bool STOCK>
 __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab,
-                                                        double *rec, int lane, int j, bool head, double s, double c, double y,
+                                                        double *rec, int lane, int j, int own, bool head, double y,
                                                         unsigned long long &tprev)
 {
   (void)tprev; // only the -DCCMP_FLAT_TIMING build ticks it
@@ -127,11 +139,11 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
   {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
     const double2 *tab = reinterpret_cast<const double2 *>(steptab + W * 7 * kStepDoubles);
-    const double2 *sct = reinterpret_cast<const double2 *>(rec + fSC + 2 * W * 7);
     double2 cur[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) cur[k] = tab[k];
-    flat_chain_from<W, STOCK, 0>(tab, sct, j, s, c, cur, sct[0], R, o);
+    const double2 sc0 = *reinterpret_cast<const double2 *>(rec + ((j == 0) ? own : fSC + 2 * W * 7));
+    flat_chain_from<W, STOCK, 0>(tab, rec, j, own, cur, sc0, R, o);
     tool_pose_t<STOCK>(KC, W, R, o, &Tw[0], &Tw[9]);
     if (lane == kXLane) {
 #pragma unroll
@@ -186,31 +198,35 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
   const bool head = ev && pt == 0;
   const bool plus = pt < 3;
   const int nstep = (plus ? pt : pt - 3) + 1;
+  // LDS slots of this lane (doubles): the joint value it starts from, its own (sin, cos), where it stores what it computes
+  const int own = fOwn + 2 * tid;
+  const int x_at = fX + (ev ? w * 7 + j : (sc_lane ? w * 7 + lane - kScLane0 : 0));
+  const int sc_to = sc_lane ? fSC + 2 * (w * 7 + lane - kScLane0) : own;
   unsigned long long tprev = __builtin_readcyclecounter();
   for (;;) {
-    // ---- A: angles.  y1[j] += h / y2[j] -= h by sequential adds as OMPL does; one sincos per lane -----------
-    double y = 0.0, s, c;
-    if (ev) {
-      const double xj = rec[fX + w * 7 + j];
-      const double axj = ccmp_abs(xj);
-      const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
-      const double hh = plus ? h : -h;
-      y = xj + hh;
-      if (nstep >= 2) y = y + hh;
-      if (nstep >= 3) y = y + hh;
-    } else if (sc_lane) {
-      y = rec[fX + w * 7 + lane - kScLane0];
-    }
+    // ---- A: angles.  y1[j] += h / y2[j] -= h by sequential adds as OMPL does; one sincos per lane, without a branch:
+    // every lane reads the joint it is concerned with (x_at), steps it (evaluation lanes) or not (sine/cosine lanes), and
+    // stores (sin, cos) to its slot — the arm's table at x for the sine/cosine lanes, the lane's own slot otherwise
+    double s, c;
+    const double xj = rec[x_at];
+    const double axj = ccmp_abs(xj);
+    const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
+    const double hh = plus ? h : -h;
+    const double y1 = xj + hh, y2 = y1 + hh, y3 = y2 + hh;
+    const double ys = nstep == 1 ? y1 : (nstep == 2 ? y2 : y3);
+    const double y = ev ? ys : xj;
     ccmp_sincos(y, &s, &c);
-    if (sc_lane) {
-      rec[fSC + 2 * (w * 7 + lane - kScLane0)] = s;
-      rec[fSC + 2 * (w * 7 + lane - kScLane0) + 1] = c;
+    {
+      double2 scv;
+      scv.x = s;
+      scv.y = c;
+      *reinterpret_cast<double2 *>(rec + sc_to) = scv;
     }
     // an arm's sines and cosines are written and read by the arm's own wave: no block barrier
     wave_lds_fence();
     FLAT_TICK(0);
-    if (w == 0) flat_chain_and_residual<0, STOCK>(K, KC, steptab, rec, lane, j, head, s, c, y, tprev);
-    else flat_chain_and_residual<1, STOCK>(K, KC, steptab, rec, lane, j, head, s, c, y, tprev);
+    if (w == 0) flat_chain_and_residual<0, STOCK>(K, KC, steptab, rec, lane, j, own, head, y, tprev);
+    else flat_chain_and_residual<1, STOCK>(K, KC, steptab, rec, lane, j, own, head, y, tprev);
     __syncthreads();
     FLAT_TICK(2);
     const double f0 = rec[fF], f1 = rec[fF + 1];
