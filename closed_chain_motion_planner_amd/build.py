@@ -43,7 +43,7 @@ _UNITS = [
     # blocks per CU: the ~60 FP64 literals of a Newton round stay in registers instead of being re-materialised every
     # round) for calls whose end is one edge's serial chain: 16 384 edges without a round budget -16 %, with one +23 %.
     ("ccmp_kernels_geo.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
-    ("ccmp_kernels_geo.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_GEO_LATENCY", "-DCCMP_FLAT_MIN_WAVES=2", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    ("ccmp_kernels_geo.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_GEO_LATENCY", "-DCCMP_SUMS_IN_LANE", "-DCCMP_FLAT_MIN_WAVES=2", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
      "ccmp_kernels_geo_lat.hip.o"),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords

@@ -64,9 +64,72 @@ __device__ __forceinline__ void flat_tick(int k, unsigned long long &prev)
 #define FLAT_TICK(k) do { } while (0)
 #endif
 
-// record of one sample in LDS (doubles): x 14 | sin,cos 28 | tool poses at x 24 | f(x) 2 | J as [column][row] 28 | flag |
-// one (sin, cos) slot per thread: the sine and cosine of the lane's own perturbed angle
-constexpr int fX = 0, fSC = 14, fEE = 42, fF = 66, fJ = 68, fV = 96, fOwn = 98, fRec = fOwn + 2 * 128;
+// record of one sample in LDS (doubles): x 14 | sin,cos 28 | tool poses at x 24 | f(x) 2 | J 84 | flag |
+// one (sin, cos) slot per thread: the sine and cosine of the lane's own perturbed angle.
+// J: six doubles per column c, (J0c, J0c | J1c, J1c | J0c, J1c) — the operand pairs of the three serial sums of a Jacobi
+// sweep (sum J0c^2, sum J1c^2, sum J0c J1c), so that a lane forms ONE of them from one 16-byte read per column.
+// CCMP_SUMS_IN_LANE (the build with machine LICM, which measured 4-7 % slower with the split sums): two doubles per
+// column, every lane forms all three sums.
+#ifdef CCMP_SUMS_IN_LANE
+constexpr int kJCol = 2, kJPair = 0;
+#else
+constexpr int kJCol = 6, kJPair = 4;
+#endif
+constexpr int fX = 0, fSC = 14, fEE = 42, fF = 66, fJ = 68, fV = fJ + 14 * kJCol, fOwn = fV + 2, fRec = fOwn + 2 * 128;
+static_assert(fJ % 2 == 0 && fOwn % 2 == 0, "16-byte slots");
+
+// column (v0, v1) of J into its slot
+__device__ __forceinline__ void store_column(double *slot, double v0, double v1)
+{
+  double2 p;
+#ifndef CCMP_SUMS_IN_LANE
+  p.x = v0; p.y = v0;
+  *reinterpret_cast<double2 *>(slot) = p;
+  p.x = v1; p.y = v1;
+  *reinterpret_cast<double2 *>(slot + 2) = p;
+#endif
+  p.x = v0; p.y = v1;
+  *reinterpret_cast<double2 *>(slot + kJPair) = p;
+}
+// one of the three serial sums over the 14 columns, chosen by the lane's slot offset (0: row 0 squared, 2: row 1 squared,
+// 4: the product), in column order — solve_minnorm's order (ccmp_solve.h)
+__device__ __forceinline__ double column_sum(const double *jx)
+{
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 14; k++) {
+    const double2 uv = *reinterpret_cast<const double2 *>(jx + kJCol * k);
+    acc = CCMP_FMA(uv.x, uv.y, acc);
+  }
+  return acc;
+}
+// the value lane N of the row holds, in every lane of the row (the three sums are formed in lanes 0, 1, 2 of EVERY row, so
+// all 64 lanes end up with the same numbers).  By readlane into a scalar pair, or — CCMP_SUM_BCAST_DPP, the build with
+// machine LICM, whose scalar registers are spilled already — by a DPP row broadcast that stays in vector registers.
+// all three in every lane (CCMP_SUMS_IN_LANE: the build with machine LICM measured 5 % slower with the split sums)
+__device__ __forceinline__ void column_sums(const double *jbase, double &a, double &d, double &b)
+{
+  a = 0.0; d = 0.0; b = 0.0;
+#pragma unroll
+  for (int k = 0; k < 14; k++) {
+    const double2 p = *reinterpret_cast<const double2 *>(jbase + kJCol * k + kJPair);
+    a = CCMP_FMA(p.x, p.x, a);
+    d = CCMP_FMA(p.y, p.y, d);
+    b = CCMP_FMA(p.x, p.y, b);
+  }
+}
+template <int N>
+__device__ __forceinline__ double lane_value(double v)
+{
+#ifdef CCMP_SUM_BCAST_DPP
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + N, 0xf, 0xf, false); // row_newbcast:N
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#else
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), N), __builtin_amdgcn_readlane(__double2loint(v), N));
+#endif
+}
 constexpr int kXLane = 54, kScLane0 = 55; // chain at x; first sine/cosine lane
 
 // value of the lane CTRL says: 0x100 + n = row_shl:n (lane i takes lane i + n of its 16-lane row)
@@ -170,18 +233,11 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
     double2 col;
     col.x = CCMP_FMA(0.1, m0c, CCMP_FMA(-0.6, m0b, 1.5 * m0));
     col.y = CCMP_FMA(0.1, m1c, CCMP_FMA(-0.6, m1b, 1.5 * m1));
-    *reinterpret_cast<double2 *>(rec + fJ + 2 * (W * 7 + j)) = col;
+    store_column(rec + fJ + kJCol * (W * 7 + j), col.x, col.y);
   } else if (W == 0 && lane == kXLane) {
     rec[fF] = tt[0];
     rec[fF + 1] = tt[1];
   }
-}
-
-// the 2 x 14 rows as every lane needs them for the serial dot products (the oracle's order): fourteen 16-byte reads
-__device__ __forceinline__ void load_rows(const double *rec, double2 *P)
-{
-#pragma unroll
-  for (int k = 0; k < 14; k++) P[k] = *reinterpret_cast<const double2 *>(rec + fJ + 2 * k);
 }
 
 template <bool STOCK>
@@ -231,14 +287,14 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
     FLAT_TICK(2);
     const double f0 = rec[fF], f1 = rec[fF + 1];
     // ---- loop condition of ConstraintFunction.h:68 (block-uniform) ------------------------------------------
-    bool cont = false;
-    {
-      const bool c1 = f0 > K.tol_pos;
-      norm1 = c1 ? 1.0 : 0.0;
-      bool resid = c1;
-      if (!c1) { norm2 = f1; resid = f1 > K.tol_rot; }
-      if (resid) { cont = iter < max_iter; iter++; }
-    }
+    // (norm1 = f0 > tol1) || (norm2 = f1) > tol2: norm2 is assigned only when the first test fails; iter++ only when the
+    // residual test holds — written as selects, one branch
+    const bool c1 = f0 > K.tol_pos;
+    const bool resid = c1 || (f1 > K.tol_rot);
+    norm1 = c1 ? 1.0 : 0.0;
+    norm2 = c1 ? norm2 : f1;
+    const bool cont = resid && iter < max_iter;
+    iter += resid ? 1 : 0;
     if (!cont) return (norm1 < K.tol_pos) && (norm2 < K.tol_rot);
     // ---- E on wave 0 alone: minimum-norm step (solve_minnorm's operations in its order, ccmp_solve.h), lane c < 14
     // owning column c.  A second wave repeating it would only take issue slots from other blocks; wave 1 waits at the
@@ -247,20 +303,23 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
 #ifdef CCMP_FLAT_SOLVE_PRIO
       __builtin_amdgcn_s_setprio(CCMP_FLAT_SOLVE_PRIO); // the serial solve is every block's critical path: first in line on its SIMD
 #endif
-      double2 P[14];
-      load_rows(rec, P);
+      // lanes 0, 1 and 2+ of every 16-lane row form sum J0c^2, sum J1c^2 and sum J0c J1c; lane_value hands them round
+#ifndef CCMP_SUMS_IN_LANE
+      const double *jx = rec + fJ + 2 * (rl < 2 ? rl : 2);
+#endif
       const int me = lane < 14 ? lane : 13;
-      double2 mine = *reinterpret_cast<const double2 *>(rec + fJ + 2 * me);
+      double2 mine = *reinterpret_cast<const double2 *>(rec + fJ + kJCol * me + kJPair);
       double g0 = f0, g1 = f1, a, d, b;
 #pragma unroll
       for (int sweep = 0; sweep < 2; sweep++) {
-        a = 0; d = 0; b = 0;
-#pragma unroll
-        for (int k = 0; k < 14; k++) {
-          a = CCMP_FMA(P[k].x, P[k].x, a);
-          d = CCMP_FMA(P[k].y, P[k].y, d);
-          b = CCMP_FMA(P[k].x, P[k].y, b);
-        }
+#ifdef CCMP_SUMS_IN_LANE
+        column_sums(rec + fJ, a, d, b);
+#else
+        const double acc = column_sum(jx);
+        a = lane_value<0>(acc);
+        d = lane_value<1>(acc);
+        b = lane_value<2>(acc);
+#endif
         if (b != 0.0) { // the same value in every lane
           const double zeta = (d - a) / (2.0 * b);
           double t = 1.0 / (ccmp_abs(zeta) + ccmp_sqrt(CCMP_FMA(zeta, zeta, 1.0)));
@@ -273,20 +332,29 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
           const double h0 = g0, h1 = g1;
           g0 = CCMP_FMA(cr, h0, -(sr * h1));
           g1 = CCMP_FMA(sr, h0, cr * h1);
-          if (lane < 14) *reinterpret_cast<double2 *>(rec + fJ + 2 * lane) = mine;
+          if (lane < 14) store_column(rec + fJ + kJCol * lane, mine.x, mine.y);
           wave_lds_fence();
-          load_rows(rec, P);
         }
       }
-      a = 0; d = 0;
-#pragma unroll
-      for (int k = 0; k < 14; k++) { a = CCMP_FMA(P[k].x, P[k].x, a); d = CCMP_FMA(P[k].y, P[k].y, d); }
+#ifdef CCMP_SUMS_IN_LANE
+      column_sums(rec + fJ, a, d, b);
       const double s0 = ccmp_sqrt(a), s1 = ccmp_sqrt(d);
       const double smax = s0 > s1 ? s0 : s1;
       double thr = smax * (2.0 * 2.220446049250313e-16);
       if (thr < 2.2250738585072014e-308) thr = 2.2250738585072014e-308;
       const double k0 = s0 > thr ? g0 / a : 0.0;
       const double k1 = s1 > thr ? g1 / d : 0.0;
+#else
+      // singular values and quotients of the two rows side by side: lane 0 takes row 0 (sqrt(a), g0 / a), lane 1 row 1
+      const double acc = column_sum(jx);
+      const double root = ccmp_sqrt(acc), quot = (rl == 0 ? g0 : g1) / acc;
+      const double s0 = lane_value<0>(root), s1 = lane_value<1>(root);
+      const double smax = s0 > s1 ? s0 : s1;
+      double thr = smax * (2.0 * 2.220446049250313e-16);
+      if (thr < 2.2250738585072014e-308) thr = 2.2250738585072014e-308;
+      const double k0 = s0 > thr ? lane_value<0>(quot) : 0.0; // g0 / a where the row counts (ccmp_solve.h), 0 otherwise
+      const double k1 = s1 > thr ? lane_value<1>(quot) : 0.0;
+#endif
       const double dxm = CCMP_FMA(k1, mine.y, k0 * mine.x);
       if (lane < 14) rec[fX + lane] = CCMP_FMA(-K.step, dxm, rec[fX + lane]);
 #ifdef CCMP_FLAT_SOLVE_PRIO
