@@ -1,7 +1,7 @@
 // ccmp_kernels_flat.hip — the latency kernel of the reference-arithmetic path: one sample per 128-thread block,
 // every residual evaluation of a Newton iteration in ONE round (ccmp_flat_newton.h).  Built like ccmp_kernels_fd.hip
 // with -mllvm -disable-machine-licm.
-// __launch_bounds__(128, 4): four waves per SIMD, eight blocks per CU (107-123 VGPRs, no scratch; with a budget of 256
+// __launch_bounds__(128, 4): four waves per SIMD, eight blocks per CU (116-118 VGPRs and no scratch for the stock-structure instantiations, 128 and 5-7 spilled dwords outside the Newton loop for the general ones; with a budget of 256
 // registers the max-ilp scheduler takes 181 and halves the occupancy).
 #include "ccmp_flat_newton.h"
 
