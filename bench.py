@@ -521,6 +521,36 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts[4:]) * 1e6)
 
+    def single_latency_c_abi_us(reps=64):
+        # the same call as the C++ adapter makes it — ccmp_project_host with ready pointers, no Python in the timed region
+        # but the ctypes call itself — from uniform samples and from states near the manifold (what the planner's samplers
+        # and extend steps hand it: a valid state moved by up to 0.05 rad per joint)
+        import ctypes as C
+        from closed_chain_motion_planner_amd import _lib
+        c.setJacobianMode(main_mode)
+        L = _lib.lib()
+        dp = C.POINTER(C.c_double)
+        okb = (C.c_uint8 * 1)()
+        far = c.ambient_uniform_batch(0xC1, 0, reps).cpu().numpy()
+        q, ok, _ = c.project_batch(c.ambient_uniform_batch(0xC7, 0, 16 * reps))
+        valid = q[ok == 1][:reps].cpu().numpy()
+        rng = np.random.default_rng(0xC7)
+        near = valid + rng.uniform(-0.05, 0.05, valid.shape)
+        out = {}
+        for name, xs in (("uniform_sample", far), ("near_manifold", near)):
+            ts, its = [], []
+            for i in range(xs.shape[0]):
+                xi, xo = np.ascontiguousarray(xs[i]), np.zeros(14)
+                it = (C.c_uint16 * 1)()
+                a, b = xi.ctypes.data_as(dp), xo.ctypes.data_as(dp)
+                t0 = time.perf_counter()
+                L.ccmp_project_host(c.ctx.handle, C.byref(c.problem), a, b, okb, it, 1)
+                ts.append(time.perf_counter() - t0)
+                its.append(int(it[0]))
+            out[name + "_median_us"] = float(np.median(ts[8:]) * 1e6)
+            out[name + "_median_newton_iters"] = float(np.median(its[8:]))
+        return out
+
     def geodesic(n_edges=16384, first_pass=16, budget=128):
         # growTree-shaped edges (src/planner/stefanBiPRM.cpp:307-351: a milestone towards a near neighbour): from a valid
         # projected state to a projected sampleUniformNear state within 0.6 rad per joint (about 1.0 rad apart, ~4 states
@@ -699,6 +729,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
     out["batch4096"] = s4
     out["batch32768_projections_per_s"] = s32["projections_per_s"]
     out["single_project_call_median_us"] = single_latency_us()
+    out["single_project_c_abi"] = single_latency_c_abi_us()
     out[("analytic" if args.mode == "fd" else "fd") + "_mode_projections_per_s"] = quick(c, other, B, 5)["projections_per_s"]
     c.setJacobianMode(main_mode)
     # BASELINE configs[3]: stefan (arms left + top), the reference's tolerances and the tighter set the baseline asks for

@@ -51,6 +51,9 @@ def test_bench_line_contract():
     c1 = sec["c1_dumbbell"]  # BASELINE configs[0]
     assert c1["samples"] == 1024 and c1["cpu_threads"] == 1 and c1["cpu_single_thread_projections_per_s"] > 50
     assert c1["parity_vs_det_oracle"]["bit_identical"] is True and c1["same_ambient_samples_on_both_sides"] is True
+    sp = sec["single_project_c_abi"]  # ccmp_project_host as the C++ adapter calls it: from a uniform sample and near the manifold
+    assert 10 < sp["near_manifold_median_us"] < sp["uniform_sample_median_us"] < 1000
+    assert sp["near_manifold_median_newton_iters"] < sp["uniform_sample_median_newton_iters"]
     g = sec["discrete_geodesic"]  # the complete operation is timed, overflowing edges are counted
     assert set(g) >= {"edges_per_s", "overflowed_edges", "complete_ms", "complete_edges_per_s", "growtree_5_edges_ms", "max_states_first_pass"}
     assert g["parity_vs_det_oracle"]["bit_identical"] is True and g["overflowed_edges"] < 0.01 * g["edges"]
