@@ -131,7 +131,16 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
  * are ordered longest-predicted-first by the FP32 scout and the samples predicted past "analytic_split_pred" iterations
  * (default 90) run on "analytic_split_front" wavefronts (default 128) of the six-lane kernel on a side stream BESIDE the
  * one-lane kernel, which hands over past "analytic_split_cap" iterations (default 160); 0 = off); proxy clearance: "clearance_per_state_max" (batches up to this many states run one block per state,
- * larger ones 64-state tiles; default 8192).  CCMP_EINVAL for unknown names. */
+ * larger ones 64-state tiles; default 8192); latency work: "latency_blocks_per_cu" (persistent blocks of the latency kernel
+ * per CU, default 8 = what is resident), "pool_long_remaining" (hand-over in two classes: samples the scout predicts to need
+ * at least this many more iterations are taken first; default 24, 0 = one class); extend step: "geodesic_order" (0 = edges in
+ * index order, 1 = far-apart edges first, 2 = FP32 scout order from "geodesic_scout_min" edges on, default), "geodesic_order_min"
+ * (no ordering pass below this many edges; default 4096), "geodesic_long_steps" (order 1: edges longer than this many delta steps
+ * count as long; default 12), "geodesic_scout_min" (default 6144), "geodesic_scout_rounds" (cap of the scout's traversal; default
+ * 64), "geodesic_flavour" (the extend step is built twice from one source — same bits: 0 = throughput build for calls with a
+ * round budget and more edges than the latency build has blocks, latency build otherwise (default); 1 / 2 = always the throughput
+ * / latency build), "geodesic_blocks_per_cu" (persistent blocks of the latency build per CU; default 4).  None of these changes a
+ * result bit.  CCMP_EINVAL for unknown names. */
 int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
 /* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
  * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is
