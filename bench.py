@@ -423,6 +423,9 @@ def main():
                     valu = {"executed_valu_wave_insts_per_launch": n, "cycles_per_inst": 4,
                             "frac_of_fp64_issue_ceiling": n * 4.0 / (kms * 1e-3 * 2.4e9 * 1024),
                             "source": "SQ_INSTS_VALU, profiles/%s" % tj.get("tag")}
+                    if tj.get("vector_pipes_busy_frac"):  # of that profiled launch, at the clock the chip held under it
+                        valu["vector_pipes_busy_in_profiled_launch"] = tj["vector_pipes_busy_frac"]
+                        valu["effective_clock_ghz_in_profiled_launch"] = tj.get("effective_clock_ghz")
         except Exception:
             traffic = None
     fp64_tflops = FLOP_PER_NEWTON_ITER * sum_iters / (kms * 1e-3) / 1e12

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """round-3 scratch experiments on the GPU box (not part of the product)"""
 import ctypes as C
+import os
 import sys
 import time
 
@@ -232,7 +233,7 @@ def handover():
     ctx = Context(0)
     for obj in ("Wine_Bottle", "stefan"):
         c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
-        for B in (12288, 16384, 24576, 32768, 49152, 65536):
+        for B in [int(b) for b in os.environ.get("HO_SIZES", "12288,16384,24576,32768,49152,65536").split(",")]:
             q = c.ambient_uniform_batch(0xC3, 0, B)
             out = torch.empty_like(q)
             row = []

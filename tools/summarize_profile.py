@@ -139,6 +139,17 @@ def main():
             if "GRBM_GUI_ACTIVE" in allc:
                 f.write("effective clock = %.2f GHz." % (allc["GRBM_GUI_ACTIVE"] / 8 / (avg_ms * 1e-3) / 1e9))
             f.write("\n")
+            if "GRBM_GUI_ACTIVE" in allc:
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+                busy = allc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * allc["GRBM_GUI_ACTIVE"] / 8)
+                f.write("\nVector pipes busy: SQ_ACTIVE_INST_VALU x 4 = %.3e SIMD-cycles of %.3e (1024 SIMDs x GRBM_GUI_ACTIVE / 8) = "
+                        "**%.1f %%** of the launch at the clock the chip actually held.\n"
+                        % (allc["SQ_ACTIVE_INST_VALU"] * 4.0, 1024 * allc["GRBM_GUI_ACTIVE"] / 8, 100 * busy))
+                if headline and os.path.exists(os.path.join(dst, "traffic_latest.json")):
+                    tj = json.load(open(os.path.join(dst, "traffic_latest.json")))
+                    tj["vector_pipes_busy_frac"] = busy
+                    tj["effective_clock_ghz"] = allc["GRBM_GUI_ACTIVE"] / 8 / (avg_ms * 1e-3) / 1e9
+                    json.dump(tj, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
     print(open(os.path.join(dst, tag + "_summary.md")).read())
 
 
