@@ -45,11 +45,17 @@ __device__ unsigned long long g_geo_trace[3 * 65536];
 // INSIDE the wave with row shifts (DPP): lane p < 3 takes its minus-point partner from lane p + 3 and forms
 // m_s = (t1 - t2) / (y1 - y2), lane 0 of the column takes m_2, m_3 from lanes 1, 2 and forms 1.5 m1 - 0.6 m2 + 0.1 m3 —
 // no trip through LDS, no extra barrier, and wave 1 combines its own arm's columns instead of waiting for wave 0.
-// Then the min-norm solve runs on wave 0 with lane c < 14 owning column c of the 2 x 14 system: the three serial dot
-// products of a Jacobi sweep are formed by every lane from an LDS copy of the rows (the oracle's order), the rotation,
-// the step and the update of x touch only the lane's own column (3 operations instead of 84 per sweep).
+// Then the min-norm solve runs on wave 0 with lane c < 14 owning column c of the 2 x 14 system: the three serial sums
+// of a Jacobi sweep are formed in the oracle's order by three lanes — one sum each, from the operand pairs the columns
+// are stored as — and handed round by readlane; the rotation, the step and the update of x touch only the lane's own
+// column (3 operations instead of 84 per sweep).
+//
+// What a round costs a lone block is its NUMBER of instructions (one wavefront issues one per ~4.25 cycles, whatever it
+// is: tools/ubench/), so the routine is written to keep moves, selects, exec-mask regions and branches out of the
+// round: lanes find "their" joint, their (sin, cos) slot and every joint's (sin, cos) through per-lane LDS addresses
+// computed once; literals of the elementary functions come from an LDS table (CCMP_K).
 #ifdef CCMP_FLAT_TIMING
-// phase timing of thread 0 of block 0 (tools/time_phases.py; never defined in the product build)
+// phase timing of thread 0 of block 0 (tools/exp_r3.py phases; never defined in the product build)
 __device__ unsigned long long g_flat_timing[8];
 __device__ __forceinline__ void flat_tick(int k, unsigned long long &prev)
 {
