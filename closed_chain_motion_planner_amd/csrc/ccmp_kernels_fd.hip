@@ -286,6 +286,23 @@ __device__ __forceinline__ void jacobian_columns(const ccmp_consts &K, double *r
         }
       }
     }
+#if defined(CCMP_FD_PROBE_MOV) || defined(CCMP_FD_PROBE_FMA)
+    // probe (never in the product; tools/ab.py): what one more instruction per stencil evaluation costs THIS kernel at its
+    // occupancy — N independent 32-bit moves or N independent FP64 FMAs beside the evaluation's own stream
+    {
+      int pv = j;
+      double pa = xj, pb = xj;
+#ifdef CCMP_FD_PROBE_MOV
+#pragma unroll
+      for (int k = 0; k < CCMP_FD_PROBE_MOV; k++) asm volatile("v_mov_b32 %0, 0x12345678" : "=v"(pv));
+#endif
+#ifdef CCMP_FD_PROBE_FMA
+#pragma unroll
+      for (int k = 0; k < CCMP_FD_PROBE_FMA / 2; k++) asm volatile("v_fma_f64 %0, %0, %2, %2\n v_fma_f64 %1, %1, %2, %2" : "+v"(pa), "+v"(pb) : "v"(h));
+#endif
+      if (pv == 0x7fffffff || pa + pb == 12345.678) rec[kX] = pa; // never true: keeps the probe alive
+    }
+#endif
     double Tw[12], t[2];
     tool_pose_t<STOCK>(K, ARM, R, o, &Tw[0], &Tw[9]);
     if (ARM == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], t, nullptr, nullptr);
