@@ -336,13 +336,15 @@ class KinematicChainConstraint:
                                                 1 if check_target else 0, _stream_handle(stream)), "ccmp_geodesic_batch_ex")
         return (states, n, ok, its, carry) if want_carry else (states, n, ok, its)
 
-    def continue_geodesics(self, to, states, n, ok, its, carry, max_states, round_budget=0, max_calls=1 << 20):
+    def continue_geodesics(self, to, states, n, ok, its, carry, max_states, round_budget=0, max_calls=1 << 20, cont_states=None):
         """Finishes the edges of a `discrete_geodesic_batch(..., want_carry=True)` result that did not reach their end
         (list full: n == max_states + 1; round budget spent: ok == 2), each from its last stored state.  Returns {edge index:
         (states (m,14) numpy, ok, newton iterations)} with the complete list of every such edge — what one uninterrupted
-        traversal produces, bit for bit."""
+        traversal produces, bit for bit.  `max_states` is the list length of the result passed in, `cont_states` (default:
+        the same) the one the continuation calls use."""
         torch = _torch()
-        if max_states < 2:
+        cs = max_states if cont_states is None else int(cont_states)
+        if max_states < 2 or cs < 2:
             raise ValueError("a continuation starts from a stored state other than `from`: max_states >= 2")
         long = torch.nonzero((n > max_states) | (ok == 2)).flatten()
         out = {}
@@ -358,23 +360,23 @@ class KinematicChainConstraint:
         cur_to = to[long].contiguous()
         cur_carry = carry[long].contiguous()
         for _ in range(max_calls):
-            s2, n2, ok2, it2, c2 = self.discrete_geodesic_batch(cur_from, cur_to, max_states, carry_in=cur_carry, want_carry=True,
+            s2, n2, ok2, it2, c2 = self.discrete_geodesic_batch(cur_from, cur_to, cs, carry_in=cur_carry, want_carry=True,
                                                                 round_budget=round_budget)
             n2c, ok2c, it2c = n2.cpu().numpy(), ok2.cpu().numpy(), it2.cpu().numpy()
             s2h = s2.cpu().numpy()
             again = []
             for k, e in enumerate(idx):
-                m = min(int(n2c[k]), max_states)
+                m = min(int(n2c[k]), cs)
                 parts[e].append(s2h[k, 1:m])  # row 0 repeats the state the continuation started from
                 total_its[e] += int(it2c[k])
-                if n2c[k] > max_states or ok2c[k] == 2:
+                if n2c[k] > cs or ok2c[k] == 2:
                     again.append(k)
                 else:
                     out[e] = (np.concatenate(parts[e], axis=0), int(ok2c[k]), total_its[e])
             if not again:
                 break
             sel = torch.as_tensor(again, device=to.device)
-            last = (n2.clamp(max=max_states)[sel] - 1).long()
+            last = (n2.clamp(max=cs)[sel] - 1).long()
             cur_from = s2[sel, last].contiguous()
             cur_to = cur_to[sel].contiguous()
             cur_carry = c2[sel].contiguous()

@@ -144,12 +144,17 @@ class jy_ProjectedStateSpace:
         dev = "cuda:%d" % self.constraint_.ctx.device
         f = torch.as_tensor(np.ascontiguousarray(frm, dtype=np.float64)).to(dev)
         t = torch.as_tensor(np.ascontiguousarray(to, dtype=np.float64)).to(dev)
-        states, n, ok, its, carry = self.constraint_.discrete_geodesic_batch(f, t, self.max_states, check_target=check_target,
-                                                                             want_carry=True)
-        # n_states == max_states + 1: these lists did not fit and the traversal stopped there.  Continue them from
-        # their last stored state until they are whole (ccmp_geodesic_batch_ex: the same states as one uninterrupted
-        # traversal) — a cut list must never reach the validity test or the caller as if it were complete.
-        whole = self.constraint_.continue_geodesics(t, states, n, ok, its, carry, self.max_states)
+        # A large batch takes the shape the library is fastest with: lists of 16 states and at most 128 Newton
+        # rounds per edge in the first launch — no creeping edge can hold it — then the few edges that stopped short.
+        big = f.shape[0] >= 1024
+        cap = min(self.max_states, 16) if big else self.max_states
+        states, n, ok, its, carry = self.constraint_.discrete_geodesic_batch(f, t, cap, check_target=check_target, want_carry=True,
+                                                                             round_budget=128 if big else 0)
+        # n_states == cap + 1: these lists did not fit and the traversal stopped there (ok == 2: the edge had spent the
+        # call's Newton rounds).  Continue them from their last stored state until they are whole (ccmp_geodesic_batch_ex:
+        # the same states as one uninterrupted traversal) — a cut list must never reach the validity test or the caller
+        # as if it were complete.
+        whole = self.constraint_.continue_geodesics(t, states, n, ok, its, carry, cap, cont_states=max(self.max_states, 2))
         n, ok = n.cpu().numpy(), ok.cpu().numpy()
         rows = [None] * len(n)
         for e, (st_e, ok_e, _) in whole.items():

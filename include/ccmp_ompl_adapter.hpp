@@ -260,8 +260,15 @@ inline void discreteGeodesicBatch(const Projector &proj, const double *from, con
   if (geodesics) geodesics->assign(E, {});
   if (E == 0) return;
   if (max_states < 2) max_states = 2; // a continuation starts from a stored state other than `from`
+  // A large batch takes the shape the library is fastest with: a first pass with lists of 16 states and at
+  // most 128 Newton rounds per edge — one launch that no creeping edge can hold — and the few edges that stop short
+  // (list full: n = cap + 1; rounds spent: ok = 2) are continued below, which gives the states of one uninterrupted
+  // traversal bit for bit.  growTree's handful of neighbours goes through unchanged.
+  const bool big = E >= 1024;
+  const int first_cap = big && max_states > 16 ? 16 : max_states;
+  const int first_budget = big ? 128 : 0;
   ccmp_problem pb;
-  std::vector<double> states(E * (size_t)max_states * 14), carry(E * 2);
+  std::vector<double> states(E * (size_t)first_cap * 14), carry(E * 2);
   std::vector<int32_t> n(E);
   std::vector<uint8_t> ok(E);
   {
@@ -269,14 +276,14 @@ inline void discreteGeodesicBatch(const Projector &proj, const double *from, con
     pb = proj.problem();
     if (delta > 0) pb.delta = delta;
     if (lambda > 0) pb.lambda = lambda;
-    check(ccmp_geodesic_host_ex(proj.ctx(), &pb, from, to, E, max_states, states.data(), n.data(), ok.data(), nullptr, carry.data(), 0,
-                                check_target ? 1 : 0),
+    check(ccmp_geodesic_host_ex(proj.ctx(), &pb, from, to, E, first_cap, states.data(), n.data(), ok.data(), nullptr, carry.data(),
+                                first_budget, check_target ? 1 : 0),
           "ccmp_geodesic_host_ex");
   }
   std::vector<double> more((size_t)max_states * 14);
   for (size_t e = 0; e < E; ++e) {
     std::vector<std::vector<double>> list;
-    const double *st = &states[e * (size_t)max_states * 14];
+    const double *st = &states[e * (size_t)first_cap * 14];
     const double *to_e = to + 14 * e;
     double cr[2] = {carry[2 * e], carry[2 * e + 1]};
     int32_t ne = n[e];
@@ -284,8 +291,9 @@ inline void discreteGeodesicBatch(const Projector &proj, const double *from, con
     bool good = false, cut = false;
     std::vector<double> last(14);
     int first = 0; // a continuation's row 0 repeats the state it started from
+    int cap = first_cap;
     for (;;) {
-      const int have = ne > max_states ? max_states : ne;
+      const int have = ne > cap ? cap : ne;
       for (int k = first; k < have && !cut; ++k) {
         const double *row = st + (size_t)k * 14;
         if (!interpolate && !(list.empty() && k == 0) && !valid(row)) {
@@ -300,8 +308,9 @@ inline void discreteGeodesicBatch(const Projector &proj, const double *from, con
         list.emplace_back(row, row + 14);
       }
       if (cut) break;
-      if (ne <= max_states) { good = oke != 0; break; }
-      // ne == max_states + 1: the list was full and the traversal stopped there — go on from its last state
+      if (ne <= cap && oke != 2) { good = oke != 0; break; }
+      // ne == cap + 1: the list was full and the traversal stopped there; ok == 2: it had spent the call's Newton rounds —
+      // either way go on from its last state
       double cr_out[2];
       {
         std::lock_guard<std::mutex> hold(proj.mutex());
@@ -311,6 +320,7 @@ inline void discreteGeodesicBatch(const Projector &proj, const double *from, con
       cr[0] = cr_out[0];
       cr[1] = cr_out[1];
       st = more.data();
+      cap = max_states;
       first = 1;
     }
     if (reached) (*reached)[e] = good ? 1 : 0;

@@ -87,6 +87,29 @@ int main(int argc, char **argv)
         }
         std::printf("gbatch checker_calls %d\n", calls);
       }
+      // a LARGE batch takes another shape inside the adapter (lists of 16 + a budget of Newton rounds, then continuation of
+      // the edges that stop short): every edge must come out as the single-edge call gives it
+      {
+        const size_t E = 1200;
+        std::vector<double> fr, tt;
+        for (size_t e = 0; e < E; e++) {
+          const size_t a = e % B, b = (e + 1 + e / B) % B;
+          fr.insert(fr.end(), &out[14 * a], &out[14 * a] + 14);
+          tt.insert(tt.end(), &out[14 * b], &out[14 * b] + 14);
+        }
+        std::vector<std::vector<std::vector<double>>> lists;
+        std::vector<char> reached;
+        ccmp::discreteGeodesicBatch(P, fr.data(), tt.data(), E, true, [](const double *) { return true; }, &lists, &reached, 64);
+        int bad = 0;
+        for (size_t e = 0; e < E; e += 7) { // a seventh of them, one by one
+          std::vector<std::vector<double>> one;
+          const bool g = ccmp::discreteGeodesic(P, &fr[14 * e], &tt[14 * e], true, [](const double *) { return true; }, &one, 64);
+          bool same = (g ? 1 : 0) == (int)reached[e] && one.size() == lists[e].size();
+          for (size_t k = 0; same && k < one.size(); k++) same = std::memcmp(one[k].data(), lists[e][k].data(), 14 * sizeof(double)) == 0;
+          if (!same) bad++;
+        }
+        std::printf("gbatch_big edges %zu mismatches %d\n", E, bad);
+      }
       // sampleUniformNear / sampleGaussian around the first projected state through the look-ahead buffers
       ccmp::RefSampleBuffer nb(P, 42, ccmp::RefSampleBuffer::Near, 4), gb(P, 42, ccmp::RefSampleBuffer::Gaussian, 4);
       for (int i = 0; i < 6; i++) {  // 6 > look-ahead: the second refill continues the stream

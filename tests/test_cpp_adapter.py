@@ -88,6 +88,8 @@ def test_adapter_matches_oracle(ccmp_built, oracle_det, tmp_path):
         k += 2
     assert out[k] == "gbatch checker_calls %d" % calls  # every state but `from`, edge by edge
     k += 1
+    assert out[k] == "gbatch_big edges 1200 mismatches 0"  # the large-batch shape (short lists + round budget + continuation)
+    k += 1
 
     def around(kind, salt, index, param):
         amb = oracle_det.ambient_ref_batch(P, kind, 42 ^ salt, index, proj[0], param, 1)
