@@ -70,8 +70,10 @@ __device__ __forceinline__ void flat_tick(int k, unsigned long long &prev)
 #define FLAT_TICK(k) do { } while (0)
 #endif
 
-// record of one sample in LDS (doubles): x 14 | sin,cos 28 | tool poses at x 24 | f(x) 2 | J 84 | flag |
-// one (sin, cos) slot per thread: the sine and cosine of the lane's own perturbed angle.
+// record of one sample in LDS (doubles): x 14 | joint rotations at x 14 x 12 | tool poses at x 24 | f(x) 2 | J | flag |
+// one joint-rotation slot per evaluation lane (its own perturbed joint).
+// A joint-rotation slot: (sin, cos | the nine entries of Rot(axis, angle), ccmp_kin.h rot_sc | pad) — formed ONCE per round
+// and joint by the lane that takes the joint's sine and cosine, instead of by every lane of the chain for every joint.
 // J: six doubles per column c, (J0c, J0c | J1c, J1c | J0c, J1c) — the operand pairs of the three serial sums of a Jacobi
 // sweep (sum J0c^2, sum J1c^2, sum J0c J1c), so that a lane forms ONE of them from one 16-byte read per column.
 // CCMP_SUMS_IN_LANE (the build with machine LICM, which measured 4-7 % slower with the split sums): two doubles per
@@ -81,8 +83,11 @@ constexpr int kJCol = 2, kJPair = 0;
 #else
 constexpr int kJCol = 6, kJPair = 4;
 #endif
-constexpr int fX = 0, fSC = 14, fEE = 42, fF = 66, fJ = 68, fV = fJ + 14 * kJCol, fOwn = fV + 2, fRec = fOwn + 2 * 128;
-static_assert(fJ % 2 == 0 && fOwn % 2 == 0, "16-byte slots");
+constexpr int kRot = 14;  // doubles per joint-rotation slot: 11 used; 28 dwords apart, sixteen lanes' 16-byte accesses fall on distinct LDS banks
+constexpr int kEvLanes = 42; // evaluation lanes per wavefront
+constexpr int fX = 0, fSC = 14, fEE = fSC + 14 * kRot, fF = fEE + 24, fJ = fF + 2, fV = fJ + 14 * kJCol, fOwn = fV + 2,
+              fDummy = fOwn + 2 * kEvLanes * kRot, fRec = fDummy + kRot;
+static_assert(fSC % 2 == 0 && fEE % 2 == 0 && fJ % 2 == 0 && fOwn % 2 == 0 && fDummy % 2 == 0, "16-byte slots");
 
 // column (v0, v1) of J into its slot
 __device__ __forceinline__ void store_column(double *slot, double v0, double v1)
@@ -101,12 +106,15 @@ __device__ __forceinline__ void store_column(double *slot, double v0, double v1)
 // 4: the product), in column order — solve_minnorm's order (ccmp_solve.h)
 __device__ __forceinline__ double column_sum(const double *jx)
 {
+  // all fourteen reads in flight before the first FMA (the scheduler otherwise — seen — serialises read, wait, FMA through
+  // one register quad: fourteen exposed LDS round trips on the critical path of every round)
+  double2 uv[14];
+#pragma unroll
+  for (int k = 0; k < 14; k++) uv[k] = *reinterpret_cast<const double2 *>(jx + kJCol * k);
+  __builtin_amdgcn_sched_barrier(0);
   double acc = 0.0;
 #pragma unroll
-  for (int k = 0; k < 14; k++) {
-    const double2 uv = *reinterpret_cast<const double2 *>(jx + kJCol * k);
-    acc = CCMP_FMA(uv.x, uv.y, acc);
-  }
+  for (int k = 0; k < 14; k++) acc = CCMP_FMA(uv[k].x, uv[k].y, acc);
   return acc;
 }
 // the value lane N of the row holds, in every lane of the row (the three sums are formed in lanes 0, 1, 2 of EVERY row, so
@@ -116,9 +124,13 @@ __device__ __forceinline__ double column_sum(const double *jx)
 __device__ __forceinline__ void column_sums(const double *jbase, double &a, double &d, double &b)
 {
   a = 0.0; d = 0.0; b = 0.0;
+  double2 pp[14];
+#pragma unroll
+  for (int k = 0; k < 14; k++) pp[k] = *reinterpret_cast<const double2 *>(jbase + kJCol * k + kJPair);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 14; k++) {
-    const double2 p = *reinterpret_cast<const double2 *>(jbase + kJCol * k + kJPair);
+    const double2 p = pp[k];
     a = CCMP_FMA(p.x, p.x, a);
     d = CCMP_FMA(p.y, p.y, d);
     b = CCMP_FMA(p.x, p.y, b);
@@ -156,9 +168,9 @@ __device__ __forceinline__ void wave_lds_fence()
                                      // scheduler otherwise hoists the next phase's loads to the top and spills)
 }
 
-// Per-joint constants of both arms in chain order, 12 doubles per joint (offset 3, axis 3, axis products 6), so that a
-// joint's constants are six 16-byte LDS reads that can be issued one joint ahead of their use.
-constexpr int kStepDoubles = 12, kStepTab = 2 * 7 * kStepDoubles;
+// Per-joint constants of both arms in chain order, 14 doubles per joint: offset 3 + pad (read by the chain, one joint ahead
+// of its use) | axis 3, axis products 6 + pad (read by the lane that forms the joint's rotation).
+constexpr int kStepDoubles = 14, kStepAxis = 4, kStepTab = 2 * 7 * kStepDoubles;
 
 __device__ __forceinline__ void stage_step_table(const ccmp_consts &K, double *tab, int tid)
 {
@@ -167,33 +179,41 @@ __device__ __forceinline__ void stage_step_table(const ccmp_consts &K, double *t
 #endif
   for (int k = tid; k < kStepTab; k += 128) {
     const int a = k / (7 * kStepDoubles), r = k - a * 7 * kStepDoubles, i = r / kStepDoubles, c = r - i * kStepDoubles;
-    tab[k] = c < 3 ? K.offset[a][i][c] : (c < 6 ? K.axis[a][i][c - 3] : K.aprod[a][i][c - 6]);
+    tab[k] = c < 3 ? K.offset[a][i][c] : (c < 4 ? 0.0 : (c < 7 ? K.axis[a][i][c - 4] : (c < 13 ? K.aprod[a][i][c - 7] : 0.0)));
   }
 }
 
 // joints I..6 of the chain of arm W with compile-time joint indices (STOCK: the exact-zero structure of the uncalibrated
-// Panda is known to the compiler, ccmp_kin.h); the constants of joint I+1 are read while joint I is computed.  A lane
-// finds joint I's (sin, cos) at rec[sc_at(I)]: the arm's table at x, or — for the lane's own perturbed joint — the
-// lane's slot (an address select per joint instead of four register selects).
+// Panda is known to the compiler, ccmp_kin.h); the offset and the rotation slot of joint I+1 are read while joint I is
+// computed.  A lane finds joint I's rotation at rec[slot]: the arm's table at x, or — for the lane's own perturbed joint —
+// the lane's slot (an address select per joint).  A stock z joint needs the slot's (sin, cos) only.
 template <int W, bool STOCK, int I>
-__device__ __forceinline__ void flat_chain_from(const double2 *tab, const double *rec, int j, int own, const double2 *cur, double2 sc_cur,
+__device__ __forceinline__ void flat_chain_from(const double2 *tab, const double *rec, int j, int own, const double2 *off_cur, const double2 *rot_cur,
                                                 double *R, double *o)
 {
   if constexpr (I < 7) {
-    double2 nxt[6], sc_nxt = sc_cur;
-    if constexpr (I < 6) {
+    double2 off_nxt[2] = {off_cur[0], off_cur[1]}, rot_nxt[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) nxt[k] = tab[6 * (I + 1) + k];
-      sc_nxt = *reinterpret_cast<const double2 *>(rec + ((I + 1 == j) ? own : fSC + 2 * (W * 7 + I + 1)));
+    for (int k = 0; k < 6; k++) rot_nxt[k] = rot_cur[k];
+    if constexpr (I < 6) {
+      off_nxt[0] = tab[(kStepDoubles / 2) * (I + 1)];
+      off_nxt[1] = tab[(kStepDoubles / 2) * (I + 1) + 1];
+      const double2 *slot = reinterpret_cast<const double2 *>(rec + ((I + 1 == j) ? own : fSC + kRot * (W * 7 + I + 1)));
+#pragma unroll
+      for (int k = 0; k < 6; k++) rot_nxt[k] = slot[k];
     }
     double Rn[9];
-    const double off[3] = {cur[0].x, cur[0].y, cur[1].x};
-    const double ax[3] = {cur[1].y, cur[2].x, cur[2].y};
-    const double ap[6] = {cur[3].x, cur[3].y, cur[4].x, cur[4].y, cur[5].x, cur[5].y};
-    chain_step<I, STOCK>(off, ax, ap, sc_cur.x, sc_cur.y, R, Rn, o);
+    const double off[3] = {off_cur[0].x, off_cur[0].y, off_cur[1].x};
+    mulvec_acc_nz<STOCK ? kStockOff[I] : 7>(R, off, o);
+    if constexpr (STOCK && kStockZ[I] != 0) {
+      mul_zrot(R, rot_cur[0].x, rot_cur[0].y, Rn);
+    } else {
+      const double Rj[9] = {rot_cur[1].x, rot_cur[1].y, rot_cur[2].x, rot_cur[2].y, rot_cur[3].x, rot_cur[3].y, rot_cur[4].x, rot_cur[4].y, rot_cur[5].x};
+      mul33(R, Rj, Rn);
+    }
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = Rn[k];
-    flat_chain_from<W, STOCK, I + 1>(tab, rec, j, own, nxt, sc_nxt, R, o);
+    flat_chain_from<W, STOCK, I + 1>(tab, rec, j, own, off_nxt, rot_nxt, R, o);
   }
 }
 
@@ -208,11 +228,13 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
   {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
     const double2 *tab = reinterpret_cast<const double2 *>(steptab + W * 7 * kStepDoubles);
-    double2 cur[6];
+    double2 off0[2] = {tab[0], tab[1]}, rot0[6];
+    {
+      const double2 *slot = reinterpret_cast<const double2 *>(rec + ((j == 0) ? own : fSC + kRot * W * 7));
 #pragma unroll
-    for (int k = 0; k < 6; k++) cur[k] = tab[k];
-    const double2 sc0 = *reinterpret_cast<const double2 *>(rec + ((j == 0) ? own : fSC + 2 * W * 7));
-    flat_chain_from<W, STOCK, 0>(tab, rec, j, own, cur, sc0, R, o);
+      for (int k = 0; k < 6; k++) rot0[k] = slot[k];
+    }
+    flat_chain_from<W, STOCK, 0>(tab, rec, j, own, off0, rot0, R, o);
     tool_pose_t<STOCK>(KC, W, R, o, &Tw[0], &Tw[9]);
     if (lane == kXLane) {
 #pragma unroll
@@ -261,9 +283,13 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
   const bool plus = pt < 3;
   const int nstep = (plus ? pt : pt - 3) + 1;
   // LDS slots of this lane (doubles): the joint value it starts from, its own (sin, cos), where it stores what it computes
-  const int own = fOwn + 2 * tid;
-  const int x_at = fX + (ev ? w * 7 + j : (sc_lane ? w * 7 + lane - kScLane0 : 0));
-  const int sc_to = sc_lane ? fSC + 2 * (w * 7 + lane - kScLane0) : own;
+  // evaluation lanes own a rotation slot each (42 per wavefront), the sine/cosine lanes fill the arm's table at x, the rest
+  // write a dummy slot
+  const int my_joint = ev ? j : (sc_lane ? lane - kScLane0 : 0);
+  const int own = ev ? fOwn + kRot * (w * kEvLanes + row * 12 + rl) : fDummy;
+  const int x_at = fX + w * 7 + my_joint;
+  const int sc_to = sc_lane ? fSC + kRot * (w * 7 + lane - kScLane0) : own;
+  const int ax_at = (w * 7 + my_joint) * kStepDoubles + kStepAxis; // axis + axis products of "my" joint in the step table
   unsigned long long tprev = __builtin_readcyclecounter();
   for (;;) {
     // ---- A: angles.  y1[j] += h / y2[j] -= h by sequential adds as OMPL does; one sincos per lane, without a branch:
@@ -279,10 +305,21 @@ __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_con
     const double y = ev ? ys : xj;
     ccmp_sincos(y, &s, &c);
     {
-      double2 scv;
-      scv.x = s;
-      scv.y = c;
-      *reinterpret_cast<double2 *>(rec + sc_to) = scv;
+      // the joint's rotation, by the lane that has its sine and cosine (ccmp_kin.h rot_sc: the chain's operations, once)
+      const double2 *ac = reinterpret_cast<const double2 *>(steptab + ax_at);
+      const double2 a01 = ac[0], a2p0 = ac[1], p12 = ac[2], p34 = ac[3], p5 = ac[4];
+      const double axv[3] = {a01.x, a01.y, a2p0.x};
+      const double apv[6] = {a2p0.y, p12.x, p12.y, p34.x, p34.y, p5.x};
+      double Rj[9];
+      rot_sc(axv, apv, s, c, Rj);
+      double2 *slot = reinterpret_cast<double2 *>(rec + sc_to);
+      double2 v;
+      v.x = s; v.y = c; slot[0] = v;
+      v.x = Rj[0]; v.y = Rj[1]; slot[1] = v;
+      v.x = Rj[2]; v.y = Rj[3]; slot[2] = v;
+      v.x = Rj[4]; v.y = Rj[5]; slot[3] = v;
+      v.x = Rj[6]; v.y = Rj[7]; slot[4] = v;
+      v.x = Rj[8]; v.y = 0.0; slot[5] = v;
     }
     // an arm's sines and cosines are written and read by the arm's own wave: no block barrier
     wave_lds_fence();
