@@ -578,7 +578,8 @@ def secondary(args, c, ctx, B, torch, cfg_path):
 
         def complete():
             r = call()
-            return r, c.continue_geodesics(to, r[0], r[1], r[2], r[3], r[4], first_pass, round_budget=budget)
+            # the continuation as the callers run it (space.discreteGeodesicBatch, ccmp::discreteGeodesicBatch): lists of 64, no round bound
+            return r, c.continue_geodesics(to, r[0], r[1], r[2], r[3], r[4], first_pass, cont_states=64)
 
         complete()
         torch.cuda.synchronize()
