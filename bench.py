@@ -189,7 +189,7 @@ def cpu_baseline(obj, seed, gpu_check=None):
     parity, vs_libm = None, None
     if gpu_check is not None:
         m = 2048
-        parity = det_parity(gpu_check["problem_bytes"], gpu_check["q_in"][:m], gpu_check["q_out"][:m], gpu_check["ok"][:m],
+        parity = det_parity(obj, gpu_check["problem"], gpu_check["q_in"][:m], gpu_check["q_out"][:m], gpu_check["ok"][:m],
                             gpu_check["iters"][:m], cores)
         # how far the GPU's results are from what the reference's libm gives — the glibc build timed
         # above, on the same leading samples of the batch.  (The GPU is bit-identical to the det build; this is the
@@ -213,7 +213,19 @@ def cpu_baseline(obj, seed, gpu_check=None):
     }
 
 
-def det_parity(problem_bytes, q_in, q_out, ok, iters, threads):
+def checker_problem(O, obj, product_problem):
+    """The checker's problem: built by the ORACLE'S OWN set-up code from the YAML fixture of `obj` (never adopted from the
+    product's struct), with the parameters this bench changes after loading — the two tolerances and the Jacobian switch —
+    carried over as plain numbers, then compared with the product's problem byte for byte: the two set-up paths check
+    each other in every in-run parity figure."""
+    own = O.checker_problem(os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml"))
+    own.tol_pos, own.tol_rot, own.jacobian_mode = product_problem.tol_pos, product_problem.tol_rot, product_problem.jacobian_mode
+    if bytes(own) != bytes(product_problem):
+        raise RuntimeError("set-up mismatch: the product's problem for %s differs from the oracle's own" % obj)
+    return own
+
+
+def det_parity(obj, product_problem, q_in, q_out, ok, iters, threads):
     """the det build of the oracle on the very inputs the GPU projected"""
     import numpy as np
 
@@ -221,7 +233,7 @@ def det_parity(problem_bytes, q_in, q_out, ok, iters, threads):
     from oracle_binding import Oracle
 
     Od = Oracle("det")
-    Pd = Od.problem_from_bytes(problem_bytes)
+    Pd = checker_problem(Od, obj, product_problem)
     qd, okd, itd = Od.project_batch(Pd, q_in, threads)
     d = np.abs(qd - q_out).max(axis=1)
     return {"samples": len(q_in), "max_abs_dq": float(d.max()), "n_gt_1e-6": int((d > 1e-6).sum()),
@@ -465,7 +477,7 @@ def main():
             gpu_check = None
             if args.mode == "fd" and not args.tol:
                 m = min(B, 131072)  # the CPU leg's sample is at most this long
-                gpu_check = {"problem_bytes": bytes(c.problem), "q_in": q_in[:m].cpu().numpy(), "q_out": q_out[:m].cpu().numpy(),
+                gpu_check = {"problem": c.problem, "q_in": q_in[:m].cpu().numpy(), "q_out": q_out[:m].cpu().numpy(),
                              "ok": ok[:m].cpu().numpy(), "iters": it[:m].cpu().numpy().astype("int32")}
             line["cpu_baseline"] = cpu_baseline(args.obj, seed, gpu_check)
         except Exception as e:  # the oracle is a checker; its absence must not fail the GPU bench
@@ -496,7 +508,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
-    def quick(con, mode, b, reps, check=False):
+    def quick(con, mode, b, reps, check=False, obj=None):
         con.setJacobianMode(mode)
         qi = con.ambient_uniform_batch(SEEDS.get(b, 0xC3), 0, b)
         qo = torch.empty_like(qi)
@@ -505,7 +517,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         if check and mode == CCMP_JAC_FD:
             _, ok, it = con.project_batch(qi, out=qo)
             try:
-                res["parity_vs_det_oracle"] = det_parity(bytes(con.problem), qi[:1024].cpu().numpy(), qo[:1024].cpu().numpy(),
+                res["parity_vs_det_oracle"] = det_parity(obj or args.obj, con.problem, qi[:1024].cpu().numpy(), qo[:1024].cpu().numpy(),
                                                          ok[:1024].cpu().numpy(), it[:1024].cpu().numpy().astype("int32"), threads)
             except Exception as e:
                 res["parity_vs_det_oracle"] = {"error": repr(e)}
@@ -609,7 +621,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             from oracle_binding import Oracle
 
             Od = Oracle("det")
-            Pd = Od.problem_from_bytes(bytes(c.problem))
+            Pd = checker_problem(Od, args.obj, c.problem)
             m = 1024
             sc, nc, okc, itc = Od.discrete_geodesic_batch(Pd, frm[:m].cpu().numpy(), to[:m].cpu().numpy(), first_pass, threads)
             sg, ng, og, ig = st[:m].cpu().numpy(), n[:m].cpu().numpy(), gok[:m].cpu().numpy(), its[:m].cpu().numpy()
@@ -684,7 +696,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
                "gpu_projections_per_s": b / sec, "gpu_ms": sec * 1e3, "same_ambient_samples_on_both_sides": True,
                "gpu_ok_fraction": float(okg.to(torch.float64).mean().item())}
         try:
-            res["parity_vs_det_oracle"] = det_parity(bytes(db.problem), qi.cpu().numpy(), qo.cpu().numpy(), okg.cpu().numpy(),
+            res["parity_vs_det_oracle"] = det_parity("dumbbell", db.problem, qi.cpu().numpy(), qo.cpu().numpy(), okg.cpu().numpy(),
                                                      itg.cpu().numpy().astype("int32"), threads)
         except Exception as e:
             res["parity_vs_det_oracle"] = {"error": repr(e)}
@@ -716,7 +728,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             from oracle_binding import Oracle
 
             Od = Oracle("det")
-            Pd = Od.problem_from_bytes(bytes(c.problem))
+            Pd = checker_problem(Od, args.obj, c.problem)
             m = 2048
             co, po = Od.clearance_batch(Pd, sc.spheres, sc.boxes, sc.allowed, q[:m].cpu().numpy())
             cg = clr[:m].cpu().numpy()
@@ -738,9 +750,9 @@ def secondary(args, c, ctx, B, torch, cfg_path):
     c.setJacobianMode(main_mode)
     # BASELINE configs[3]: stefan (arms left + top), the reference's tolerances and the tighter set the baseline asks for
     st = KinematicChainConstraint.from_yaml(cfg_path("stefan"), ctx=ctx)
-    out["stefan_batch%d_tol_1e-3_5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True)
+    out["stefan_batch%d_tol_1e-3_5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True, obj="stefan")
     st.setTolerance(5e-4, 2.5e-3)
-    out["stefan_batch%d_tol_5e-4_2.5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True)
+    out["stefan_batch%d_tol_5e-4_2.5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True, obj="stefan")
     out["discrete_geodesic"] = geodesic()
     out["proxy_clearance"] = proxy_clearance()
     for name, fn in (("host_buffer", host_buffer), ("c1_dumbbell", c1_dumbbell)):

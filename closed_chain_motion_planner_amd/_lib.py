@@ -63,7 +63,7 @@ CCMP_JAC_ANALYTIC = 1
 
 # every symbol include/ccmp.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "ccmp_problem_from_yaml", "ccmp_problem_init", "ccmp_set_arms", "ccmp_set_start", "ccmp_set_tolerance", "ccmp_set_calibration",
+    "ccmp_problem_from_yaml", "ccmp_problem_init", "ccmp_set_arms", "ccmp_set_base_frame", "ccmp_set_start", "ccmp_set_tolerance", "ccmp_set_calibration",
     "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_set_schedule", "ccmp_ctx_set_option", "ccmp_ctx_set_lpt", "ccmp_ctx_device", "ccmp_ctx_num_cus",
     "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
     "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
@@ -105,6 +105,7 @@ def lib():
         "ccmp_set_arms": ([pp, C.c_char_p, C.c_int, C.c_char_p, C.c_int], C.c_int),
         "ccmp_set_start": ([pp, dp], C.c_int),
         "ccmp_set_tolerance": ([pp, C.c_double, C.c_double], C.c_int),
+        "ccmp_set_base_frame": ([pp, C.c_int, dp, dp], C.c_int),
         "ccmp_set_calibration": ([pp, C.c_int, dp], C.c_int),
         "ccmp_ctx_create": ([C.c_int, C.POINTER(vp)], C.c_int),
         "ccmp_ctx_destroy": ([vp], None),

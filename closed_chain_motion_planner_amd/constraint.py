@@ -108,11 +108,14 @@ class Communicator:
 
 
 class ArmModel:
-    """The two fields of the reference's `ArmModel` (panda_model.h:7-23) the projector reads."""
+    """The fields of the reference's `ArmModel` (panda_model.h:7-23) the projector reads: name, index and — optionally —
+    `t_wb`, the base frame in the world as a (3, 4) / (4, 4) array [R | p] (None = the frame of that index in
+    src/kinematics/grasping_point.cpp:11-20, which is what the reference fills it with, ConstrainedPlanningCommon.cpp:98)."""
 
-    def __init__(self, name, index):
+    def __init__(self, name, index, t_wb=None):
         self.name = str(name)
         self.index = int(index)
+        self.t_wb = t_wb
 
 
 def load_config(yaml_path):
@@ -166,20 +169,27 @@ class KinematicChainConstraint:
         return 14
 
     def setArmModels(self, arm1, arm2):
-        """ConstraintFunction.h:122-126.  Callers pass arms in std::map (alphabetical) order, as
-        ConstrainedPlanningCommon.cpp:126 does."""
+        """ConstraintFunction.h:122-126: arm1 = the first seven joints, arm2 the other seven, in the order given (the
+        reference's callers pass std::map order, ConstrainedPlanningCommon.cpp:126).  An arm object may carry `t_wb` — a
+        (3, 4) or (4, 4) array [R | p], ArmModel::t_wb of panda_model.h:15 — which then replaces the frame looked up from its
+        index (src/kinematics/grasping_point.cpp:11-20)."""
         self._arms = [arm1, arm2]
+        L = _lib.lib()
         if self.problem is None:
             P = CcmpProblem()
-            check(_lib.lib().ccmp_problem_init(C.byref(P), arm1.name.encode(), arm1.index, arm2.name.encode(), arm2.index,
-                                               _dptr(np.zeros(14)), None, None, None, None), "ccmp_problem_init")
+            check(L.ccmp_problem_init(C.byref(P), arm1.name.encode(), arm1.index, arm2.name.encode(), arm2.index,
+                                      _dptr(np.zeros(14)), None, None, None, None), "ccmp_problem_init")
             self.problem = P
-        else:
-            # the reference calls this AFTER loadConfig (ConstrainedPlanningCommon.cpp:126): only the arm / base-frame
-            # fields change; object poses, start state, tolerances, delta / lambda, calibration and mode are kept and
-            # init_chain_ / t_o7 are recomputed for the new arms
-            check(_lib.lib().ccmp_set_arms(C.byref(self.problem), arm1.name.encode(), arm1.index, arm2.name.encode(),
-                                           arm2.index), "ccmp_set_arms")
+        # the reference calls this AFTER loadConfig (ConstrainedPlanningCommon.cpp:126): only the arm / base-frame
+        # fields change; object poses, start state, tolerances, delta / lambda, calibration and mode are kept and
+        # init_chain_ / t_o7 are recomputed for the new arms
+        check(L.ccmp_set_arms(C.byref(self.problem), arm1.name.encode(), arm1.index, arm2.name.encode(), arm2.index), "ccmp_set_arms")
+        for slot, arm in enumerate((arm1, arm2)):
+            t_wb = getattr(arm, "t_wb", None)
+            if t_wb is not None:
+                T = np.asarray(t_wb, dtype=np.float64)
+                R, p = np.ascontiguousarray(T[:3, :3]), np.ascontiguousarray(T[:3, 3])
+                check(L.ccmp_set_base_frame(C.byref(self.problem), slot, _dptr(R), _dptr(p)), "ccmp_set_base_frame")
 
     def setInitialPosition(self, init_joint):
         """ConstraintFunction.h:31-40."""
@@ -381,6 +391,9 @@ class KinematicChainConstraint:
             cur_to = cur_to[sel].contiguous()
             cur_carry = c2[sel].contiguous()
             idx = [idx[k] for k in again]
+        else:
+            # max_calls spent with edges still open: a partial dict would let a caller take a cut list for a whole one
+            raise RuntimeError("continue_geodesics: %d edges unfinished after %d calls (first: %s)" % (len(idx), max_calls, idx[:8]))
         return out
 
     def ambient_uniform_batch(self, seed, first_index, B, stream=None):

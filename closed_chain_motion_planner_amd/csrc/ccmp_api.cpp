@@ -640,6 +640,9 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   if (p->jacobian_mode != CCMP_JAC_FD) return CCMP_EINVAL; // the extend step exists in reference arithmetic only
   if (carry_in && check_target) return CCMP_EINVAL;        // a continuation's target was tested by the call it continues
   if (round_budget > 0 && !carry_out) return CCMP_EINVAL;  // a suspended edge is useless without what its continuation needs
+  // a resumable call needs room for one state besides `from`: with a one-entry list the first accepted state already reports
+  // max_states + 1 with `from` as its last stored state, and a caller following the protocol would continue from `from` for ever
+  if ((carry_in || carry_out || round_budget > 0) && max_states < 2) return CCMP_EINVAL;
   // One 128-thread block per edge.  Up to the resident capacity every edge has its block at once and
   // the hardware dispatcher is the queue.  Beyond it the blocks are persistent and take tickets from an atomic word,
   // handed out through a long-edges-first order when the batch is large enough for the ordering pass to pay: the
@@ -954,6 +957,7 @@ static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const doub
   if (!ctx || !p) return CCMP_EINVAL;
   if (E == 0) return CCMP_OK;
   if (!from || !to || !states || !n_states || !ok || max_states < 1) return CCMP_EINVAL;
+  if ((carry_in || carry_out || round_budget > 0) && max_states < 2) return CCMP_EINVAL; // as geodesic_common: before any buffer is touched
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
   const size_t eb = E * 14 * sizeof(double);

@@ -9,7 +9,7 @@
 // compiler re-materialises a literal with two move instructions per use (machine LICM is off here, and hoisting them
 // costs the registers that eight blocks per CU live on), one 16-byte LDS read brings two.  -DCCMP_FLAT_LITERALS: as before.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CCMP_FLAT_LITERALS)
-__shared__ __attribute__((aligned(16))) double ccmp_ktab[36];
+static __shared__ __attribute__((aligned(16))) double ccmp_ktab[36]; // internal linkage: three translation units include this header
 #define CCMP_K(i, v) (ccmp_ktab[i])
 #define CCMP_KTAB_IN_LDS 1
 #endif

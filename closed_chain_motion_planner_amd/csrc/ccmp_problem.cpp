@@ -351,18 +351,42 @@ int ccmp_problem_init(ccmp_problem *out, const char *arm1_name, int arm1_index, 
 }
 
 // KinematicChainConstraint::setArmModels on a problem that is already set up (the reference calls it after loadConfig,
-// ConstrainedPlanningCommon.cpp:126): only the arm selection and the base frames change; init_chain_ and t_o7 follow
+// ConstrainedPlanningCommon.cpp:126): only the arm selection and the base frames change; init_chain_ and t_o7 follow.
+// The arms are stored IN THE ORDER GIVEN, as ConstraintFunction.h:122-126 does (arm_models_.push_back(arm1), then arm2);
+// putting them in std::map order is the caller's business there (ConstrainedProblem::_setEnvironment, :89-91) and
+// ccmp_problem_init's / ccmp_problem_from_yaml's here.  The names are accepted for symmetry with ccmp_problem_init only.
 int ccmp_set_arms(ccmp_problem *p, const char *arm1_name, int arm1_index, const char *arm2_name, int arm2_index)
 {
   if (!p || !arm1_name || !arm2_name) return CCMP_EINVAL;
   if (arm1_index < 0 || arm1_index > 2 || arm2_index < 0 || arm2_index > 2) return CCMP_EINVAL;
-  int idx[2];
-  if (strcmp(arm1_name, arm2_name) <= 0) { idx[0] = arm1_index; idx[1] = arm2_index; }
-  else { idx[0] = arm2_index; idx[1] = arm1_index; }
+  const int idx[2] = {arm1_index, arm2_index};
   for (int a = 0; a < 2; a++) {
     p->arm_index[a] = idx[a];
     base_frame(idx[a], p->base_R[a], p->base_p[a]);
   }
+  return ccmp_set_start(p, p->start_joint);
+}
+
+// ArmModel::t_wb of one arm (include/closed_chain_motion_planner/kinematics/panda_model.h:15, filled from
+// config->t_wb[index] at ConstrainedPlanningCommon.cpp:98 and read by KinematicChainConstraint::function at
+// ConstraintFunction.h:89-90): the adapter hands over the frame the ArmModel really carries instead of re-deriving it
+// from the index.  R must be a rotation (orthonormal to 1e-9, determinant +1) and everything finite.
+int ccmp_set_base_frame(ccmp_problem *p, int arm_slot, const double R[9], const double pos[3])
+{
+  if (!p || !R || !pos || arm_slot < 0 || arm_slot > 1) return CCMP_EINVAL;
+  for (int k = 0; k < 9; k++)
+    if (!(R[k] - R[k] == 0.0)) return CCMP_EINVAL;
+  for (int k = 0; k < 3; k++)
+    if (!(pos[k] - pos[k] == 0.0)) return CCMP_EINVAL;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const double d = R[3 * i] * R[3 * j] + R[3 * i + 1] * R[3 * j + 1] + R[3 * i + 2] * R[3 * j + 2] - (i == j ? 1.0 : 0.0);
+      if (d > 1e-9 || d < -1e-9) return CCMP_EINVAL;
+    }
+  const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+  if (!(det > 0.0)) return CCMP_EINVAL;
+  memcpy(p->base_R[arm_slot], R, 9 * sizeof(double));
+  memcpy(p->base_p[arm_slot], pos, 3 * sizeof(double));
   return ccmp_set_start(p, p->start_joint);
 }
 

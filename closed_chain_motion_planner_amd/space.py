@@ -147,7 +147,9 @@ class jy_ProjectedStateSpace:
         # A large batch takes the shape the library is fastest with: lists of 16 states and at most 128 Newton
         # rounds per edge in the first launch — no creeping edge can hold it — then the few edges that stopped short.
         big = f.shape[0] >= 1024
-        cap = min(self.max_states, 16) if big else self.max_states
+        # a continuation starts from a stored state other than `from`: lists hold at least two states (the C++ adapter clamps
+        # the same way); max_states = 1 therefore behaves like 2 — nothing is ever cut, edges that need more are continued
+        cap = max(2, min(self.max_states, 16) if big else self.max_states)
         states, n, ok, its, carry = self.constraint_.discrete_geodesic_batch(f, t, cap, check_target=check_target, want_carry=True,
                                                                              round_budget=128 if big else 0)
         # n_states == cap + 1: these lists did not fit and the traversal stopped there (ok == 2: the edge had spent the
@@ -159,6 +161,9 @@ class jy_ProjectedStateSpace:
         rows = [None] * len(n)
         for e, (st_e, ok_e, _) in whole.items():
             rows[e], n[e], ok[e] = st_e, st_e.shape[0], ok_e
+        left = [e for e in range(len(n)) if rows[e] is None and (n[e] > cap or ok[e] == 2)]
+        if left:  # a truncated or suspended edge must never be reported as reached (ok == 2 is not a bool)
+            raise RuntimeError("discreteGeodesicBatch: edges %s were not traversed to their end" % left[:8])
         states = states.cpu().numpy()
         delta = self.constraint_.problem.delta
         out = []

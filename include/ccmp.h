@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CCMP_VERSION 300
+#define CCMP_VERSION 400
 
 enum {
   CCMP_OK = 0,
@@ -86,10 +86,19 @@ int ccmp_problem_init(ccmp_problem *out, const char *arm1_name, int arm1_index, 
                       const double obj_start_quat_xyzw[4], const double obj_goal_pos[3],
                       const double obj_goal_quat_xyzw[4]);
 /* KinematicChainConstraint::setArmModels (ConstraintFunction.h:122-126) on a problem that is already set up — the
- * reference calls it after loadConfig (ConstrainedPlanningCommon.cpp:126): arm selection and base frames change
- * (arms are ordered by name, as the reference's std::map does), init_chain_ and t_o7 are recomputed from the stored
- * start_joint and object pose; tolerances, delta/lambda, calibration (kept per slot), mode and object poses stay */
+ * reference calls it after loadConfig (ConstrainedPlanningCommon.cpp:126): arm selection and base frames change, init_chain_
+ * and t_o7 are recomputed from the stored start_joint and object pose; tolerances, delta/lambda, calibration (kept per
+ * slot), mode and object poses stay.  The arms are stored IN THE ORDER GIVEN (arm1 = the first seven joints), as the
+ * reference's setArmModels does; std::map (alphabetical) order is what ConstrainedProblem::_setEnvironment hands it
+ * (ConstrainedPlanningCommon.cpp:89-91) and what ccmp_problem_init / ccmp_problem_from_yaml establish here.  Base frames come
+ * from the index through the table of src/kinematics/grasping_point.cpp:11-20; ccmp_set_base_frame overrides one. */
 int ccmp_set_arms(ccmp_problem *p, const char *arm1_name, int arm1_index, const char *arm2_name, int arm2_index);
+/* ArmModel::t_wb of the arm in `arm_slot` (0 / 1), row-major rotation + translation — the frame
+ * KinematicChainConstraint::function multiplies with (ConstraintFunction.h:89-90; panda_model.h:15; filled at
+ * ConstrainedPlanningCommon.cpp:98).  The adapter's setArmModels passes what the ArmModel carries, so an edit of
+ * grasping_point.cpp:11-20 reaches the GPU without touching this library.  init_chain_ / t_o7 are recomputed.
+ * CCMP_EINVAL unless R is a finite rotation (orthonormal to 1e-9, determinant > 0) and pos is finite. */
+int ccmp_set_base_frame(ccmp_problem *p, int arm_slot, const double R[9], const double pos[3]);
 /* KinematicChainConstraint::setInitialPosition (ConstraintFunction.h:31-40) and the t_o7 of
  * ConstrainedPlanningCommon.cpp:110-111 */
 int ccmp_set_start(ccmp_problem *p, const double q0[14]);
@@ -209,7 +218,9 @@ int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from
  * A call thereby bounds the serial work it spends on any one edge — one edge in 16 384 near-neighbour edges creeps (952
  * states, 12 379 Newton rounds) and two dozen need more than 128 rounds; without a bound a launch lasts as long as its
  * longest edge.  round_budget = 0: no bound (ok is 0 / 1 only).  check_target as in ccmp_check_motion_batch (not together
- * with carry_in: the target was tested by the call being continued). */
+ * with carry_in: the target was tested by the call being continued).  A resumable call (carry_in, carry_out or round_budget
+ * given) needs max_states >= 2 — a one-entry list holds `from` only and its continuation would start from `from` again:
+ * CCMP_EINVAL otherwise. */
 int ccmp_geodesic_batch_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                            double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, const double *carry_in,
                            double *carry_out, int round_budget, int check_target, void *hip_stream);

@@ -91,19 +91,23 @@ public:
     check(ccmp_problem_from_yaml(yaml_path.c_str(), &problem_), "ccmp_problem_from_yaml");
     configured_ = true;
   }
-  // KinematicChainConstraint::setArmModels (ConstraintFunction.h:122-126).  On a configured problem (the reference calls
-  // it after loadConfig, ConstrainedPlanningCommon.cpp:126) only the arm / base-frame fields change: object poses,
-  // tolerances, delta / lambda, calibration and mode are kept, init_chain_ and t_o7 are recomputed.
+  // KinematicChainConstraint::setArmModels (ConstraintFunction.h:122-126): arm1 = the first seven joints, arm2 the other
+  // seven — the order given, as the reference stores them (sorting by name is ConstrainedProblem::_setEnvironment's
+  // business, ConstrainedPlanningCommon.cpp:89-91).  On a configured problem (the reference calls it after loadConfig,
+  // ConstrainedPlanningCommon.cpp:126) only the arm / base-frame fields change: object poses, tolerances, delta / lambda,
+  // calibration and mode are kept, init_chain_ and t_o7 are recomputed.
   void setArmModels(const std::string &name1, int index1, const std::string &name2, int index2)
   {
-    if (configured_) {
-      check(ccmp_set_arms(&problem_, name1.c_str(), index1, name2.c_str(), index2), "ccmp_set_arms");
-    } else {
+    if (!configured_) {
       const double q0[14] = {0};
       check(ccmp_problem_init(&problem_, name1.c_str(), index1, name2.c_str(), index2, q0, nullptr, nullptr, nullptr, nullptr), "ccmp_problem_init");
       configured_ = true;
     }
+    check(ccmp_set_arms(&problem_, name1.c_str(), index1, name2.c_str(), index2), "ccmp_set_arms");
   }
+  // ArmModel::t_wb of the arm in `slot` (panda_model.h:15; row-major rotation, translation): what function() multiplies
+  // with (ConstraintFunction.h:89-90).  After setArmModels.
+  void setBaseFrame(int slot, const double *R9, const double *p3) { check(ccmp_set_base_frame(&problem_, slot, R9, p3), "ccmp_set_base_frame"); }
   void setInitialPosition(const double *init_joint14) { check(ccmp_set_start(&problem_, init_joint14), "ccmp_set_start"); }
   // throws where the reference throws ompl::Exception (ConstraintFunction.h:106-108)
   void setTolerance(double tolerance1, double tolerance2) { check(ccmp_set_tolerance(&problem_, tolerance1, tolerance2), "setTolerance: tolerance must be positive"); }
@@ -547,7 +551,23 @@ public:
   using ompl::base::Constraint::project;
   using ompl::base::Constraint::isSatisfied;
 
-  void setArmModels(const ArmModelPtr &arm1, const ArmModelPtr &arm2) { impl_->setArmModels(arm1->name, arm1->index, arm2->name, arm2->index); }
+  // ConstraintFunction.h:122-126: the two ArmModels in the order given; the base frame of each is the t_wb the ArmModel
+  // carries (panda_model.h:15, filled from config->t_wb[index] at ConstrainedPlanningCommon.cpp:98) — not a table of this
+  // library's — so function() multiplies with the very frame the reference's does (ConstraintFunction.h:89-90)
+  void setArmModels(const ArmModelPtr &arm1, const ArmModelPtr &arm2)
+  {
+    impl_->setArmModels(arm1->name, arm1->index, arm2->name, arm2->index);
+    const ArmModelPtr arms[2] = {arm1, arm2};
+    for (int a = 0; a < 2; ++a) {
+      const Eigen::Isometry3d &t_wb = arms[a]->t_wb;
+      double R[9], p[3];
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = t_wb.linear()(r, c);
+        p[r] = t_wb.translation()(r);
+      }
+      impl_->setBaseFrame(a, R, p);
+    }
+  }
   void setInitialPosition(const Eigen::Ref<const Eigen::VectorXd> init_joint)
   {
     Eigen::VectorXd q = init_joint;  // contiguous copy

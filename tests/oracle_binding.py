@@ -159,8 +159,31 @@ class Oracle:
         assert rc == 0
         return P
 
+    def checker_problem(self, yaml_path, product_problem=None):
+        """The checker's problem for a product problem that still is what the product's loader made of `yaml_path`: built
+        by the ORACLE'S OWN set-up code (orc_problem_init / orc_set_start: arm order, base frames, DH constants,
+        init_chain_) from the YAML file, never from the product's struct — and, when the product's problem is given,
+        compared with it byte for byte (jacobian_mode aside: a switch of this library, not part of the reference's
+        set-up), so that the two set-up paths check each other wherever a result is checked."""
+        import yaml
+
+        with open(yaml_path) as f:
+            own = self.problem(yaml.safe_load(f))
+        if product_problem is not None:
+            own.jacobian_mode = product_problem.jacobian_mode
+            assert bytes(own) == bytes(product_problem), "the product's set-up and the oracle's disagree on %s" % yaml_path
+        return own
+
+    def set_start(self, P, q0):
+        """orc_set_start: init_chain_ and t_o7 again from the problem's present arms and base frames"""
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        self.lib.orc_set_start(C.byref(P), _dptr(q0))
+        return P
+
     def problem_from_bytes(self, raw):
-        """Adopt the bytes of a ccmp_problem built by the product library (layouts are identical)."""
+        """Adopt the bytes of a ccmp_problem built by the product library (layouts are identical).  ONLY for problems the
+        caller has modified after loading (tolerances, iteration cap, calibration, arms, tilted bases): everything else goes
+        through checker_problem, which does not trust the product's set-up."""
         assert len(raw) == C.sizeof(OrcProblem), (len(raw), C.sizeof(OrcProblem))
         return OrcProblem.from_buffer_copy(raw)
 

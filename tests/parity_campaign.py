@@ -58,7 +58,12 @@ for obj, tol, seed, mode, N, variant in cases:
             c.problem.base_R[9 + k] = float(tilt[k])
         c.problem.base_R[0] = float(np.nextafter(1.0, 0.0))
         c.setInitialPosition(np.array(c.problem.start_joint[:]))
-    P = orc.problem_from_bytes(bytes(c.problem))
+    if variant:  # a problem this script modified after loading (calibration, tilted base): adopted as bytes
+        P = orc.problem_from_bytes(bytes(c.problem))
+    else:  # a shipped configuration: the oracle's own set-up from the YAML, compared with the product's byte for byte
+        P = orc.checker_problem(os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml"))
+        P.tol_pos, P.tol_rot, P.jacobian_mode = c.problem.tol_pos, c.problem.tol_rot, c.problem.jacobian_mode
+        assert bytes(P) == bytes(c.problem)
     # projector on resident inputs
     q = c.ambient_uniform_batch(seed, 0, N)
     out, ok, it = c.project_batch(q)

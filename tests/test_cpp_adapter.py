@@ -33,7 +33,7 @@ def test_adapter_matches_oracle(ccmp_built, oracle_det, tmp_path):
     from closed_chain_motion_planner_amd import load_config
 
     exe = _build(ccmp_built)
-    P = oracle_det.problem_from_bytes(bytes(load_config(config_path("Wine_Bottle"))))
+    P = oracle_det.checker_problem(config_path("Wine_Bottle"), load_config(config_path("Wine_Bottle")))  # the oracle's own set-up
     q = oracle_det.ambient_uniform_batch(P, 0xAD, 0, 6)
     q[0] = np.array(P.start_joint[:])
     np.savetxt(tmp_path / "states.txt", q, fmt="%.17g")
@@ -160,7 +160,7 @@ def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
     from closed_chain_motion_planner_amd import load_config
 
     exe = _build_part2(ccmp_built)
-    P = oracle_det.problem_from_bytes(bytes(load_config(config_path("Wine_Bottle"))))
+    P = oracle_det.checker_problem(config_path("Wine_Bottle"), load_config(config_path("Wine_Bottle")))  # the oracle's own set-up
     start = np.array(P.start_joint[:])
     from closed_chain_motion_planner_amd import splitmix64
 
@@ -227,3 +227,121 @@ def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
     # the sampler's two-argument constructor: third sampler of the space, its own stream
     exp3, _, _ = oracle_det.sample_project_batch(P, splitmix64(space_seed + 2), 0, 1, 1)
     assert np.array_equal(_hex_row(out[k + 7], "uniform3").view(np.uint64), exp3[0].view(np.uint64))
+
+
+# ---- the drop-in recipe of INTEGRATION.md section 2, compiled: both replacement headers, two translation units --------------
+OVERLAY = os.path.join(ROOT, "include", "reference_overlay")
+DROPIN_EXE = os.path.join(ROOT, "tests", "cpp", "dropin_check")
+REFERENCE = "/root/reference"
+
+
+def _build_dropin(ccmp_built, tmp):
+    libdir = os.path.dirname(ccmp_built)
+    objs = []
+    for tu in ("dropin_problem", "dropin_planner"):
+        obj = os.path.join(str(tmp), tu + ".o")
+        # include path order = the patched reference's: its own include/ (here: the overlay holding the two replaced headers),
+        # third-party headers (here: the interface mock), $CCMP_ROOT/include
+        subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", OVERLAY, "-I", os.path.join(ROOT, "tests", "cpp", "mock_ompl"),
+                        "-I", os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "tests", "cpp", tu + ".cpp"), "-o", obj], check=True)
+        objs.append(obj)
+    subprocess.run(["g++"] + objs + ["-L", libdir, "-lccmp", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", DROPIN_EXE],
+                   check=True)
+    return DROPIN_EXE, objs
+
+
+def test_dropin_headers_compile_in_two_translation_units_and_link(ccmp_built, tmp_path):
+    """the recipe replaces BOTH headers that define the path's classes — ConstraintFunction.h and
+    jy_ProjectedStateSpace.h — and drops src/base/jy_ProjectedStateSpace.cpp from SOURCES.  Two translation units include
+    both replacement headers (in either order: each must stand alone), use the classes as ConstrainedPlanningCommon.cpp
+    and stefanBiPRM.cpp do, and link into one program: nothing is defined twice, everything in the adapter is inline."""
+    exe, objs = _build_dropin(ccmp_built, tmp_path)
+    assert os.path.exists(exe)
+    # every adapter class really is emitted in both objects (weak, to be merged by the linker) — the test would be empty otherwise
+    weak = []
+    for obj in objs:
+        syms = subprocess.run(["nm", "-C", obj], check=True, capture_output=True, text=True).stdout.splitlines()
+        weak.append({l.split(" W ", 1)[1] for l in syms if " W " in l and ("jy_" in l or "ccmp::" in l or "KinematicChainConstraint" in l)})
+    both = weak[0] & weak[1]
+    assert any(n.startswith("jy_ProjectedStateSpace::traverse(") for n in both), sorted(both)[:5]
+    assert len(both) >= 3, sorted(both)
+    for hdr in ("closed_chain_motion_planner/base/constraints/ConstraintFunction.h", "closed_chain_motion_planner/base/jy_ProjectedStateSpace.h"):
+        text = open(os.path.join(OVERLAY, hdr)).read()
+        code = "\n".join(l.split("//")[0] for l in text.split("#pragma once")[1].splitlines())
+        assert "#include <ccmp_ompl_adapter.hpp>" in code and "class " not in code  # no class body left behind
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference checkout is not on this box")
+def test_overlay_matches_the_reference_it_replaces(tmp_path):
+    """With the reference at hand: (1) CMakeLists.diff applies to its CMakeLists.txt and takes jy_ProjectedStateSpace.cpp out
+    of SOURCES; (2) each replacement header keeps every #include and the namespace / using line of the header it replaces —
+    what the reference's other sources get through them; (3) the classes the adapter defines are exactly those the two
+    original headers define, and the dropped source file defines members of no other class."""
+    import shutil
+
+    cm = tmp_path / "CMakeLists.txt"
+    shutil.copy(os.path.join(REFERENCE, "CMakeLists.txt"), cm)
+    subprocess.run(["patch", "-s", "-p1", str(cm)], stdin=open(os.path.join(OVERLAY, "CMakeLists.diff")), check=True, cwd=tmp_path)
+    patched = cm.read_text()
+    assert "src/base/jy_ProjectedStateSpace.cpp" not in patched and "${CCMP_LIB}" in patched and "CCMP_ROOT}/include" in patched
+    import re
+
+    inc = re.compile(r'^\s*#\s*include\s*[<"]([^>"]+)[>"]', re.M)
+    for hdr, keep in (("closed_chain_motion_planner/base/constraints/ConstraintFunction.h", "using namespace std;"),
+                      ("closed_chain_motion_planner/base/jy_ProjectedStateSpace.h", "namespace ob = ompl::base;")):
+        orig = open(os.path.join(REFERENCE, "include", hdr)).read()
+        ours = open(os.path.join(OVERLAY, hdr)).read()
+        assert set(inc.findall(orig)) <= set(inc.findall(ours)), (hdr, set(inc.findall(orig)) - set(inc.findall(ours)))
+        assert keep in orig and keep in ours
+    cls = re.compile(r"^\s*class\s+(\w+)\s*:", re.M)
+    originals = set()
+    for hdr in ("closed_chain_motion_planner/base/constraints/ConstraintFunction.h", "closed_chain_motion_planner/base/jy_ProjectedStateSpace.h"):
+        originals |= set(cls.findall(open(os.path.join(REFERENCE, "include", hdr)).read()))
+    adapter = open(os.path.join(ROOT, "include", "ccmp_ompl_adapter.hpp")).read()
+    part2 = adapter[adapter.index("#ifdef CCMP_WITH_OMPL"):]
+    assert originals <= set(cls.findall(part2)), originals - set(cls.findall(part2))
+    members = set(re.findall(r"^\w[\w:<> \*&]*?\b(\w+)::\w+\(", open(os.path.join(REFERENCE, "src", "base", "jy_ProjectedStateSpace.cpp")).read(), re.M))
+    assert members <= {"jy_ProjectedStateSampler", "jy_ProjectedStateSpace"}, members
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obj,shift", [("Wine_Bottle", 0.0), ("stefan", 0.0), ("stefan", 0.0125)])
+def test_dropin_program_runs_and_matches_the_oracle(ccmp_built, oracle_det, tmp_path, obj, shift):
+    """The linked two-unit program on the GPU: ConstrainedProblem's constructor order, ArmModels carrying t_wb by value
+    (stefan's top arm: linear part diag(-1, -1, 1); with `shift` its base moved 12.5 mm — an edit of grasping_point.cpp that
+    must reach the projector without touching the library), growTree's loop call by call and as one launch."""
+    exe, _ = _build_dropin(ccmp_built, tmp_path)
+    cfg = load_cfg(obj)
+    P = oracle_det.checker_problem(config_path(obj))  # the oracle's own set-up from the YAML fixture
+    if shift:
+        P.base_p[3] += shift  # second arm's base along x, then init_chain_ / t_o7 again by the oracle's own code
+        oracle_det.set_start(P, np.array(cfg["start_joint"], dtype=np.float64))
+    start = np.array(cfg["start_joint"], dtype=np.float64)
+    # arm2 first on the command line for stefan: std::map order (panda_left < panda_top) must come from the replayed
+    # _setEnvironment, not from the order of the arguments
+    a1, a2 = cfg["arm1"], cfg["arm2"]
+    out = subprocess.run([exe, a1["name"], str(a1["index"]), a2["name"], str(a2["index"]), repr(shift)] + ["%.17g" % v for v in start],
+                         check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == "arms %d %d name ProjectedKinematicChainSpace cap 250 delta 0.25 lambda 2.0" % (a1["index"], a2["index"])
+    assert np.array_equal(_hex_row(out[1], "base_p").view(np.uint64), np.array(P.base_p[:]).view(np.uint64))
+    assert np.array_equal(_hex_row(out[2], "init_p").view(np.uint64), np.array(P.init_p[:]).view(np.uint64))
+    i = np.arange(14)
+    x0 = [start + 0.05 * ((i % 3) - 1), start - 0.04 * ((i % 4) - 1.5), start + 0.03 * ((i % 5) - 2)]
+    proj = [oracle_det.project(P, x) for x in x0]
+    assert out[3] == "project %d %d %d" % tuple(int(p[0]) for p in proj)
+    for k, tag in enumerate(("xa", "xb", "xc")):
+        assert np.array_equal(_hex_row(out[4 + k], tag).view(np.uint64), proj[k][1].view(np.uint64))
+    assert np.array_equal(_hex_row(out[7], "fa"), oracle_det.function(P, proj[0][1]))
+    geo = [oracle_det.discrete_geodesic(P, proj[e][1], proj[2][1], interpolate=True, max_states=256) for e in (0, 1)]
+    n = [len(g[1]) for g in geo]
+    connected = sum(int(g[0]) for g in geo)
+    calls = sum(n) - 2  # every state but `from`, the checker accepts all
+    assert out[8] == "grow connected %d %d n %d %d | %d %d checker_calls %d %d" % (connected, connected, n[0], n[1], n[0], n[1], calls, calls)
+    k = 9
+    for e in (0, 1):
+        assert out[k] == "edge %d same 1" % e
+        for j in range(n[e]):
+            assert np.array_equal(_hex_row(out[k + 1 + j], "g").view(np.uint64), geo[e][1][j].view(np.uint64))
+        k += 1 + n[e]
+    assert out[k] == "checkMotion %d" % int(oracle_det.is_satisfied(P, proj[2][1]) and geo[0][0])
+    assert out[k + 1].startswith("sampled_satisfied ")

@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(L, ccmp_built):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ccmp_version() == 300
+    assert L.ccmp_version() == 400
 
 
 def test_library_does_not_link_rccl(ccmp_built):
@@ -156,7 +156,7 @@ def test_set_arms_keeps_the_configured_problem(L, oracle_det):
     P = load_config(config_path("stefan"))
     P.tol_pos, P.delta, P.jacobian_mode = 5e-4, 0.2, 1
     before = bytes(P)
-    assert L.ccmp_set_arms(C.byref(P), b"panda_top", 2, b"panda_left", 0) == 0  # same arms, given in the other order
+    assert L.ccmp_set_arms(C.byref(P), b"panda_left", 0, b"panda_top", 2) == 0  # the arms the YAML chose, in its (std::map) order
     assert bytes(P) == before
     assert L.ccmp_set_arms(C.byref(P), b"panda_left", 0, b"panda_right", 1) == 0
     assert list(P.arm_index) == [0, 1] and (P.tol_pos, P.delta, P.jacobian_mode) == (5e-4, 0.2, 1)
@@ -165,6 +165,41 @@ def test_set_arms_keeps_the_configured_problem(L, oracle_det):
     Po = oracle_det.problem(dict(load_cfg("stefan"), arm2={"name": "panda_right", "index": 1}))
     assert bytes(P.init_R) == bytes(Po.init_R) and bytes(P.init_p) == bytes(Po.init_p)  # init_chain_ follows the new arm
     assert L.ccmp_set_arms(C.byref(P), b"panda_left", 0, b"panda_top", 3) == -1
+
+
+def test_set_arms_stores_the_order_given_and_base_frames_by_value(L, oracle_det):
+    """KinematicChainConstraint::setArmModels pushes arm1, then arm2 (ConstraintFunction.h:122-126): no sorting — that is
+    ConstrainedProblem::_setEnvironment's std::map (ConstrainedPlanningCommon.cpp:89-91), i.e. ccmp_problem_init /
+    _from_yaml here.  ccmp_set_base_frame takes ArmModel::t_wb by value (panda_model.h:15) and reproduces the index
+    table's problem byte for byte when given the table's frames."""
+    from closed_chain_motion_planner_amd import load_config
+    from closed_chain_motion_planner_amd._lib import CcmpProblem
+
+    P = load_config(config_path("stefan"))  # YAML order: panda_left (0), panda_top (2)
+    ref = CcmpProblem.from_buffer_copy(bytes(P))
+    assert L.ccmp_set_arms(C.byref(P), b"panda_top", 2, b"panda_left", 0) == 0  # the other order is KEPT
+    assert list(P.arm_index) == [2, 0]
+    assert bytes(P.base_R)[:72] == bytes(ref.base_R)[72:] and bytes(P.base_p)[:24] == bytes(ref.base_p)[24:]
+    assert bytes(P.init_p) != bytes(ref.init_p)  # init_chain_ = inverse(second) * first with the bases swapped (its rotation
+    # happens to survive: top = diag(-1, -1, 1) is symmetric and left is the identity)
+    # frames by value: left = trans(0, 0.3, 1.006), top = trans(1.35, 0.3, 1.006) * Rz(pi) (grasping_point.cpp:11-20)
+    Q = load_config(config_path("Wine_Bottle"))  # left + right
+    assert L.ccmp_set_arms(C.byref(Q), b"panda_left", 0, b"panda_right", 1) == 0
+    I3 = np.eye(3)
+    Rz = np.diag([-1.0, -1.0, 1.0])
+    dp = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    assert L.ccmp_set_base_frame(C.byref(Q), 1, dp(Rz), dp([1.35, 0.3, 1.006])) == 0
+    Q.arm_index[1] = 2  # the index is bookkeeping; the frame is what function() multiplies with
+    S = load_config(config_path("Wine_Bottle"))
+    assert L.ccmp_set_arms(C.byref(S), b"panda_left", 0, b"panda_top", 2) == 0
+    assert bytes(Q) == bytes(S)
+    assert L.ccmp_set_base_frame(C.byref(Q), 0, dp(I3), dp([0.0, 0.3, 1.006])) == 0 and bytes(Q) == bytes(S)
+    # refused: not a rotation, a reflection, non-finite, bad slot
+    assert L.ccmp_set_base_frame(C.byref(Q), 0, dp(2 * I3), dp([0, 0, 0])) == -1
+    assert L.ccmp_set_base_frame(C.byref(Q), 0, dp(np.diag([1.0, 1.0, -1.0])), dp([0, 0, 0])) == -1
+    assert L.ccmp_set_base_frame(C.byref(Q), 0, dp(I3), dp([0, np.nan, 0])) == -1
+    assert L.ccmp_set_base_frame(C.byref(Q), 2, dp(I3), dp([0, 0, 0])) == -1
+    assert bytes(Q) == bytes(S)
 
 
 def test_every_sampler_gets_its_own_seed(monkeypatch):
