@@ -482,9 +482,64 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.obj, seed, gpu_check)
         except Exception as e:  # the oracle is a checker; its absence must not fail the GPU bench
             line["cpu_baseline"] = {"error": repr(e)}
+    flatten_for_the_driver(line, B)
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def flatten_for_the_driver(line, B):
+    """The driver's record of this line keeps only first-level SCALARS of `config`, `roofline` and `cpu_baseline`
+    (VERDICT r3 #3): the figures SURVEY.md section 8(d) asks for — C1..C4, the extend step, single states, the three
+    efficiency numbers, the parity classification — are therefore repeated there as flat keys (the nested forms stay)."""
+    def get(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    rf, cfgd, sec, cb = line["roofline"], line["config"], line.get("secondary") or {}, line.get("cpu_baseline") or {}
+    rf["fp64_algorithmic_frac"] = get(rf, "fp64", "frac")
+    rf["fp64_executed_frac"] = get(rf, "fp64_executed", "frac")
+    rf["valu_issue_frac"] = get(rf, "valu_issue", "frac_of_fp64_issue_ceiling")
+    rf["pipes_busy_frac"] = get(rf, "valu_issue", "vector_pipes_busy_in_profiled_launch")
+    rf["pmc_source"] = get(rf, "valu_issue", "source")  # builder-side counters rescaled by this run's kernel time
+    if sec:
+        st1, st2 = "stefan_batch%d_tol_1e-3_5e-3" % B, "stefan_batch%d_tol_5e-4_2.5e-3" % B
+        geo = sec.get("discrete_geodesic") or {}
+        flat = {
+            "c1_dumbbell_cpu_single_thread_per_s": get(sec, "c1_dumbbell", "cpu_single_thread_projections_per_s"),
+            "c1_dumbbell_gpu_per_s": get(sec, "c1_dumbbell", "gpu_projections_per_s"),
+            "c1_bitwise": get(sec, "c1_dumbbell", "parity_vs_det_oracle", "bit_identical"),
+            "c2_batch4096_per_s": sec.get("batch4096_projections_per_s"),
+            "c2_bitwise": get(sec, "batch4096", "parity_vs_det_oracle", "bit_identical"),
+            "batch32768_per_s": sec.get("batch32768_projections_per_s"),
+            "c4_stefan_per_s": get(sec, st1, "projections_per_s"),
+            "c4_stefan_tight_per_s": get(sec, st2, "projections_per_s"),
+            "c4_bitwise": None if get(sec, st1, "parity_vs_det_oracle", "bit_identical") is None else bool(
+                get(sec, st1, "parity_vs_det_oracle", "bit_identical") and get(sec, st2, "parity_vs_det_oracle", "bit_identical")),
+            "extend_first_pass_edges_per_s": geo.get("edges_per_s"), "extend_first_pass_ms": geo.get("ms"),
+            "extend_unfinished_edges": geo.get("overflowed_edges"), "extend_complete_ms": geo.get("complete_ms"),
+            "extend_bitwise": None if get(geo, "parity_vs_det_oracle", "bit_identical") is None else bool(
+                get(geo, "parity_vs_det_oracle", "bit_identical") and get(geo, "parity_vs_det_oracle", "continued_edges", "bit_identical")),
+            "growtree_5_edges_ms": geo.get("growtree_5_edges_ms"),
+            "single_project_us": get(sec, "single_project_c_abi", "uniform_sample_median_us"),
+            "single_project_near_manifold_us": get(sec, "single_project_c_abi", "near_manifold_median_us"),
+            "host_buffer_pageable_per_s": get(sec, "host_buffer", "pageable", "projections_per_s"),
+            "host_buffer_pinned_per_s": get(sec, "host_buffer", "pinned", "projections_per_s"),
+            "analytic_mode_per_s": sec.get("analytic_mode_projections_per_s"),
+            "proxy_clearance_states_per_s": get(sec, "proxy_clearance", "states_per_s"),
+        }
+        cfgd.update(flat)
+    if cb and "error" not in cb:
+        cb["det_bit_identical"] = get(cb, "parity_gpu_vs_det_oracle", "bit_identical")
+        cb["det_samples"] = get(cb, "parity_gpu_vs_det_oracle", "samples")
+        cb["libm_samples"] = get(cb, "parity_gpu_vs_libm_oracle", "samples")
+        cb["libm_n_gt_1e-6"] = get(cb, "parity_gpu_vs_libm_oracle", "n_gt_1e-6")
+        cb["libm_max_abs_dq"] = get(cb, "parity_gpu_vs_libm_oracle", "max_abs_dq")
+        cb["libm_iter_diffs_gt1"] = get(cb, "parity_gpu_vs_libm_oracle", "iteration_diffs_gt1")
+        cb["libm_ok_mismatches"] = get(cb, "parity_gpu_vs_libm_oracle", "ok_mismatches")
 
 
 def secondary(args, c, ctx, B, torch, cfg_path):
@@ -654,7 +709,10 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         L = _lib.lib()
         qh = c.ambient_uniform_batch(SEEDS.get(B, 0xC3), 0, B).cpu()
         res = {"samples": B}
-        for name, pin in (("pageable", False), ("pinned", True)):
+        # page-locked caller buffers ("host_zero_copy", include/ccmp.h): the kernels write q_out in place (default, "pinned"),
+        # read q_in in place too, or everything is staged as for pageable memory
+        for name, pin, zc in (("pageable", False, 1), ("pinned", True, 1), ("pinned_q_in_read_in_place", True, 2), ("pinned_staged", True, 0)):
+            ctx.set_option("host_zero_copy", zc)
             mk = (lambda t: t.pin_memory()) if pin else (lambda t: t)
             qi, qo = mk(qh.clone()), mk(torch.empty_like(qh))
             okh, ith = mk(torch.empty(B, dtype=torch.uint8)), mk(torch.empty(B, dtype=torch.int16))
@@ -669,6 +727,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
                     raise RuntimeError("ccmp_project_host: %d" % rc)
             sec = float(np.median(ts[1:]))
             res[name] = {"projections_per_s": B / sec, "ms": sec * 1e3}
+        ctx.set_option("host_zero_copy", 1)
         return res
 
     def c1_dumbbell(b=1024, seed=0xC1):

@@ -68,7 +68,7 @@ EXPORTS = [
     "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
     "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
     "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_check_motion_batch", "ccmp_geodesic_batch_ex", "ccmp_geodesic_host_ex", "ccmp_check_motion_host", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid", "ccmp_compact_valid_capped",
-    "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_sample_project_host", "ccmp_sample_ref_project_host", "ccmp_geodesic_host", "ccmp_project_sharded_host", "ccmp_sample_project_sharded_host",
+    "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_sample_project_host", "ccmp_sample_ref_project_host", "ccmp_geodesic_host", "ccmp_project_sharded_host", "ccmp_sample_project_sharded_host", "ccmp_sharded_host_last_timing",
     "ccmp_comm_create", "ccmp_comm_destroy", "ccmp_comm_last_timing", "ccmp_project_sharded", "ccmp_sample_project_sharded", "ccmp_ctx_set_order_experimental",
     "ccmp_scene_create", "ccmp_scene_destroy", "ccmp_scene_num_pairs", "ccmp_clearance_batch", "ccmp_clearance_host",
     "ccmp_ctx_debug_lpt_pred", "ccmp_detmath_probe", "ccmp_strerror",
@@ -143,6 +143,7 @@ def lib():
         "ccmp_geodesic_host": ([vp, pp, dp, dp, C.c_size_t, C.c_int, dp, C.POINTER(C.c_int32), u8p], C.c_int),
         "ccmp_project_sharded_host": ([C.POINTER(vp), C.c_int, pp, dp, dp, u8p, u16p, C.c_size_t], C.c_int),
         "ccmp_sample_project_sharded_host": ([C.POINTER(vp), C.c_int, pp, C.c_uint64, C.c_uint64, dp, u8p, u16p, C.c_size_t], C.c_int),
+        "ccmp_sharded_host_last_timing": ([C.POINTER(vp), C.c_int, dp, dp], C.c_int),
         "ccmp_comm_create": ([C.POINTER(vp), C.c_int, C.POINTER(vp)], C.c_int),
         "ccmp_comm_destroy": ([vp], None),
         "ccmp_comm_last_timing": ([vp, dp, dp], C.c_int),

@@ -504,6 +504,17 @@ class KinematicChainConstraint:
                                                    it.ctypes.data_as(C.POINTER(C.c_uint16)), B), "ccmp_project_sharded_host")
         return out, ok, it
 
+    @staticmethod
+    def sharded_host_last_timing(contexts):
+        """(launch_ms, start_ms) per context of the last sharded call (ccmp_sharded_host_last_timing): when the host had each
+        shard's upload behind it and issued its kernels, on the host clock and on the GPU's timeline relative to the first
+        context (-1 on another device).  Shards driven one after the other would show values growing with the index."""
+        n = len(contexts)
+        arr = (C.c_void_p * n)(*[cx.handle for cx in contexts])
+        a, b = np.zeros(n), np.zeros(n)
+        check(_lib.lib().ccmp_sharded_host_last_timing(arr, n, _dptr(a), _dptr(b)), "ccmp_sharded_host_last_timing")
+        return a.tolist(), b.tolist()
+
     def sample_project_sharded_host(self, seed, first_index, B, contexts):
         self._need_problem()
         out = np.empty((B, 14))

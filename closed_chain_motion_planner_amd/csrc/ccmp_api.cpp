@@ -5,6 +5,10 @@
 // isSatisfied batches run on the GPU or fail with CCMP_ENODEV / CCMP_EHIP.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <thread>
+#include <vector>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +35,48 @@ int ensure_stage(ccmp_ctx *ctx, size_t bytes)
   ctx->stage_cap = 0;
   HIP_TRY(hipMalloc(&ctx->stage, bytes));
   ctx->stage_cap = bytes;
+  return CCMP_OK;
+}
+
+void *pinned_alias(const void *host, size_t bytes)
+{
+  if (!host || bytes == 0) return nullptr;
+  hipPointerAttribute_t a, b;
+  memset(&a, 0, sizeof a);
+  memset(&b, 0, sizeof b);
+  // an unregistered (pageable) pointer is reported as an error by older runtimes and as hipMemoryTypeUnregistered by newer
+  // ones; the error is sticky for hipGetLastError only and is cleared here
+  if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+  if (hipPointerGetAttributes(&b, (const char *)host + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (b.type != hipMemoryTypeHost || (const char *)b.devicePointer != (const char *)a.devicePointer + (bytes - 1)) return nullptr;
+  return a.devicePointer;
+}
+
+int for_each_shard(int n, int (*fn)(int g, void *arg), void *arg)
+{
+  if (n <= 1) return n == 1 ? fn(0, arg) : CCMP_OK;
+  struct Res { int rc = CCMP_OK; char err[sizeof g_hip_err] = ""; };
+  std::vector<Res> res((size_t)n);
+  std::vector<std::thread> th;
+  th.reserve((size_t)n);
+  for (int g = 0; g < n; g++) {
+    try {
+      th.emplace_back([g, fn, arg, &res] {
+        res[(size_t)g].rc = fn(g, arg);
+        if (res[(size_t)g].rc != CCMP_OK) memcpy(res[(size_t)g].err, g_hip_err, sizeof g_hip_err); // thread_local: hand it to the caller
+      });
+    } catch (...) { // no thread to be had: this shard runs here
+      res[(size_t)g].rc = fn(g, arg);
+      if (res[(size_t)g].rc != CCMP_OK) memcpy(res[(size_t)g].err, g_hip_err, sizeof g_hip_err);
+    }
+  }
+  for (auto &t : th) t.join();
+  for (int g = 0; g < n; g++)
+    if (res[(size_t)g].rc != CCMP_OK) {
+      memcpy(g_hip_err, res[(size_t)g].err, sizeof g_hip_err);
+      return res[(size_t)g].rc;
+    }
   return CCMP_OK;
 }
 }  // namespace ccmp_host
@@ -264,6 +310,7 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx)
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
   if (ctx->fork) (void)hipEventDestroy(ctx->fork);
   if (ctx->join) (void)hipEventDestroy(ctx->join);
+  if (ctx->ev_shard) (void)hipEventDestroy(ctx->ev_shard);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -320,6 +367,9 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "clearance_per_state_max")) { // proxy clearance: one block per state up to this many states
     if (value < 0) return CCMP_EINVAL;
     ctx->clearance_per_state_max = (size_t)value;
+  } else if (!strcmp(name, "host_zero_copy")) { // *_host calls on page-locked caller buffers: 0 staged, 1 q_out direct, 2 q_in too
+    if (value < 0 || value > 2) return CCMP_EINVAL;
+    ctx->host_zero_copy = (int)value;
   } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the projector's latency kernel per CU (8 resident)
     if (value < 1 || value > 32) return CCMP_EINVAL;
     ctx->latency_blocks_per_cu = (int)value;
@@ -789,6 +839,43 @@ int ccmp_detmath_probe(ccmp_ctx *ctx, const double *x_dev, const double *y_dev, 
 }
 
 // ---- host-pointer conveniences ----------------------------------------------------------------------
+// A batch whose q_in and q_out the caller keeps in PAGE-LOCKED memory (the reference's entry is host memory: an Eigen::Ref
+// over the OMPL state's values, src/base/jy_ProjectedStateSpace.cpp:10-15; a planner that batches keeps its states in a
+// pinned arena) is not staged like pageable memory: the kernels write every projected row straight into the caller's q_out
+// (and, with host_zero_copy = 2, read q_in from it) — no 29 MB download behind the last kernel, no second copy of the batch
+// on the device.  Only the flags and iteration counts (3 bytes per sample) go through device staging.  kNotPinned: the
+// buffers are not both page-locked (or not 16-byte aligned): the caller falls back to the staged path.
+static const int kNotPinned = 1;
+static int project_host_pinned(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, double *q_out, uint8_t *ok, uint16_t *iters,
+                               size_t B)
+{
+  const size_t qb = B * 14 * sizeof(double);
+  const double *din = (const double *)ccmp_host::pinned_alias(q_in, qb);
+  double *dout = q_out == q_in ? (double *)din : (double *)ccmp_host::pinned_alias(q_out, qb);
+  if (!din || !dout || ((uintptr_t)din & 15) || ((uintptr_t)dout & 15)) return kNotPinned;
+  const bool copy_in = ctx->host_zero_copy < 2;
+  const size_t off_ok = copy_in ? ((qb + 255) & ~(size_t)255) : 0;
+  const size_t off_it = (off_ok + B + 255) & ~(size_t)255;
+  int rc = ensure_stage(ctx, off_it + B * sizeof(uint16_t));
+  if (rc != CCMP_OK) return rc;
+  char *stage = (char *)ctx->stage;
+  ctx->want_done = ctx->done_armed = false;
+  const double *src = din;
+  if (copy_in) { // one asynchronous copy at the link's rate; the scout and the projector then read device memory
+    HIP_TRY(hipMemcpyAsync(stage, q_in, qb, hipMemcpyHostToDevice, ctx->stream));
+    src = (const double *)stage;
+  }
+  rc = ccmp_project_batch(ctx, p, src, dout, (uint8_t *)(stage + off_ok), (uint16_t *)(stage + off_it), B, ctx->stream);
+  if (rc == CCMP_OK) {
+    hipError_t e = hipMemcpyAsync(ok, stage + off_ok, B, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && iters) e = hipMemcpyAsync(iters, stage + off_it, B * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H flags)");
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream); // also on the error path: the caller's buffers must be quiet
+  if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize");
+  return rc;
+}
+
 int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, double *q_out, uint8_t *ok,
                       uint16_t *iters, size_t B)
 {
@@ -798,6 +885,10 @@ int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, 
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
   const size_t qb = B * 14 * sizeof(double);
+  if (qb > kPinData && ctx->host_zero_copy) {
+    const int done = project_host_pinned(ctx, p, q_in, q_out, ok, iters, B);
+    if (done != kNotPinned) return done;
+  }
   const size_t off_ok = (qb + 255) & ~(size_t)255;
   const size_t off_it = (off_ok + B + 255) & ~(size_t)255;
   HostIO io(ctx);
@@ -1008,65 +1099,94 @@ int ccmp_geodesic_host_ex(ccmp_ctx *ctx, const ccmp_problem *p, const double *fr
   return geodesic_host_common(ctx, p, from, to, E, max_states, states, n_states, ok, carry_in, carry_out, round_budget, check_target);
 }
 
+// One shard of ccmp_*_sharded_host, on its context's device and stream: upload (mode 0), project, download, wait.  Runs
+// on its own thread when there are several (for_each_shard): a copy from pageable memory returns only when the data is
+// staged and a copy into pageable memory only when it has arrived, so shards driven from ONE thread start and finish one
+// after the other — 8 x 1.2 ms of stagger against a 16 ms kernel at 8 GPUs.
+struct ShardedArgs {
+  ccmp_ctx *const *ctxs;
+  int n, mode;
+  const ccmp_problem *p;
+  const double *q_in;
+  double *q_out;
+  uint8_t *ok;
+  uint16_t *iters;
+  uint64_t seed, first_index;
+  size_t B;
+  std::chrono::steady_clock::time_point t0;
+};
+
+static int sharded_one(int g, void *arg)
+{
+  const ShardedArgs &A = *(const ShardedArgs *)arg;
+  const size_t base = A.B / (size_t)A.n, rem = A.B % (size_t)A.n;
+  const size_t lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem), nb = base + ((size_t)g < rem ? 1 : 0);
+  ccmp_ctx *ctx = A.ctxs[g];
+  ctx->shard_launch_ms = -1.0;
+  if (nb == 0) return CCMP_OK;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return CCMP_ENODEV;
+  const size_t qb = nb * 14 * sizeof(double);
+  const size_t off_ok = (qb + 255) & ~(size_t)255, off_it = (off_ok + nb + 255) & ~(size_t)255;
+  int rc = ensure_stage(ctx, off_it + nb * sizeof(uint16_t));
+  if (rc != CCMP_OK) return rc;
+  if (!ctx->ev_shard && hipEventCreate(&ctx->ev_shard) != hipSuccess) ctx->ev_shard = nullptr; // timing is optional
+  char *stage = (char *)ctx->stage;
+  hipError_t e = hipSuccess;
+  if (A.mode == 0) e = hipMemcpyAsync(stage, A.q_in + lo * 14, qb, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(H2D shard)");
+  // the upload is behind the host now (pageable source) or queued (page-locked source): from here the stream runs kernels
+  if (ctx->ev_shard) (void)hipEventRecord(ctx->ev_shard, ctx->stream);
+  ctx->shard_launch_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - A.t0).count();
+  if (A.mode == 0)
+    rc = ccmp_project_batch(ctx, A.p, (const double *)stage, (double *)stage, (uint8_t *)(stage + off_ok), (uint16_t *)(stage + off_it), nb,
+                            ctx->stream);
+  else
+    rc = ccmp_sample_project_batch(ctx, A.p, A.seed, A.first_index + lo, (double *)stage, (uint8_t *)(stage + off_ok),
+                                   (uint16_t *)(stage + off_it), nullptr, nb, ctx->stream);
+  if (rc == CCMP_OK) {
+    e = hipMemcpyAsync(A.q_out + lo * 14, stage, qb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(A.ok + lo, stage + off_ok, nb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && A.iters) e = hipMemcpyAsync(A.iters + lo, stage + off_it, nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H shard)");
+  }
+  e = hipStreamSynchronize(ctx->stream); // also on the error path: the caller's buffers must be quiet
+  if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize(shard)");
+  return rc;
+}
+
 static int sharded_common(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, int mode, const double *q_in, double *q_out,
                           uint8_t *ok, uint16_t *iters, uint64_t seed, uint64_t first_index, size_t B)
 {
   if (!ctxs || n < 1 || n > 64 || !p) return CCMP_EINVAL;
-  for (int g = 0; g < n; g++)
+  for (int g = 0; g < n; g++) {
     if (!ctxs[g]) return CCMP_EINVAL;
+    for (int h = 0; h < g; h++)
+      if (ctxs[h] == ctxs[g]) return CCMP_EINVAL; // one context holds one shard's staging and queues
+  }
   if (B == 0) return CCMP_OK;
   if (!q_out || !ok || (mode == 0 && !q_in)) return CCMP_EINVAL;
-  struct Shard { size_t lo, hi, off_ok, off_it; bool busy; } sh[64];
-  for (int g = 0; g < n; g++) sh[g] = Shard{0, 0, 0, 0, false};
-  int rc = CCMP_OK;
-  // phase 1: upload and launch on every context's stream.  Copies from pageable host memory return once the data is
-  // staged, so the next GPU starts while this one computes.
-  for (int g = 0; g < n && rc == CCMP_OK; g++) {
-    const size_t base = B / (size_t)n, rem = B % (size_t)n;
-    sh[g].lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem);
-    sh[g].hi = sh[g].lo + base + ((size_t)g < rem ? 1 : 0);
-    const size_t nb = sh[g].hi - sh[g].lo;
-    if (nb == 0) continue;
-    ccmp_ctx *ctx = ctxs[g];
-    DeviceGuard guard(ctx->device);
-    if (!guard.ok) { rc = CCMP_ENODEV; break; }
-    const size_t qb = nb * 14 * sizeof(double);
-    sh[g].off_ok = (qb + 255) & ~(size_t)255;
-    sh[g].off_it = (sh[g].off_ok + nb + 255) & ~(size_t)255;
-    if ((rc = ensure_stage(ctx, sh[g].off_it + nb * sizeof(uint16_t))) != CCMP_OK) break;
-    char *stage = (char *)ctx->stage;
-    sh[g].busy = true;
-    if (mode == 0) {
-      hipError_t e = hipMemcpyAsync(stage, q_in + sh[g].lo * 14, qb, hipMemcpyHostToDevice, ctx->stream);
-      if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync(H2D shard)"); break; }
-      rc = ccmp_project_batch(ctx, p, (const double *)stage, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
-                              (uint16_t *)(stage + sh[g].off_it), nb, ctx->stream);
-    } else {
-      rc = ccmp_sample_project_batch(ctx, p, seed, first_index + sh[g].lo, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
-                                     (uint16_t *)(stage + sh[g].off_it), nullptr, nb, ctx->stream);
-    }
-  }
-  // phase 2: downloads (a copy into pageable memory waits for its shard's kernels; the other GPUs keep computing)
-  for (int g = 0; g < n && rc == CCMP_OK; g++) {
-    if (!sh[g].busy) continue;
-    ccmp_ctx *ctx = ctxs[g];
-    DeviceGuard guard(ctx->device);
-    const size_t nb = sh[g].hi - sh[g].lo;
-    const char *stage = (const char *)ctx->stage;
-    hipError_t e = hipMemcpyAsync(q_out + sh[g].lo * 14, stage, nb * 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ok + sh[g].lo, stage + sh[g].off_ok, nb, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && iters)
-      e = hipMemcpyAsync(iters + sh[g].lo, stage + sh[g].off_it, nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H shard)");
-  }
-  // phase 3: wait for every stream that was given work, also on the error path (the caller's buffers must be quiet)
+  ShardedArgs A{ctxs, n, mode, p, q_in, q_out, ok, iters, seed, first_index, B, std::chrono::steady_clock::now()};
+  return ccmp_host::for_each_shard(n, sharded_one, &A);
+}
+
+int ccmp_sharded_host_last_timing(ccmp_ctx *const *ctxs, int n, double *launch_ms, double *start_ms)
+{
+  if (!ctxs || n < 1 || n > 64 || !launch_ms || !start_ms) return CCMP_EINVAL;
   for (int g = 0; g < n; g++) {
-    if (!sh[g].busy) continue;
-    DeviceGuard guard(ctxs[g]->device);
-    hipError_t e = hipStreamSynchronize(ctxs[g]->stream);
-    if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize(shard)");
+    if (!ctxs[g]) return CCMP_EINVAL;
+    launch_ms[g] = ctxs[g]->shard_launch_ms;
+    start_ms[g] = -1.0;
+    if (ctxs[g]->device != ctxs[0]->device || !ctxs[g]->ev_shard || !ctxs[0]->ev_shard || ctxs[g]->shard_launch_ms < 0 ||
+        ctxs[0]->shard_launch_ms < 0)
+      continue;
+    DeviceGuard guard(ctxs[0]->device);
+    float ms = 0.0f;
+    if (g == 0) start_ms[g] = 0.0;
+    else if (hipEventElapsedTime(&ms, ctxs[0]->ev_shard, ctxs[g]->ev_shard) == hipSuccess) start_ms[g] = (double)ms;
+    else (void)hipGetLastError();
   }
-  return rc;
+  return CCMP_OK;
 }
 
 int ccmp_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, const double *q_in, double *q_out,

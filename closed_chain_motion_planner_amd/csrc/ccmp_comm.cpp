@@ -4,6 +4,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -167,6 +168,102 @@ static int comm_ensure_blocks(ccmp_comm *c, size_t cap)
   return CCMP_OK;
 }
 
+// The three phases of a sharded call.  Phases 1 and 3 touch the caller's host buffers — uploads from and downloads into
+// memory that is usually pageable, i.e. copies that block the thread that issues them — and therefore run on one
+// short-lived thread per GPU (ccmp_host::for_each_shard): issued from one thread, GPU g would start g uploads late and
+// hand its results back g downloads late (8-9 ms of stagger against a 16 ms kernel at 8 GPUs).
+struct CommShard { size_t lo, nb, off_ok, off_it; };
+struct CommArgs {
+  ccmp_comm *c;
+  const ccmp_problem *p;
+  int mode;
+  const double *q_in;
+  uint64_t seed, first_index;
+  size_t B;
+  double *q_out;
+  uint8_t *ok;
+  uint16_t *iters;
+  std::vector<CommShard> *sh;
+  std::chrono::steady_clock::time_point t0;
+};
+
+// phase 1: upload (mode 0), project and compact one shard into its send block, all on its GPU's stream
+static int comm_phase1(int g, void *arg)
+{
+  CommArgs &A = *(CommArgs *)arg;
+  ccmp_comm *c = A.c;
+  const int n = c->n;
+  CommShard &S = (*A.sh)[(size_t)g];
+  const size_t base = A.B / (size_t)n, rem = A.B % (size_t)n;
+  S.lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem);
+  S.nb = base + ((size_t)g < rem ? 1 : 0);
+  ccmp_ctx *ctx = c->ctxs[g];
+  ctx->shard_launch_ms = -1.0;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return CCMP_ENODEV;
+  const size_t nb = S.nb, qb = nb * 14 * sizeof(double);
+  S.off_ok = (qb + 255) & ~(size_t)255;
+  S.off_it = (S.off_ok + nb + 255) & ~(size_t)255;
+  if (c->ev[3 * g]) (void)hipEventRecord(c->ev[3 * g], ctx->stream);
+  hipError_t e = hipMemsetAsync(c->send[g], 0, 14 * sizeof(double), ctx->stream); // row 0: count 0 for an empty shard
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(send block)");
+  if (nb == 0) return CCMP_OK;
+  int rc = ensure_stage(ctx, S.off_it + nb * sizeof(uint16_t));
+  if (rc != CCMP_OK) return rc;
+  char *stage = (char *)ctx->stage;
+  if (A.mode == 0) {
+    e = hipMemcpyAsync(stage, A.q_in + S.lo * 14, qb, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(H2D shard)");
+  }
+  ctx->shard_launch_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - A.t0).count();
+  if (A.mode == 0)
+    rc = ccmp_project_batch(ctx, A.p, (const double *)stage, (double *)stage, (uint8_t *)(stage + S.off_ok), (uint16_t *)(stage + S.off_it), nb,
+                            ctx->stream);
+  else
+    rc = ccmp_sample_project_batch(ctx, A.p, A.seed, A.first_index + S.lo, (double *)stage, (uint8_t *)(stage + S.off_ok),
+                                   (uint16_t *)(stage + S.off_it), nullptr, nb, ctx->stream);
+  if (rc != CCMP_OK) return rc;
+  rc = ccmp_compact_valid_capped(ctx, (const double *)stage, (const uint8_t *)(stage + S.off_ok), nb, c->send[g] + 14, c->cap,
+                                 (uint64_t *)c->send[g], ctx->stream);
+  if (rc == CCMP_OK && c->ev[3 * g + 1]) (void)hipEventRecord(c->ev[3 * g + 1], ctx->stream);
+  return rc;
+}
+
+// phase 3: GPU 0 returns the gathered blocks; every GPU returns its shard's full results if the caller wants them; wait
+static int comm_phase3(int g, void *arg)
+{
+  CommArgs &A = *(CommArgs *)arg;
+  ccmp_comm *c = A.c;
+  const CommShard &S = (*A.sh)[(size_t)g];
+  ccmp_ctx *ctx = c->ctxs[g];
+  DeviceGuard guard(ctx->device);
+  int rc = CCMP_OK;
+  hipError_t e = hipSuccess;
+  if (g == 0) {
+    e = hipMemcpyAsync(c->host_recv, c->recv[0], (c->cap + 1) * 14 * sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H gathered blocks)");
+  }
+  if (rc == CCMP_OK && S.nb != 0 && (A.q_out || A.ok || A.iters)) {
+    const char *stage = (const char *)ctx->stage;
+    if (A.q_out) e = hipMemcpyAsync(A.q_out + S.lo * 14, stage, S.nb * 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && A.ok) e = hipMemcpyAsync(A.ok + S.lo, stage + S.off_ok, S.nb, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && A.iters)
+      e = hipMemcpyAsync(A.iters + S.lo, stage + S.off_it, S.nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H shard)");
+  }
+  e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize(shard)");
+  return rc;
+}
+
+static int comm_sync_one(int g, void *arg)
+{
+  ccmp_comm *c = ((CommArgs *)arg)->c;
+  DeviceGuard guard(c->ctxs[g]->device);
+  (void)hipStreamSynchronize(c->ctxs[g]->stream);
+  return CCMP_OK;
+}
+
 static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, const double *q_in, uint64_t seed, uint64_t first_index,
                                size_t B, double *q_out, uint8_t *ok, uint16_t *iters, size_t block_rows, double *valid_out,
                                size_t valid_capacity, uint64_t *counts, uint64_t *n_valid)
@@ -179,42 +276,9 @@ static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, co
   int rc = comm_ensure_blocks(c, block_rows);
   if (rc != CCMP_OK) return rc;
   const size_t cap = c->cap, block_doubles = (cap + 1) * 14;
-  struct Shard { size_t lo, nb, off_ok, off_it; };
-  std::vector<Shard> sh(n);
-  // phase 1: every GPU uploads (mode 0), projects and compacts its shard into its send block, all on its own stream
-  for (int g = 0; g < n && rc == CCMP_OK; g++) {
-    const size_t base = B / (size_t)n, rem = B % (size_t)n;
-    sh[g].lo = (size_t)g * base + ((size_t)g < rem ? (size_t)g : rem);
-    sh[g].nb = base + ((size_t)g < rem ? 1 : 0);
-    ccmp_ctx *ctx = c->ctxs[g];
-    DeviceGuard guard(ctx->device);
-    if (!guard.ok) { rc = CCMP_ENODEV; break; }
-    const size_t nb = sh[g].nb, qb = nb * 14 * sizeof(double);
-    sh[g].off_ok = (qb + 255) & ~(size_t)255;
-    sh[g].off_it = (sh[g].off_ok + nb + 255) & ~(size_t)255;
-    if (c->ev[3 * g]) (void)hipEventRecord(c->ev[3 * g], ctx->stream);
-    hipError_t e = hipMemsetAsync(c->send[g], 0, 14 * sizeof(double), ctx->stream); // row 0: count 0 for an empty shard
-    if (e != hipSuccess) { rc = hip_fail(e, "hipMemsetAsync(send block)"); break; }
-    if (nb == 0) continue;
-    if ((rc = ensure_stage(ctx, sh[g].off_it + nb * sizeof(uint16_t))) != CCMP_OK) break;
-    char *stage = (char *)ctx->stage;
-    if (mode == 0) {
-      e = hipMemcpyAsync(stage, q_in + sh[g].lo * 14, qb, hipMemcpyHostToDevice, ctx->stream);
-      if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync(H2D shard)"); break; }
-      rc = ccmp_project_batch(ctx, p, (const double *)stage, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
-                              (uint16_t *)(stage + sh[g].off_it), nb, ctx->stream);
-    } else {
-      rc = ccmp_sample_project_batch(ctx, p, seed, first_index + sh[g].lo, (double *)stage, (uint8_t *)(stage + sh[g].off_ok),
-                                     (uint16_t *)(stage + sh[g].off_it), nullptr, nb, ctx->stream);
-    }
-    if (rc != CCMP_OK) break;
-    rc = ccmp_compact_valid_capped(ctx, (const double *)stage, (const uint8_t *)(stage + sh[g].off_ok), nb, c->send[g] + 14, cap,
-                                   (uint64_t *)c->send[g], ctx->stream);
-  }
-  for (int g = 0; g < n && rc == CCMP_OK; g++) {
-    DeviceGuard guard(c->ctxs[g]->device);
-    if (c->ev[3 * g + 1]) (void)hipEventRecord(c->ev[3 * g + 1], c->ctxs[g]->stream);
-  }
+  std::vector<CommShard> sh((size_t)n, CommShard{0, 0, 0, 0});
+  CommArgs A{c, p, mode, q_in, seed, first_index, B, q_out, ok, iters, &sh, std::chrono::steady_clock::now()};
+  rc = ccmp_host::for_each_shard(n, comm_phase1, &A);
   // phase 2: ONE all-gather of the fixed-capacity blocks over the n devices (grouped: one call per rank of this process)
   if (rc == CCMP_OK) {
     ncclResult_t r = rccl().GroupStart();
@@ -227,30 +291,8 @@ static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, co
       if (c->ev[3 * g + 2]) (void)hipEventRecord(c->ev[3 * g + 2], c->ctxs[g]->stream);
     }
   }
-  // phase 3: GPU 0 returns the gathered blocks; every GPU returns its shard's full results if the caller wants them
-  if (rc == CCMP_OK) {
-    DeviceGuard guard(c->ctxs[0]->device);
-    hipError_t e = hipMemcpyAsync(c->host_recv, c->recv[0], block_doubles * sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
-                                  c->ctxs[0]->stream);
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H gathered blocks)");
-  }
-  for (int g = 0; g < n && rc == CCMP_OK; g++) {
-    if (sh[g].nb == 0 || (!q_out && !ok && !iters)) continue;
-    ccmp_ctx *ctx = c->ctxs[g];
-    DeviceGuard guard(ctx->device);
-    const char *stage = (const char *)ctx->stage;
-    hipError_t e = hipSuccess;
-    if (q_out) e = hipMemcpyAsync(q_out + sh[g].lo * 14, stage, sh[g].nb * 14 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && ok) e = hipMemcpyAsync(ok + sh[g].lo, stage + sh[g].off_ok, sh[g].nb, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && iters)
-      e = hipMemcpyAsync(iters + sh[g].lo, stage + sh[g].off_it, sh[g].nb * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H shard)");
-  }
-  for (int g = 0; g < n; g++) { // wait for every stream, also on the error path
-    DeviceGuard guard(c->ctxs[g]->device);
-    hipError_t e = hipStreamSynchronize(c->ctxs[g]->stream);
-    if (e != hipSuccess && rc == CCMP_OK) rc = hip_fail(e, "hipStreamSynchronize(shard)");
-  }
+  if (rc == CCMP_OK) rc = ccmp_host::for_each_shard(n, comm_phase3, &A);
+  else (void)ccmp_host::for_each_shard(n, comm_sync_one, &A); // the error path still waits for every stream
   if (rc != CCMP_OK) return rc;
   for (int g = 0; g < n; g++) {
     c->kernel_ms[g] = c->gather_ms[g] = -1.0f;

@@ -148,7 +148,8 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
  * count as long; default 12), "geodesic_scout_min" (default 6144), "geodesic_scout_rounds" (cap of the scout's traversal; default
  * 64), "geodesic_flavour" (the extend step is built twice from one source — same bits: 0 = throughput build for calls with a
  * round budget and more edges than the latency build has blocks, latency build otherwise (default); 1 / 2 = always the throughput
- * / latency build), "geodesic_blocks_per_cu" (persistent blocks of the latency build per CU; default 4).  None of these changes a
+ * / latency build), "geodesic_blocks_per_cu" (persistent blocks of the latency build per CU; default 4); host entry points: "host_zero_copy"
+ * (see ccmp_project_host).  None of these changes a
  * result bit.  CCMP_EINVAL for unknown names. */
 int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
 /* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
@@ -244,7 +245,10 @@ int ccmp_compact_valid(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t
 int ccmp_compact_valid_capped(ccmp_ctx *ctx, const double *q, const uint8_t *ok, size_t B, double *q_valid,
                               size_t capacity, uint64_t *count_dev, void *hip_stream);
 
-/* ---- host-pointer conveniences (H2D, kernel, D2H; synchronous) ---------------------------------- */
+/* ---- host-pointer conveniences (H2D, kernel, D2H; synchronous) ----------------------------------
+ * ccmp_project_host recognises a caller's PAGE-LOCKED q_in / q_out (hipHostMalloc, hipHostRegister; a batch larger than 64 KB,
+ * both 16-byte aligned): the kernels then write the projected rows straight into q_out instead of staging and downloading
+ * them (option "host_zero_copy": 1 = that, default; 2 = q_in is read in place as well; 0 = staged like pageable memory). */
 int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, double *q_out, uint8_t *ok,
                       uint16_t *iters, size_t B);
 int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, double *f, size_t B);
@@ -276,6 +280,13 @@ int ccmp_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *
 /* sampleUniform x B across the contexts; sample i is a function of (seed, first_index + i) only */
 int ccmp_sample_project_sharded_host(ccmp_ctx *const *ctxs, int n, const ccmp_problem *p, uint64_t seed, uint64_t first_index,
                                      double *q_out, uint8_t *ok, uint16_t *iters, size_t B);
+/* Per context (n values each) of the last ccmp_*_sharded_host / ccmp_*_sharded call: launch_ms = milliseconds from the
+ * call's entry to the moment the host had that shard's upload behind it and issued its kernels; start_ms = the same moment
+ * on the GPU's timeline relative to ctxs[0]'s (an event on each context's stream; -1 for a context on another device than
+ * ctxs[0], where no common timeline exists).  Every shard is driven by its own short-lived host thread, so both stay
+ * within a fraction of a millisecond of each other for any number of GPUs; a serial upload would show as values growing
+ * with the shard index (a pageable 29 MB shard: ~1.2 ms each). */
+int ccmp_sharded_host_last_timing(ccmp_ctx *const *ctxs, int n, double *launch_ms, double *start_ms);
 
 /* ---- one process, several GPUs, with the collective (ccmp_project_sharded) ------------------------- */
 /* A communicator over the devices of n contexts (one context per device, 1 <= n <= 64): ncclCommInitAll in this

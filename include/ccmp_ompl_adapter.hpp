@@ -7,18 +7,21 @@
 // ccmp::ProxyScene (sphere / box pre-filter ahead of the MoveIt validity test); and
 // the dump formats of the reference's planner run (ccmp::printAsMatrix, ccmp::printGraphML, ccmp::printGraphviz).
 //
-// Part 2 (compiled only with -DCCMP_WITH_OMPL, i.e. inside the reference's catkin workspace where
-// OMPL and Eigen exist): drop-in replacements that keep the reference's class names and virtual
-// signatures, so src/planner/stefanBiPRM.cpp, src/base/constraints/ConstrainedPlanningCommon.cpp
-// and src/main.cpp compile unchanged against them:
-//   class KinematicChainConstraint : public ompl::base::Constraint
-//       (replaces include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:21-137)
-//   class jy_ProjectedStateSampler : public ompl::base::WrapperStateSampler
-//       (replaces src/base/jy_ProjectedStateSpace.cpp:5-29)
-//   class jy_ProjectedStateSpace : public ompl::base::ConstrainedStateSpace
-//       (replaces src/base/jy_ProjectedStateSpace.cpp:32-96)
-// Neither OMPL nor Eigen is installed in the build image of this repository, so part 2 is exercised
-// only by inspection; part 1 is compiled and run by tests/test_cpp_adapter.py.
+// Part 2 (compiled only with CCMP_WITH_OMPL defined, i.e. inside the reference's catkin workspace where OMPL and Eigen
+// exist): drop-in replacements that keep the reference's class names and virtual signatures, so
+// src/planner/stefanBiPRM.cpp, src/base/constraints/ConstrainedPlanningCommon.cpp and src/main.cpp compile unchanged
+// against them.  They replace the class bodies of TWO headers and the members of ONE source file of the reference:
+//   class KinematicChainConstraint : public ompl::base::Constraint, typedef ChainConstraintPtr
+//       (include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:21-140)
+//   typedef jy_ProjectedStateSpacePtr, class jy_ProjectedStateSampler : public ompl::base::WrapperStateSampler,
+//   class jy_ProjectedStateSpace : public ompl::base::ConstrainedStateSpace,
+//   class jy_MotionValidator : public ompl::base::ConstrainedMotionValidator
+//       (include/closed_chain_motion_planner/base/jy_ProjectedStateSpace.h:15-69; members: src/base/jy_ProjectedStateSpace.cpp:5-96,
+//        which therefore leaves the build)
+// The replacement headers and the CMake edit are in include/reference_overlay/ (INTEGRATION.md section 2).
+// Neither OMPL nor Eigen is installed in the build image of this repository: part 2 is compiled against an interface mock
+// (tests/cpp/mock_ompl) — two translation units including both replacement headers, linked into one program — and run on
+// the GPU box by tests/test_cpp_adapter.py; part 1 is compiled and run there as plain C++14.
 #ifndef CCMP_OMPL_ADAPTER_HPP
 #define CCMP_OMPL_ADAPTER_HPP
 

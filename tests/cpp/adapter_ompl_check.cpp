@@ -94,6 +94,10 @@ int main(int argc, char **argv)
     auto arm2 = std::make_shared<ArmModel>();
     arm1->name = "panda_left"; arm1->index = 0;
     arm2->name = "panda_right"; arm2->index = 1;
+    // t_wb as ConstrainedProblem::_setEnvironment fills it from config->t_wb[index] (ConstrainedPlanningCommon.cpp:98;
+    // frames of src/kinematics/grasping_point.cpp:11-13): the adapter takes the base frame from the ArmModel, by value
+    arm1->t_wb.translation()(1) = 0.3;  arm1->t_wb.translation()(2) = 1.006;
+    arm2->t_wb.translation()(1) = -0.3; arm2->t_wb.translation()(2) = 1.006;
     ChainConstraintPtr constraint = std::make_shared<KinematicChainConstraint>(14);
     constraint->setArmModels(arm1, arm2);
     constraint->setInitialPosition(start);

@@ -59,6 +59,71 @@ def test_bench_line_contract():
     assert g["parity_vs_det_oracle"]["bit_identical"] is True and g["overflowed_edges"] < 0.01 * g["edges"]
     assert g["parity_vs_det_oracle"]["continued_edges"]["bit_identical"] is True and g["parity_vs_det_oracle"]["continued_edges"]["edges"] >= 1
     assert g["overflowed_edges"] == g["overflowed_list_full"] + g["overflowed_budget_spent"] and g["ms_unbounded_rounds"] > 0
+    # the driver's record keeps first-level scalars of config / roofline / cpu_baseline only — the figures of
+    # SURVEY.md section 8(d) are repeated there, flat
+    for k in FLAT_CONFIG:
+        assert k in j["config"] and isinstance(j["config"][k], (int, float, bool)), k
+    for k in ("c1_bitwise", "c2_bitwise", "c4_bitwise", "extend_bitwise"):
+        assert j["config"][k] is True, k
+    assert j["config"]["c2_batch4096_per_s"] == sec["batch4096_projections_per_s"] and j["config"]["extend_complete_ms"] == g["complete_ms"]
+    for k in ("fp64_algorithmic_frac",):
+        assert isinstance(r[k], float) and 0 < r[k] < 1
+    for k in ("fp64_executed_frac", "valu_issue_frac", "pipes_busy_frac"):  # PMC-derived: None unless profiles/traffic_latest.json is for this batch
+        assert k in r and (r[k] is None or 0 < r[k] < 1.5)
+    for k in FLAT_CPU:
+        assert k in cb and isinstance(cb[k], (int, float, bool)), k
+    assert cb["det_bit_identical"] is True and cb["libm_n_gt_1e-6"] == pl["n_gt_1e-6"] and cb["libm_samples"] == pl["samples"]
+
+
+FLAT_CONFIG = ("c1_dumbbell_cpu_single_thread_per_s", "c1_dumbbell_gpu_per_s", "c1_bitwise", "c2_batch4096_per_s", "c2_bitwise", "batch32768_per_s",
+               "c4_stefan_per_s", "c4_stefan_tight_per_s", "c4_bitwise", "extend_first_pass_edges_per_s", "extend_first_pass_ms",
+               "extend_unfinished_edges", "extend_complete_ms", "extend_bitwise", "growtree_5_edges_ms", "single_project_us",
+               "single_project_near_manifold_us", "host_buffer_pageable_per_s", "host_buffer_pinned_per_s", "analytic_mode_per_s",
+               "proxy_clearance_states_per_s")
+FLAT_CPU = ("det_bit_identical", "det_samples", "libm_samples", "libm_n_gt_1e-6", "libm_max_abs_dq", "libm_iter_diffs_gt1", "libm_ok_mismatches")
+
+
+def test_flat_keys_are_first_level_scalars():
+    """bench.flatten_for_the_driver on a line shaped like the real one (no GPU needed): every figure the driver must keep
+    lands as a first-level scalar of config / roofline / cpu_baseline, equal to its nested source."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    B = 262144
+    par = {"bit_identical": True, "samples": 1024}
+    line = {
+        "config": {"workload": "w"},
+        "roofline": {"bound": "hbm", "fp64": {"frac": 0.016}, "fp64_executed": {"frac": 0.449},
+                     "valu_issue": {"frac_of_fp64_issue_ceiling": 0.824, "vector_pipes_busy_in_profiled_launch": 0.905, "source": "profiles/r03f"}},
+        "secondary": {
+            "batch4096_projections_per_s": 5.1e6, "batch4096": {"parity_vs_det_oracle": par}, "batch32768_projections_per_s": 11.4e6,
+            "single_project_c_abi": {"uniform_sample_median_us": 122.0, "near_manifold_median_us": 54.7},
+            "analytic_mode_projections_per_s": 1.4e8,
+            "stefan_batch%d_tol_1e-3_5e-3" % B: {"projections_per_s": 9.9e6, "parity_vs_det_oracle": par},
+            "stefan_batch%d_tol_5e-4_2.5e-3" % B: {"projections_per_s": 9.0e6, "parity_vs_det_oracle": par},
+            "discrete_geodesic": {"edges_per_s": 10.7e6, "ms": 1.52, "overflowed_edges": 29, "complete_ms": 42.8, "growtree_5_edges_ms": 0.41,
+                                  "parity_vs_det_oracle": {"bit_identical": True, "continued_edges": {"bit_identical": True}}},
+            "proxy_clearance": {"states_per_s": 6.6e8},
+            "host_buffer": {"pageable": {"projections_per_s": 14.5e6}, "pinned": {"projections_per_s": 13.2e6}},
+            "c1_dumbbell": {"cpu_single_thread_projections_per_s": 560.0, "gpu_projections_per_s": 1.1e6, "parity_vs_det_oracle": par},
+        },
+        "cpu_baseline": {"value": 14800.0, "parity_gpu_vs_det_oracle": {"bit_identical": True, "samples": 2048},
+                         "parity_gpu_vs_libm_oracle": {"samples": 131072, "n_gt_1e-6": 26221, "max_abs_dq": 0.046, "iteration_diffs_gt1": 8620,
+                                                       "ok_mismatches": 3}},
+    }
+    bench.flatten_for_the_driver(line, B)
+    for k in FLAT_CONFIG:
+        assert isinstance(line["config"][k], (int, float, bool)), k
+    assert line["config"]["c4_stefan_tight_per_s"] == 9.0e6 and line["config"]["extend_complete_ms"] == 42.8 and line["config"]["c4_bitwise"] is True
+    rf = line["roofline"]
+    assert (rf["fp64_algorithmic_frac"], rf["fp64_executed_frac"], rf["valu_issue_frac"], rf["pipes_busy_frac"]) == (0.016, 0.449, 0.824, 0.905)
+    for k in FLAT_CPU:
+        assert isinstance(line["cpu_baseline"][k], (int, float, bool)), k
+    assert line["cpu_baseline"]["libm_n_gt_1e-6"] == 26221 and line["cpu_baseline"]["det_bit_identical"] is True
+    # a line without secondaries / with a failed CPU leg (N > 1, --no-secondary) must not break
+    bare = {"config": {}, "roofline": {"fp64": {"frac": 0.01}}, "cpu_baseline": {"error": "x"}}
+    bench.flatten_for_the_driver(bare, B)
+    assert bare["roofline"]["fp64_executed_frac"] is None and "det_bit_identical" not in bare["cpu_baseline"]
 
 
 def _run_bench(*argv, env=None, timeout=600):

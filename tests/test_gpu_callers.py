@@ -276,6 +276,82 @@ def test_single_process_sharding_over_contexts(gpu_ctx, oracle_det):
     assert np.array_equal(s_out.view(np.uint64), e_out.view(np.uint64)) and np.array_equal(s_ok, e_ok)
 
 
+def test_sharded_host_uploads_are_not_serial(gpu_ctx, oracle_det):
+    """ccmp_project_sharded_host drove its shards from ONE host thread, and an upload from pageable memory
+    blocks its caller: GPU g started g uploads late (29 MB shards: ~1.2 ms each, 8-9 ms at 8 GPUs against a 16 ms kernel).
+    Each shard now has its own short-lived thread.  Two contexts on this box's one GPU, C3-sized shards from PAGEABLE
+    memory: the second shard's upload is complete — its stream reaches its first kernel — within 0.6 ms of the first's on
+    the GPU's own timeline (one shard's upload takes about twice that, so a serial upload cannot pass), and on the host
+    clock both launches are issued within 0.6 ms of each other.  Results stay those of one context."""
+    from closed_chain_motion_planner_amd import Context
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    B = 2 * 262144
+    q = c.ambient_uniform_batch(0x5D, 0, B).cpu().numpy()  # pageable
+    ctxs = [gpu_ctx, Context(0)]
+    c.project_sharded_host(q[:4096], ctxs)  # staging buffers and events exist after this
+    best = None
+    for _ in range(3):
+        out, ok, it = c.project_sharded_host(q, ctxs)
+        launch, start = c.sharded_host_last_timing(ctxs)
+        assert start[0] == 0.0 and launch[0] > 0 and launch[1] > 0
+        gap = (abs(start[1]), abs(launch[1] - launch[0]), min(launch))
+        best = gap if best is None or gap[0] < best[0] else best
+    assert best[0] < 0.6 and best[1] < 0.6, best      # side by side, not one after the other
+    assert best[2] > 0.25, best                        # a pageable 29 MB upload is not free: the gap above is not trivially small
+    m = 8192  # the same rows through one context (the first rows of each shard)
+    for lo in (0, B // 2):
+        o1, k1, i1 = c.project_host(q[lo:lo + m])
+        assert np.array_equal(out[lo:lo + m].view(np.uint64), o1.view(np.uint64)) and np.array_equal(ok[lo:lo + m], k1)
+        assert np.array_equal(it[lo:lo + m], i1)
+
+
+def test_project_host_writes_straight_into_pinned_buffers(gpu_ctx, oracle_det):
+    """ccmp_project_host on PAGE-LOCKED caller buffers (torch pin_memory = hipHostMalloc): every "host_zero_copy" setting —
+    staged like pageable memory, q_out written in place by the kernels, q_in read in place as well — and pageable buffers
+    give the same bits as the device-pointer call; in-place (q_out == q_in) included."""
+    import ctypes as C
+
+    import torch
+    from closed_chain_motion_planner_amd import _lib
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    B = 20000  # above the 64 KB pinned block of single-state calls, scout + throughput kernel + hand-over
+    qd = c.ambient_uniform_batch(0x5E, 0, B)
+    ref, ok_ref, it_ref = c.project_batch(qd)
+    ref, ok_ref, it_ref = ref.cpu(), ok_ref.cpu(), it_ref.cpu().to(torch.int32)
+    q_cpu, ok_cpu, _ = oracle_det.project_batch(P, qd[:512].cpu().numpy(), NCPU)
+    assert np.array_equal(ref[:512].numpy().view(np.uint64), q_cpu.view(np.uint64))
+    L = _lib.lib()
+    dp, u8, u16 = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
+
+    def run(qi, qo, okh, ith):
+        rc = L.ccmp_project_host(gpu_ctx.handle, C.byref(c.problem), C.cast(qi.data_ptr(), dp), C.cast(qo.data_ptr(), dp),
+                                 C.cast(okh.data_ptr(), u8), C.cast(ith.data_ptr(), u16), B)
+        assert rc == 0
+        assert torch.equal(qo.view(torch.int64), ref.view(torch.int64)) and torch.equal(okh, ok_ref)
+        assert torch.equal(ith.to(torch.int32), it_ref)
+
+    try:
+        for mode in (0, 1, 2):
+            gpu_ctx.set_option("host_zero_copy", mode)
+            for pin in (False, True):
+                mk = (lambda t: t.pin_memory()) if pin else (lambda t: t)
+                qi, qo = mk(qd.cpu().clone()), mk(torch.zeros(B, 14, dtype=torch.float64))
+                okh, ith = mk(torch.zeros(B, dtype=torch.uint8)), mk(torch.zeros(B, dtype=torch.int16))
+                run(qi, qo, okh, ith)
+                run(qi, qi, okh, ith)  # in place, as the reference's project(x)
+            # a pinned q_in with a pageable q_out (and the reverse) falls back to staging
+            run(qd.cpu().pin_memory(), torch.zeros(B, 14, dtype=torch.float64), torch.zeros(B, dtype=torch.uint8), torch.zeros(B, dtype=torch.int16))
+            # a window into a pinned buffer that is not 16-byte aligned... rows are 112 bytes: every row start is
+            big = torch.zeros(B + 3, 14, dtype=torch.float64).pin_memory()
+            big[1:B + 1] = qd.cpu()
+            run(big[1:B + 1], big[1:B + 1], torch.zeros(B, dtype=torch.uint8).pin_memory(), torch.zeros(B, dtype=torch.int16).pin_memory())
+    finally:
+        gpu_ctx.set_option("host_zero_copy", 1)
+
+
 def test_single_process_rccl_all_gather(gpu_ctx, oracle_det):
     """ccmp_project_sharded / ccmp_sample_project_sharded: projection, capped compaction into the
     gather block, ONE ncclAllGather, valid states back in global order.  This box has one GPU and RCCL wants one rank
