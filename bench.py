@@ -709,9 +709,9 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         L = _lib.lib()
         qh = c.ambient_uniform_batch(SEEDS.get(B, 0xC3), 0, B).cpu()
         res = {"samples": B}
-        # page-locked caller buffers ("host_zero_copy", include/ccmp.h): the kernels write q_out in place (default, "pinned"),
-        # read q_in in place too, or everything is staged as for pageable memory
-        for name, pin, zc in (("pageable", False, 1), ("pinned", True, 1), ("pinned_q_in_read_in_place", True, 2), ("pinned_staged", True, 0)):
+        # page-locked caller buffers ("host_zero_copy", include/ccmp.h): the kernels read q_in and write q_out in place (default,
+        # "pinned"), q_in is uploaded by one copy first, or everything is staged as for pageable memory
+        for name, pin, zc in (("pageable", False, 2), ("pinned", True, 2), ("pinned_q_in_uploaded_first", True, 1), ("pinned_staged", True, 0)):
             ctx.set_option("host_zero_copy", zc)
             mk = (lambda t: t.pin_memory()) if pin else (lambda t: t)
             qi, qo = mk(qh.clone()), mk(torch.empty_like(qh))
@@ -727,7 +727,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
                     raise RuntimeError("ccmp_project_host: %d" % rc)
             sec = float(np.median(ts[1:]))
             res[name] = {"projections_per_s": B / sec, "ms": sec * 1e3}
-        ctx.set_option("host_zero_copy", 1)
+        ctx.set_option("host_zero_copy", 2)
         return res
 
     def c1_dumbbell(b=1024, seed=0xC1):

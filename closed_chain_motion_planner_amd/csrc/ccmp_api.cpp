@@ -97,6 +97,10 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
                                     unsigned int done_seq, size_t pool_records, hipStream_t st);
+hipError_t ccmp_launch_project_dense(const ccmp_consts *K, int src, int slots, const double *q_in, double *q_out, uint8_t *ok,
+                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
+                                     unsigned long long seed, unsigned long long first, const double *pool,
+                                     const unsigned long long *pool_count, int wrap_output, int nblocks, size_t pool_records, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
@@ -370,6 +374,12 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "host_zero_copy")) { // *_host calls on page-locked caller buffers: 0 staged, 1 q_out direct, 2 q_in too
     if (value < 0 || value > 2) return CCMP_EINVAL;
     ctx->host_zero_copy = (int)value;
+  } else if (!strcmp(name, "dense_slots")) { // latency work on dense blocks: 0 = one sample per 128-thread block, 2 / 4 = slots per block
+    if (value != 0 && value != 2 && value != 4) return CCMP_EINVAL;
+    ctx->dense_slots = (int)value;
+  } else if (!strcmp(name, "dense_min")) { // ... from this many samples (handed-over samples) on
+    if (value < 1) return CCMP_EINVAL;
+    ctx->dense_min = (size_t)value;
   } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the projector's latency kernel per CU (8 resident)
     if (value < 1 || value > 32) return CCMP_EINVAL;
     ctx->latency_blocks_per_cu = (int)value;
@@ -578,10 +588,20 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   const FdPlan pl = plan_fd_batch(ctx, B, ctx->order != nullptr);
   // queue[0]: sample queue of the throughput kernel; queue[1]: pool fill count; queue[2]: read head of the latency kernel
   unsigned long long *const q_group = ctx->queue, *const q_pool_count = ctx->queue + 1, *const q_latency = ctx->queue + 2;
-  if (!pl.latency_static) HIP_TRY(ccmp_launch_clear_words(ctx->queue, 16, st)); // the eight 64-bit words of this path (6: pool count from the back)
+  // Dense latency blocks (ccmp_kernels_dense.hip): S samples per block, their min-norm solves side by side in one wavefront.
+  // Fewer instructions per sample-round, the same rounds: for latency work that keeps the chip busy — never for a handful of
+  // samples, whose blocks have a CU to themselves either way.
+  const int dense = (ctx->flat_kernel && ctx->dense_slots >= 2) ? ctx->dense_slots : 0;
+  const int dense_blocks_cap = dense ? ctx->num_cus * (8 / dense) : 0; // 16 wavefronts per CU, as the flat kernel's eight blocks
+  const bool dense_small = dense && pl.group_blocks == 0 && B >= ctx->dense_min;
+  if (!pl.latency_static || dense_small) HIP_TRY(ccmp_launch_clear_words(ctx->queue, 16, st)); // the eight 64-bit words of this path (6: pool count from the back)
 
   if (pl.group_blocks == 0) { // small batches and single states
-    if (ctx->flat_kernel) {
+    if (dense_small) {
+      const size_t want = (B + (size_t)dense - 1) / (size_t)dense;
+      HIP_TRY(ccmp_launch_project_dense(&K, mode, dense, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count,
+                                        mode, (int)(want < (size_t)dense_blocks_cap ? want : (size_t)dense_blocks_cap), 0, st));
+    } else if (ctx->flat_kernel) {
       unsigned int *flag = arm_done_word(ctx, B);
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
                                        ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, st));
@@ -616,7 +636,12 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
                                     pl.handover ? ctx->pool : nullptr, pl.dump_threshold, order, pred, ctx->pool_long_remaining, pool_records,
                                     st));
   if (pl.handover) { // the pool's fill count is read on the device: the latency kernel's surplus blocks exit at once
-    if (ctx->flat_kernel)
+    if (dense && (size_t)pl.latency_blocks >= ctx->dense_min)
+      HIP_TRY(ccmp_launch_project_dense(&K, 2, dense, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
+                                        (pl.latency_blocks + dense - 1) / dense < dense_blocks_cap ? (pl.latency_blocks + dense - 1) / dense
+                                                                                                   : dense_blocks_cap,
+                                        pool_records, st));
+    else if (ctx->flat_kernel)
       HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
                                        pl.latency_blocks, nullptr, 0, pool_records, st));
     else

@@ -87,6 +87,8 @@ struct ccmp_ctx {
                                          // front of the pool and are taken first by the latency kernel (0 = one class).  Wine_Bottle, ms,
                                          // one class | 16 | 24 | 32 | 48 | 64: 28672: 2.83 | 2.62 | 2.42 | 2.41 | 2.44 | 2.78; 32768: 3.18 |
                                          // 2.88 | 2.71 | 2.73 | 2.74 | 3.01; 40960: 3.44 | 3.31 | 3.28 | 3.27 | 3.38 | 3.47; >= 49152 and stefan: +-2 %
+  int dense_slots = 0;                   // latency work on dense blocks (ccmp_kernels_dense.hip): 0 = off, 2 / 4 = samples (edges) per block
+  size_t dense_min = 1024;               // ... from this many samples / handed-over samples / edges on
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency
@@ -114,9 +116,10 @@ struct ccmp_ctx {
   bool want_done = false;  // set by the host entry point that is going to poll
   // *_host calls on a caller's PAGE-LOCKED buffers (hipHostMalloc / hipHostRegister; found with hipPointerGetAttributes):
   // 0 = stage them like pageable memory, 1 = q_in is uploaded by one asynchronous copy and the kernels write q_out straight
-  // into the caller's buffer, 2 = the kernels also read q_in from it (nothing is staged but the flags).  A projection reads
-  // and writes each 112-byte row once: 3.7 GB/s at 16 M projections/s, a fraction of what the link carries.
-  int host_zero_copy = 1;
+  // into the caller's buffer, 2 = the kernels also read q_in from it (nothing is staged but the flags; default).  A projection
+  // reads and writes each 112-byte row once: 3.7 GB/s at 16 M projections/s, a fraction of what the link carries.  C3 batch
+  // through ccmp_project_host, ms (kernels alone 16.24): pageable 18.71 | pinned staged 18.04 | 1: 18.40 | 2: 17.50.
+  int host_zero_copy = 2;
   // ccmp_*_sharded_host / ccmp_*_sharded: when this context's shard had its upload behind it (host clock, ms from the
   // call's entry) and the event recorded on its stream at that point (ccmp_sharded_host_last_timing)
   double shard_launch_ms = -1.0;

@@ -217,41 +217,39 @@ __device__ __forceinline__ void flat_chain_from(const double2 *tab, const double
   }
 }
 
+// ---- B: the chain of arm W, joint j at (s, c), the others at x; the x lane leaves the arm's pose at x in the record -------
 template <int W, bool STOCK>
-__device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab,
-                                                        double *rec, int lane, int j, int own, bool head, double y,
-                                                        unsigned long long &tprev)
+__device__ __forceinline__ void flat_chain_pose(const ccmp_consts &KC, const double *steptab, double *rec, int lane, int j, int own,
+                                                double *Tw)
 {
-  (void)tprev; // only the -DCCMP_FLAT_TIMING build ticks it
-  // ---- B: the chain of arm W, joint j at (s, c), the others at x --------------------------------------------------
-  double Tw[12];
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+  const double2 *tab = reinterpret_cast<const double2 *>(steptab + W * 7 * kStepDoubles);
+  double2 off0[2] = {tab[0], tab[1]}, rot0[6];
   {
-    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
-    const double2 *tab = reinterpret_cast<const double2 *>(steptab + W * 7 * kStepDoubles);
-    double2 off0[2] = {tab[0], tab[1]}, rot0[6];
-    {
-      const double2 *slot = reinterpret_cast<const double2 *>(rec + ((j == 0) ? own : fSC + kRot * W * 7));
+    const double2 *slot = reinterpret_cast<const double2 *>(rec + ((j == 0) ? own : fSC + kRot * W * 7));
 #pragma unroll
-      for (int k = 0; k < 6; k++) rot0[k] = slot[k];
-    }
-    flat_chain_from<W, STOCK, 0>(tab, rec, j, own, off0, rot0, R, o);
-    tool_pose_t<STOCK>(KC, W, R, o, &Tw[0], &Tw[9]);
-    if (lane == kXLane) {
-#pragma unroll
-      for (int k = 0; k < 12; k++) rec[fEE + W * 12 + k] = Tw[k];
-    }
+    for (int k = 0; k < 6; k++) rot0[k] = slot[k];
   }
-  __syncthreads();
-  FLAT_TICK(1);
-  // ---- C: residuals against the partner arm's pose at x; the x lane of wave 0 yields f(x) ------------------------
+  flat_chain_from<W, STOCK, 0>(tab, rec, j, own, off0, rot0, R, o);
+  tool_pose_t<STOCK>(KC, W, R, o, &Tw[0], &Tw[9]);
+  if (lane == kXLane) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) rec[fEE + W * 12 + k] = Tw[k];
+  }
+}
+
+// ---- C, D: residuals against the partner arm's pose at x (the x lane of wave 0 yields f(x)), then OMPL's stencil inside the
+// wave: m_s = (t1 - t2) / (y1[j] - y2[j]) on the plus lane of each pair (its minus partner sits three lanes up the row),
+// J[.][col] = 1.5 m1 - 0.6 m2 + 0.1 m3 on the column's first lane.  Lanes that own no plus point compute on whatever their row
+// neighbours hold and are not stored.  Behind a block barrier (both arms' poses at x are in the record).
+template <int W, bool STOCK>
+__device__ __forceinline__ void flat_residual_stencil(const ccmp_consts &K, double *rec, int lane, int j, bool head, double y, const double *Tw)
+{
   double To[12], tt[2];
 #pragma unroll
   for (int k = 0; k < 12; k++) To[k] = rec[fEE + (1 - W) * 12 + k];
   if (W == 0) chain_residual(K, &Tw[0], &Tw[9], &To[0], &To[9], tt, nullptr, nullptr);
   else chain_residual(K, &To[0], &To[9], &Tw[0], &Tw[9], tt, nullptr, nullptr);
-  // ---- D: OMPL's stencil inside the wave.  m_s = (t1 - t2) / (y1[j] - y2[j]) on the plus lane of each pair (its minus
-  // partner sits three lanes up the row), J[.][col] = 1.5 m1 - 0.6 m2 + 0.1 m3 on the column's first lane.  Lanes that own
-  // no plus point compute on whatever their row neighbours hold and are not stored.
   const double t0m = dpp_f64<0x103>(tt[0]), t1m = dpp_f64<0x103>(tt[1]), ym = dpp_f64<0x103>(y);
   const double den = y - ym;
   const double m0 = (tt[0] - t0m) / den, m1 = (tt[1] - t1m) / den;
@@ -268,59 +266,92 @@ __device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, co
   }
 }
 
+template <int W, bool STOCK>
+__device__ __forceinline__ void flat_chain_and_residual(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab,
+                                                        double *rec, int lane, int j, int own, bool head, double y,
+                                                        unsigned long long &tprev)
+{
+  (void)tprev; // only the -DCCMP_FLAT_TIMING build ticks it
+  double Tw[12];
+  flat_chain_pose<W, STOCK>(KC, steptab, rec, lane, j, own, Tw);
+  __syncthreads();
+  FLAT_TICK(1);
+  flat_residual_stencil<W, STOCK>(K, rec, lane, j, head, y, Tw);
+}
+
+// what a lane of the wavefront of arm `w` does in a round, as LDS slots (doubles) and flags computed once: the joint value it
+// starts from, where it stores the (sin, cos | rotation) it computes — evaluation lanes own a rotation slot each (42 per
+// wavefront), the sine/cosine lanes fill the arm's table at x, the rest write a dummy slot — and where "its" joint's axis sits
+// in the step table
+struct FlatLane {
+  int j, own, x_at, sc_to, ax_at, nstep;
+  bool ev, head, plus;
+};
+__device__ __forceinline__ FlatLane flat_lane(int w, int lane)
+{
+  FlatLane L;
+  const int row = lane >> 4, rl = lane & 15;
+  L.ev = row < 3 ? rl < 12 : rl < 6;                               // stencil evaluation
+  const bool sc_lane = lane >= kScLane0 && lane < kScLane0 + 7;  // sincos of joint lane - kScLane0 of arm w
+  const int hi6 = (row < 3 && rl >= 6) ? 1 : 0;
+  L.j = L.ev ? 2 * row + hi6 : -1;
+  const int pt = L.ev ? rl - 6 * hi6 : 0;
+  L.head = L.ev && pt == 0;
+  L.plus = pt < 3;
+  L.nstep = (L.plus ? pt : pt - 3) + 1;
+  const int my_joint = L.ev ? L.j : (sc_lane ? lane - kScLane0 : 0);
+  L.own = L.ev ? fOwn + kRot * (w * kEvLanes + row * 12 + rl) : fDummy;
+  L.x_at = fX + w * 7 + my_joint;
+  L.sc_to = sc_lane ? fSC + kRot * (w * 7 + lane - kScLane0) : L.own;
+  L.ax_at = (w * 7 + my_joint) * kStepDoubles + kStepAxis; // axis + axis products of "my" joint in the step table
+  return L;
+}
+
+// ---- A: angles.  y1[j] += h / y2[j] -= h by sequential adds as OMPL does; one sincos per lane, without a branch: every lane
+// reads the joint it is concerned with (x_at), steps it (evaluation lanes) or not (sine/cosine lanes), and stores (sin, cos)
+// and the joint's rotation (ccmp_kin.h rot_sc: the chain's operations, once) to its slot — the arm's table at x for the
+// sine/cosine lanes, the lane's own slot otherwise.  Returns the angle the lane evaluated at.
+__device__ __forceinline__ double flat_angles(const double *steptab, double *rec, const FlatLane &L)
+{
+  double s, c;
+  const double xj = rec[L.x_at];
+  const double axj = ccmp_abs(xj);
+  const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
+  const double hh = L.plus ? h : -h;
+  const double y1 = xj + hh, y2 = y1 + hh, y3 = y2 + hh;
+  const double ys = L.nstep == 1 ? y1 : (L.nstep == 2 ? y2 : y3);
+  const double y = L.ev ? ys : xj;
+  ccmp_sincos(y, &s, &c);
+  const double2 *ac = reinterpret_cast<const double2 *>(steptab + L.ax_at);
+  const double2 a01 = ac[0], a2p0 = ac[1], p12 = ac[2], p34 = ac[3], p5 = ac[4];
+  const double axv[3] = {a01.x, a01.y, a2p0.x};
+  const double apv[6] = {a2p0.y, p12.x, p12.y, p34.x, p34.y, p5.x};
+  double Rj[9];
+  rot_sc(axv, apv, s, c, Rj);
+  double2 *slot = reinterpret_cast<double2 *>(rec + L.sc_to);
+  double2 v;
+  v.x = s; v.y = c; slot[0] = v;
+  v.x = Rj[0]; v.y = Rj[1]; slot[1] = v;
+  v.x = Rj[2]; v.y = Rj[3]; slot[2] = v;
+  v.x = Rj[4]; v.y = Rj[5]; slot[3] = v;
+  v.x = Rj[6]; v.y = Rj[7]; slot[4] = v;
+  v.x = Rj[8]; v.y = 0.0; slot[5] = v;
+  return y;
+}
+
 template <bool STOCK>
 __device__ __forceinline__ bool flat_newton(const ccmp_consts &K, const ccmp_consts &KC, const double *steptab, double *rec, int tid,
                                             int &iter, int &updates, double &norm1, double &norm2, int max_iter)
 {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform arm
   const int lane = tid & 63;
-  const int row = lane >> 4, rl = lane & 15;
-  const bool ev = row < 3 ? rl < 12 : rl < 6;                    // stencil evaluation
-  const bool sc_lane = lane >= kScLane0 && lane < kScLane0 + 7;  // sincos of joint lane - kScLane0 of arm w
-  const int hi6 = (row < 3 && rl >= 6) ? 1 : 0;
-  const int j = ev ? 2 * row + hi6 : -1, pt = ev ? rl - 6 * hi6 : 0;
-  const bool head = ev && pt == 0;
-  const bool plus = pt < 3;
-  const int nstep = (plus ? pt : pt - 3) + 1;
-  // LDS slots of this lane (doubles): the joint value it starts from, its own (sin, cos), where it stores what it computes
-  // evaluation lanes own a rotation slot each (42 per wavefront), the sine/cosine lanes fill the arm's table at x, the rest
-  // write a dummy slot
-  const int my_joint = ev ? j : (sc_lane ? lane - kScLane0 : 0);
-  const int own = ev ? fOwn + kRot * (w * kEvLanes + row * 12 + rl) : fDummy;
-  const int x_at = fX + w * 7 + my_joint;
-  const int sc_to = sc_lane ? fSC + kRot * (w * 7 + lane - kScLane0) : own;
-  const int ax_at = (w * 7 + my_joint) * kStepDoubles + kStepAxis; // axis + axis products of "my" joint in the step table
+  const int rl = lane & 15;
+  const FlatLane L = flat_lane(w, lane);
+  const int j = L.j, own = L.own;
+  const bool head = L.head;
   unsigned long long tprev = __builtin_readcyclecounter();
   for (;;) {
-    // ---- A: angles.  y1[j] += h / y2[j] -= h by sequential adds as OMPL does; one sincos per lane, without a branch:
-    // every lane reads the joint it is concerned with (x_at), steps it (evaluation lanes) or not (sine/cosine lanes), and
-    // stores (sin, cos) to its slot — the arm's table at x for the sine/cosine lanes, the lane's own slot otherwise
-    double s, c;
-    const double xj = rec[x_at];
-    const double axj = ccmp_abs(xj);
-    const double h = 1.4901161193847656e-08 * (axj >= 1 ? axj : 1);
-    const double hh = plus ? h : -h;
-    const double y1 = xj + hh, y2 = y1 + hh, y3 = y2 + hh;
-    const double ys = nstep == 1 ? y1 : (nstep == 2 ? y2 : y3);
-    const double y = ev ? ys : xj;
-    ccmp_sincos(y, &s, &c);
-    {
-      // the joint's rotation, by the lane that has its sine and cosine (ccmp_kin.h rot_sc: the chain's operations, once)
-      const double2 *ac = reinterpret_cast<const double2 *>(steptab + ax_at);
-      const double2 a01 = ac[0], a2p0 = ac[1], p12 = ac[2], p34 = ac[3], p5 = ac[4];
-      const double axv[3] = {a01.x, a01.y, a2p0.x};
-      const double apv[6] = {a2p0.y, p12.x, p12.y, p34.x, p34.y, p5.x};
-      double Rj[9];
-      rot_sc(axv, apv, s, c, Rj);
-      double2 *slot = reinterpret_cast<double2 *>(rec + sc_to);
-      double2 v;
-      v.x = s; v.y = c; slot[0] = v;
-      v.x = Rj[0]; v.y = Rj[1]; slot[1] = v;
-      v.x = Rj[2]; v.y = Rj[3]; slot[2] = v;
-      v.x = Rj[4]; v.y = Rj[5]; slot[3] = v;
-      v.x = Rj[6]; v.y = Rj[7]; slot[4] = v;
-      v.x = Rj[8]; v.y = 0.0; slot[5] = v;
-    }
+    const double y = flat_angles(steptab, rec, L);
     // an arm's sines and cosines are written and read by the arm's own wave: no block barrier
     wave_lds_fence();
     FLAT_TICK(0);

@@ -248,7 +248,8 @@ int ccmp_compact_valid_capped(ccmp_ctx *ctx, const double *q, const uint8_t *ok,
 /* ---- host-pointer conveniences (H2D, kernel, D2H; synchronous) ----------------------------------
  * ccmp_project_host recognises a caller's PAGE-LOCKED q_in / q_out (hipHostMalloc, hipHostRegister; a batch larger than 64 KB,
  * both 16-byte aligned): the kernels then write the projected rows straight into q_out instead of staging and downloading
- * them (option "host_zero_copy": 1 = that, default; 2 = q_in is read in place as well; 0 = staged like pageable memory). */
+ * them (option "host_zero_copy": 2 = that and q_in is read in place as well, default; 1 = q_in is uploaded by one copy first;
+ * 0 = staged like pageable memory). */
 int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, double *q_out, uint8_t *ok,
                       uint16_t *iters, size_t B);
 int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, double *f, size_t B);

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, config_path
+from conftest import ROOT, config_path, load_cfg
 
 EXE = os.path.join(ROOT, "tests", "cpp", "adapter_check")
 

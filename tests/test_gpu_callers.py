@@ -349,7 +349,7 @@ def test_project_host_writes_straight_into_pinned_buffers(gpu_ctx, oracle_det):
             big[1:B + 1] = qd.cpu()
             run(big[1:B + 1], big[1:B + 1], torch.zeros(B, dtype=torch.uint8).pin_memory(), torch.zeros(B, dtype=torch.int16).pin_memory())
     finally:
-        gpu_ctx.set_option("host_zero_copy", 1)
+        gpu_ctx.set_option("host_zero_copy", 2)
 
 
 def test_single_process_rccl_all_gather(gpu_ctx, oracle_det):
