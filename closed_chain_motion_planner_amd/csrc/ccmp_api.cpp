@@ -130,6 +130,10 @@ hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double l
                                     size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                     int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
                                     const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
+hipError_t ccmp_launch_geodesic_dense(const ccmp_consts *K, int slots, double delta, double lambda, const double *from, const double *to,
+                                      size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
+                                      int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
+                                      const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -729,10 +733,12 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   const size_t lat_resident = (size_t)ctx->num_cus * (size_t)ctx->geodesic_blocks_per_cu;
   const bool latency_flavour = ctx->geodesic_flavour == 2 || (ctx->geodesic_flavour == 0 && (round_budget == 0 || E <= lat_resident));
   const size_t resident = latency_flavour ? lat_resident : (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
+  // dense blocks (ccmp_kernels_dense.hip): several edges per block; for calls the throughput flavour would take
+  const int dense = (!latency_flavour && ctx->dense_slots >= 2 && E >= ctx->dense_min) ? ctx->dense_slots : 0;
   size_t nb = E;
   unsigned long long *queue = nullptr;
   const unsigned int *order = nullptr;
-  if (E > resident) {
+  if (E > resident || dense) {
     nb = resident;
     queue = ctx->queue + 3; // word 3: ticket; word 4: the two counters of the ordering pass
     HIP_TRY(ccmp_launch_clear_words(queue, 4, st));
@@ -752,6 +758,12 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
       }
       order = ord;
     }
+  }
+  if (dense) {
+    const size_t want = (E + (size_t)dense - 1) / (size_t)dense, capb = (size_t)ctx->num_cus * (size_t)(8 / dense);
+    HIP_TRY(ccmp_launch_geodesic_dense(&K, dense, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target,
+                                       (int)(want < capb ? want : capb), queue, order, carry_in, carry_out, round_budget, st));
+    return CCMP_OK;
   }
   HIP_TRY((latency_flavour ? ccmp_launch_geodesic_lat : ccmp_launch_geodesic)(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok,
                                                                              newton_iters, check_target, (int)nb, queue, order, carry_in, carry_out,

@@ -236,9 +236,253 @@ __global__ __launch_bounds__(128 * S, CCMP_FLAT_MIN_WAVES) void project_fd_dense
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// geodesic_dense_kernel — jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96), S edges per
+// block.  What geodesic_flat_kernel (ccmp_kernels_geo.hip) does with a block per edge, as a slot state machine: the slot
+// master walks its edge — interpolate a delta step (KinematicChainSpace::interpolate, KinematicChain.h:145-171), let the
+// block's rounds project it, apply the reference's four break tests, record the state — between two rounds, wave-locally;
+// isSatisfied(to) (check_target) is one round with an iteration cap of zero.  Resumable exactly as the flat kernel
+// (carry_in / carry_out / round_budget: same values at the same places), so first call + continuation on EITHER kernel give the
+// states of one uninterrupted traversal.
+__device__ __forceinline__ double dense_distance(const double *a, const double *b)
+{
+  double dist = 0.0;
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    const double diff = a[i] - b[i];
+    dist = CCMP_FMA(diff, diff, dist);
+  }
+  return ccmp_sqrt(dist);
+}
+
+// A wave-uniform condition as the scalar unit sees it: the slot masters' bookkeeping branches on values read from LDS (the
+// same in every lane, which the compiler cannot know); through readfirstlane the branches are scalar and the counters that
+// change under them stay in scalar registers.
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+
+template <bool STOCK, int S>
+__global__ __launch_bounds__(128 * S, CCMP_FLAT_MIN_WAVES) void geodesic_dense_kernel(
+    const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
+    const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
+    int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,
+    unsigned long long *queue, const unsigned int *__restrict__ order, const double *__restrict__ carry_in,
+    double *__restrict__ carry_out, int round_budget)
+{
+  __shared__ __attribute__((aligned(16))) double lds[S * fSlot];
+  __shared__ double ktab[kConstsDoubles + 1];
+  __shared__ __attribute__((aligned(16))) double steptab[kStepTab];
+  __shared__ __attribute__((aligned(16))) int ctl[S * cWords];
+  // the slot masters' floating-point state between two rounds (registers are what eight blocks per CU live on; these are
+  // touched once per round): dist, total, maxd, norm2
+  __shared__ __attribute__((aligned(16))) double mst[S * 4];
+  const int tid = threadIdx.x;
+  {
+    const double *src = reinterpret_cast<const double *>(&K);
+    for (int k = tid; k < kConstsDoubles; k += 128 * S) ktab[k] = src[k];
+  }
+  if (tid < 128) stage_step_table(K, steptab, tid);
+  const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), slot = w >> 1, arm = w & 1, lane = tid & 63;
+  double *rec = lds + slot * fSlot;
+  int *myctl = ctl + slot * cWords;
+  double *ms = mst + slot * 4;
+  const FlatLane L = flat_lane(arm, lane);
+  const bool master = arm == 0;
+  const double pi = 3.14159265358979323846;
+
+  // slot master's state (scalar): the edge ...
+  unsigned long long t = 0ull;
+  int n = 1, its = 0, rounds = 0;
+  bool suspended = false, fits = true, target_ok = true, target_pass = false;
+  // ... and the projection in flight
+  int iter = 0, updates = 0, cap = 0;
+
+  if (tid < S) { ctl[tid * cWords + cRun] = 2; ctl[tid * cWords + cIter] = 0; ctl[tid * cWords + cCap] = 0; } // 2: the slot wants its first edge
+  __syncthreads();
+  for (;;) {
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < S; s++) any = any || ctl[s * cWords + cRun] != 0;
+    if (!any) break;
+    const int my_state = __builtin_amdgcn_readfirstlane(myctl[cRun]);
+    const bool my_run = my_state == 1;
+    const int srow = (lane >> 4) < S ? (lane >> 4) : S - 1;
+    const bool may_step = (lane >> 4) < S && ctl[srow * cWords + cRun] == 1 && ctl[srow * cWords + cIter] < ctl[srow * cWords + cCap];
+    dense_round<STOCK>(K, KL, steptab, rec, arm, lane, L, my_run);
+    if (w == 1) dense_solve<S>(K, lds, may_step, lane);
+    if (master && my_state != 0) {
+      // What the master does between two rounds, as ONE pass through a small state machine (every step is inlined once):
+      // aNone: the projection goes on; aNext: interpolate the next state and project it; aFinish: write the edge's results;
+      // aTicket: take the next edge; aBegin: the edge proper (behind the optional isSatisfied(to) round)
+      enum { aNone, aNext, aFinish, aTicket, aBegin };
+      int action = aTicket; // my_state == 2: first edge
+      int acc_at = dPrev;   // where the accepted state sits from which the next one is interpolated
+      double dist = 0.0, total = 0.0, maxd = 0.0;
+      bool run = true;
+      if (my_run) {
+        const double f0 = rec[fF], f1 = rec[fF + 1];
+        const bool c1 = f0 > K.tol_pos;
+        const bool resid = uni(c1 || (f1 > K.tol_rot));
+        const double norm1 = c1 ? 1.0 : 0.0;
+        const double norm2 = c1 ? ms[3] : f1;
+        const bool cont = resid && iter < cap;
+        iter += resid ? 1 : 0;
+        if (cont) {
+          updates++;
+          if (lane == 0) ms[3] = norm2;
+          action = aNone;
+        } else if (target_pass) {
+          // KinematicChainConstraint::isSatisfied's test (finite, f0 <= tol1, f1 <= tol2; ConstraintFunction.h:114-120)
+          target_ok = uni((f0 - f0 == 0.0) && (f1 - f1 == 0.0) && f0 <= K.tol_pos && f1 <= K.tol_rot);
+          action = aBegin;
+        } else {
+          const bool conv = (norm1 < K.tol_pos) && (norm2 < K.tol_rot);
+          dist = ms[0]; total = ms[1]; maxd = ms[2];
+          its += updates;
+          rounds += updates + 1;
+          // the reference's bookkeeping between two projections, in one pass over the 14 joints: jointValid(x), step =
+          // |previous - x| and newDist = |x - to| side by side (two independent serial sums, the canonical order each), then the
+          // tests in the reference's order (jy_ProjectedStateSpace.cpp:65-84)
+          bool jv = true;
+          double s_acc = 0.0, d_acc = 0.0;
+#pragma unroll
+          for (int i = 0; i < 14; i++) {
+            const double xi = rec[fX + i];
+            const int jj = i < 7 ? i : i - 7;
+            if (xi < KL.lbe[jj]) jv = false; // KinematicChainConstraint::jointValid (ConstraintFunction.h:43-55)
+            if (xi > KL.ube[jj]) jv = false;
+            const double ds = rec[dPrev + i] - xi, dd = xi - rec[dTo + i];
+            s_acc = CCMP_FMA(ds, ds, s_acc); // distance(previous, scratch)
+            d_acc = CCMP_FMA(dd, dd, d_acc); // distance(scratch, to)
+          }
+          action = aFinish;
+          if (uni(conv && jv)) {                               // else: not on manifold
+            const double step = ccmp_sqrt(s_acc), newDist = ccmp_sqrt(d_acc);
+            if (uni(!(step > lambda * delta))) {               // else: deviated
+              const double total_before = total;
+              total += step;
+              if (uni(!(total > maxd) && !(newDist >= dist))) { // else: wandered too far / no closer than before
+                if (n >= max_states) { // the list is full: the edge stops here and says so (ccmp_kernels_geo.hip)
+                  fits = false; n = max_states + 1; total = total_before; its -= updates;
+                } else {
+                  dist = newDist;
+                  if (lane < 14) states[(t * (unsigned long long)max_states + (unsigned long long)n) * 14ull + lane] = rec[fX + lane];
+                  n++;
+                  if (uni(dist >= delta)) {
+                    // the call's budget of Newton rounds for one edge is spent: it stops between two states (ok = 2)
+                    if (round_budget > 0 && rounds >= round_budget) suspended = true;
+                    else { action = aNext; acc_at = fX; }
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      while (action != aNone) {
+        if (action == aFinish) {
+          if (lane == 0) {
+            n_states[t] = n;
+            ok_out[t] = suspended ? (uint8_t)2 : (uint8_t)(target_ok && fits && dist <= delta);
+            if (newton_iters) newton_iters[t] = its;
+            if (carry_out) { carry_out[2 * t] = total; carry_out[2 * t + 1] = maxd; }
+          }
+          action = aTicket;
+        }
+        if (action == aTicket) {
+          const unsigned long long tk = wave_ticket(queue, lane);
+          if (tk >= E) { run = false; iter = 0; cap = 0; break; }
+          t = tk;
+          if (order) t = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)order[tk]);
+          if (lane < 14) {
+            const double a = from[t * 14 + lane];
+            rec[dPrev + lane] = a;
+            rec[dTo + lane] = to[t * 14 + lane];
+            if (max_states > 0) states[t * (unsigned long long)max_states * 14ull + lane] = a; // geodesic->push_back(cloneState(from))
+          }
+          n = 1; its = 0; rounds = 0;
+          suspended = false; fits = true; target_ok = true;
+          wave_lds_fence(); // previous / target were written by this wave's lanes < 14
+          if (check_target) {
+            // ConstrainedMotionValidator::checkMotion (src/planner/stefanBiPRM.cpp:397-398): isSatisfied(s2) first —
+            // function(to) through one evaluation round (iteration cap 0: no update)
+            if (lane < 14) rec[fX + lane] = rec[dTo + lane];
+            if (lane == 0) ms[3] = 0.0;
+            iter = 0; updates = 0; cap = 0;
+            target_pass = true;
+            break;
+          }
+          action = aBegin;
+        }
+        if (action == aBegin) { // the edge proper
+          dist = dense_distance(rec + dPrev, rec + dTo);
+          total = 0.0;
+          maxd = dist * lambda;
+          // a continuation is in the middle of the reference's do-while: it re-enters on the loop's own condition
+          // (dist >= delta) with the running length and the bound of the first call
+          bool enter = dist > delta;
+          if (carry_in) {
+            total = carry_in[2 * t];
+            maxd = carry_in[2 * t + 1];
+            enter = dist >= delta;
+          }
+          acc_at = dPrev;
+          action = uni(target_ok && enter) ? aNext : aFinish;
+        }
+        if (action == aNext) {
+          // WrapperStateSpace::interpolate(previous, to, delta_ / dist, scratch) by the joints' owners; previous := the
+          // accepted state (the lane's joint of it sits at rec[acc_at + lane])
+          if (lane < 14) {
+            const double tt = delta / dist;
+            const double fr = rec[acc_at + lane];
+            double diff = rec[dTo + lane] - fr, v;
+            if (ccmp_abs(diff) <= pi) v = CCMP_FMA(diff, tt, fr);
+            else {
+              if (diff > 0.0) diff = 2.0 * pi - diff;
+              else diff = -2.0 * pi - diff;
+              v = CCMP_FMA(-diff, tt, fr);
+              if (v > pi) v -= 2.0 * pi;
+              else if (v < -pi) v += 2.0 * pi;
+            }
+            rec[fX + lane] = v;
+            rec[dPrev + lane] = fr;
+          }
+          if (lane == 0) { ms[0] = dist; ms[1] = total; ms[2] = maxd; ms[3] = 0.0; }
+          iter = 0; updates = 0;
+          cap = K.max_iter;
+          target_pass = false;
+          break;
+        }
+      }
+      if (lane == 0) { myctl[cRun] = run ? 1 : 0; myctl[cIter] = iter; myctl[cCap] = cap; }
+    }
+    __syncthreads();
+  }
+}
+
 } // namespace
 
 extern "C" {
+
+hipError_t ccmp_launch_geodesic_dense(const ccmp_consts *K, int slots, double delta, double lambda, const double *from, const double *to,
+                                      size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
+                                      int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
+                                      const double *carry_in, double *carry_out, int round_budget, hipStream_t st)
+{
+  if ((slots != 2 && slots != 4) || !queue) return hipErrorInvalidValue;
+#define CCMP_LAUNCH_GEO_DENSE(STOCK, S)                                                                                                  \
+  hipLaunchKernelGGL((geodesic_dense_kernel<STOCK, S>), dim3(nblocks), dim3(128 * S), 0, st, *K, delta, lambda, from, to, (unsigned long long)E, \
+                     max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget)
+  if (K->stock) {
+    if (slots == 4) CCMP_LAUNCH_GEO_DENSE(true, 4);
+    else CCMP_LAUNCH_GEO_DENSE(true, 2);
+  } else {
+    if (slots == 4) CCMP_LAUNCH_GEO_DENSE(false, 4);
+    else CCMP_LAUNCH_GEO_DENSE(false, 2);
+  }
+#undef CCMP_LAUNCH_GEO_DENSE
+  return hipGetLastError();
+}
 
 // S = 2 or 4 slots per block; nblocks persistent blocks; queue_head: a zeroed 64-bit word
 hipError_t ccmp_launch_project_dense(const ccmp_consts *K, int src, int slots, const double *q_in, double *q_out, uint8_t *ok,

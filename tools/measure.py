@@ -265,6 +265,24 @@ def dense(argv):
                     row.append("S=%d %.3f/%.3f" % (S, mean, best))
             ctx.set_option("dense_slots", 0)
             print("%-11s B=%6d  mean/best ms  %s" % (obj, B, "  ".join(row)), flush=True)
+        # the extend step: growTree-shaped edges, lists of 16, 128 rounds per edge and call (the callers' large-batch shape)
+        for E in (1024, 4096, 16384, 65536):
+            frm, to = near_edges(c, E)
+            row, ref = [], None
+            for rnd in range(2):
+                for S in (0, 2, 4):
+                    ctx.set_option("dense_slots", S)
+                    r = c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128)
+                    torch.cuda.synchronize()
+                    if ref is None:
+                        ref = [x.clone() for x in r]
+                    m = ref[1].clamp(max=16)
+                    assert torch.equal(r[1], ref[1]) and torch.equal(r[2], ref[2]) and torch.equal(r[3], ref[3]), (obj, E, S)
+                    assert all(torch.equal(r[0][e, :m[e]].view(torch.int64), ref[0][e, :m[e]].view(torch.int64)) for e in range(0, E, 97))
+                    best = timed(lambda: c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128), 5)
+                    row.append("S=%d %.3f" % (S, best))
+            ctx.set_option("dense_slots", 0)
+            print("%-11s E=%6d  extend best ms  %s" % (obj, E, "  ".join(row)), flush=True)
 
 
 def sampler(argv):
