@@ -5,7 +5,6 @@ Translation units with deliberately different flags:
                          -DCCMP_LEAN_SQRT: ccmp_detmath.h's wave-uniform fast path of the IEEE square root (same bits, -1.9 %)
   ccmp_kernels_wave.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one-wave-per-sample kernels
   ccmp_kernels_flat.hip  -ffp-contract=off -DCCMP_USE_FMA   same arithmetic, one 128-thread block per sample (latency kernel)
-  ccmp_kernels_dense.hip -ffp-contract=off -DCCMP_USE_FMA   the same Newton round, several samples / edges per block (dense latency blocks)
   ccmp_kernels_geo.hip   -ffp-contract=off -DCCMP_USE_FMA   the extend step on the same Newton routine (ccmp_flat_newton.h), built twice:
                          like the flat unit (throughput flavour) and -DCCMP_GEO_LATENCY with machine LICM and a 256-register
                          budget (latency flavour)
@@ -39,8 +38,6 @@ _UNITS = [
     ("ccmp_kernels_wave.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
     # max-ilp scheduling: -0.6 % (throughput kernel) ... -1.5 % (latency kernel, single state), in-process A/B
     ("ccmp_kernels_flat.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
-    # dense latency blocks (round 4): several samples / edges per block, their solves side by side in one wavefront; the flat unit's flags
-    ("ccmp_kernels_dense.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     # the extend step, built twice from one source.  Throughput flavour (the projector's latency kernel's flags: eight blocks
     # per CU) for calls that bound the Newton rounds per edge; latency flavour (machine LICM on, 256-register budget, four
     # blocks per CU: the ~60 FP64 literals of a Newton round stay in registers instead of being re-materialised every

@@ -97,10 +97,6 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
                                     unsigned int done_seq, size_t pool_records, hipStream_t st);
-hipError_t ccmp_launch_project_dense(const ccmp_consts *K, int src, int slots, const double *q_in, double *q_out, uint8_t *ok,
-                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
-                                     unsigned long long seed, unsigned long long first, const double *pool,
-                                     const unsigned long long *pool_count, int wrap_output, int nblocks, size_t pool_records, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
@@ -130,10 +126,6 @@ hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double l
                                     size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                     int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
                                     const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
-hipError_t ccmp_launch_geodesic_dense(const ccmp_consts *K, int slots, double delta, double lambda, const double *from, const double *to,
-                                      size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
-                                      int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                      const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -378,12 +370,6 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "host_zero_copy")) { // *_host calls on page-locked caller buffers: 0 staged, 1 q_out direct, 2 q_in too
     if (value < 0 || value > 2) return CCMP_EINVAL;
     ctx->host_zero_copy = (int)value;
-  } else if (!strcmp(name, "dense_slots")) { // latency work on dense blocks: 0 = one sample per 128-thread block, 2 / 4 = slots per block
-    if (value != 0 && value != 2 && value != 4) return CCMP_EINVAL;
-    ctx->dense_slots = (int)value;
-  } else if (!strcmp(name, "dense_min")) { // ... from this many samples (handed-over samples) on
-    if (value < 1) return CCMP_EINVAL;
-    ctx->dense_min = (size_t)value;
   } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the projector's latency kernel per CU (8 resident)
     if (value < 1 || value > 32) return CCMP_EINVAL;
     ctx->latency_blocks_per_cu = (int)value;
@@ -592,20 +578,10 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   const FdPlan pl = plan_fd_batch(ctx, B, ctx->order != nullptr);
   // queue[0]: sample queue of the throughput kernel; queue[1]: pool fill count; queue[2]: read head of the latency kernel
   unsigned long long *const q_group = ctx->queue, *const q_pool_count = ctx->queue + 1, *const q_latency = ctx->queue + 2;
-  // Dense latency blocks (ccmp_kernels_dense.hip): S samples per block, their min-norm solves side by side in one wavefront.
-  // Fewer instructions per sample-round, the same rounds: for latency work that keeps the chip busy — never for a handful of
-  // samples, whose blocks have a CU to themselves either way.
-  const int dense = (ctx->flat_kernel && ctx->dense_slots >= 2) ? ctx->dense_slots : 0;
-  const int dense_blocks_cap = dense ? ctx->num_cus * (8 / dense) : 0; // 16 wavefronts per CU, as the flat kernel's eight blocks
-  const bool dense_small = dense && pl.group_blocks == 0 && B >= ctx->dense_min;
-  if (!pl.latency_static || dense_small) HIP_TRY(ccmp_launch_clear_words(ctx->queue, 16, st)); // the eight 64-bit words of this path (6: pool count from the back)
+  if (!pl.latency_static) HIP_TRY(ccmp_launch_clear_words(ctx->queue, 16, st)); // the eight 64-bit words of this path (6: pool count from the back)
 
   if (pl.group_blocks == 0) { // small batches and single states
-    if (dense_small) {
-      const size_t want = (B + (size_t)dense - 1) / (size_t)dense;
-      HIP_TRY(ccmp_launch_project_dense(&K, mode, dense, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count,
-                                        mode, (int)(want < (size_t)dense_blocks_cap ? want : (size_t)dense_blocks_cap), 0, st));
-    } else if (ctx->flat_kernel) {
+    if (ctx->flat_kernel) {
       unsigned int *flag = arm_done_word(ctx, B);
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
                                        ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, st));
@@ -640,12 +616,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
                                     pl.handover ? ctx->pool : nullptr, pl.dump_threshold, order, pred, ctx->pool_long_remaining, pool_records,
                                     st));
   if (pl.handover) { // the pool's fill count is read on the device: the latency kernel's surplus blocks exit at once
-    if (dense && (size_t)pl.latency_blocks >= ctx->dense_min)
-      HIP_TRY(ccmp_launch_project_dense(&K, 2, dense, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
-                                        (pl.latency_blocks + dense - 1) / dense < dense_blocks_cap ? (pl.latency_blocks + dense - 1) / dense
-                                                                                                   : dense_blocks_cap,
-                                        pool_records, st));
-    else if (ctx->flat_kernel)
+    if (ctx->flat_kernel)
       HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
                                        pl.latency_blocks, nullptr, 0, pool_records, st));
     else
@@ -733,12 +704,10 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   const size_t lat_resident = (size_t)ctx->num_cus * (size_t)ctx->geodesic_blocks_per_cu;
   const bool latency_flavour = ctx->geodesic_flavour == 2 || (ctx->geodesic_flavour == 0 && (round_budget == 0 || E <= lat_resident));
   const size_t resident = latency_flavour ? lat_resident : (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
-  // dense blocks (ccmp_kernels_dense.hip): several edges per block; for calls the throughput flavour would take
-  const int dense = (!latency_flavour && ctx->dense_slots >= 2 && E >= ctx->dense_min) ? ctx->dense_slots : 0;
   size_t nb = E;
   unsigned long long *queue = nullptr;
   const unsigned int *order = nullptr;
-  if (E > resident || dense) {
+  if (E > resident) {
     nb = resident;
     queue = ctx->queue + 3; // word 3: ticket; word 4: the two counters of the ordering pass
     HIP_TRY(ccmp_launch_clear_words(queue, 4, st));
@@ -758,12 +727,6 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
       }
       order = ord;
     }
-  }
-  if (dense) {
-    const size_t want = (E + (size_t)dense - 1) / (size_t)dense, capb = (size_t)ctx->num_cus * (size_t)(8 / dense);
-    HIP_TRY(ccmp_launch_geodesic_dense(&K, dense, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target,
-                                       (int)(want < capb ? want : capb), queue, order, carry_in, carry_out, round_budget, st));
-    return CCMP_OK;
   }
   HIP_TRY((latency_flavour ? ccmp_launch_geodesic_lat : ccmp_launch_geodesic)(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok,
                                                                              newton_iters, check_target, (int)nb, queue, order, carry_in, carry_out,

@@ -87,8 +87,6 @@ struct ccmp_ctx {
                                          // front of the pool and are taken first by the latency kernel (0 = one class).  Wine_Bottle, ms,
                                          // one class | 16 | 24 | 32 | 48 | 64: 28672: 2.83 | 2.62 | 2.42 | 2.41 | 2.44 | 2.78; 32768: 3.18 |
                                          // 2.88 | 2.71 | 2.73 | 2.74 | 3.01; 40960: 3.44 | 3.31 | 3.28 | 3.27 | 3.38 | 3.47; >= 49152 and stefan: +-2 %
-  int dense_slots = 0;                   // latency work on dense blocks (ccmp_kernels_dense.hip): 0 = off, 2 / 4 = samples (edges) per block
-  size_t dense_min = 1024;               // ... from this many samples / handed-over samples / edges on
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency

@@ -550,73 +550,6 @@ def test_geodesic_flavours_are_bitwise_identical(gpu_ctx, oracle_det):
         assert np.array_equal(got[0][E - 128 + k, :m].cpu().numpy().view(np.uint64), s_cpu[k, :m].view(np.uint64))
 
 
-@pytest.mark.parametrize("slots", [2, 4])
-def test_dense_extend_step_is_bitwise_identical(gpu_ctx, oracle_det, slots):
-    """geodesic_dense_kernel (`slots` edges per block, slot state machine; option "dense_slots") against the block-per-edge
-    kernel and the oracle: plain lists, lists that overflow, a round budget with carries (and the continuation of what stops
-    short, on either kernel), checkMotion's isSatisfied(to) round, fewer edges than slots."""
-    import torch
-
-    c = _constraint("Wine_Bottle", gpu_ctx)
-    P = _oracle_problem(oracle_det, c)
-    E = 1500
-    q, ok, _, _ = c.sample_project_batch(0x6F1, 0, 8 * E, want_iters=False)
-    frm = q[ok == 1][:E].contiguous()
-    to, _, _, _ = c.sample_near_project_batch(0x6F2, 0, frm, 0.6, E, want_iters=False)
-    to[7] = float("nan")
-    to[8] = frm[8]
-    nodes = torch.as_tensor(load_roadmap("Wine_Bottle")[0][2:10]).to(to.device)
-    to[10:18] = nodes  # IK milestones of the recorded roadmap: mostly off the manifold (check_target refuses them)
-
-    def run(**kw):
-        return c.discrete_geodesic_batch(frm, to, kw.pop("cap", 6), **kw)
-
-    def same(a, b, cap):
-        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
-        live = torch.arange(cap, device=frm.device)[None, :] < a[1].clamp(max=cap)[:, None]
-        assert torch.equal(a[0][live].view(torch.int64), b[0][live].view(torch.int64))
-        if len(a) > 4:
-            assert torch.equal(a[4].view(torch.int64), b[4].view(torch.int64))
-
-    gpu_ctx.set_option("geodesic_flavour", 1)  # the throughput build, whose place the dense blocks take
-    gpu_ctx.set_option("dense_min", 1)
-    try:
-        cases = [dict(cap=6), dict(cap=3), dict(cap=16, want_carry=True, round_budget=24), dict(cap=6, check_target=True),
-                 dict(cap=5, want_carry=True)]
-        refs = [run(**dict(k)) for k in cases]
-        gpu_ctx.set_option("dense_slots", slots)
-        for k, ref in zip(cases, refs):
-            got = run(**dict(k))
-            same(got, ref, k["cap"])
-        # edges that stopped short of their end in the dense launch, continued (dense again): the uninterrupted traversal
-        st, n, gok, its, carry = run(cap=4, want_carry=True, round_budget=16)
-        assert int(((n > 4) | (gok == 2)).sum()) > 20
-        whole = c.continue_geodesics(to, st, n, gok, its, carry, 4, cont_states=8)
-        some = sorted(whole)[:24]
-        for e in some:
-            okf, stf, itf = oracle_det.discrete_geodesic(P, frm[e].cpu().numpy(), to[e].cpu().numpy(), interpolate=True, max_states=512)
-            assert stf.shape == whole[e][0].shape and np.array_equal(np.ascontiguousarray(whole[e][0]).view(np.uint64), stf.view(np.uint64))
-            assert bool(whole[e][1]) == okf and whole[e][2] == itf
-        for m in (1, 2, slots + 1):  # fewer edges than a block has slots
-            a = c.discrete_geodesic_batch(frm[:m].contiguous(), to[:m].contiguous(), 6)
-            assert torch.equal(a[1], refs[0][1][:m]) and torch.equal(a[2], refs[0][2][:m])
-            lv = torch.arange(6, device=frm.device)[None, :] < a[1].clamp(max=6)[:, None]
-            assert torch.equal(a[0][lv].view(torch.int64), refs[0][0][:m][lv].view(torch.int64))
-        # and against the oracle directly
-        sl = slice(100, 292)
-        s_cpu, n_cpu, ok_cpu, it_cpu = oracle_det.discrete_geodesic_batch(P, frm[sl].cpu().numpy(), to[sl].cpu().numpy(), 6, NCPU)
-        got = run(cap=6)
-        assert np.array_equal(got[1][sl].cpu().numpy(), n_cpu) and np.array_equal(got[2][sl].cpu().numpy(), ok_cpu)
-        assert np.array_equal(got[3][sl].cpu().numpy(), it_cpu)
-        for k in range(192):
-            m = min(int(n_cpu[k]), 6)
-            assert np.array_equal(got[0][100 + k, :m].cpu().numpy().view(np.uint64), s_cpu[k, :m].view(np.uint64))
-    finally:
-        gpu_ctx.set_option("dense_slots", 0)
-        gpu_ctx.set_option("dense_min", 1024)
-        gpu_ctx.set_option("geodesic_flavour", 0)
-
-
 def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):
     """more edges than resident blocks (8 per CU): persistent blocks + ticket queue, with and without the long-edges-first
     order — the same bits as the one-block-per-edge launches of the same edges, and as the oracle on a slice"""

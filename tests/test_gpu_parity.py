@@ -173,71 +173,6 @@ def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, l
     assert it_cpu.max() == 250  # the cap was exercised
 
 
-@pytest.mark.parametrize("slots", [2, 4])
-def test_dense_blocks_are_bitwise_identical(gpu_ctx, oracle_det, slots):
-    """Dense latency blocks (ccmp_kernels_dense.hip, option "dense_slots"): `slots` samples per block, their min-norm solves
-    side by side in one wavefront (a 16-lane row each), every slot finalising and refilling by itself.  Latency kernel alone
-    (q_in and the fused sampler), behind the throughput kernel's two-class hand-over, the general instantiation
-    (calibrated arms), fewer samples than one block has slots: all bit-identical to the oracle, the 250 cap exercised."""
-    import ctypes as C
-
-    import torch
-    from closed_chain_motion_planner_amd import _lib
-
-    gpu_ctx.set_option("dense_slots", slots)
-    gpu_ctx.set_option("dense_min", 1)
-    try:
-        c = _constraint("stefan", gpu_ctx)
-        P = _oracle_problem(oracle_det, c)
-        B = 3000
-        if "stefan" not in _SCHED_CACHE:
-            q = oracle_det.ambient_uniform_batch(P, 0x5C, 0, B)
-            _SCHED_CACHE["stefan"] = (q,) + oracle_det.project_batch(P, q, NCPU)
-        q, q_cpu, ok_cpu, it_cpu = _SCHED_CACHE["stefan"]
-        assert it_cpu.max() == 250
-
-        def check(n, **sched):
-            gpu_ctx.set_schedule(sched.get("schedule", 1), sched.get("small", None))
-            gpu_ctx.set_lpt(sched.get("lpt", 1), sched.get("lpt_min", None))
-            gpu_ctx.set_option("handover_threshold", sched.get("thr", -1))
-            try:
-                q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q[:n]).cuda())
-                torch.cuda.synchronize()
-            finally:
-                gpu_ctx.set_schedule(1)
-                gpu_ctx.set_lpt(1)
-                gpu_ctx.set_option("handover_threshold", -1)
-            assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu[:n].view(np.uint64)), (n, sched)
-            assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu[:n]) and np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu[:n])
-
-        check(B, schedule=2)                                # latency kernel alone: dense blocks on everything
-        check(B, schedule=1, small=0, lpt=1, lpt_min=0)     # scout order, throughput kernel, two-class hand-over into dense blocks
-        check(B, schedule=1, small=0, lpt=0, thr=60)        # occupancy-driven hand-over, one class
-        for n in (1, 2, 3, slots + 1, 257):                 # fewer samples than slots; ragged
-            check(n, schedule=2)
-        # the fused sampler through dense blocks
-        w = _constraint("Wine_Bottle", gpu_ctx)
-        Pw = _oracle_problem(oracle_det, w)
-        qs, oks, its, _ = w.sample_project_batch(0xD5, 77, 1500)
-        e_q, e_ok, e_it = oracle_det.sample_project_batch(Pw, 0xD5, 77, 1500, NCPU)
-        assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
-        assert np.array_equal(its.cpu().numpy().astype(np.int32), e_it)
-        # calibrated arms: the general instantiation
-        g = _constraint("Wine_Bottle", gpu_ctx)
-        for arm in (0, 1):
-            dh = (C.c_double * 28)(*[1e-3 * ((7 * i + 3 * arm) % 5 - 2) for i in range(28)])
-            assert _lib.lib().ccmp_set_calibration(C.byref(g.problem), arm, dh) == 0
-        Pg = _oracle_problem(oracle_det, g)
-        qg = oracle_det.ambient_uniform_batch(Pg, 0xD6, 0, 700)
-        o_q, o_ok, o_it = oracle_det.project_batch(Pg, qg, NCPU)
-        g_q, g_ok, g_it = g.project_batch(torch.as_tensor(qg).cuda())
-        assert np.array_equal(g_q.cpu().numpy().view(np.uint64), o_q.view(np.uint64)) and np.array_equal(g_ok.cpu().numpy(), o_ok)
-        assert np.array_equal(g_it.cpu().numpy().astype(np.int32), o_it)
-    finally:
-        gpu_ctx.set_option("dense_slots", 0)
-        gpu_ctx.set_option("dense_min", 1024)
-
-
 def test_sample_project_bitwise(gpu_ctx, oracle_det):
     c = _constraint("Wine_Bottle", gpu_ctx)
     P = _oracle_problem(oracle_det, c)

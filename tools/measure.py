@@ -8,7 +8,6 @@
     python tools/measure.py analytic                        analytic mode against batch size and waves per CU
     python tools/measure.py host                            PCIe-inclusive rate of ccmp_project_host (pageable / pinned)
     python tools/measure.py sharded [n_gpus [B]]            one process, n GPUs, RCCL all-gather inside the C ABI: per-GPU stream times
-    python tools/measure.py dense [reps]                    A/B of the dense latency blocks (0 / 2 / 4 samples per block), projector
     python tools/measure.py sampler                         project_batch vs the fused sampler
     python tools/measure.py soak                            25 repeats of the default policy, outputs compared bit for bit
     python tools/measure.py scout                           FP32 scout's predictions against the true iteration counts
@@ -233,58 +232,6 @@ def sharded(argv):
     comm.close()
 
 
-def dense(argv):
-    """A/B of the dense latency blocks (option "dense_slots": 0 = one sample per 128-thread block, 2 / 4 = slots per block),
-    interleaved on one device: projector at the sizes where the latency kernel does the work, both objects; mean of `reps`
-    launches back to back (bench.py's shape) and best single launch"""
-    reps = int(argv[0]) if argv else 10
-    ctx = Context(0)
-    for obj in ("Wine_Bottle", "stefan"):
-        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
-        for B in (1024, 2048, 4096, 8192, 10240, 16384, 32768, 65536):
-            q = c.ambient_uniform_batch(0xC2 if B == 4096 else 0xC3, 0, B)
-            out = torch.empty_like(q)
-            row = []
-            ref = None
-            for rnd in range(2):  # two interleaved rounds: drift shows as disagreement between them
-                for S in (0, 2, 4):
-                    ctx.set_option("dense_slots", S)
-                    c.project_batch(q, out=out)
-                    torch.cuda.synchronize()
-                    if ref is None:
-                        ref = out.clone()
-                    assert torch.equal(out.view(torch.int64), ref.view(torch.int64)), (obj, B, S)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(reps):
-                        c.project_batch(q, out=out)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    mean = e0.elapsed_time(e1) / reps
-                    best = timed(lambda: c.project_batch(q, out=out), 5)
-                    row.append("S=%d %.3f/%.3f" % (S, mean, best))
-            ctx.set_option("dense_slots", 0)
-            print("%-11s B=%6d  mean/best ms  %s" % (obj, B, "  ".join(row)), flush=True)
-        # the extend step: growTree-shaped edges, lists of 16, 128 rounds per edge and call (the callers' large-batch shape)
-        for E in (1024, 4096, 16384, 65536):
-            frm, to = near_edges(c, E)
-            row, ref = [], None
-            for rnd in range(2):
-                for S in (0, 2, 4):
-                    ctx.set_option("dense_slots", S)
-                    r = c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128)
-                    torch.cuda.synchronize()
-                    if ref is None:
-                        ref = [x.clone() for x in r]
-                    m = ref[1].clamp(max=16)
-                    assert torch.equal(r[1], ref[1]) and torch.equal(r[2], ref[2]) and torch.equal(r[3], ref[3]), (obj, E, S)
-                    assert all(torch.equal(r[0][e, :m[e]].view(torch.int64), ref[0][e, :m[e]].view(torch.int64)) for e in range(0, E, 97))
-                    best = timed(lambda: c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128), 5)
-                    row.append("S=%d %.3f" % (S, best))
-            ctx.set_option("dense_slots", 0)
-            print("%-11s E=%6d  extend best ms  %s" % (obj, E, "  ".join(row)), flush=True)
-
-
 def sampler(argv):
     ctx = Context(0)
     c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
@@ -419,7 +366,7 @@ def run(argv):
 
 
 if __name__ == "__main__":
-    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sharded, dense, sampler, soak, scout, clearance, run)}
+    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sharded, sampler, soak, scout, clearance, run)}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
     cmds[sys.argv[1]](sys.argv[2:])
