@@ -232,6 +232,43 @@ def sharded(argv):
     comm.close()
 
 
+def afterload(argv):
+    """Does a latency-bound batch (4 096 / 32 768 samples: the serial chain of its longest sample) run slower right behind a
+    saturated launch?  bench.py times its secondaries behind 20 C3 steps (0.33 s of FP64 at the power limit: the chip holds
+    2.27 GHz there, 2.4 idle).  Mean of 10 launches back to back: cold, immediately behind 20 x C3, and after pauses."""
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    big = c.ambient_uniform_batch(0xC3, 0, 262144)
+    bout = torch.empty_like(big)
+    qs = {B: c.ambient_uniform_batch(0xC2 if B == 4096 else 0xC3, 0, B) for B in (4096, 32768)}
+    outs = {B: torch.empty_like(q) for B, q in qs.items()}
+
+    def mean10(B):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            c.project_batch(qs[B], out=outs[B])
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10
+
+    def load():
+        for _ in range(20):
+            c.project_batch(big, out=bout)
+        torch.cuda.synchronize()
+
+    for B in qs:
+        c.project_batch(qs[B], out=outs[B])
+    torch.cuda.synchronize()
+    for B in qs:
+        row = ["cold %.3f %.3f" % (mean10(B), mean10(B))]
+        for pause in (0.0, 0.05, 0.25, 1.0, 3.0):
+            load()
+            time.sleep(pause)
+            row.append("load+%.2fs %.3f %.3f" % (pause, mean10(B), mean10(B)))
+        print("B=%6d  mean-of-10 ms  %s" % (B, " | ".join(row)), flush=True)
+
+
 def sampler(argv):
     ctx = Context(0)
     c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
@@ -366,7 +403,7 @@ def run(argv):
 
 
 if __name__ == "__main__":
-    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sharded, sampler, soak, scout, clearance, run)}
+    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sharded, afterload, sampler, soak, scout, clearance, run)}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
     cmds[sys.argv[1]](sys.argv[2:])
