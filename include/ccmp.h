@@ -112,7 +112,13 @@ int ccmp_set_calibration(ccmp_problem *p, int arm_slot, const double dh_offsets[
 /* A context owns one device, one internal stream (used by the *_host entry points) and the work queues and
  * workspaces of the projector kernels.  Launches made through ONE context must be ordered: issue them on one
  * stream, or synchronise between streams — two projector launches of the same context running at once would
- * share queue words.  Calls on one context from several threads must be serialised by the caller (the
+ * share queue words.  The same holds for EVERY launch-making call of a context, not only ccmp_project_* /
+ * ccmp_sample_*: ccmp_geodesic_* and ccmp_check_motion_* keep their ticket and order counters in the context's queue words
+ * and take their FP32 scout's workspace (predictions, histogram, processing order) from the same context-owned buffer the
+ * projector's scout and two-class hand-over use — a buffer that grows (is freed and reallocated) on the first call at a
+ * larger size — and the *_host / *_sharded* entry points use the context's staging buffer.  Overlapping any two of them on
+ * different streams of ONE context is a data race; use one context per stream.  Calls on one context from several
+ * threads must be serialised by the caller (the
  * reference serialises its constraint calls with graphMutex_, src/planner/stefanBiPRM.cpp:280,383,449); use one
  * context per thread or per stream for concurrency.  The problem description is passed by value into every
  * launch: it may be changed between calls without synchronising. */
