@@ -553,8 +553,16 @@ def secondary(args, c, ctx, B, torch, cfg_path):
     other = CCMP_JAC_ANALYTIC if args.mode == "fd" else CCMP_JAC_FD
 
     def timed(fn, reps):
-        fn()
-        torch.cuda.synchronize()
+        # steady state, as the headline's warm-up steps give it: the chip drops its clocks within ~50 ms of idling (host-side
+        # set-up between two secondaries is enough) and the first launches behind that run 7-10 % slower — measured with
+        # tools/measure.py afterload: 4 096 samples 0.85 ms as the first ten launches after a pause, 0.77 ms as the next ten.
+        # So: launches for ~10 ms (at least one, at most 32), then the timed ones back to back.
+        t_w = time.perf_counter()
+        for _ in range(32):
+            fn()
+            torch.cuda.synchronize()
+            if time.perf_counter() - t_w > 0.010:
+                break
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
