@@ -96,7 +96,9 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
-                                    unsigned int done_seq, size_t pool_records, hipStream_t st);
+                                    unsigned int done_seq, size_t pool_records, const unsigned int *order,
+                                    const unsigned long long *total_ptr, hipStream_t st);
+hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
@@ -370,6 +372,21 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "host_zero_copy")) { // *_host calls on page-locked caller buffers: 0 staged, 1 q_out direct, 2 q_in too
     if (value < 0 || value > 2) return CCMP_EINVAL;
     ctx->host_zero_copy = (int)value;
+  } else if (!strcmp(name, "fd_split")) { // reference arithmetic, mid-size batches: the predicted-longest samples on latency blocks beside the throughput kernel
+    if (value != 0 && value != 1) return CCMP_EINVAL;
+    ctx->fd_split = (int)value;
+  } else if (!strcmp(name, "fd_split_min")) {
+    if (value < 0) return CCMP_EINVAL;
+    ctx->fd_split_min = (size_t)value;
+  } else if (!strcmp(name, "fd_split_max")) {
+    if (value < 0) return CCMP_EINVAL;
+    ctx->fd_split_max = (size_t)value;
+  } else if (!strcmp(name, "fd_split_pred")) { // predicted iterations from which a sample belongs to the front
+    if (value < 1 || value > 1023) return CCMP_EINVAL;
+    ctx->fd_split_pred = (int)value;
+  } else if (!strcmp(name, "fd_split_front")) { // latency blocks (= samples at most) of the front
+    if (value < 0 || value > 4096) return CCMP_EINVAL;
+    ctx->fd_split_front = (int)value;
   } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the projector's latency kernel per CU (8 resident)
     if (value < 1 || value > 32) return CCMP_EINVAL;
     ctx->latency_blocks_per_cu = (int)value;
@@ -584,7 +601,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     if (ctx->flat_kernel) {
       unsigned int *flag = arm_done_word(ctx, B);
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
-                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, st));
+                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, nullptr, nullptr, st));
     }
     else
       HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count,
@@ -593,6 +610,8 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   }
 
   const unsigned int *order = ctx->order;
+  bool fd_split = false;
+  int group_blocks = pl.group_blocks;
   if (pl.scout) { // FP32 scout pass -> predicted iteration counts -> descending counting sort -> processing order
     int rc = ensure_lpt_buffers(ctx, B);
     if (rc != CCMP_OK) return rc;
@@ -603,6 +622,24 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     // one 256-thread block per CU, 4 samples per lane at 262144: more lanes only lengthen the per-wave maximum
     HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus, st));
     order = ord;
+    // Split launch (round 4).  A mid-size batch ends on the serial chain of its longest samples: they start first in the
+    // throughput kernel, do ~22 iterations there at 26-62 us each, and only after the hand-over — a millisecond into the call —
+    // go on at the latency kernel's pace (a 250-round sample: 125 rounds while that kernel is loaded, then 100 more alone =
+    // 0.3 ms behind everybody else).  With the split the front of the order — the samples predicted >= fd_split_pred
+    // iterations, at most fd_split_front — runs on latency blocks on the side stream FROM THE START, beside the throughput
+    // kernel, which takes the rest of the order (two wavefronts per CU fewer: a latency block needs two SIMDs with a free
+    // register slot, and the persistent throughput waves never leave theirs) and hands over as before.
+    if (pl.handover && ctx->flat_kernel && ctx->fd_split && B >= ctx->fd_split_min && B <= ctx->fd_split_max && ctx->fd_split_front > 0) {
+      fd_split = true;
+      HIP_TRY(ccmp_launch_fd_split(hist, ctx->fd_split_pred, (unsigned int)ctx->fd_split_front, ctx->queue, st));
+      HIP_TRY(hipEventRecord(ctx->fork, st));
+      HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
+      HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 7, seed, first, ctx->pool, q_pool_count, mode,
+                                       ctx->fd_split_front, nullptr, 0, 0, ord, ctx->queue + 4, ctx->side));
+      HIP_TRY(hipEventRecord(ctx->join, ctx->side));
+      const int room = ctx->num_cus * ((ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12) - 2);
+      if (group_blocks > room) group_blocks = room;
+    }
   }
   if (pl.handover) {
     int rc = ensure_pool(ctx, (size_t)pl.group_blocks * 10);
@@ -611,18 +648,19 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   // hand-over in two classes (scout's prediction minus the iterations done): the pool is filled from both ends and the
   // latency kernel takes the long samples first; only with the scout's predictions and the default latency kernel
   const uint16_t *pred = (pl.scout && pl.handover && ctx->flat_kernel && ctx->pool_long_remaining > 0) ? (const uint16_t *)ctx->lpt_buf : nullptr;
-  const size_t pool_records = pred ? (size_t)pl.group_blocks * 10 : 0;
-  HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_group, seed, first, pl.group_blocks,
+  const size_t pool_records = pred ? (size_t)group_blocks * 10 : 0;
+  HIP_TRY(ccmp_launch_project_group(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_group, seed, first, group_blocks,
                                     pl.handover ? ctx->pool : nullptr, pl.dump_threshold, order, pred, ctx->pool_long_remaining, pool_records,
                                     st));
   if (pl.handover) { // the pool's fill count is read on the device: the latency kernel's surplus blocks exit at once
     if (ctx->flat_kernel)
       HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
-                                       pl.latency_blocks, nullptr, 0, pool_records, st));
+                                       pl.latency_blocks, nullptr, 0, pool_records, nullptr, nullptr, st));
     else
       HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
                                        pl.latency_blocks, st));
   }
+  if (fd_split) HIP_TRY(hipStreamWaitEvent(st, ctx->join, 0)); // the call is complete on `st` when the front is
   return CCMP_OK;
 }
 

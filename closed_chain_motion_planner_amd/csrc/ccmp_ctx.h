@@ -87,6 +87,11 @@ struct ccmp_ctx {
                                          // front of the pool and are taken first by the latency kernel (0 = one class).  Wine_Bottle, ms,
                                          // one class | 16 | 24 | 32 | 48 | 64: 28672: 2.83 | 2.62 | 2.42 | 2.41 | 2.44 | 2.78; 32768: 3.18 |
                                          // 2.88 | 2.71 | 2.73 | 2.74 | 3.01; 40960: 3.44 | 3.31 | 3.28 | 3.27 | 3.38 | 3.47; >= 49152 and stefan: +-2 %
+  int fd_split = 0;                      // reference arithmetic, mid-size batches: split launch (front of the scout order on latency blocks beside
+                                         // the throughput kernel, side stream); off until measured
+  size_t fd_split_min = 16384, fd_split_max = 100000;
+  int fd_split_pred = 64;                // predicted iterations from which a sample goes to the front ...
+  int fd_split_front = 192;              // ... at most this many (one latency block each)
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
     const unsigned long long *__restrict__ pool_count, int wrap_output, unsigned int *done_flag, unsigned int done_seq,
-    unsigned long long pool_records)
+    unsigned long long pool_records, const unsigned int *__restrict__ order, const unsigned long long *__restrict__ total_ptr)
 {
   __shared__ __attribute__((aligned(16))) double lds[fRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -33,7 +33,9 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
   // the pool is filled from both ends (ccmp_kernels_fd.hip): pool_count[0] records predicted long at the front — taken
   // first — and pool_count[5] others from the back (pool_records == 0: front only)
   const unsigned long long n_front = (SRC == 2) ? pool_count[0] : 0ull;
-  const unsigned long long total = (SRC == 2) ? n_front + (pool_records ? pool_count[5] : 0ull) : B;
+  // order / total_ptr (SRC 0, 1; the split launch of mid-size batches, ccmp_api.cpp): the block's tickets run through the
+  // first *total_ptr entries of a processing order — the samples the scout predicts longest — beside the throughput kernel
+  const unsigned long long total = (SRC == 2) ? n_front + (pool_records ? pool_count[5] : 0ull) : (total_ptr ? *total_ptr : B);
   unsigned long long t = blockIdx.x;
 
   for (;;) {
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
       norm2 = ent[17];
       if (tid < 14) rec[fX + tid] = ent[tid];
     } else {
-      idx = t;
+      idx = order ? (unsigned long long)order[t] : t;
       if (tid < 14) {
         double v;
         if (SRC == 0) v = q_in[idx * 14 + tid];
@@ -105,13 +107,14 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue_head,
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
-                                    unsigned int done_seq, size_t pool_records, hipStream_t st)
+                                    unsigned int done_seq, size_t pool_records, const unsigned int *order,
+                                    const unsigned long long *total_ptr, hipStream_t st)
 {
   if (nblocks != 1) done_flag = nullptr; // the completion word is written by the one block of a single-state call
 #define CCMP_LAUNCH_FLAT(SRC, STOCK)                                                                                             \
   hipLaunchKernelGGL((project_fd_flat_kernel<SRC, STOCK>), dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
                      (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output, done_flag, done_seq, \
-                     (unsigned long long)pool_records)
+                     (unsigned long long)pool_records, order, total_ptr)
   if (src == 0) {
     if (K->stock) CCMP_LAUNCH_FLAT(0, true);
     else CCMP_LAUNCH_FLAT(0, false);

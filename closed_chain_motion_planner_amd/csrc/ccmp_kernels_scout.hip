@@ -474,9 +474,30 @@ __global__ void split_kernel(const unsigned int *__restrict__ hist, int pred_min
   }
 }
 
+// The split launch of the reference-arithmetic path (mid-size batches, ccmp_api.cpp): the front of the descending order — the
+// samples predicted >= pred_min iterations, at most `limit` — goes to latency blocks BESIDE the throughput kernel.  queue[4]:
+// the front's length (the latency blocks' ticket limit); queue[0]: the throughput kernel's queue starts behind the front;
+// queue[3]: its count of finished samples starts there too (its occupancy rule counts B minus that as "in flight").
+__global__ void fd_split_kernel(const unsigned int *__restrict__ hist, int pred_min, unsigned int limit, unsigned long long *__restrict__ queue)
+{
+  if (threadIdx.x == 0) {
+    const unsigned int c = hist[pred_min < kBins ? pred_min : kBins - 1];
+    const unsigned long long n = c < limit ? c : limit;
+    queue[4] = n;
+    queue[0] = n;
+    queue[3] = n;
+  }
+}
+
 } // namespace
 
 extern "C" hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st); // ccmp_kernels_fd.hip
+
+extern "C" hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st)
+{
+  hipLaunchKernelGGL(fd_split_kernel, dim3(1), dim3(64), 0, st, hist, pred_min, limit, queue);
+  return hipGetLastError();
+}
 
 extern "C" hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st)
 {
