@@ -384,6 +384,9 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "fd_split_pred")) { // predicted iterations from which a sample belongs to the front
     if (value < 1 || value > 1023) return CCMP_EINVAL;
     ctx->fd_split_pred = (int)value;
+  } else if (!strcmp(name, "fd_split_group_cut")) { // throughput wavefronts per CU given up for the front's blocks
+    if (value < 0 || value > 8) return CCMP_EINVAL;
+    ctx->fd_split_group_cut = (int)value;
   } else if (!strcmp(name, "fd_split_front")) { // latency blocks (= samples at most) of the front
     if (value < 0 || value > 4096) return CCMP_EINVAL;
     ctx->fd_split_front = (int)value;
@@ -495,7 +498,10 @@ static FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order)
   }
   pl.group_blocks = projector_blocks(ctx, B, 10, 12);
   pl.handover = ctx->wave_kernel == 1;
-  pl.scout = !external_order && ctx->lpt > 0 && B >= ctx->lpt_min_batch && B < 0xffffffffull;
+  // the scout pays from lpt_min_batch samples on by its order alone, and earlier where the split launch (project_common) uses
+  // its predictions to start the longest samples on latency blocks at once
+  const bool split_range = ctx->fd_split && ctx->flat_kernel && ctx->wave_kernel == 1 && B >= ctx->fd_split_min && B <= ctx->fd_split_max;
+  pl.scout = !external_order && ctx->lpt > 0 && (B >= ctx->lpt_min_batch || split_range) && B < 0xffffffffull;
   // Large ordered batches end on their shortest samples, and the scout is accurate there (tools/scout_tail.py: in the
   // last fill of a 262144-sample batch it predicts <= 21 iterations and the truth is <= 23): nothing worth handing
   // over is left (-3 % at 262144 Wine_Bottle without it, tools/time_lpt3.py).  An explicit threshold keeps hand-over.
@@ -637,7 +643,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 7, seed, first, ctx->pool, q_pool_count, mode,
                                        ctx->fd_split_front, nullptr, 0, 0, ord, ctx->queue + 4, ctx->side));
       HIP_TRY(hipEventRecord(ctx->join, ctx->side));
-      const int room = ctx->num_cus * ((ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12) - 2);
+      const int room = ctx->num_cus * ((ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12) - ctx->fd_split_group_cut);
       if (group_blocks > room) group_blocks = room;
     }
   }

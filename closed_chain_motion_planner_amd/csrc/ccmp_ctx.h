@@ -87,11 +87,21 @@ struct ccmp_ctx {
                                          // front of the pool and are taken first by the latency kernel (0 = one class).  Wine_Bottle, ms,
                                          // one class | 16 | 24 | 32 | 48 | 64: 28672: 2.83 | 2.62 | 2.42 | 2.41 | 2.44 | 2.78; 32768: 3.18 |
                                          // 2.88 | 2.71 | 2.73 | 2.74 | 3.01; 40960: 3.44 | 3.31 | 3.28 | 3.27 | 3.38 | 3.47; >= 49152 and stefan: +-2 %
-  int fd_split = 0;                      // reference arithmetic, mid-size batches: split launch (front of the scout order on latency blocks beside
-                                         // the throughput kernel, side stream); off until measured
-  size_t fd_split_min = 16384, fd_split_max = 100000;
-  int fd_split_pred = 64;                // predicted iterations from which a sample goes to the front ...
-  int fd_split_front = 192;              // ... at most this many (one latency block each)
+  // Split launch of mid-size reference-arithmetic batches (round 4): the front of the scout's descending order — samples
+  // predicted >= fd_split_pred iterations, at most fd_split_front, one latency block each — runs on the side stream BESIDE the
+  // throughput kernel from the start (which gives up fd_split_group_cut wavefronts per CU: a latency block needs two SIMDs
+  // with a free register slot) instead of behind its hand-over.  Interleaved A/B, ms, off | on (profiles/r04_split_launch_ab2.log;
+  // below 16384 "off" = the policy before: latency kernel alone / no scout):
+  //   Wine_Bottle 10240: 1.638 | 1.418   12288: 1.789 | 1.502   16384: 1.92 | 1.686   24576: 2.29 | 2.066   32768: 2.655 | 2.607
+  //               40960: 3.165 | 3.20    57344: 4.366 | 3.963   65536: 4.80 | 4.60    81920: 6.095 | 5.756   98304: 6.75 | 6.87
+  //   stefan      10240: 2.397 | 2.60    12288: 2.724 | 2.74    16384: 3.05 | 3.01    32768: 4.65 | 4.67     65536: 7.47 | 7.66   81920: 9.37 | 9.27
+  // (stefan / dumbbell: thousands of samples never converge — the front is full of them whatever it takes; neutral.)  A cut of
+  // one wavefront per CU leaves the blocks nowhere to go (+5 % from 28672 on); 128 instead of 256 blocks: +1 %.
+  int fd_split = 1;
+  size_t fd_split_min = 12288, fd_split_max = 90112;
+  int fd_split_pred = 56;                // predicted iterations from which a sample goes to the front ...
+  int fd_split_front = 256;              // ... at most this many (one latency block each: one per CU)
+  int fd_split_group_cut = 2;            // throughput wavefronts per CU the split launch leaves out
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency

@@ -154,7 +154,11 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
  * count as long; default 12), "geodesic_scout_min" (default 6144), "geodesic_scout_rounds" (cap of the scout's traversal; default
  * 64), "geodesic_flavour" (the extend step is built twice from one source — same bits: 0 = throughput build for calls with a
  * round budget and more edges than the latency build has blocks, latency build otherwise (default); 1 / 2 = always the throughput
- * / latency build), "geodesic_blocks_per_cu" (persistent blocks of the latency build per CU; default 4); host entry points: "host_zero_copy"
+ * / latency build), "geodesic_blocks_per_cu" (persistent blocks of the latency build per CU; default 4); reference arithmetic, mid-size batches: "fd_split" (1 = split
+ * launch, default: for batches of fd_split_min..fd_split_max samples, default 12288..90112, the samples the FP32 scout predicts
+ * to need at least "fd_split_pred" iterations, default 56 — at most "fd_split_front", default 256 — run on latency blocks on a
+ * side stream beside the throughput kernel, which gives up "fd_split_group_cut" wavefronts per CU, default 2; 0 = off);
+ * host entry points: "host_zero_copy"
  * (see ccmp_project_host).  None of these changes a
  * result bit.  CCMP_EINVAL for unknown names. */
 int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);

@@ -173,6 +173,42 @@ def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, l
     assert it_cpu.max() == 250  # the cap was exercised
 
 
+@pytest.mark.parametrize("obj,pred,front", [("stefan", 40, 64), ("stefan", 96, 7), ("Wine_Bottle", 30, 500), ("Wine_Bottle", 1, 3)])
+def test_split_launch_is_bitwise_identical(gpu_ctx, oracle_det, obj, pred, front):
+    """The split launch of mid-size batches (option "fd_split"): the front of the scout's descending order — samples predicted
+    >= `pred` iterations, at most `front` — runs on latency blocks on the side stream beside the throughput kernel, the rest
+    goes the usual way (throughput kernel, two-class hand-over).  A front smaller and larger than the number of such samples,
+    a front of everything predicted at all, q_in and the fused sampler: bit-identical to the oracle."""
+    import torch
+
+    c = _constraint(obj, gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    B = 6000
+    q = oracle_det.ambient_uniform_batch(P, 0x5F, 0, B)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+    gpu_ctx.set_schedule(1, 0)
+    gpu_ctx.set_lpt(1, 0)
+    for name, val in (("fd_split", 1), ("fd_split_min", 0), ("fd_split_pred", pred), ("fd_split_front", front)):
+        gpu_ctx.set_option(name, val)
+    try:
+        for _ in range(2):  # twice: queue words and events are reused
+            q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
+            torch.cuda.synchronize()
+            assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+            assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu) and np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
+        qs, oks, its, amb = c.sample_project_batch(0x5F, 0, B, want_ambient=True)  # the same samples through the fused sampler
+        torch.cuda.synchronize()
+        assert np.array_equal(amb.cpu().numpy().view(np.uint64), q.view(np.uint64))
+        assert np.array_equal(oks.cpu().numpy(), ok_cpu) and np.array_equal(its.cpu().numpy().astype(np.int32), it_cpu)
+        wrapped = np.array([oracle_det.enforce_bounds(x) for x in q_cpu[:64]])
+        assert np.array_equal(qs[:64].cpu().numpy().view(np.uint64), wrapped.view(np.uint64))
+    finally:
+        gpu_ctx.set_schedule(1)
+        gpu_ctx.set_lpt(1)
+        for name, val in (("fd_split", 1), ("fd_split_min", 12288), ("fd_split_pred", 56), ("fd_split_front", 256)):
+            gpu_ctx.set_option(name, val)
+
+
 def test_sample_project_bitwise(gpu_ctx, oracle_det):
     c = _constraint("Wine_Bottle", gpu_ctx)
     P = _oracle_problem(oracle_det, c)
