@@ -105,6 +105,8 @@ struct ccmp_ctx {
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency
+  int geodesic_head_start = 0;           // extend step with the scout order: the first resident-capacity edges start at once in index order on the
+                                         // side stream while the scout runs (off until measured)
   int geodesic_order = 2;                // extend step, batches beyond the resident blocks: 1 = far-apart edges first, 2 = FP32 scout order
   size_t geodesic_scout_min = 6144;      // ... the scout from this many edges on (below: the two-class order by distance)
   int geodesic_scout_rounds = 64;        // ... the scout stops an edge after this many Newton rounds (all such edges are "long");
