@@ -123,11 +123,11 @@ hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride,
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, int round_budget, size_t skip_below, hipStream_t st);
+                                const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
 hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                     size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                     int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                    const double *carry_in, double *carry_out, int round_budget, size_t skip_below, hipStream_t st);
+                                    const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -372,9 +372,6 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "host_zero_copy")) { // *_host calls on page-locked caller buffers: 0 staged, 1 q_out direct, 2 q_in too
     if (value < 0 || value > 2) return CCMP_EINVAL;
     ctx->host_zero_copy = (int)value;
-  } else if (!strcmp(name, "geodesic_head_start")) { // extend step: the first resident-capacity edges start in index order while the scout runs
-    if (value != 0 && value != 1) return CCMP_EINVAL;
-    ctx->geodesic_head_start = (int)value;
   } else if (!strcmp(name, "fd_split")) { // reference arithmetic, mid-size batches: the predicted-longest samples on latency blocks beside the throughput kernel
     if (value != 0 && value != 1) return CCMP_EINVAL;
     ctx->fd_split = (int)value;
@@ -511,8 +508,8 @@ static FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order)
   if (pl.scout && (ctx->lpt == 2 || (ctx->dump_threshold < 0 && B >= 120000))) pl.handover = false;
   // the samples still in flight go to the latency kernel (it iterates ~15x faster than a fully occupied throughput wave but
   // spends twice the SIMD-cycles per iteration): at once for large batches; for batches of about one fill of the
-  // throughput kernel only when the samples in flight no longer fill 80 % of its group slots (value 90 = 10 + 80 %)
-  pl.dump_threshold = ctx->dump_threshold >= 0 ? ctx->dump_threshold : (B < kOccupancyHandoverBelow ? 90 : 10);
+  // throughput kernel only when the samples in flight no longer fill 70 % of its group slots (value 80 = 10 + 70 %)
+  pl.dump_threshold = ctx->dump_threshold >= 0 ? ctx->dump_threshold : (B < kOccupancyHandoverBelow ? kOccupancyHandoverValue : 10);
   if (pl.handover) {
     const size_t in_flight = (size_t)pl.group_blocks * 10;
     pl.latency_blocks = (int)(in_flight < lat_cap ? in_flight : lat_cap);
@@ -751,7 +748,7 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   const size_t lat_resident = (size_t)ctx->num_cus * (size_t)ctx->geodesic_blocks_per_cu;
   const bool latency_flavour = ctx->geodesic_flavour == 2 || (ctx->geodesic_flavour == 0 && (round_budget == 0 || E <= lat_resident));
   const size_t resident = latency_flavour ? lat_resident : (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
-  size_t nb = E, head = 0;
+  size_t nb = E;
   unsigned long long *queue = nullptr;
   const unsigned int *order = nullptr;
   if (E > resident) {
@@ -765,17 +762,6 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
       unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
       unsigned int *ord = (unsigned int *)((char *)hist + 4096);
       if (ctx->geodesic_order == 2 && E >= ctx->geodesic_scout_min && !carry_in) {
-        // Head start (round 4): the scout takes 0.16 ms of a 1.4 ms call (16 384 edges) during which the chip sat idle.  The first
-        // `resident` edges — as many as blocks fit — start AT ONCE in index order on the side stream (one block each, no queue);
-        // the launch below takes the rest through the scout's order as the first blocks retire, skipping those edges.
-        if (ctx->geodesic_head_start && !latency_flavour && E >= 2 * resident) {
-          head = resident;
-          HIP_TRY(hipEventRecord(ctx->fork, st));
-          HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
-          HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, head, max_states, states, n_states, ok, newton_iters, check_target,
-                                       (int)head, nullptr, nullptr, carry_in, carry_out, round_budget, 0, ctx->side));
-          HIP_TRY(hipEventRecord(ctx->join, ctx->side));
-        }
         // FP32 scout of every edge (the traversal in single precision with the exact Jacobian, one edge per lane, rounds
         // capped) -> predicted Newton rounds -> descending counting sort: longest-predicted-first
         HIP_TRY(ccmp_launch_geodesic_scout_order(&K, from, to, E, p->delta, p->lambda, max_states, ctx->geodesic_scout_rounds,
@@ -788,8 +774,7 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   }
   HIP_TRY((latency_flavour ? ccmp_launch_geodesic_lat : ccmp_launch_geodesic)(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok,
                                                                              newton_iters, check_target, (int)nb, queue, order, carry_in, carry_out,
-                                                                             round_budget, head, st));
-  if (head) HIP_TRY(hipStreamWaitEvent(st, ctx->join, 0));
+                                                                             round_budget, st));
   return CCMP_OK;
 }
 

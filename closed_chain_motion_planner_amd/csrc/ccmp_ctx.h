@@ -55,7 +55,12 @@ constexpr size_t kDefaultSmallBatch = 10240;   // up to here the latency kernel 
 constexpr size_t kDefaultLptMinBatch = 16384;  // from here on the scout pays (round 3: its predictions also sort the hand-over into two classes
                                                // and its sort lost 0.09 ms; Wine_Bottle / stefan, ms without | with: 16384: 1.99 | 1.92 / 3.16 | 3.15;
                                                // 20480: 2.37 | 2.16 / 3.60 | 3.43; 26624: 2.72 | 2.38 / 4.40 | 3.94; 14336: 1.85 | 1.87 / 2.91 | 2.98)
-constexpr size_t kOccupancyHandoverBelow = 40960; // smaller batches: keep the throughput kernel going while >= 80 % of its slots are busy
+// smaller batches: keep the throughput kernel going while >= 70 % of its slots are busy.  Re-swept in round 4 with the split
+// launch on (profiles/r04_handover_sweep_with_split.log; ms, 80 % below 40960 and at once above = the rule before | 70 %):
+// Wine_Bottle 32768: 2.61 | 2.59   40960: 3.21 | 3.05   49152: 3.69 | 3.53   65536: 4.61 | 4.80 (stays "at once");
+// stefan 16384 ... 32768: +-0.5 %   40960: 5.60 | 5.37   49152: 6.12 | 6.16   65536: 7.68 | 7.99
+constexpr size_t kOccupancyHandoverBelow = 53248;
+constexpr int kOccupancyHandoverValue = 80; // 10 + per cent
 
 struct ccmp_ctx {
   int device = 0;
@@ -105,8 +110,6 @@ struct ccmp_ctx {
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency
-  int geodesic_head_start = 0;           // extend step with the scout order: the first resident-capacity edges start at once in index order on the
-                                         // side stream while the scout runs (off until measured)
   int geodesic_order = 2;                // extend step, batches beyond the resident blocks: 1 = far-apart edges first, 2 = FP32 scout order
   size_t geodesic_scout_min = 6144;      // ... the scout from this many edges on (below: the two-class order by distance)
   int geodesic_scout_rounds = 64;        // ... the scout stops an edge after this many Newton rounds (all such edges are "long");
