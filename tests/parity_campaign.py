@@ -80,6 +80,19 @@ for obj, tol, seed, mode, N, variant in cases:
         "max_abs_dq": float(np.nanmax(np.abs(out_h - q_cpu))), "ok_fraction": float(ok_cpu.mean()), "mean_iterations": float(it_cpu.mean()),
         "max_iterations": int(it_cpu.max()), "oracle_seconds": round(t_cpu, 1), "oracle_threads": NCPU,
     }
+    # the same samples again in mid-size batches — the sizes of the split launch (round 4: the predicted-longest samples on latency
+    # blocks beside the throughput kernel, 12288 .. 90112 samples) — against the oracle rows already computed
+    if mode == 0:
+        mid_same, mid_n = 0, 0
+        for chunk in (20000, 60000, 13000):
+            for a in range(0, min(N, 180000) - chunk + 1, chunk):
+                o2, k2, i2 = c.project_batch(q[a:a + chunk].contiguous())
+                mid_same += int(((o2.cpu().numpy().view(np.uint64) == q_cpu[a:a + chunk].view(np.uint64)).all(axis=1)
+                                 & (k2.cpu().numpy() == ok_cpu[a:a + chunk]) & (i2.cpu().numpy().astype(np.int32) == it_cpu[a:a + chunk])).sum())
+                mid_n += chunk
+        entry["mid_size_batches_samples"] = mid_n
+        entry["mid_size_batches_rows_bit_identical"] = mid_same
+        assert mid_same == mid_n
     # fused sampler path: sampleUniform = ambient sample -> project -> enforceBounds
     n2 = N // 4
     sq, sok, sit, _ = c.sample_project_batch(seed + 0x100, 12345, n2)
