@@ -372,6 +372,9 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "host_zero_copy")) { // *_host calls on page-locked caller buffers: 0 staged, 1 q_out direct, 2 q_in too
     if (value < 0 || value > 2) return CCMP_EINVAL;
     ctx->host_zero_copy = (int)value;
+  } else if (!strcmp(name, "latency_order_min")) { // latency kernel alone: FP32 scout order from this many samples on
+    if (value < 0) return CCMP_EINVAL;
+    ctx->latency_order_min = (size_t)value;
   } else if (!strcmp(name, "fd_split")) { // reference arithmetic, mid-size batches: the predicted-longest samples on latency blocks beside the throughput kernel
     if (value != 0 && value != 1) return CCMP_EINVAL;
     ctx->fd_split = (int)value;
@@ -606,8 +609,21 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (pl.group_blocks == 0) { // small batches and single states
     if (ctx->flat_kernel) {
       unsigned int *flag = arm_done_word(ctx, B);
+      // Longest-predicted-first on the latency kernel alone (round 4): a batch of a few fills of its blocks ends on the serial
+      // chain of whichever long sample the index order happened to start late (8 192 samples = 4 fills: a 250-round sample
+      // starts anywhere in the first 0.9 ms and needs 0.8 ms alone); the FP32 scout's order starts them first.
+      const unsigned int *lat_order = nullptr;
+      if (!pl.latency_static && ctx->lpt > 0 && !ctx->order && B >= ctx->latency_order_min && B < 0xffffffffull) {
+        int rc = ensure_lpt_buffers(ctx, B);
+        if (rc != CCMP_OK) return rc;
+        char *base = (char *)ctx->lpt_buf;
+        unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
+        unsigned int *ord = (unsigned int *)((char *)hist + 4096);
+        HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, (uint16_t *)base, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus, st));
+        lat_order = ord;
+      }
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
-                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, nullptr, nullptr, st));
+                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, lat_order, nullptr, st));
     }
     else
       HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count,

@@ -107,6 +107,7 @@ struct ccmp_ctx {
   int fd_split_pred = 56;                // predicted iterations from which a sample goes to the front ...
   int fd_split_front = 256;              // ... at most this many (one latency block each: one per CU)
   int fd_split_group_cut = 2;            // throughput wavefronts per CU the split launch leaves out
+  size_t latency_order_min = (size_t)-1; // latency kernel alone (batches <= small_batch): scout order from this many samples on (off until measured)
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency
