@@ -51,7 +51,14 @@ struct DeviceGuard {
 //   28672    4.01 / 6.26            3.20 / 5.42                      3.02 / 4.93                        2.85 / 4.45
 //   32768    4.24 / 7.10            3.44 / 5.69                      3.43 / 5.38                        3.09 / 4.88
 // (from 49152 on the scout with immediate hand-over is best or equal; from 120000 on no hand-over at all)
-constexpr size_t kDefaultSmallBatch = 10240;   // up to here the latency kernel alone is quickest
+// Up to here the latency kernel alone is quickest.  Round 4: it now runs in the FP32 scout's longest-predicted-first order from
+// kDefaultLatencyOrderMin samples on (profiles/r04_latency_order_ab.log, mean of six seeds, index order | scout order, ms: Wine_Bottle
+// 4096: 0.792 | 0.733, 8192: 1.252 | 1.063, 10240: 1.464 | 1.293; stefan 4096: 1.347 | 1.130, 8192: 2.034 | 1.650, 10240: 2.400 | 2.000;
+// 3072: +0.5 % / -8 %), which moved its crossover with scout + throughput kernel + split launch upward
+// (profiles/r04_small_batch_crossover.log, latency alone | split path, ms: Wine_Bottle 12288: 1.488 | 1.523, 14336: 1.694 | 1.608,
+// 16384: 1.917 | 1.677; stefan 12288: 2.324 | 2.753, 14336: 2.663 | 2.887, 16384: 3.028 | 3.029, 20480: 3.706 | 3.302)
+constexpr size_t kDefaultSmallBatch = 14336;
+constexpr size_t kDefaultLatencyOrderMin = 3072;
 constexpr size_t kDefaultLptMinBatch = 16384;  // from here on the scout pays (round 3: its predictions also sort the hand-over into two classes
                                                // and its sort lost 0.09 ms; Wine_Bottle / stefan, ms without | with: 16384: 1.99 | 1.92 / 3.16 | 3.15;
                                                // 20480: 2.37 | 2.16 / 3.60 | 3.43; 26624: 2.72 | 2.38 / 4.40 | 3.94; 14336: 1.85 | 1.87 / 2.91 | 2.98)
@@ -107,7 +114,7 @@ struct ccmp_ctx {
   int fd_split_pred = 56;                // predicted iterations from which a sample goes to the front ...
   int fd_split_front = 256;              // ... at most this many (one latency block each: one per CU)
   int fd_split_group_cut = 2;            // throughput wavefronts per CU the split launch leaves out
-  size_t latency_order_min = (size_t)-1; // latency kernel alone (batches <= small_batch): scout order from this many samples on (off until measured)
+  size_t latency_order_min = kDefaultLatencyOrderMin; // latency kernel alone (batches <= small_batch): FP32 scout order from this many samples on
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency

@@ -129,7 +129,8 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx);
 int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
 /* projector scheduling: hand_over 0 = throughput kernel (10 samples per wavefront) only, 1 = that kernel until the
  * sample queue drains, then the latency kernel on the samples still in flight (default), 2 = latency kernel only;
- * batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = built-in default, 10240).
+ * batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = built-in default, 14336), from
+ * "latency_order_min" samples on (option, default 3072) in the FP32 scout's longest-predicted-first order.
  * Results are bit-identical under every setting. */
 #define CCMP_DEFAULT ((size_t)-1)
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);

@@ -139,12 +139,14 @@ def test_latency_kernels_agree_and_repeat(gpu_ctx, obj, seed):
         gpu_ctx.set_option("flat_kernel", 1)
 
 
-@pytest.mark.parametrize("obj,n", [("Wine_Bottle", 11000), ("Wine_Bottle", 20480), ("stefan", 30000), ("Wine_Bottle", 50000)])
+@pytest.mark.parametrize("obj,n", [("stefan", 2500), ("Wine_Bottle", 5000), ("Wine_Bottle", 11000), ("Wine_Bottle", 15000), ("Wine_Bottle", 20480),
+                                   ("stefan", 30000), ("Wine_Bottle", 50000), ("stefan", 60000), ("Wine_Bottle", 95000)])
 def test_default_policy_at_mid_sizes_is_bitwise_the_oracle(gpu_ctx, oracle_det, obj, n):
-    """the default scheduling policy where its regimes meet — the latency kernel alone (<= 10 240), the throughput kernel
-    with the occupancy-driven hand-over (all waves hand over together once the samples in flight fill < 80 % of the group
-    slots), the same behind the scout's longest-first order (>= 26 624), hand-over at once (>= 40 960) — against the
-    oracle, every sample, bit for bit"""
+    """the default scheduling policy where its regimes meet — the latency kernel alone in index order (< 3 072 samples) and in
+    the FP32 scout's longest-first order (up to 14 336); above that scout + throughput kernel with the predicted-longest
+    samples on latency blocks beside it (split launch, up to 90 112) and the occupancy-driven hand-over (all waves hand over
+    together once the samples in flight fill < 70 % of the group slots, up to 53 248; at once above) — against the oracle,
+    every sample, bit for bit"""
     import torch
 
     c = _constraint(obj, gpu_ctx)
