@@ -717,23 +717,37 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         L = _lib.lib()
         qh = c.ambient_uniform_batch(SEEDS.get(B, 0xC3), 0, B).cpu()
         res = {"samples": B}
+        # ONE pageable and ONE page-locked set of buffers for every variant, variants interleaved over two rounds, best median
+        # per variant: a freshly pinned allocation is slow on its first uses (the first pinned variant measured read 1 ms worse
+        # than the second, whichever it was)
+        bufs = {}
+        for pin in (False, True):
+            mk = (lambda t: t.pin_memory()) if pin else (lambda t: t)
+            bufs[pin] = (mk(qh.clone()), mk(torch.empty_like(qh)), mk(torch.empty(B, dtype=torch.uint8)), mk(torch.empty(B, dtype=torch.int16)))
+
+        def run(pin):
+            qi, qo, okh, ith = bufs[pin]
+            rc = L.ccmp_project_host(ctx.handle, C.byref(c.problem), C.cast(qi.data_ptr(), C.POINTER(C.c_double)),
+                                     C.cast(qo.data_ptr(), C.POINTER(C.c_double)), C.cast(okh.data_ptr(), C.POINTER(C.c_uint8)),
+                                     C.cast(ith.data_ptr(), C.POINTER(C.c_uint16)), B)
+            if rc != 0:
+                raise RuntimeError("ccmp_project_host: %d" % rc)
+
         # page-locked caller buffers ("host_zero_copy", include/ccmp.h): the kernels read q_in and write q_out in place (default,
         # "pinned"), q_in is uploaded by one copy first, or everything is staged as for pageable memory
-        for name, pin, zc in (("pageable", False, 2), ("pinned", True, 2), ("pinned_q_in_uploaded_first", True, 1), ("pinned_staged", True, 0)):
-            ctx.set_option("host_zero_copy", zc)
-            mk = (lambda t: t.pin_memory()) if pin else (lambda t: t)
-            qi, qo = mk(qh.clone()), mk(torch.empty_like(qh))
-            okh, ith = mk(torch.empty(B, dtype=torch.uint8)), mk(torch.empty(B, dtype=torch.int16))
-            ts = []
-            for _ in range(4):
-                t0 = time.perf_counter()
-                rc = L.ccmp_project_host(ctx.handle, C.byref(c.problem), C.cast(qi.data_ptr(), C.POINTER(C.c_double)),
-                                         C.cast(qo.data_ptr(), C.POINTER(C.c_double)), C.cast(okh.data_ptr(), C.POINTER(C.c_uint8)),
-                                         C.cast(ith.data_ptr(), C.POINTER(C.c_uint16)), B)
-                ts.append(time.perf_counter() - t0)
-                if rc != 0:
-                    raise RuntimeError("ccmp_project_host: %d" % rc)
-            sec = float(np.median(ts[1:]))
+        variants = (("pageable", False, 2), ("pinned", True, 2), ("pinned_q_in_uploaded_first", True, 1), ("pinned_staged", True, 0))
+        best = {}
+        for rnd in range(2):
+            for name, pin, zc in variants:
+                ctx.set_option("host_zero_copy", zc)
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    run(pin)
+                    ts.append(time.perf_counter() - t0)
+                sec = float(np.median(ts[1:]))
+                best[name] = min(best.get(name, 1e9), sec)
+        for name, sec in best.items():
             res[name] = {"projections_per_s": B / sec, "ms": sec * 1e3}
         ctx.set_option("host_zero_copy", 2)
         return res
