@@ -115,7 +115,6 @@ struct ccmp_ctx {
   int fd_split_front = 256;              // ... at most this many (one latency block each: one per CU)
   int fd_split_group_cut = 2;            // throughput wavefronts per CU the split launch leaves out
   size_t latency_order_min = kDefaultLatencyOrderMin; // latency kernel alone (batches <= small_batch): FP32 scout order from this many samples on
-  int latency_scout_cap = 0;             // ... its predictions capped at this many iterations (0 = the scout's own 96)
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency

@@ -545,15 +545,11 @@ static void make_consts_f(const ccmp_consts *K, consts_f &F, bool *stock_out)
 
 extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                               unsigned int *hist, unsigned int *order, unsigned long long *queue,
-                                              unsigned long long seed, unsigned long long first, int nblocks, int cap, hipStream_t st)
+                                              unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st)
 {
   consts_f F;
   bool stock;
   make_consts_f(K, F, &stock);
-  // cap > 0: stop the prediction there (samples still unconverged are all "long").  For an order that only has to decide who
-  // gets into the FIRST fill of the latency kernel's blocks, a low cap is as good as a high one and the scout — whose run
-  // time is its longest lane's — ends that much sooner.
-  if (cap > 0 && cap < F.max_iter) F.max_iter = cap;
   hipError_t e = ccmp_launch_clear_words(queue, 2, st); // kernels, so that a stream capture replays them
   if (e != hipSuccess) return e;
   e = ccmp_launch_clear_words(hist, kBins, st);
