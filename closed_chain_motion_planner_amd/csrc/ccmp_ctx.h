@@ -115,6 +115,9 @@ struct ccmp_ctx {
   int fd_split_front = 256;              // ... at most this many (one latency block each: one per CU)
   int fd_split_group_cut = 2;            // throughput wavefronts per CU the split launch leaves out
   size_t latency_order_min = kDefaultLatencyOrderMin; // latency kernel alone (batches <= small_batch): FP32 scout order from this many samples on
+  int scout_pairs = 0;                   // FP32 scouts on lane pairs (ccmp_kernels_scout.hip; off until measured)
+  int scout_pair_blocks_per_cu = 2;      // ... projector scout: batches of up to 128 x this x CUs samples (one pair each, all at once)
+  size_t scout_pair_max_edges = 131072;  // ... extend-step scout: up to this many edges
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency

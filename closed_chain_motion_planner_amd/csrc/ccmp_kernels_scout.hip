@@ -322,6 +322,291 @@ __device__ __forceinline__ void interpolatef(const float *from, const float *to,
   }
 }
 
+// ---- two lanes per sample (round 4) --------------------------------------------------------------------------------------
+// The scout's run time is its longest lane's: cap x (instructions per round).  Where lanes are plentiful — small and mid-size
+// batches, the extend step — a LANE PAIR takes a sample, the even lane arm 0 and the odd lane arm 1: one chain per pass and
+// lane instead of two, seven joints of x, J and the update instead of fourteen; the two tool poses, the Gram sums and (extend
+// step) the partial distances cross with a quad_perm swap.  Stock structure with twin arms only (both arms read arm 0's chain
+// constants; the base frame is selected per lane); everything else keeps the one-lane scout.  Predictions may differ from the
+// one-lane scout's in the last bit of a sum — an order, never a result.
+__device__ __forceinline__ float pair_swap(float v) // the partner lane's value (lanes 2k <-> 2k + 1)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ bool pair_and(bool v)
+{
+  return v && __builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true) != 0;
+}
+
+struct pair_base { // the lane's arm: base frame (diagonal, to single precision) and its place in the chain T2^-1 T1
+  float d[3], p[3], sgn;
+  bool second;
+};
+__device__ __forceinline__ pair_base pair_base_of(const consts_f &K, bool second)
+{
+  pair_base b;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { b.d[k] = second ? K.base_R[1][4 * k] : K.base_R[0][4 * k]; b.p[k] = second ? K.base_p[1][k] : K.base_p[0][k]; }
+  b.sgn = second ? -1.0f : 1.0f;
+  b.second = second;
+  return b;
+}
+
+// chain_stock_f for the lane's own arm with arm 0's chain constants (twin arms) and the lane's base frame
+template <int PASS>
+__device__ __forceinline__ void chain_pair_f(const consts_f &K, const pair_base &Bs, const float *q, float *Rw, float *pw, const float *al,
+                                             const float *bl, const float *pl, float *J0, float *J1)
+{
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    float s, c;
+    __sincosf(q[i], &s, &c);
+    s *= kAxSgn[i];
+    const float *off = K.offset[0][i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (kOffNz[i] & 1) o[k] += R[3 * k] * off[0];
+      if (kOffNz[i] & 4) o[k] += R[3 * k + 2] * off[2];
+    }
+    if (PASS == 1) {
+      float z[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) z[k] = kAxSgn[i] * R[3 * k + kAxIdx[i]];
+      const float r0 = pl[0] - o[0], r1 = pl[1] - o[1], r2 = pl[2] - o[2];
+      const float cx = z[1] * r2 - z[2] * r1, cy = z[2] * r0 - z[0] * r2, cz = z[0] * r1 - z[1] * r0;
+      J0[i] = Bs.sgn * (al[0] * cx + al[1] * cy + al[2] * cz);
+      J1[i] = Bs.sgn * (bl[0] * z[0] + bl[1] * z[1] + bl[2] * z[2]);
+    }
+    if (PASS == 0 || i < 6) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (kAxIdx[i] == 2) {
+          const float a = R[3 * k], b = R[3 * k + 1];
+          R[3 * k] = a * c + b * s;
+          R[3 * k + 1] = b * c - a * s;
+        } else {
+          const float a = R[3 * k], b = R[3 * k + 2];
+          R[3 * k] = a * c - b * s;
+          R[3 * k + 2] = a * s + b * c;
+        }
+      }
+    }
+  }
+  if (PASS == 0) {
+    const float *T = K.R_tool[0];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float pf = o[k] + R[3 * k + 2] * K.ee[0][2];
+      pw[k] = Bs.p[k] + Bs.d[k] * pf;
+      Rw[3 * k] = Bs.d[k] * (R[3 * k] * T[0] + R[3 * k + 1] * T[3]);
+      Rw[3 * k + 1] = Bs.d[k] * (R[3 * k] * T[1] + R[3 * k + 1] * T[4]);
+      Rw[3 * k + 2] = Bs.d[k] * (R[3 * k + 2] * T[8]);
+    }
+  }
+}
+
+// scout_round for a lane pair: xa = the seven joints of the lane's arm.  Both lanes of a pair see the same residual (the same
+// operations on the same numbers) and therefore take the same decisions.
+__device__ __forceinline__ bool scout_round_pair(const consts_f &K, const pair_base &Bs, float *xa, bool active, int iter, bool &resid)
+{
+  float Ro[9], po[3], Rp[9], pp[3];
+  chain_pair_f<0>(K, Bs, xa, Ro, po, nullptr, nullptr, nullptr, nullptr, nullptr);
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rp[k] = pair_swap(Ro[k]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) pp[k] = pair_swap(po[k]);
+  float Rw0[9], pw0[3], Rw1[9], pw1[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) { Rw0[k] = Bs.second ? Rp[k] : Ro[k]; Rw1[k] = Bs.second ? Ro[k] : Rp[k]; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { pw0[k] = Bs.second ? pp[k] : po[k]; pw1[k] = Bs.second ? po[k] : pp[k]; }
+  float Rc[9], pc[3], qc[4];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) Rc[3 * i + j] = Rw1[i] * Rw0[j] + Rw1[3 + i] * Rw0[3 + j] + Rw1[6 + i] * Rw0[6 + j];
+  {
+    const float d0 = pw0[0] - pw1[0], d1 = pw0[1] - pw1[1], d2 = pw0[2] - pw1[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) pc[i] = Rw1[i] * d0 + Rw1[3 + i] * d1 + Rw1[6 + i] * d2;
+  }
+  quatf(Rc, qc);
+  const float bx = -K.init_q[0], by = -K.init_q[1], bz = -K.init_q[2], bw = K.init_q[3];
+  const float dw = qc[3] * bw - qc[0] * bx - qc[1] * by - qc[2] * bz;
+  const float dx = qc[3] * bx + qc[0] * bw + qc[1] * bz - qc[2] * by;
+  const float dy = qc[3] * by + qc[1] * bw + qc[2] * bx - qc[0] * bz;
+  const float dz = qc[3] * bz + qc[2] * bw + qc[0] * by - qc[1] * bx;
+  const float vn = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float f1 = 2.0f * atan2f(vn, fabsf(dw));
+  const float e0 = pc[0] - K.init_p[0], e1 = pc[1] - K.init_p[1], e2 = pc[2] - K.init_p[2];
+  const float f0 = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+  resid = (f0 > K.tol_pos) || (f1 > K.tol_rot);
+  const bool cont = active && resid && iter < K.max_iter;
+  if (__builtin_amdgcn_ballot_w64(cont) == 0ull) return false;
+
+  float u[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+  if (f0 > 0.0f) { const float inv = 1.0f / f0; u[0] = e0 * inv; u[1] = e1 * inv; u[2] = e2 * inv; }
+  if (vn > 0.0f) { const float sg = (dw < 0.0f ? -1.0f : 1.0f) / vn; n[0] = dx * sg; n[1] = dy * sg; n[2] = dz * sg; }
+  float al[3], bl[3], pl[3]; // the probes in the lane's own base frame (diagonal base: B^T v = d * v)
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float aw = Rw1[3 * k] * u[0] + Rw1[3 * k + 1] * u[1] + Rw1[3 * k + 2] * u[2];
+    const float bv = Rw1[3 * k] * n[0] + Rw1[3 * k + 1] * n[1] + Rw1[3 * k + 2] * n[2];
+    al[k] = Bs.d[k] * aw;
+    bl[k] = Bs.d[k] * bv;
+    pl[k] = Bs.d[k] * (pw0[k] - Bs.p[k]);
+  }
+  float J0[7], J1[7];
+  chain_pair_f<1>(K, Bs, xa, nullptr, nullptr, al, bl, pl, J0, J1);
+  float ga = 0, gd = 0, gb = 0;
+#pragma unroll
+  for (int e = 0; e < 7; e++) { ga += J0[e] * J0[e]; gd += J1[e] * J1[e]; gb += J0[e] * J1[e]; }
+  // the same three numbers in both lanes: own + partner's, summed in arm order
+  const float pa = pair_swap(ga), pd = pair_swap(gd), pb = pair_swap(gb);
+  ga = Bs.second ? pa + ga : ga + pa;
+  gd = Bs.second ? pd + gd : gd + pd;
+  gb = Bs.second ? pb + gb : gb + pb;
+  const float det = ga * gd - gb * gb;
+  float y0 = 0.0f, y1 = 0.0f;
+  if (det > 1e-30f) { const float inv = 1.0f / det; y0 = (gd * f0 - gb * f1) * inv; y1 = (ga * f1 - gb * f0) * inv; }
+  if (cont) {
+#pragma unroll
+    for (int e = 0; e < 7; e++) xa[e] -= K.step * (J0[e] * y0 + J1[e] * y1);
+  }
+  return cont;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void scout_pair_kernel(const consts_f K, const ccmp_consts KD, const double *__restrict__ q_in,
+                                                         uint16_t *__restrict__ pred, unsigned long long B, unsigned long long seed,
+                                                         unsigned long long first_index)
+{
+  const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = (gtid & 1ull) != 0ull;
+  const pair_base Bs = pair_base_of(K, second);
+  float xa[7];
+  unsigned long long idx = 0, next = gtid >> 1;
+  int iter = 0;
+  bool active = false, drained = false;
+  for (;;) {
+    if (!active && !drained) {
+      const unsigned long long t = next;
+      next += ((unsigned long long)gridDim.x * blockDim.x) >> 1;
+      if (t < B) {
+        idx = t; active = true; iter = 0;
+#pragma unroll
+        for (int e = 0; e < 7; e++) {
+          const int j = e + (second ? 7 : 0);
+          xa[e] = (float)(MODE == 0 ? q_in[idx * 14 + j] : ccmp::ambient_uniform(KD, seed, first_index + idx, j));
+        }
+      } else drained = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+    bool resid;
+    const bool cont = scout_round_pair(K, Bs, xa, active, iter, resid);
+    if (active && !cont) {
+      if (!second) pred[idx] = (uint16_t)iter;
+      active = false;
+    }
+    if (cont) iter++;
+  }
+}
+
+// the extend-step scout on lane pairs: each lane keeps its arm's half of x, previous and target; the distances are sums of two
+// partial sums (arm order)
+__device__ __forceinline__ float pair_dist(const pair_base &Bs, const float *a, const float *b)
+{
+  float d = 0.f;
+#pragma unroll
+  for (int i = 0; i < 7; i++) { const float v = a[i] - b[i]; d += v * v; }
+  const float o = pair_swap(d);
+  return sqrtf(Bs.second ? o + d : d + o);
+}
+__device__ __forceinline__ void interpolate7f(const float *from, const float *to, float t, float *out)
+{
+  const float pi = 3.14159265358979f;
+#pragma unroll
+  for (int i = 0; i < 7; i++) {
+    float diff = to[i] - from[i], v;
+    if (fabsf(diff) <= pi) v = from[i] + diff * t;
+    else {
+      diff = diff > 0.f ? 2.f * pi - diff : -2.f * pi - diff;
+      v = from[i] - diff * t;
+      if (v > pi) v -= 2.f * pi;
+      else if (v < -pi) v += 2.f * pi;
+    }
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void scout_geodesic_pair_kernel(const consts_f K, const double *__restrict__ from, const double *__restrict__ to,
+                                                                 unsigned long long E, float delta, float lambda, int max_states, int round_cap,
+                                                                 uint16_t *__restrict__ pred)
+{
+  const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = (gtid & 1ull) != 0ull;
+  const pair_base Bs = pair_base_of(K, second);
+  const int h = second ? 7 : 0;
+  float x[7], prev[7], tgt[7];
+  unsigned long long idx = 0, next = gtid >> 1;
+  int iter = 0, rounds = 0, n = 1;
+  float dist = 0.f, total = 0.f, maxd = 0.f;
+  bool active = false, drained = false;
+  for (;;) {
+    if (!active && !drained) {
+      const unsigned long long t = next;
+      next += ((unsigned long long)gridDim.x * blockDim.x) >> 1;
+      if (t < E) {
+        idx = t;
+#pragma unroll
+        for (int e = 0; e < 7; e++) { prev[e] = (float)from[idx * 14 + h + e]; tgt[e] = (float)to[idx * 14 + h + e]; }
+        dist = pair_dist(Bs, prev, tgt);
+        if (dist > delta) {
+          active = true; iter = 0; rounds = 0; n = 1; total = 0.f; maxd = dist * lambda;
+          interpolate7f(prev, tgt, delta / dist, x);
+        } else if (!second) {
+          pred[idx] = 0; // already there (or not a number): nothing to traverse
+        }
+      } else drained = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
+      if (__builtin_amdgcn_ballot_w64(!drained) == 0ull) break;
+      continue;
+    }
+    bool resid;
+    const bool cont = scout_round_pair(K, Bs, x, active, iter, resid);
+    // the distances below cross lanes: every lane of the wave goes through them, inactive pairs on stale values
+    bool inside = true;
+#pragma unroll
+    for (int e = 0; e < 7; e++) inside = inside && x[e] >= K.lbe[e] && x[e] <= K.ube[e];
+    inside = pair_and(inside);
+    const float step = pair_dist(Bs, prev, x), nd = pair_dist(Bs, x, tgt);
+    if (!active) continue;
+    rounds++;
+    if (cont) iter++;
+    bool done = rounds >= round_cap;
+    if (!cont && !done) { // project() of this state has returned: the reference's break tests, then the next state
+      done = resid || !inside;
+      if (!done) {
+        total += step;
+        done = step > lambda * delta || total > maxd || nd >= dist || ++n > max_states || !(nd >= delta);
+        if (!done) {
+          dist = nd;
+#pragma unroll
+          for (int e = 0; e < 7; e++) prev[e] = x[e];
+          interpolate7f(prev, tgt, delta / dist, x);
+          iter = 0;
+        }
+      }
+    }
+    if (done) {
+      if (!second) pred[idx] = (uint16_t)rounds;
+      active = false;
+    }
+  }
+}
+
 template <bool STOCK>
 __global__ __launch_bounds__(64) void scout_geodesic_kernel(const consts_f K, const double *__restrict__ from, const double *__restrict__ to,
                                                             unsigned long long E, float delta, float lambda, int max_states, int round_cap,
@@ -545,7 +830,7 @@ static void make_consts_f(const ccmp_consts *K, consts_f &F, bool *stock_out)
 
 extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                               unsigned int *hist, unsigned int *order, unsigned long long *queue,
-                                              unsigned long long seed, unsigned long long first, int nblocks, hipStream_t st)
+                                              unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks, hipStream_t st)
 {
   consts_f F;
   bool stock;
@@ -556,6 +841,13 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
   if (e != hipSuccess) return e;
 #define CCMP_LAUNCH_SCOUT(MODE, STOCK) \
   hipLaunchKernelGGL((scout_kernel<MODE, STOCK>), dim3(nblocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, queue, seed, first)
+  // two lanes per sample while every sample still gets its pair at once (pair_max_blocks blocks of 128 pairs); larger batches
+  // keep one lane per sample, several samples per lane
+  const size_t pair_blocks = (2 * B + 255) / 256;
+  if (stock && K->twin_arms && pair_max_blocks > 0 && pair_blocks <= (size_t)pair_max_blocks) {
+    if (mode == 0) hipLaunchKernelGGL(scout_pair_kernel<0>, dim3((unsigned)pair_blocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, seed, first);
+    else hipLaunchKernelGGL(scout_pair_kernel<1>, dim3((unsigned)pair_blocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, seed, first);
+  } else
   if (mode == 0) {
     if (stock) CCMP_LAUNCH_SCOUT(0, true);
     else CCMP_LAUNCH_SCOUT(0, false);
@@ -574,7 +866,7 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
 // extend-step order: FP32 scout of every edge (rounds capped at round_cap < 1024), then the descending counting sort
 extern "C" hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta,
                                                         double lambda, int max_states, int round_cap, uint16_t *pred, unsigned int *hist,
-                                                        unsigned int *order, hipStream_t st)
+                                                        unsigned int *order, int pairs, hipStream_t st)
 {
   consts_f F;
   bool stock;
@@ -585,7 +877,10 @@ extern "C" hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, con
   hipError_t e = ccmp_launch_clear_words(hist, (size_t)nbins, st);
   if (e != hipSuccess) return e;
   const unsigned blocks = (unsigned)((E + 63) / 64);
-  if (stock)
+  if (stock && K->twin_arms && pairs)
+    hipLaunchKernelGGL(scout_geodesic_pair_kernel, dim3((unsigned)((2 * E + 63) / 64)), dim3(64), 0, st, F, from, to, (unsigned long long)E,
+                       (float)delta, (float)lambda, max_states, round_cap, pred);
+  else if (stock)
     hipLaunchKernelGGL(scout_geodesic_kernel<true>, dim3(blocks), dim3(64), 0, st, F, from, to, (unsigned long long)E, (float)delta,
                        (float)lambda, max_states, round_cap, pred);
   else
