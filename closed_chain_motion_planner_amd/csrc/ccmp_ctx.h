@@ -115,8 +115,13 @@ struct ccmp_ctx {
   int fd_split_front = 256;              // ... at most this many (one latency block each: one per CU)
   int fd_split_group_cut = 2;            // throughput wavefronts per CU the split launch leaves out
   size_t latency_order_min = kDefaultLatencyOrderMin; // latency kernel alone (batches <= small_batch): FP32 scout order from this many samples on
-  int scout_pairs = 0;                   // FP32 scouts on lane pairs (ccmp_kernels_scout.hip; off until measured)
-  int scout_pair_blocks_per_cu = 2;      // ... projector scout: batches of up to 128 x this x CUs samples (one pair each, all at once)
+  // FP32 scouts on LANE PAIRS (round 4, ccmp_kernels_scout.hip): the even lane takes arm 0, the odd lane arm 1 — half the chain
+  // work per lane and round, and the scout's run time is its longest lane's.  Same predictions (equal to the one-lane scout's on
+  // 84 % of samples, within 1 on 91 %; both equal the true count on 84 %).  profiles/r04_scout_pairs_ab.log, one lane | pairs, ms:
+  // Wine_Bottle 4096: 0.698 | 0.656   8192: 1.064 | 1.024   16384: 1.681 | 1.638   32768: 2.580 | 2.524   65536: 4.60 | 4.61;
+  // extend step 8192 edges: 0.88 | 0.84   16384: 1.411 | 1.360   65536: 5.00 | 4.96; stefan -1 ... -4 % / -3 ... -6 %.
+  int scout_pairs = 1;
+  int scout_pair_blocks_per_cu = 1;      // ... projector scout: while every sample gets its pair at once (128 x this x CUs samples = 32768)
   size_t scout_pair_max_edges = 131072;  // ... extend-step scout: up to this many edges
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)

@@ -671,6 +671,10 @@ __global__ __launch_bounds__(64) void scout_geodesic_kernel(const consts_f K, co
 }
 
 constexpr int kBins = 1024;
+#ifndef CCMP_SORT_FUSED_MAX
+#define CCMP_SORT_FUSED_MAX 16384
+#endif
+constexpr int kSortFusedMax = CCMP_SORT_FUSED_MAX; // up to this many keys the counting sort is one launch (sort_fused_kernel)
 
 __global__ void hist_kernel(const uint16_t *__restrict__ pred, unsigned long long B, unsigned int *__restrict__ hist)
 {
@@ -748,6 +752,48 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint16_t *__restrict
   for (int k = 0; k < kScatterPerThread; k++)
     if (key[k] != 0xffffffffu) order[base[key[k]] + atomicAdd(&cnt[key[k]], 1u)] = (unsigned int)(i0 + k);
 }
+
+// The whole descending counting sort in ONE launch for small batches (round 4): histogram, scan and scatter of up to a few ten
+// thousand keys are microseconds of work each, and three launches (plus the one that clears the histogram) cost more than
+// that in dispatch alone — a tenth of a 4 096-sample call was launch gaps.  One 1024-thread block: LDS histogram, thread t
+// owns bin kBins - 1 - t for the descending exclusive scan (wave scan + sixteen wave sums), LDS-atomic ranks for the scatter.
+// Leaves in hist what the three-kernel form leaves: at k the number of keys >= k (the split kernels read it).
+__global__ __launch_bounds__(1024) void sort_fused_kernel(const uint16_t *__restrict__ pred, unsigned int B, unsigned int *__restrict__ hist,
+                                                          unsigned int *__restrict__ order)
+{
+  __shared__ unsigned int cnt[kBins], base[kBins], wsum[16];
+  const int t = threadIdx.x, lane = t & 63;
+  cnt[t] = 0;
+  __syncthreads();
+  for (unsigned int i = t; i < B; i += 1024) {
+    const unsigned int v = pred[i];
+    atomicAdd(&cnt[v < kBins ? v : kBins - 1], 1u);
+  }
+  __syncthreads();
+  const int k = kBins - 1 - t;
+  const unsigned int c = cnt[k];
+  unsigned int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int v = (unsigned int)__shfl_up((int)incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[t >> 6] = incl;
+  __syncthreads();
+  unsigned int above = 0;
+  for (int w = 0; w < (t >> 6); w++) above += wsum[w];
+  const unsigned int excl = above + incl - c; // keys in the bins above k
+  base[k] = excl;
+  hist[k] = excl + c;
+  cnt[k] = 0;
+  __syncthreads();
+  for (unsigned int i = t; i < B; i += 1024) {
+    const unsigned int v = pred[i];
+    const unsigned int key = v < kBins ? v : kBins - 1;
+    order[base[key] + atomicAdd(&cnt[key], 1u)] = i;
+  }
+}
+static_assert(kBins == 1024, "sort_fused_kernel: one thread per bin");
 
 // after scatter_kernel the cursor array holds, at k, the number of samples predicted >= k iterations: the front of
 // the order that a split launch gives to the latency kernel = those predicted >= pred_min, at most `limit`
@@ -835,10 +881,16 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
   consts_f F;
   bool stock;
   make_consts_f(K, F, &stock);
-  hipError_t e = ccmp_launch_clear_words(queue, 2, st); // kernels, so that a stream capture replays them
+  const bool fused = B <= (size_t)kSortFusedMax; // the fused sort writes every bin itself: nothing to clear
+  hipError_t e = hipSuccess;
+#ifdef CCMP_SCOUT_ATOMIC_QUEUE
+  e = ccmp_launch_clear_words(queue, 2, st); // kernels, so that a stream capture replays them
   if (e != hipSuccess) return e;
-  e = ccmp_launch_clear_words(hist, kBins, st);
-  if (e != hipSuccess) return e;
+#endif
+  if (!fused) {
+    e = ccmp_launch_clear_words(hist, kBins, st);
+    if (e != hipSuccess) return e;
+  }
 #define CCMP_LAUNCH_SCOUT(MODE, STOCK) \
   hipLaunchKernelGGL((scout_kernel<MODE, STOCK>), dim3(nblocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, queue, seed, first)
   // two lanes per sample while every sample still gets its pair at once (pair_max_blocks blocks of 128 pairs); larger batches
@@ -856,6 +908,10 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
     else CCMP_LAUNCH_SCOUT(1, false);
   }
 #undef CCMP_LAUNCH_SCOUT
+  if (fused) {
+    hipLaunchKernelGGL(sort_fused_kernel, dim3(1), dim3(1024), 0, st, pred, (unsigned int)B, hist, order);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(hist_kernel, dim3(256), dim3(256), 0, st, pred, (unsigned long long)B, hist);
   hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist, kBins);
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((B + 256 * kScatterPerThread - 1) / (256 * kScatterPerThread))), dim3(256), 0, st, pred,
@@ -874,8 +930,12 @@ extern "C" hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, con
   if (round_cap > kBins - 1) round_cap = kBins - 1;
   F.max_iter = K->max_iter < round_cap ? K->max_iter : round_cap;
   const int nbins = round_cap + 1;
-  hipError_t e = ccmp_launch_clear_words(hist, (size_t)nbins, st);
-  if (e != hipSuccess) return e;
+  const bool fused = E <= (size_t)kSortFusedMax;
+  hipError_t e = hipSuccess;
+  if (!fused) {
+    e = ccmp_launch_clear_words(hist, (size_t)nbins, st);
+    if (e != hipSuccess) return e;
+  }
   const unsigned blocks = (unsigned)((E + 63) / 64);
   if (stock && K->twin_arms && pairs)
     hipLaunchKernelGGL(scout_geodesic_pair_kernel, dim3((unsigned)((2 * E + 63) / 64)), dim3(64), 0, st, F, from, to, (unsigned long long)E,
@@ -886,6 +946,10 @@ extern "C" hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, con
   else
     hipLaunchKernelGGL(scout_geodesic_kernel<false>, dim3(blocks), dim3(64), 0, st, F, from, to, (unsigned long long)E, (float)delta,
                        (float)lambda, max_states, round_cap, pred);
+  if (fused) {
+    hipLaunchKernelGGL(sort_fused_kernel, dim3(1), dim3(1024), 0, st, pred, (unsigned int)E, hist, order);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(hist_kernel, dim3(64), dim3(256), 0, st, pred, (unsigned long long)E, hist);
   hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist, nbins);
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((E + 256 * kScatterPerThread - 1) / (256 * kScatterPerThread))), dim3(256), 0, st, pred,

@@ -159,6 +159,9 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
  * launch, default: for batches of fd_split_min..fd_split_max samples, default 12288..90112, the samples the FP32 scout predicts
  * to need at least "fd_split_pred" iterations, default 56 — at most "fd_split_front", default 256 — run on latency blocks on a
  * side stream beside the throughput kernel, which gives up "fd_split_group_cut" wavefronts per CU, default 2; 0 = off);
+ * the FP32 scouts: "scout_pairs" (1 = two lanes per sample / edge,
+ * one arm each, where lanes are plentiful — projector batches of up to 128 x "scout_pair_blocks_per_cu" (default 1) x CUs samples,
+ * extend-step batches of up to "scout_pair_max_edges" (default 131072) edges; stock twin arms only; default 1);
  * host entry points: "host_zero_copy"
  * (see ccmp_project_host).  None of these changes a
  * result bit.  CCMP_EINVAL for unknown names. */
