@@ -9,6 +9,7 @@ results, bit for bit."""
 import numpy as np
 import pytest
 
+from conftest import config_path
 from test_gpu_parity import _constraint
 
 pytestmark = pytest.mark.gpu
