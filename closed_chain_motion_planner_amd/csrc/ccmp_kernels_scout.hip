@@ -494,7 +494,6 @@ __global__ __launch_bounds__(256) void scout_pair_kernel(const consts_f K, const
   float xa[7];
   unsigned long long idx = 0, next = gtid >> 1;
   int iter = 0;
-  unsigned int unfl = 0, tick = 0; // completions not yet added to *done; rounds since the kernel started
   bool active = false, drained = false;
   for (;;) {
     if (!active && !drained) {
@@ -509,10 +508,7 @@ __global__ __launch_bounds__(256) void scout_pair_kernel(const consts_f K, const
         }
       } else drained = true;
     }
-    if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
-      if (stop_at && unfl && (threadIdx.x & 63) == 0) atomicAdd(done, (unsigned long long)unfl); // what this wavefront still owes the count
-      break;
-    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
     bool resid;
     const bool cont = scout_round_pair(K, Bs, xa, active, iter, resid);
     const bool fin = active && !cont;
@@ -522,21 +518,16 @@ __global__ __launch_bounds__(256) void scout_pair_kernel(const consts_f K, const
     }
     if (cont) iter++;
     if (stop_at) {
-      // completions are gathered in a register and the shared word is visited every eighth round only: hundreds of
-      // wavefronts on one word every round took longer than the rounds saved (one word sustains ~88 atomics per microsecond)
-      unfl += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(fin && !second));
-      if ((++tick & 7u) == 0u) {
-        unsigned long long d = 0;
-        if ((threadIdx.x & 63) == 0) {
-          if (unfl) d = atomicAdd(done, (unsigned long long)unfl) + (unsigned long long)unfl;
-          else d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unfl = 0;
-        d = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)d);
-        if (d >= stop_at) {
-          if (active && !second) pred[idx] = (uint16_t)iter;
-          break;
-        }
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(fin && !second);
+      unsigned long long d = 0;
+      if ((threadIdx.x & 63) == 0) {
+        if (m) d = atomicAdd(done, (unsigned long long)__builtin_popcountll(m)) + (unsigned long long)__builtin_popcountll(m);
+        else d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      d = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+      if (d >= stop_at) {
+        if (active && !second) pred[idx] = (uint16_t)iter;
+        break;
       }
     }
   }
