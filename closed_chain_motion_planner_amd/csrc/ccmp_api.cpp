@@ -107,8 +107,7 @@ hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double
                                     int front_blocks, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipStream_t st);
 hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                    unsigned int *hist, unsigned int *order, unsigned long long *queue,
-                                   unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks,
-                                   size_t stop_when_active, hipStream_t st);
+                                   unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks, hipStream_t st);
 hipError_t ccmp_launch_function(const ccmp_consts *K, const double *q, double *f, size_t B, unsigned int *done_flag,
                                 unsigned int done_seq, hipStream_t st);
 hipError_t ccmp_launch_is_satisfied(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, unsigned int *done_flag,
@@ -393,9 +392,6 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "scout_pair_max_edges")) { // ... extend step: up to this many edges
     if (value < 0) return CCMP_EINVAL;
     ctx->scout_pair_max_edges = (size_t)value;
-  } else if (!strcmp(name, "latency_scout_early")) { // latency kernel alone: the scout ends once no more samples are iterating than blocks are resident
-    if (value != 0 && value != 1) return CCMP_EINVAL;
-    ctx->latency_scout_early = (int)value;
   } else if (!strcmp(name, "latency_order_min")) { // latency kernel alone: FP32 scout order from this many samples on
     if (value < 0) return CCMP_EINVAL;
     ctx->latency_order_min = (size_t)value;
@@ -598,7 +594,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       unsigned int *ord = (unsigned int *)((char *)hist + 4096);
       unsigned int *split = (unsigned int *)(ctx->queue + 8 + 64 + 3);
       HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus,
-                                    ctx->scout_pairs ? ctx->num_cus * ctx->scout_pair_blocks_per_cu : 0, 0, st));
+                                    ctx->scout_pairs ? ctx->num_cus * ctx->scout_pair_blocks_per_cu : 0, st));
       // the front kernel gets analytic_split_front wavefronts, one SIMD each (a one-lane wave fills a SIMD's registers, so
       // the one-lane kernel is launched that many wavefronts short); ten samples per wavefront, one round
       const int front_blocks = ctx->analytic_split_front;
@@ -645,8 +641,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
         unsigned int *hist = (unsigned int *)(base + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
         unsigned int *ord = (unsigned int *)((char *)hist + 4096);
         HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, (uint16_t *)base, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus,
-                                    ctx->scout_pairs ? ctx->num_cus * ctx->scout_pair_blocks_per_cu : 0,
-                                        ctx->latency_scout_early ? (size_t)pl.latency_blocks : 0, st));
+                                    ctx->scout_pairs ? ctx->num_cus * ctx->scout_pair_blocks_per_cu : 0, st));
         lat_order = ord;
       }
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
@@ -670,7 +665,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     unsigned int *ord = (unsigned int *)((char *)hist + 4096);
     // one 256-thread block per CU, 4 samples per lane at 262144: more lanes only lengthen the per-wave maximum
     HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, pred, hist, ord, ctx->queue + 5, seed, first, ctx->num_cus,
-                                    ctx->scout_pairs ? ctx->num_cus * ctx->scout_pair_blocks_per_cu : 0, 0, st));
+                                    ctx->scout_pairs ? ctx->num_cus * ctx->scout_pair_blocks_per_cu : 0, st));
     order = ord;
     // Split launch (round 4).  A mid-size batch ends on the serial chain of its longest samples: they start first in the
     // throughput kernel, do ~22 iterations there at 26-62 us each, and only after the hand-over — a millisecond into the call —

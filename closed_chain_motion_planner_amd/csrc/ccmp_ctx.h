@@ -123,7 +123,6 @@ struct ccmp_ctx {
   int scout_pairs = 1;
   int scout_pair_blocks_per_cu = 1;      // ... projector scout: while every sample gets its pair at once (128 x this x CUs samples = 32768)
   size_t scout_pair_max_edges = 131072;  // ... extend-step scout: up to this many edges
-  int latency_scout_early = 0;           // ... and its scout ends once no more samples are iterating than blocks are resident (off until measured)
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency

@@ -477,16 +477,10 @@ __device__ __forceinline__ bool scout_round_pair(const consts_f &K, const pair_b
   return cont;
 }
 
-// stop_at > 0 (the latency kernel alone, ccmp_api.cpp): the order only decides who gets into the FIRST fill of that kernel's
-// blocks, so once no more samples are still iterating than blocks are resident the scout has nothing left to find out — the rest
-// all start at once whatever their order.  `done` counts finished samples (one atomic per wavefront and round with completions);
-// when it reaches stop_at every wavefront writes the iteration count reached as the prediction of its unfinished samples —
-// they sort in front of everything finished earlier — and leaves.  Saves the scout's tail: its run time is its longest
-// lane's, 96 rounds, for a batch whose median sample needs 30.
 template <int MODE>
 __global__ __launch_bounds__(256) void scout_pair_kernel(const consts_f K, const ccmp_consts KD, const double *__restrict__ q_in,
                                                          uint16_t *__restrict__ pred, unsigned long long B, unsigned long long seed,
-                                                         unsigned long long first_index, unsigned long long *done, unsigned long long stop_at)
+                                                         unsigned long long first_index)
 {
   const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool second = (gtid & 1ull) != 0ull;
@@ -511,25 +505,11 @@ __global__ __launch_bounds__(256) void scout_pair_kernel(const consts_f K, const
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
     bool resid;
     const bool cont = scout_round_pair(K, Bs, xa, active, iter, resid);
-    const bool fin = active && !cont;
-    if (fin) {
+    if (active && !cont) {
       if (!second) pred[idx] = (uint16_t)iter;
       active = false;
     }
     if (cont) iter++;
-    if (stop_at) {
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(fin && !second);
-      unsigned long long d = 0;
-      if ((threadIdx.x & 63) == 0) {
-        if (m) d = atomicAdd(done, (unsigned long long)__builtin_popcountll(m)) + (unsigned long long)__builtin_popcountll(m);
-        else d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      d = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)d);
-      if (d >= stop_at) {
-        if (active && !second) pred[idx] = (uint16_t)iter;
-        break;
-      }
-    }
   }
 }
 
@@ -896,8 +876,7 @@ static void make_consts_f(const ccmp_consts *K, consts_f &F, bool *stock_out)
 
 extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                               unsigned int *hist, unsigned int *order, unsigned long long *queue,
-                                              unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks,
-                                              size_t stop_when_active, hipStream_t st)
+                                              unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks, hipStream_t st)
 {
   consts_f F;
   bool stock;
@@ -918,14 +897,8 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
   // keep one lane per sample, several samples per lane
   const size_t pair_blocks = (2 * B + 255) / 256;
   if (stock && K->twin_arms && pair_max_blocks > 0 && pair_blocks <= (size_t)pair_max_blocks) {
-    // early end (stop_when_active > 0; `queue`: a zeroed word): once at most that many samples are still iterating
-    const unsigned long long stop_at = (stop_when_active > 0 && stop_when_active < B) ? (unsigned long long)(B - stop_when_active) : 0ull;
-    if (mode == 0)
-      hipLaunchKernelGGL(scout_pair_kernel<0>, dim3((unsigned)pair_blocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, seed, first,
-                         queue, stop_at);
-    else
-      hipLaunchKernelGGL(scout_pair_kernel<1>, dim3((unsigned)pair_blocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, seed, first,
-                         queue, stop_at);
+    if (mode == 0) hipLaunchKernelGGL(scout_pair_kernel<0>, dim3((unsigned)pair_blocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, seed, first);
+    else hipLaunchKernelGGL(scout_pair_kernel<1>, dim3((unsigned)pair_blocks), dim3(256), 0, st, F, *K, q_in, pred, (unsigned long long)B, seed, first);
   } else
   if (mode == 0) {
     if (stock) CCMP_LAUNCH_SCOUT(0, true);
