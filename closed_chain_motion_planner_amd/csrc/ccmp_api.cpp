@@ -97,7 +97,7 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
                                     unsigned int done_seq, size_t pool_records, const unsigned int *order,
-                                    const unsigned long long *total_ptr, unsigned int prio_cut, hipStream_t st);
+                                    const unsigned long long *total_ptr, hipStream_t st);
 hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
@@ -123,11 +123,11 @@ hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride,
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, int round_budget, unsigned int prio_cut, hipStream_t st);
+                                const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
 hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                     size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                     int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                    const double *carry_in, double *carry_out, int round_budget, unsigned int prio_cut, hipStream_t st);
+                                    const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -389,11 +389,6 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "scout_pair_blocks_per_cu")) { // ... projector: up to this many 256-thread blocks per CU
     if (value < 1 || value > 64) return CCMP_EINVAL;
     ctx->scout_pair_blocks_per_cu = (int)value;
-  } else if (!strcmp(name, "latency_prio_cut") || !strcmp(name, "pool_prio_cut") || !strcmp(name, "geodesic_prio_cut")) {
-    if (value < 0 || value > 0xffffffffll) return CCMP_EINVAL;
-    (name[0] == 'l' ? ctx->latency_prio_cut : name[0] == 'p' ? ctx->pool_prio_cut : ctx->geodesic_prio_cut) = value;
-  } else if (!strcmp(name, "fd_split_prio")) {
-    ctx->fd_split_prio = value != 0;
   } else if (!strcmp(name, "scout_pair_max_edges")) { // ... extend step: up to this many edges
     if (value < 0) return CCMP_EINVAL;
     ctx->scout_pair_max_edges = (size_t)value;
@@ -650,8 +645,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
         lat_order = ord;
       }
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
-                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, lat_order, nullptr,
-                                       lat_order ? (unsigned int)ctx->latency_prio_cut : 0u, st));
+                                       ctx->pool, q_pool_count, mode, pl.latency_blocks, flag, ctx->done_seq, 0, lat_order, nullptr, st));
     }
     else
       HIP_TRY(ccmp_launch_project_wave(&K, mode, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count,
@@ -686,7 +680,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       HIP_TRY(hipEventRecord(ctx->fork, st));
       HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 7, seed, first, ctx->pool, q_pool_count, mode,
-                                       ctx->fd_split_front, nullptr, 0, 0, ord, ctx->queue + 4, ctx->fd_split_prio ? 0xffffffffu : 0u, ctx->side));
+                                       ctx->fd_split_front, nullptr, 0, 0, ord, ctx->queue + 4, ctx->side));
       HIP_TRY(hipEventRecord(ctx->join, ctx->side));
       const int room = ctx->num_cus * ((ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12) - ctx->fd_split_group_cut);
       if (group_blocks > room) group_blocks = room;
@@ -706,7 +700,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (pl.handover) { // the pool's fill count is read on the device: the latency kernel's surplus blocks exit at once
     if (ctx->flat_kernel)
       HIP_TRY(ccmp_launch_project_flat(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
-                                       pl.latency_blocks, nullptr, 0, pool_records, nullptr, nullptr, (unsigned int)ctx->pool_prio_cut, st));
+                                       pl.latency_blocks, nullptr, 0, pool_records, nullptr, nullptr, st));
     else
       HIP_TRY(ccmp_launch_project_wave(&K, 2, q_in, q_out, ok, iters, q_ambient, B, q_latency, seed, first, ctx->pool, q_pool_count, mode,
                                        pl.latency_blocks, st));
@@ -819,7 +813,7 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   }
   HIP_TRY((latency_flavour ? ccmp_launch_geodesic_lat : ccmp_launch_geodesic)(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok,
                                                                              newton_iters, check_target, (int)nb, queue, order, carry_in, carry_out,
-                                                                             round_budget, order ? (unsigned int)ctx->geodesic_prio_cut : 0u, st));
+                                                                             round_budget, st));
   return CCMP_OK;
 }
 

@@ -123,11 +123,6 @@ struct ccmp_ctx {
   int scout_pairs = 1;
   int scout_pair_blocks_per_cu = 1;      // ... projector scout: while every sample gets its pair at once (128 x this x CUs samples = 32768)
   size_t scout_pair_max_edges = 131072;  // ... extend-step scout: up to this many edges
-  // wave priority 3 for the head of a longest-first order (the serial chains a launch ends on): tickets below these
-  long long latency_prio_cut = 0;   // latency kernel alone in the scout's order
-  long long pool_prio_cut = 0;      // latency kernel on the hand-over pool (front = predicted long)
-  int fd_split_prio = 0;            // the split launch's front blocks beside the throughput kernel: 1 = all of them
-  long long geodesic_prio_cut = 0;  // extend step in an order
   int latency_blocks_per_cu = 8;         // persistent 128-thread blocks of the projector's latency kernel per CU (8 resident: 128 registers)
   int geodesic_blocks_per_cu = 4;        // ... of the extend step's latency flavour (ccmp_kernels_geo.hip: 256-register budget, 4 resident)
   int geodesic_flavour = 0;              // extend step build: 0 = by call shape (round budget and size), 1 = throughput, 2 = latency

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
     const unsigned long long *__restrict__ pool_count, int wrap_output, unsigned int *done_flag, unsigned int done_seq,
-    unsigned long long pool_records, const unsigned int *__restrict__ order, const unsigned long long *__restrict__ total_ptr, unsigned int prio_cut)
+    unsigned long long pool_records, const unsigned int *__restrict__ order, const unsigned long long *__restrict__ total_ptr)
 {
   __shared__ __attribute__((aligned(16))) double lds[fRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -45,10 +45,6 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
       t = ticket;
     }
     if (t >= total) break;
-    // tickets below prio_cut — the head of a longest-first order, whose serial chains the launch ends on — run at wave
-    // priority 3: the SIMD's arbiter takes their instructions first, whoever else is resident (s_setprio takes an immediate)
-    if (__builtin_amdgcn_readfirstlane((unsigned int)(t < 0xffffffffull ? t : 0xffffffffull)) < prio_cut) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
     unsigned long long idx;
     int iter = 0, updates = 0;
     double norm1 = 0.0, norm2 = 0.0;
@@ -112,13 +108,13 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned long long seed, unsigned long long first, const double *pool,
                                     const unsigned long long *pool_count, int wrap_output, int nblocks, unsigned int *done_flag,
                                     unsigned int done_seq, size_t pool_records, const unsigned int *order,
-                                    const unsigned long long *total_ptr, unsigned int prio_cut, hipStream_t st)
+                                    const unsigned long long *total_ptr, hipStream_t st)
 {
   if (nblocks != 1) done_flag = nullptr; // the completion word is written by the one block of a single-state call
 #define CCMP_LAUNCH_FLAT(SRC, STOCK)                                                                                             \
   hipLaunchKernelGGL((project_fd_flat_kernel<SRC, STOCK>), dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
                      (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output, done_flag, done_seq, \
-                     (unsigned long long)pool_records, order, total_ptr, prio_cut)
+                     (unsigned long long)pool_records, order, total_ptr)
   if (src == 0) {
     if (K->stock) CCMP_LAUNCH_FLAT(0, true);
     else CCMP_LAUNCH_FLAT(0, false);

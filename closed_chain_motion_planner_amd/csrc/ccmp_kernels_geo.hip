@@ -53,7 +53,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,
     unsigned long long *queue, const unsigned int *__restrict__ order, const double *__restrict__ carry_in,
-    double *__restrict__ carry_out, int round_budget, unsigned int prio_cut)
+    double *__restrict__ carry_out, int round_budget)
 {
   __shared__ __attribute__((aligned(16))) double lds[gRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -78,9 +78,6 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
       tk = ticket;
     }
     if (tk >= E) break;
-    // the head of a longest-first order at wave priority 3 (ccmp_kernels_flat.hip)
-    if (__builtin_amdgcn_readfirstlane((unsigned int)(tk < 0xffffffffull ? tk : 0xffffffffull)) < prio_cut) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
     const unsigned long long t = order ? (unsigned long long)order[tk] : tk;
 #ifdef CCMP_GEO_TRACE
     if (tid == 0 && t < 65536) { g_geo_trace[3 * t] = wall_clock64(); g_geo_trace[3 * t + 2] = ((unsigned long long)blockIdx.x << 32) | tk; }
@@ -253,14 +250,14 @@ extern "C" {
 hipError_t CCMP_LAUNCH_GEODESIC(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, int round_budget, unsigned int prio_cut, hipStream_t st)
+                                const double *carry_in, double *carry_out, int round_budget, hipStream_t st)
 {
   if (K->stock)
     hipLaunchKernelGGL(geodesic_flat_kernel<true>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, prio_cut);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget);
   else
     hipLaunchKernelGGL(geodesic_flat_kernel<false>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, prio_cut);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget);
   return hipGetLastError();
 }
 
