@@ -225,6 +225,17 @@ def checker_problem(O, obj, product_problem):
     return own
 
 
+def libm_problem(O, obj, product_problem):
+    """The glibc build's problem for the CPU TIMING legs: its own set-up from the YAML fixture (its start frame is computed with
+    glibc's sine/cosine, so its bytes legitimately differ from the product's in the last place — no comparison here), with the
+    tolerances the bench has set."""
+    import yaml
+
+    own = O.problem(yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "config", obj + ".yaml"))))
+    own.tol_pos, own.tol_rot, own.jacobian_mode = product_problem.tol_pos, product_problem.tol_rot, product_problem.jacobian_mode
+    return own
+
+
 def det_parity(obj, product_problem, q_in, q_out, ok, iters, threads):
     """the det build of the oracle on the very inputs the GPU projected"""
     import numpy as np
@@ -524,8 +535,12 @@ def flatten_for_the_driver(line, B):
             "extend_bitwise": None if get(geo, "parity_vs_det_oracle", "bit_identical") is None else bool(
                 get(geo, "parity_vs_det_oracle", "bit_identical") and get(geo, "parity_vs_det_oracle", "continued_edges", "bit_identical")),
             "growtree_5_edges_ms": geo.get("growtree_5_edges_ms"),
+            "extend_cpu_edges_per_s": get(geo, "cpu", "edges_per_s"), "extend_cpu_threads": get(geo, "cpu", "threads"),
+            "growtree_5_edges_cpu_single_thread_ms": get(geo, "cpu", "growtree_5_edges_single_thread_ms"),
             "single_project_us": get(sec, "single_project_c_abi", "uniform_sample_median_us"),
             "single_project_near_manifold_us": get(sec, "single_project_c_abi", "near_manifold_median_us"),
+            "single_project_cpu_us": get(sec, "single_project_c_abi", "uniform_sample_cpu_median_us"),
+            "single_project_near_manifold_cpu_us": get(sec, "single_project_c_abi", "near_manifold_cpu_median_us"),
             "host_buffer_pageable_per_s": get(sec, "host_buffer", "pageable", "projections_per_s"),
             "host_buffer_pinned_per_s": get(sec, "host_buffer", "pinned", "projections_per_s"),
             "analytic_mode_per_s": sec.get("analytic_mode_projections_per_s"),
@@ -627,6 +642,22 @@ def secondary(args, c, ctx, B, torch, cfg_path):
                 its.append(int(it[0]))
             out[name + "_median_us"] = float(np.median(ts[8:]) * 1e6)
             out[name + "_median_newton_iters"] = float(np.median(its[8:]))
+        try:
+            # the CPU path beside it: the same states through the glibc build of the oracle, one call at a time on one thread
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_binding import Oracle
+
+            Ol = Oracle("libm")
+            Pl = libm_problem(Ol, args.obj, c.problem)
+            for name, xs in (("uniform_sample", far), ("near_manifold", near)):
+                ts = []
+                for i in range(xs.shape[0]):
+                    t0 = time.perf_counter()
+                    Ol.project(Pl, xs[i])
+                    ts.append(time.perf_counter() - t0)
+                out[name + "_cpu_median_us"] = float(np.median(ts[8:]) * 1e6)
+        except Exception as e:
+            out["cpu_error"] = repr(e)
         return out
 
     def geodesic(n_edges=16384, first_pass=16, budget=128):
@@ -704,6 +735,25 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             res["parity_vs_det_oracle"]["continued_edges"] = {"edges": len(cand), "bit_identical": bool(okc_all)}
         except Exception as e:
             res["parity_vs_det_oracle"] = {"error": repr(e)}
+        try:
+            # the CPU path beside it: the glibc build of the oracle — what the reference's loop would call — on
+            # the first 4096 of the same edges with every usable core (lists of 64), and growTree's five edges on one thread
+            Ol = Oracle("libm")
+            Pl = libm_problem(Ol, args.obj, c.problem)
+            mc = 4096
+            fc, tc = frm[:mc].cpu().numpy(), to[:mc].cpu().numpy()
+            t0 = time.perf_counter()
+            Ol.discrete_geodesic_batch(Pl, fc, tc, 64, threads)
+            cpu_sec = time.perf_counter() - t0
+            best5 = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                Ol.discrete_geodesic_batch(Pl, fc[:5], tc[:5], 64, 1)
+                best5 = min(best5, time.perf_counter() - t0)
+            res["cpu"] = {"kind": "port (glibc build of the oracle)", "edges": mc, "threads": threads, "edges_per_s": mc / cpu_sec,
+                          "growtree_5_edges_single_thread_ms": best5 * 1e3}
+        except Exception as e:
+            res["cpu"] = {"error": repr(e)}
         return res
 
     def host_buffer():

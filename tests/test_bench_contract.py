@@ -59,6 +59,9 @@ def test_bench_line_contract():
     assert g["parity_vs_det_oracle"]["bit_identical"] is True and g["overflowed_edges"] < 0.01 * g["edges"]
     assert g["parity_vs_det_oracle"]["continued_edges"]["bit_identical"] is True and g["parity_vs_det_oracle"]["continued_edges"]["edges"] >= 1
     assert g["overflowed_edges"] == g["overflowed_list_full"] + g["overflowed_budget_spent"] and g["ms_unbounded_rounds"] > 0
+    # the CPU path timed beside the latency rows: slower than the GPU on the same work
+    assert g["cpu"]["edges_per_s"] < g["edges_per_s"] and g["cpu"]["growtree_5_edges_single_thread_ms"] > g["growtree_5_edges_ms"]
+    assert sp["uniform_sample_cpu_median_us"] > sp["uniform_sample_median_us"]
     # the driver's record keeps first-level scalars of config / roofline / cpu_baseline only — the figures of
     # SURVEY.md section 8(d) are repeated there, flat
     for k in FLAT_CONFIG:
@@ -79,7 +82,8 @@ FLAT_CONFIG = ("c1_dumbbell_cpu_single_thread_per_s", "c1_dumbbell_gpu_per_s", "
                "c4_stefan_per_s", "c4_stefan_tight_per_s", "c4_bitwise", "extend_first_pass_edges_per_s", "extend_first_pass_ms",
                "extend_unfinished_edges", "extend_complete_ms", "extend_bitwise", "growtree_5_edges_ms", "single_project_us",
                "single_project_near_manifold_us", "host_buffer_pageable_per_s", "host_buffer_pinned_per_s", "analytic_mode_per_s",
-               "proxy_clearance_states_per_s")
+               "proxy_clearance_states_per_s", "extend_cpu_edges_per_s", "extend_cpu_threads", "growtree_5_edges_cpu_single_thread_ms",
+               "single_project_cpu_us", "single_project_near_manifold_cpu_us")
 FLAT_CPU = ("det_bit_identical", "det_samples", "libm_samples", "libm_n_gt_1e-6", "libm_max_abs_dq", "libm_iter_diffs_gt1", "libm_ok_mismatches")
 
 
@@ -97,11 +101,13 @@ def test_flat_keys_are_first_level_scalars():
                      "valu_issue": {"frac_of_fp64_issue_ceiling": 0.824, "vector_pipes_busy_in_profiled_launch": 0.905, "source": "profiles/r03f"}},
         "secondary": {
             "batch4096_projections_per_s": 5.1e6, "batch4096": {"parity_vs_det_oracle": par}, "batch32768_projections_per_s": 11.4e6,
-            "single_project_c_abi": {"uniform_sample_median_us": 122.0, "near_manifold_median_us": 54.7},
+            "single_project_c_abi": {"uniform_sample_median_us": 122.0, "near_manifold_median_us": 54.7, "uniform_sample_cpu_median_us": 1100.0,
+                                     "near_manifold_cpu_median_us": 350.0},
             "analytic_mode_projections_per_s": 1.4e8,
             "stefan_batch%d_tol_1e-3_5e-3" % B: {"projections_per_s": 9.9e6, "parity_vs_det_oracle": par},
             "stefan_batch%d_tol_5e-4_2.5e-3" % B: {"projections_per_s": 9.0e6, "parity_vs_det_oracle": par},
             "discrete_geodesic": {"edges_per_s": 10.7e6, "ms": 1.52, "overflowed_edges": 29, "complete_ms": 42.8, "growtree_5_edges_ms": 0.41,
+                                  "cpu": {"edges_per_s": 9000.0, "threads": 16, "growtree_5_edges_single_thread_ms": 7.5},
                                   "parity_vs_det_oracle": {"bit_identical": True, "continued_edges": {"bit_identical": True}}},
             "proxy_clearance": {"states_per_s": 6.6e8},
             "host_buffer": {"pageable": {"projections_per_s": 14.5e6}, "pinned": {"projections_per_s": 13.2e6}},
