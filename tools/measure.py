@@ -369,8 +369,8 @@ def run(argv):
     if what in ("c3", "stefan"):
         q = c.ambient_uniform_batch(0xC3, 0, 262144)
         fn = lambda: c.project_batch(q)
-    elif what == "flat4096":
-        q = c.ambient_uniform_batch(0xC2, 0, 4096)
+    elif what.startswith("flat") and what[4:].isdigit() and int(what[4:]) > 1:  # flat4096 (C2), flat14336 ...: the latency kernel alone
+        q = c.ambient_uniform_batch(0xC2, 0, int(what[4:]))
         fn = lambda: c.project_batch(q)
     elif what.startswith("mid"):  # mid32768, mid65536 ...: scout + throughput kernel + hand-over to the latency kernel
         q = c.ambient_uniform_batch(0xC3, 0, int(what[3:]))
