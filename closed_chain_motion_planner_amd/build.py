@@ -10,6 +10,7 @@ Translation units with deliberately different flags:
                          budget (latency flavour)
   ccmp_problem.cpp       -ffp-contract=off -DCCMP_USE_FMA   host set-up (problem, constants) in the same rounding model
   ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   context, scheduling, launches
+  ccmp_host_io.cpp                                          *_host conveniences (staging, pinned block, page-locked caller buffers), sharded host calls
   ccmp_comm.cpp                                             one process / several GPUs: RCCL communicator and sharded entry points
   ccmp_kernels_fast.hip  -ffp-contract=off -DCCMP_USE_FMA   analytic fast mode, bit-identical to the oracle's analytic mode
   ccmp_kernels_scout.hip -ffast-math                        FP32 iteration-count predictor + ordering (never touches results)
@@ -49,6 +50,7 @@ _UNITS = [
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_problem.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
+    ("ccmp_host_io.cpp", ["-O2", "-x", "hip"]),
     ("ccmp_comm.cpp", ["-O2", "-x", "hip"]),
     ("ccmp_kernels_scene.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT"]),
     ("ccmp_scene.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),

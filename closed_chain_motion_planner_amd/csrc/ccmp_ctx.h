@@ -1,4 +1,4 @@
-/* ccmp_ctx.h — internals shared by the host translation units of libccmp (ccmp_api.cpp, ccmp_comm.cpp); not part of
+/* ccmp_ctx.h — internals shared by the host translation units of libccmp (ccmp_api.cpp, ccmp_host_io.cpp, ccmp_comm.cpp); not part of
  * the public ABI. */
 #ifndef CCMP_CTX_H
 #define CCMP_CTX_H

@@ -44,7 +44,7 @@ def main():
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     # the two adapter tests link a plain C++ program against the library: a sanitized library needs a sanitized link
     run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-m", "not gpu", "-s", "-p", "no:cacheprovider",
-                          "-k", "not cxx14 and not type_checks"], env=env, capture_output=True, text=True, cwd=ROOT)
+                          "-k", "not cxx14 and not type_checks and not dropin_headers"], env=env, capture_output=True, text=True, cwd=ROOT)
     text = run.stdout + run.stderr
     reports = re.findall(r".*(?:AddressSanitizer|runtime error).*", text)
     print("\n".join(text.strip().splitlines()[-3:]))
