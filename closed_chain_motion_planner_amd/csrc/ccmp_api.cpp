@@ -282,14 +282,17 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
     if (value < 0) return CCMP_EINVAL;
     ctx->fd_split_max = (size_t)value;
   } else if (!strcmp(name, "fd_split_pred")) { // predicted iterations from which a sample belongs to the front
-    if (value < 1 || value > 1023) return CCMP_EINVAL;
+    if ((value < 1 && value != -1) || value > 1023) return CCMP_EINVAL; // -1: by the batch size (ccmp_ctx.h)
     ctx->fd_split_pred = (int)value;
   } else if (!strcmp(name, "fd_split_group_cut")) { // throughput wavefronts per CU given up for the front's blocks
-    if (value < 0 || value > 8) return CCMP_EINVAL;
+    if (value < -1 || value > 8) return CCMP_EINVAL;
     ctx->fd_split_group_cut = (int)value;
   } else if (!strcmp(name, "fd_split_front")) { // latency blocks (= samples at most) of the front
-    if (value < 0 || value > 4096) return CCMP_EINVAL;
+    if (value < -1 || value > 4096) return CCMP_EINVAL;
     ctx->fd_split_front = (int)value;
+  } else if (!strcmp(name, "fd_split_samples")) { // samples of the front (0 = as many as blocks)
+    if (value < -1 || value > 0x7fffffffll) return CCMP_EINVAL;
+    ctx->fd_split_samples = value;
   } else if (!strcmp(name, "latency_blocks_per_cu")) { // persistent blocks of the projector's latency kernel per CU (8 resident)
     if (value < 1 || value > 32) return CCMP_EINVAL;
     ctx->latency_blocks_per_cu = (int)value;
@@ -415,6 +418,21 @@ static FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order)
     pl.latency_blocks = (int)(in_flight < lat_cap ? in_flight : lat_cap);
   }
   return pl;
+}
+
+// shape of the split launch's front for a batch of B samples (ccmp_ctx.h: fd_split*; an option that was set wins)
+struct SplitShape { int pred, blocks, cut; unsigned int samples; };
+static SplitShape split_shape(const ccmp_ctx *ctx, size_t B)
+{
+  const bool wide = B <= kSplitWideMax;
+  SplitShape s;
+  s.pred = ctx->fd_split_pred >= 0 ? ctx->fd_split_pred : (wide ? 40 : 56);
+  s.blocks = ctx->fd_split_front >= 0 ? ctx->fd_split_front : ctx->num_cus * (wide ? 2 : 1);
+  s.cut = ctx->fd_split_group_cut >= 0 ? ctx->fd_split_group_cut : (wide ? 3 : 2);
+  const long long per_cu = wide ? 4 : (B < 40960 ? 3 : 4);
+  const long long n = ctx->fd_split_samples > 0 ? ctx->fd_split_samples : (ctx->fd_split_samples == 0 ? s.blocks : per_cu * ctx->num_cus);
+  s.samples = (unsigned int)(n < s.blocks ? s.blocks : n);
+  return s;
 }
 
 // workspaces owned by the context; they grow outside any stream capture (the first call at a size is never captured)
@@ -551,15 +569,16 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     // iterations, at most fd_split_front — runs on latency blocks on the side stream FROM THE START, beside the throughput
     // kernel, which takes the rest of the order (two wavefronts per CU fewer: a latency block needs two SIMDs with a free
     // register slot, and the persistent throughput waves never leave theirs) and hands over as before.
-    if (pl.handover && ctx->flat_kernel && ctx->fd_split && B >= ctx->fd_split_min && B <= ctx->fd_split_max && ctx->fd_split_front > 0) {
+    const SplitShape sh = split_shape(ctx, B);
+    if (pl.handover && ctx->flat_kernel && ctx->fd_split && B >= ctx->fd_split_min && B <= ctx->fd_split_max && sh.blocks > 0) {
       fd_split = true;
-      HIP_TRY(ccmp_launch_fd_split(hist, ctx->fd_split_pred, (unsigned int)ctx->fd_split_front, ctx->queue, st));
+      HIP_TRY(ccmp_launch_fd_split(hist, sh.pred, sh.samples, ctx->queue, st));
       HIP_TRY(hipEventRecord(ctx->fork, st));
       HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 7, seed, first, ctx->pool, q_pool_count, mode,
-                                       ctx->fd_split_front, nullptr, 0, 0, ord, ctx->queue + 4, ctx->side));
+                                       sh.blocks, nullptr, 0, 0, ord, ctx->queue + 4, ctx->side));
       HIP_TRY(hipEventRecord(ctx->join, ctx->side));
-      const int room = ctx->num_cus * ((ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12) - ctx->fd_split_group_cut);
+      const int room = ctx->num_cus * ((ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12) - sh.cut);
       if (group_blocks > room) group_blocks = room;
     }
   }

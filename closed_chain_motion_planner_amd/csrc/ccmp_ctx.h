@@ -57,7 +57,8 @@ struct DeviceGuard {
 // 3072: +0.5 % / -8 %), which moved its crossover with scout + throughput kernel + split launch upward
 // (profiles/r04_small_batch_crossover.log, latency alone | split path, ms: Wine_Bottle 12288: 1.488 | 1.523, 14336: 1.694 | 1.608,
 // 16384: 1.917 | 1.677; stefan 12288: 2.324 | 2.753, 14336: 2.663 | 2.887, 16384: 3.028 | 3.029, 20480: 3.706 | 3.302)
-constexpr size_t kDefaultSmallBatch = 14336;
+constexpr size_t kDefaultSmallBatch = 10240; // (14336 before the wide split launch: profiles/r04_hybrid_launch_sweep.log)
+constexpr size_t kSplitWideMax = 24576;     // split launch: up to here two latency blocks per CU (ccmp_ctx: fd_split*)
 constexpr size_t kDefaultLatencyOrderMin = 3072;
 constexpr size_t kDefaultLptMinBatch = 16384;  // from here on the scout pays (round 3: its predictions also sort the hand-over into two classes
                                                // and its sort lost 0.09 ms; Wine_Bottle / stefan, ms without | with: 16384: 1.99 | 1.92 / 3.16 | 3.15;
@@ -109,11 +110,20 @@ struct ccmp_ctx {
   //   stefan      10240: 2.397 | 2.60    12288: 2.724 | 2.74    16384: 3.05 | 3.01    32768: 4.65 | 4.67     65536: 7.47 | 7.66   81920: 9.37 | 9.27
   // (stefan / dumbbell: thousands of samples never converge — the front is full of them whatever it takes; neutral.)  A cut of
   // one wavefront per CU leaves the blocks nowhere to go (+5 % from 28672 on); 128 instead of 256 blocks: +1 %.
+  // Late round 4: the front's blocks go on with the next-longest samples (fd_split_samples > blocks), and its shape follows the
+  // batch (-1 = by the rule below; profiles/r04_hybrid_launch_sweep.log, ms, old shape | new):
+  //   up to kSplitWideMax samples the throughput kernel fills half the chip or less and latency blocks fit beside it without
+  //   displacing anything: 2 blocks per CU, samples predicted >= 40, up to 4 samples per CU, 3 wavefronts per CU left out —
+  //   Wine_Bottle 12288: 1.443 (latency kernel alone) | 1.388   14336: 1.660 | 1.484   16384: 1.63 | 1.57   20480: 1.804 | 1.771
+  //   stefan      12288: 2.290 | 2.106   14336: 2.635 | 2.293   16384: 2.98 | 2.47   20480: 3.226 | 3.147   24576: 3.56 | 3.54
+  //   above: 1 block per CU, predicted >= 56, 2 wavefronts left out as before, up to 3 (from 40960: 4) samples per CU —
+  //   Wine_Bottle 28672: 2.273 | 2.227   32768: 2.535 | 2.493   49152: 3.525 | 3.424   65536: 4.591 | 4.453   stefan 65536: 7.644 | 7.495
   int fd_split = 1;
-  size_t fd_split_min = 12288, fd_split_max = 90112;
-  int fd_split_pred = 56;                // predicted iterations from which a sample goes to the front ...
-  int fd_split_front = 256;              // ... at most this many (one latency block each: one per CU)
-  int fd_split_group_cut = 2;            // throughput wavefronts per CU the split launch leaves out
+  size_t fd_split_min = 0, fd_split_max = 90112; // (batches <= small_batch never get here)
+  int fd_split_pred = -1;                // predicted iterations from which a sample goes to the front ...
+  int fd_split_front = -1;               // ... on this many latency blocks ...
+  long long fd_split_samples = -1;       // ... at most this many samples (0 = one per block); more: the blocks go on with the next-longest
+  int fd_split_group_cut = -1;           // throughput wavefronts per CU the split launch leaves out
   size_t latency_order_min = kDefaultLatencyOrderMin; // latency kernel alone (batches <= small_batch): FP32 scout order from this many samples on
   // FP32 scouts on LANE PAIRS (round 4, ccmp_kernels_scout.hip): the even lane takes arm 0, the odd lane arm 1 — half the chain
   // work per lane and round, and the scout's run time is its longest lane's.  Same predictions (equal to the one-lane scout's on

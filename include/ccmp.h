@@ -156,9 +156,11 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
  * 64), "geodesic_flavour" (the extend step is built twice from one source — same bits: 0 = throughput build for calls with a
  * round budget and more edges than the latency build has blocks, latency build otherwise (default); 1 / 2 = always the throughput
  * / latency build), "geodesic_blocks_per_cu" (persistent blocks of the latency build per CU; default 4); reference arithmetic, mid-size batches: "fd_split" (1 = split
- * launch, default: for batches of fd_split_min..fd_split_max samples, default 12288..90112, the samples the FP32 scout predicts
- * to need at least "fd_split_pred" iterations, default 56 — at most "fd_split_front", default 256 — run on latency blocks on a
- * side stream beside the throughput kernel, which gives up "fd_split_group_cut" wavefronts per CU, default 2; 0 = off);
+ * launch, default: for batches above small_batch and up to "fd_split_max" samples, default 90112, the samples the FP32 scout predicts
+ * to need at least "fd_split_pred" iterations — at most "fd_split_samples" — run on "fd_split_front" latency blocks on a side
+ * stream beside the throughput kernel, which gives up "fd_split_group_cut" wavefronts per CU; the four follow the batch size
+ * when left at -1, the default: up to 24576 samples two blocks per CU, predictions >= 40, four samples per CU, a cut of 3;
+ * above one block per CU, >= 56, three to four samples per CU, a cut of 2; 0 = off);
  * the FP32 scouts: "scout_pairs" (1 = two lanes per sample / edge,
  * one arm each, where lanes are plentiful — projector batches of up to 128 x "scout_pair_blocks_per_cu" (default 1) x CUs samples,
  * extend-step batches of up to "scout_pair_max_edges" (default 131072) edges; stock twin arms only; default 1);

@@ -173,12 +173,14 @@ def test_schedules_are_bitwise_identical(gpu_ctx, oracle_det, schedule, small, l
     assert it_cpu.max() == 250  # the cap was exercised
 
 
-@pytest.mark.parametrize("obj,pred,front", [("stefan", 40, 64), ("stefan", 96, 7), ("Wine_Bottle", 30, 500), ("Wine_Bottle", 1, 3)])
-def test_split_launch_is_bitwise_identical(gpu_ctx, oracle_det, obj, pred, front):
+@pytest.mark.parametrize("obj,pred,front,samples", [("stefan", 40, 64, 0), ("stefan", 96, 7, 50), ("Wine_Bottle", 30, 500, -1), ("Wine_Bottle", 1, 3, 0),
+                                                    ("Wine_Bottle", 20, 16, 6000)])
+def test_split_launch_is_bitwise_identical(gpu_ctx, oracle_det, obj, pred, front, samples):
     """The split launch of mid-size batches (option "fd_split"): the front of the scout's descending order — samples predicted
     >= `pred` iterations, at most `front` — runs on latency blocks on the side stream beside the throughput kernel, the rest
     goes the usual way (throughput kernel, two-class hand-over).  A front smaller and larger than the number of such samples,
-    a front of everything predicted at all, q_in and the fused sampler: bit-identical to the oracle."""
+    a front of everything predicted at all, blocks that go on with the next-longest samples (`samples` > `front`; 0 = one per
+    block, -1 = the default for the batch size) up to the whole batch, q_in and the fused sampler: bit-identical to the oracle."""
     import torch
 
     c = _constraint(obj, gpu_ctx)
@@ -188,7 +190,7 @@ def test_split_launch_is_bitwise_identical(gpu_ctx, oracle_det, obj, pred, front
     q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
     gpu_ctx.set_schedule(1, 0)
     gpu_ctx.set_lpt(1, 0)
-    for name, val in (("fd_split", 1), ("fd_split_min", 0), ("fd_split_pred", pred), ("fd_split_front", front)):
+    for name, val in (("fd_split", 1), ("fd_split_min", 0), ("fd_split_pred", pred), ("fd_split_front", front), ("fd_split_samples", samples)):
         gpu_ctx.set_option(name, val)
     try:
         for _ in range(2):  # twice: queue words and events are reused
@@ -205,7 +207,7 @@ def test_split_launch_is_bitwise_identical(gpu_ctx, oracle_det, obj, pred, front
     finally:
         gpu_ctx.set_schedule(1)
         gpu_ctx.set_lpt(1)
-        for name, val in (("fd_split", 1), ("fd_split_min", 12288), ("fd_split_pred", 56), ("fd_split_front", 256)):
+        for name, val in (("fd_split", 1), ("fd_split_min", 0), ("fd_split_pred", -1), ("fd_split_front", -1), ("fd_split_samples", -1)):
             gpu_ctx.set_option(name, val)
 
 
