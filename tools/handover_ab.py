@@ -26,7 +26,7 @@ def mean(fn, reps=10):
 
 for obj in sys.argv[1:] or ["Wine_Bottle", "stefan"]:
     c = KinematicChainConstraint.from_yaml("tests/golden/config/%s.yaml" % obj, ctx=ctx)
-    for B in (16384, 24576, 32768, 40960, 49152, 65536):
+    for B in (12288, 16384, 20480, 24576, 32768, 40960, 49152, 57344, 65536):
         q = c.ambient_uniform_batch(0xC3, 0, B)
         out = torch.empty_like(q)
         c.project_batch(q, out=out)
