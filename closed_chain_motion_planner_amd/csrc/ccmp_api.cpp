@@ -42,6 +42,7 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned int done_seq, size_t pool_records, const unsigned int *order,
                                     const unsigned long long *total_ptr, hipStream_t st);
 hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st);
+hipError_t ccmp_launch_geo_split(const unsigned int *hist, int p_min, int p_max, int permille, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
                                     uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
@@ -66,11 +67,15 @@ hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride,
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
+                                const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr, hipStream_t st);
 hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                     size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                     int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                    const double *carry_in, double *carry_out, int round_budget, hipStream_t st);
+                                    const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr, hipStream_t st);
+hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
+                                      int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
+                                      unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
+                                      hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -163,7 +168,7 @@ int ccmp_ctx_create(int device, ccmp_ctx **out)
   ctx->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate"); }
-  e = hipMalloc((void **)&ctx->queue, (8 + 64 + 4) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64 + 3: analytic kernels; 1: split count
+  e = hipMalloc((void **)&ctx->queue, (kGeoGroupWords + 8) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64 + 3: analytic kernels; 1: split count
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return hip_fail(e, "hipMalloc(queue)"); }
   // side stream of the analytic mode's split launches (latency kernel beside the throughput kernel) and the two events
   // that order it against the caller's stream
@@ -290,6 +295,24 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "fd_split_front")) { // latency blocks (= samples at most) of the front
     if (value < -1 || value > 4096) return CCMP_EINVAL;
     ctx->fd_split_front = (int)value;
+  } else if (!strcmp(name, "geodesic_group")) { // bulk extend calls: short edges on the throughput layout (1 = on)
+    if (value != 0 && value != 1) return CCMP_EINVAL;
+    ctx->geodesic_group = (int)value;
+  } else if (!strcmp(name, "geodesic_group_min")) {
+    if (value < 0) return CCMP_EINVAL;
+    ctx->geodesic_group_min = (size_t)value;
+  } else if (!strcmp(name, "geodesic_group_pred")) { // predicted Newton rounds from which an edge goes to the latency blocks
+    if (value < 1 || value > 1023) return CCMP_EINVAL;
+    ctx->geodesic_group_pred = (int)value;
+  } else if (!strcmp(name, "geodesic_group_permille")) { // share of the predicted work the front must carry (0 = cut at geodesic_group_pred)
+    if (value < 0 || value > 1000) return CCMP_EINVAL;
+    ctx->geodesic_group_permille = (int)value;
+  } else if (!strcmp(name, "geodesic_group_front_per_cu")) {
+    if (value < 1 || value > 8) return CCMP_EINVAL;
+    ctx->geodesic_group_front_per_cu = (int)value;
+  } else if (!strcmp(name, "geodesic_group_waves_per_cu")) {
+    if (value < 1 || value > 10) return CCMP_EINVAL;
+    ctx->geodesic_group_waves_per_cu = (int)value;
   } else if (!strcmp(name, "fd_split_samples")) { // samples of the front (0 = as many as blocks)
     if (value < -1 || value > 0x7fffffffll) return CCMP_EINVAL;
     ctx->fd_split_samples = value;
@@ -686,6 +709,7 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   size_t nb = E;
   unsigned long long *queue = nullptr;
   const unsigned int *order = nullptr;
+  bool scouted = false; // `order` is the FP32 scout's longest-first order and its histogram is in place
   if (E > resident) {
     nb = resident;
     queue = ctx->queue + 3; // word 3: ticket; word 4: the two counters of the ordering pass
@@ -701,15 +725,40 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
         // capped) -> predicted Newton rounds -> descending counting sort: longest-predicted-first
         HIP_TRY(ccmp_launch_geodesic_scout_order(&K, from, to, E, p->delta, p->lambda, max_states, ctx->geodesic_scout_rounds,
                                                  (uint16_t *)base, hist, ord, ctx->scout_pairs && E <= ctx->scout_pair_max_edges, st));
+        scouted = true;
       } else {
         HIP_TRY(ccmp_launch_geodesic_order(from, to, E, ctx->geodesic_long_steps * p->delta, (unsigned int *)(ctx->queue + 4), ord, st));
       }
       order = ord;
     }
   }
+  // Bulk calls (round budget, thousands of edges, scout order): the SHORT edges run on the throughput layout — ten edges per
+  // wavefront, geodesic_group_kernel, less than half the instructions per Newton round — and the front of the order, the edges
+  // predicted to need geodesic_group_pred rounds or more, on this kernel's blocks on the side stream, both from the start.
+  if (scouted && round_budget > 0 && !check_target && !carry_in && ctx->geodesic_group && E >= ctx->geodesic_group_min) {
+    unsigned long long *gq = ctx->queue + kGeoGroupWords; // [0] group kernel's ticket (starts behind the front), [4] front length, [5] front's ticket
+    unsigned int *hist = (unsigned int *)((char *)ctx->lpt_buf + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
+    HIP_TRY(ccmp_launch_clear_words(gq, 16, st));
+    if (ctx->geodesic_group_permille > 0)
+      HIP_TRY(ccmp_launch_geo_split(hist, 8, ctx->geodesic_group_pred, ctx->geodesic_group_permille, gq, st));
+    else
+      HIP_TRY(ccmp_launch_fd_split(hist, ctx->geodesic_group_pred, 0xffffffffu, gq, st));
+    HIP_TRY(hipEventRecord(ctx->fork, st));
+    HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
+    HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, 0,
+                                 ctx->num_cus * ctx->geodesic_group_front_per_cu, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, ctx->side));
+    HIP_TRY(hipEventRecord(ctx->join, ctx->side));
+    size_t waves = (E + 9) / 10;
+    const size_t cap = (size_t)ctx->num_cus * (size_t)ctx->geodesic_group_waves_per_cu;
+    if (waves > cap) waves = cap;
+    HIP_TRY(ccmp_launch_geodesic_group(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, (int)waves, gq, order,
+                                       carry_out, round_budget, st));
+    HIP_TRY(hipStreamWaitEvent(st, ctx->join, 0));
+    return CCMP_OK;
+  }
   HIP_TRY((latency_flavour ? ccmp_launch_geodesic_lat : ccmp_launch_geodesic)(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok,
                                                                              newton_iters, check_target, (int)nb, queue, order, carry_in, carry_out,
-                                                                             round_budget, st));
+                                                                             round_budget, nullptr, st));
   return CCMP_OK;
 }
 

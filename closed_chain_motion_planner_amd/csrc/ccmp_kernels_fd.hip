@@ -596,6 +596,273 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------
+// geodesic_group_kernel — the extend step (jy_ProjectedStateSpace::discreteGeodesic, src/base/jy_ProjectedStateSpace.cpp:
+// 32-96) on the THROUGHPUT layout: ten edges x six lanes per wavefront, the Newton iteration of project_fd_kernel (the same
+// device functions in the same order: same bits), and at the point where that kernel writes a finished sample back, the
+// reference's bookkeeping between two projections — jointValid, the four break tests, the state list, the next
+// interpolated state (geodesic_flat_kernel's, statement for statement: ccmp_kernels_geo.hip) — instead.  A Newton round
+// costs this layout ~1 250 wave-instructions per edge against the latency kernel's ~2 700, and ~12 times the latency: it
+// serves the SHORT edges of a bulk call (round budget, thousands of edges), beside geodesic_flat_kernel, which takes the
+// front of the FP32 scout's longest-first order on the side stream (ccmp_api.cpp: geodesic_common).  interpolate == true
+// semantics; first calls only (carry_out / round_budget as in the latency kernel; no carry_in, no check_target form).
+// Per-edge state lives in the group's LDS record behind the projector's 165 doubles: previous accepted state (14), dist,
+// running length, bound (3), and three counters — 185 doubles per group, 10 wavefronts per CU.
+constexpr int kGPrev = kRec, kGDist = kRec + 14, kGCnt = kRec + 17, kRecG = kRec + 20; // odd stride like kRec
+static_assert(kRecG % 2 == 1, "odd record stride: the ten groups stay on distinct LDS banks");
+
+// WrapperStateSpace::interpolate through KinematicChainSpace::interpolate (KinematicChain.h:145-171), one joint
+__device__ __forceinline__ double geo_interpolate(double fr, double tg, double tt)
+{
+  const double pi = 3.14159265358979323846;
+  double diff = tg - fr, v;
+  if (ccmp_abs(diff) <= pi) v = CCMP_FMA(diff, tt, fr);
+  else {
+    if (diff > 0.0) diff = 2.0 * pi - diff;
+    else diff = -2.0 * pi - diff;
+    v = CCMP_FMA(-diff, tt, fr);
+    if (v > pi) v -= 2.0 * pi;
+    else if (v < -pi) v += 2.0 * pi;
+  }
+  return v;
+}
+
+template <bool STOCK>
+__global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_kernel(
+    const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from, const double *__restrict__ to,
+    unsigned long long E, int max_states, double *__restrict__ states, int *__restrict__ n_states, uint8_t *__restrict__ ok_out,
+    int *__restrict__ newton_iters, unsigned long long *queue, const unsigned int *__restrict__ order,
+    double *__restrict__ carry_out, int round_budget)
+{
+  __shared__ double lds[kGroupsPerWave * kRecG];
+  const int lane = threadIdx.x;
+  const int g = lane / kGroup;
+  const int r = lane - kGroup * g;
+  const bool live = g < kGroupsPerWave;
+  const int leader = live ? kGroup * g : 0;
+  double *rec = lds + (live ? g : 0) * kRecG; // idle lanes alias group 0 for reads, never write
+  const bool writer = live && r == 0;
+  const bool plus = r < 3;
+  const int nstep = (plus ? r : r - 3) + 1;
+  const int arm_l = plus ? 0 : 1, row_l = plus ? r : r - 3;
+  double d_lane = 0.0, bp_lane = 0.0;
+  if constexpr (STOCK) {
+    d_lane = arm_l ? (row_l == 0 ? K.base_R[1][0] : (row_l == 1 ? K.base_R[1][4] : K.base_R[1][8]))
+                   : (row_l == 0 ? K.base_R[0][0] : (row_l == 1 ? K.base_R[0][4] : K.base_R[0][8]));
+    bp_lane = arm_l ? (row_l == 0 ? K.base_p[1][0] : (row_l == 1 ? K.base_p[1][1] : K.base_p[1][2]))
+                    : (row_l == 0 ? K.base_p[0][0] : (row_l == 1 ? K.base_p[0][1] : K.base_p[0][2]));
+  }
+
+  unsigned long long edge = 0;
+  int iter = 0, updates = 0;
+  double norm1 = 0.0, norm2 = 0.0;
+  bool active = false, drained = false;
+
+  for (;;) {
+    // ---- refill: a group without an edge takes the next ticket and sets the edge up (the reference's prologue) ----------
+    {
+      const bool want = live && !active && !drained;
+      unsigned long long t = 0;
+      if (want && r == 0) t = atomicAdd(queue, 1ull);
+      t = shfl_u64(t, leader);
+      if (want) {
+        if (t < E) {
+          edge = order ? (unsigned long long)order[t] : t;
+          const double *fr = from + edge * 14ull, *tg = to + edge * 14ull;
+          double *out = states + edge * (unsigned long long)max_states * 14ull;
+          double acc = 0.0; // RealVectorStateSpace::distance(from, to): serial sum in the canonical order, every lane for itself
+#pragma unroll
+          for (int i = 0; i < 14; i++) {
+            const double diff = fr[i] - tg[i];
+            acc = CCMP_FMA(diff, diff, acc);
+          }
+          const double dist = ccmp_sqrt(acc);
+          const double total = 0.0, maxd = dist * lambda;
+          const bool enter = dist > delta; // (continuations — carry_in — are few edges and stay on geodesic_flat_kernel)
+          const double tt = delta / dist;
+          for (int e = r; e < 14; e += kGroup) {
+            const double a = fr[e];
+            rec[kGPrev + e] = a;
+            if (max_states > 0) out[e] = a; // geodesic->push_back(cloneState(from))
+            if (enter) rec[kX + e] = geo_interpolate(a, tg[e], tt);
+          }
+          if (r == 0) {
+            rec[kGDist] = dist;
+            rec[kGDist + 1] = total;
+            rec[kGDist + 2] = maxd;
+            int *cnt = reinterpret_cast<int *>(rec + kGCnt);
+            cnt[0] = 1; cnt[1] = 0; cnt[2] = 0; // states listed, Newton updates, Newton rounds of this call
+          }
+          if (enter) {
+            active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+          } else if (r == 0) { // within delta already (or a continuation that has arrived): nothing to traverse
+            n_states[edge] = 1;
+            ok_out[edge] = (uint8_t)(dist <= delta);
+            if (newton_iters) newton_iters[edge] = 0;
+            if (carry_out) { carry_out[2ull * edge] = total; carry_out[2ull * edge + 1ull] = maxd; }
+          }
+        } else drained = true;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) {
+      if (__builtin_amdgcn_ballot_w64(live && !drained) == 0ull) break; // nothing in flight and the queue is empty
+      continue;                                                          // edges that needed no traversal: take the next tickets
+    }
+    __syncthreads();
+
+    // ---- phase 1: function(x) — sines/cosines, both chains, residual (project_fd_kernel's) -------------------------------
+    for (int e = r; e < 14; e += kGroup) {
+      double s, c;
+      ccmp_sincos(rec[kX + e], &s, &c);
+      if (live) { rec[kSC + 2 * e] = s; rec[kSC + 2 * e + 1] = c; }
+    }
+    __syncthreads();
+    bool cont = false;
+    double f0, f1;
+    {
+      double T0[12], T1[12], f[2];
+      if constexpr (STOCK && CCMP_FD_ROWS) {
+        chain_rows<true>(K, rec, arm_l, row_l, live, 0, d_lane, bp_lane);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 12; k++) { T0[k] = rec[kEE + k]; T1[k] = rec[kEE + 12 + k]; }
+      } else {
+        chain_at_x<1, false, STOCK>(K, rec, writer, T1);
+        if (writer) {
+#pragma unroll
+          for (int k = 0; k < 12; k++) rec[kEE + 12 + k] = T1[k];
+        }
+        chain_at_x<0, true, STOCK>(K, rec, writer, T0);
+        if (writer) {
+#pragma unroll
+          for (int k = 0; k < 12; k++) rec[kEE + k] = T0[k];
+        }
+      }
+      chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
+      f0 = f[0]; f1 = f[1];
+      if (active) { // loop condition of ConstraintFunction.h:68, quirks included
+        const bool c1 = f[0] > K.tol_pos;
+        norm1 = c1 ? 1.0 : 0.0;
+        bool resid = c1;
+        if (!c1) { norm2 = f[1]; resid = f[1] > K.tol_rot; }
+        if (resid) { cont = iter < K.max_iter; iter++; }
+      }
+    }
+    // ---- a projection has ended: the reference's bookkeeping between two projections (jy_ProjectedStateSpace.cpp:65-90) --
+    {
+      const bool fin = active && !cont;
+      bool bad = false;
+      if (fin) {
+#pragma unroll
+        for (int e = 0; e < 14; e++) {
+          if (e % kGroup == r) {
+            const double v = rec[kX + e];
+            if (v < K.lbe[e % 7]) bad = true;
+            if (v > K.ube[e % 7]) bad = true;
+          }
+        }
+      }
+      const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);
+      if (fin) {
+        const bool jv = ((badmask >> leader) & 0x3Full) == 0ull;         // jointValid(x)
+        const bool conv = (norm1 < K.tol_pos) && (norm2 < K.tol_rot);     // project's return test
+        int *cnt = reinterpret_cast<int *>(rec + kGCnt);
+        int n = cnt[0], its = cnt[1] + updates;
+        const int rounds = cnt[2] + updates + 1;
+        double dist = rec[kGDist], total = rec[kGDist + 1];
+        const double maxd = rec[kGDist + 2];
+        const double *tg = to + edge * 14ull;
+        double *out = states + edge * (unsigned long long)max_states * 14ull;
+        double s_acc = 0.0, d_acc = 0.0; // distance(previous, scratch), distance(scratch, to): two serial sums side by side
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+          const double xi = rec[kX + i];
+          const double ds = rec[kGPrev + i] - xi, dd = xi - tg[i];
+          s_acc = CCMP_FMA(ds, ds, s_acc);
+          d_acc = CCMP_FMA(dd, dd, d_acc);
+        }
+        bool done = true, fits = true, suspended = false;
+        do {
+          if (!(conv && jv)) break;                        // not on manifold
+          const double step = ccmp_sqrt(s_acc), newDist = ccmp_sqrt(d_acc);
+          if (step > lambda * delta) break;                // deviated
+          const double total_before = total;
+          total += step;
+          if (total > maxd) break;                         // wandered too far
+          if (newDist >= dist) break;                      // no closer than before
+          if (n >= max_states) { fits = false; n = max_states + 1; total = total_before; its -= updates; break; } // list full
+          dist = newDist;
+          for (int e = r; e < 14; e += kGroup) out[(unsigned long long)n * 14ull + e] = rec[kX + e];
+          n++;
+          if (!(dist >= delta)) break;                     // arrived
+          if (round_budget > 0 && rounds >= round_budget) { suspended = true; break; } // this call's share of the edge is spent
+          done = false;
+        } while (0);
+        if (done) {
+          if (r == 0) {
+            n_states[edge] = n;
+            ok_out[edge] = suspended ? (uint8_t)2 : (uint8_t)(fits && dist <= delta);
+            if (newton_iters) newton_iters[edge] = its;
+            if (carry_out) { carry_out[2ull * edge] = total; carry_out[2ull * edge + 1ull] = maxd; }
+          }
+          active = false;
+        } else { // the accepted state becomes `previous`; the next scratch state is interpolated towards the target
+          const double tt = delta / dist;
+          for (int e = r; e < 14; e += kGroup) {
+            const double a = rec[kX + e];
+            rec[kGPrev + e] = a;
+            rec[kX + e] = geo_interpolate(a, tg[e], tt);
+          }
+          if (r == 0) {
+            cnt[0] = n; cnt[1] = its; cnt[2] = rounds;
+            rec[kGDist] = dist;
+            rec[kGDist + 1] = total;
+          }
+          iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue; // nobody iterates: back to the top (refill, next function(x))
+    __syncthreads();
+
+    // ---- phase 2: OMPL's default Constraint::jacobian; Newton update (project_fd_kernel's) --------------------------------
+    jacobian_columns<0, STOCK>(K, rec, live, r, plus, nstep);
+    __syncthreads();
+    stencil_combine<0>(rec, r, live);
+    __syncthreads();
+    if constexpr (STOCK && CCMP_FD_ROWS) {
+      chain_rows<false>(K, rec, arm_l, row_l, live, 1, d_lane, bp_lane);
+    } else {
+      double T1[12];
+      chain_at_x<1, true, STOCK>(K, rec, writer, T1);
+    }
+    __syncthreads();
+    jacobian_columns<1, STOCK>(K, rec, live, r, plus, nstep);
+    __syncthreads();
+    stencil_combine<1>(rec, r, live);
+    __syncthreads();
+    {
+      double Jr[28], dx[14];
+#pragma unroll
+      for (int j = 0; j < 7; j++) {
+        Jr[j] = rec[kJ0 + 2 * j];
+        Jr[14 + j] = rec[kJ0 + 2 * j + 1];
+        Jr[7 + j] = rec[kSC + 2 * j];
+        Jr[21 + j] = rec[kSC + 2 * j + 1];
+      }
+      solve_minnorm(Jr, f0, f1, dx);
+      if (cont) {
+#pragma unroll
+        for (int e = 0; e < 14; e++)
+          if (e % kGroup == r) rec[kX + e] = CCMP_FMA(-K.step, dx[e], rec[kX + e]);
+        updates++;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
 // Workspace words (queue heads, counters, the scout's histogram) are cleared by a kernel, not by hipMemsetAsync: a kernel
 // node is what a stream capture records and every replay of the graph executes (with hipMemsetAsync the first replay of a
 // captured call worked and every later one found the queues exhausted and the histogram still full).
@@ -790,6 +1057,21 @@ __global__ void compact_scatter_kernel(const double *__restrict__ q, const uint8
 
 // ---- launchers (called from ccmp_api.cpp) --------------------------------------------------------
 extern "C" {
+
+// the extend step's short edges on the throughput layout (geodesic_group_kernel): one-wavefront workgroups, ten edges each
+hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
+                                      int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
+                                      unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
+                                      hipStream_t st)
+{
+  if (K->stock)
+    hipLaunchKernelGGL(geodesic_group_kernel<true>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget);
+  else
+    hipLaunchKernelGGL(geodesic_group_kernel<false>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget);
+  return hipGetLastError();
+}
 
 hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st)
 {

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,
     unsigned long long *queue, const unsigned int *__restrict__ order, const double *__restrict__ carry_in,
-    double *__restrict__ carry_out, int round_budget)
+    double *__restrict__ carry_out, int round_budget, const unsigned long long *__restrict__ total_ptr)
 {
   __shared__ __attribute__((aligned(16))) double lds[gRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
       __syncthreads();
       tk = ticket;
     }
-    if (tk >= E) break;
+    // total_ptr (bulk calls, ccmp_api.cpp: geodesic_common): this launch takes the first *total_ptr tickets of the order — the
+    // edges the scout predicts longest — beside geodesic_group_kernel, which takes the rest
+    if (tk >= (total_ptr ? *total_ptr : E)) break;
     const unsigned long long t = order ? (unsigned long long)order[tk] : tk;
 #ifdef CCMP_GEO_TRACE
     if (tid == 0 && t < 65536) { g_geo_trace[3 * t] = wall_clock64(); g_geo_trace[3 * t + 2] = ((unsigned long long)blockIdx.x << 32) | tk; }
@@ -250,14 +252,14 @@ extern "C" {
 hipError_t CCMP_LAUNCH_GEODESIC(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, int round_budget, hipStream_t st)
+                                const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr, hipStream_t st)
 {
   if (K->stock)
     hipLaunchKernelGGL(geodesic_flat_kernel<true>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr);
   else
     hipLaunchKernelGGL(geodesic_flat_kernel<false>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr);
   return hipGetLastError();
 }
 

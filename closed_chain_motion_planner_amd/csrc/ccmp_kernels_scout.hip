@@ -820,9 +820,45 @@ __global__ void fd_split_kernel(const unsigned int *__restrict__ hist, int pred_
   }
 }
 
+// Bulk extend calls (ccmp_api.cpp: geodesic_common): where to cut the scout's descending order between the latency blocks (front)
+// and the throughput layout (rest).  hist[k] = number of edges predicted >= k rounds (hist[0] = all), so the predicted work of
+// the edges predicted >= P is P * hist[P] + sum_{j > P} hist[j] and all of it is sum_{j >= 1} hist[j].  The cut is the LARGEST
+// P <= p_max whose front carries at least permille / 1000 of the predicted work — the front's share follows the batch's own
+// distribution (stefan's edges need more rounds than Wine_Bottle's), p_max bounds the longest edge the slow-per-round layout
+// is given.  queue[4] = front length, queue[0] = the group kernel's first ticket, as fd_split_kernel leaves them.
+__global__ __launch_bounds__(64) void geo_split_kernel(const unsigned int *__restrict__ hist, int p_min, int p_max, int permille,
+                                                       unsigned long long *__restrict__ queue)
+{
+  __shared__ unsigned int n[kBins];
+  for (int k = threadIdx.x; k < kBins; k += 64) n[k] = hist[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long all = 0;
+    for (int j = 1; j < kBins; j++) all += n[j];
+    if (p_max > kBins - 1) p_max = kBins - 1;
+    unsigned long long above = 0; // sum_{j > P} hist[j]
+    for (int j = kBins - 1; j > p_max; j--) above += n[j];
+    int P = p_max;
+    for (; P > p_min; P--) {
+      if (((unsigned long long)P * n[P] + above) * 1000ull >= all * (unsigned long long)permille) break;
+      above += n[P];
+    }
+    const unsigned long long front = n[P];
+    queue[4] = front;
+    queue[0] = front;
+    queue[3] = (unsigned long long)P; // for inspection (ccmp_ctx_debug): the cut that was taken
+  }
+}
+
 } // namespace
 
 extern "C" hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st); // ccmp_kernels_fd.hip
+
+extern "C" hipError_t ccmp_launch_geo_split(const unsigned int *hist, int p_min, int p_max, int permille, unsigned long long *queue, hipStream_t st)
+{
+  hipLaunchKernelGGL(geo_split_kernel, dim3(1), dim3(64), 0, st, hist, p_min, p_max, permille, queue);
+  return hipGetLastError();
+}
 
 extern "C" hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st)
 {

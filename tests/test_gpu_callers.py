@@ -550,6 +550,64 @@ def test_geodesic_flavours_are_bitwise_identical(gpu_ctx, oracle_det):
         assert np.array_equal(got[0][E - 128 + k, :m].cpu().numpy().view(np.uint64), s_cpu[k, :m].view(np.uint64))
 
 
+def test_bulk_extend_hybrid_is_bitwise_identical(gpu_ctx, oracle_det):
+    """Bulk extend calls (round budget, scout order) put their short edges on the throughput layout — geodesic_group_kernel, ten
+    edges per wavefront — and the front of the scout's order on latency blocks beside them.  Forced at a size the CPU checks in
+    seconds: everything on the group kernel, a mixed split, a split by share of the predicted work, nearly everything on the front —
+    states, counts, flags (list full, budget spent, arrived, given up), Newton counts and carries equal the latency kernel's alone
+    and, on a slice, the oracle's; then every edge that stopped short is continued and equals the oracle's uninterrupted traversal."""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    E = 8 * gpu_ctx.num_cus + 1200
+    q, ok, _, _ = c.sample_project_batch(0x6F5, 0, 8 * E, want_iters=False)
+    frm = q[ok == 1][:E].contiguous()
+    to, _, _, _ = c.sample_near_project_batch(0x6F6, 0, frm, 0.6, E, want_iters=False)
+    to[:16] = frm[:16] + 0.01   # within delta: nothing to traverse (n = 1, ok = 1)
+    to[16:24] = frm[16:24]      # from == to
+    cap, budget = 4, 30
+    opts = ("geodesic_group", "geodesic_group_min", "geodesic_group_pred", "geodesic_group_permille", "geodesic_scout_min")
+    try:
+        gpu_ctx.set_option("geodesic_scout_min", 0)
+        gpu_ctx.set_option("geodesic_group", 0)
+        ref = c.discrete_geodesic_batch(frm, to, cap, want_carry=True, round_budget=budget)
+        torch.cuda.synchronize()
+        live = torch.arange(cap, device=frm.device)[None, :] < ref[1].clamp(max=cap)[:, None]
+        assert int((ref[2] == 2).sum()) > 50 and int((ref[1] > cap).sum()) > 50 and int((ref[1] == 1).sum()) >= 24
+        gpu_ctx.set_option("geodesic_group", 1)
+        gpu_ctx.set_option("geodesic_group_min", 0)
+        for pred, permille in ((1023, 0), (12, 0), (64, 300), (1, 0)):
+            gpu_ctx.set_option("geodesic_group_pred", pred)
+            gpu_ctx.set_option("geodesic_group_permille", permille)
+            for _ in range(2):  # twice: queue words and events are reused
+                got = c.discrete_geodesic_batch(frm, to, cap, want_carry=True, round_budget=budget)
+                torch.cuda.synchronize()
+                for k in (1, 2, 3, 4):
+                    assert torch.equal(got[k], ref[k]), (pred, permille, k)
+                assert torch.equal(got[0][live], ref[0][live]), (pred, permille)
+        # the last setting's result against the oracle: first pass on a slice, then the continued edges whole
+        st, n, okf, its, carry = got
+        sl = slice(0, 160)
+        for e in range(sl.start, sl.stop):
+            ok_e, st_e, n_e, its_e, carry_e = oracle_det.discrete_geodesic_ex(P, frm[e].cpu().numpy(), to[e].cpu().numpy(), cap)
+            if int(okf[e]) == 2:
+                continue  # suspended by the budget: compared through its continuation below
+            assert int(n[e]) == n_e and bool(okf[e]) == bool(ok_e) and int(its[e]) == its_e, e
+            assert np.array_equal(st[e, : min(n_e, cap)].cpu().numpy().view(np.uint64), st_e.view(np.uint64)), e
+        gpu_ctx.set_option("geodesic_group_pred", 1023)  # continuations are few edges: they stay on the latency kernel whatever is set
+        whole = c.continue_geodesics(to, st, n, okf, its, carry, cap, round_budget=budget)
+        assert set(whole) == set(np.nonzero(((n > cap) | (okf == 2)).cpu().numpy())[0].tolist())
+        for e in sorted(whole)[:120]:
+            ok_cpu, st_cpu, its_cpu = oracle_det.discrete_geodesic(P, frm[e].cpu().numpy(), to[e].cpu().numpy(), interpolate=True, max_states=512)
+            got_e, ok_e, its_e = whole[e]
+            assert got_e.shape == st_cpu.shape and np.array_equal(np.ascontiguousarray(got_e).view(np.uint64), st_cpu.view(np.uint64)), e
+            assert bool(ok_e) == ok_cpu and its_e == its_cpu, e
+    finally:
+        for name, val in zip(opts, (1, 40960, 64, 0, 6144)):
+            gpu_ctx.set_option(name, val)
+
+
 def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):
     """more edges than resident blocks (8 per CU): persistent blocks + ticket queue, with and without the long-edges-first
     order — the same bits as the one-block-per-edge launches of the same edges, and as the oracle on a slice"""
