@@ -535,6 +535,8 @@ def flatten_for_the_driver(line, B):
             "extend_bitwise": None if get(geo, "parity_vs_det_oracle", "bit_identical") is None else bool(
                 get(geo, "parity_vs_det_oracle", "bit_identical") and get(geo, "parity_vs_det_oracle", "continued_edges", "bit_identical")),
             "growtree_5_edges_ms": geo.get("growtree_5_edges_ms"),
+            "extend_bulk_65536_edges_per_s": get(geo, "bulk", "edges_per_s"), "extend_bulk_65536_ms": get(geo, "bulk", "ms"),
+            "extend_bulk_bitwise": get(geo, "bulk", "parity_vs_det_oracle", "bit_identical"),
             "extend_cpu_edges_per_s": get(geo, "cpu", "edges_per_s"), "extend_cpu_threads": get(geo, "cpu", "threads"),
             "growtree_5_edges_cpu_single_thread_ms": get(geo, "cpu", "growtree_5_edges_single_thread_ms"),
             "single_project_us": get(sec, "single_project_c_abi", "uniform_sample_median_us"),
@@ -735,6 +737,30 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             res["parity_vs_det_oracle"]["continued_edges"] = {"edges": len(cand), "bit_identical": bool(okc_all)}
         except Exception as e:
             res["parity_vs_det_oracle"] = {"error": repr(e)}
+        try:
+            # a roadmap built in bulk: 65536 edges in one call of the same shape — from 40960 edges on the short edges run ten to a
+            # wavefront on the throughput layout beside latency blocks for the long ones; a slice against the oracle
+            nb = 65536
+            qb, okb, _, _ = c.sample_project_batch(0x6E2, 0, 8 * nb, want_iters=False)
+            fb = qb[okb == 1][:nb].contiguous()
+            tb, _, _, _ = c.sample_near_project_batch(0x6E3, 0, fb, 0.6, nb, want_iters=False)
+            bulk = lambda: c.discrete_geodesic_batch(fb, tb, first_pass, want_carry=True, round_budget=budget)
+            secb = timed(bulk, 5)
+            sb, nbs, okbs, itb, _ = bulk()
+            unfin = int(((nbs > first_pass) | (okbs == 2)).sum().item())
+            res["bulk"] = {"edges": nb, "ms": secb * 1e3, "edges_per_s": (nb - unfin) / secb, "unfinished_edges": unfin}
+            Od2 = Oracle("det")
+            Pd2 = checker_problem(Od2, args.obj, c.problem)
+            m2 = 512
+            sc2, nc2, okc2, itc2 = Od2.discrete_geodesic_batch(Pd2, fb[:m2].cpu().numpy(), tb[:m2].cpu().numpy(), first_pass, threads)
+            sg2, ng2, og2, ig2 = sb[:m2].cpu().numpy(), nbs[:m2].cpu().numpy(), okbs[:m2].cpu().numpy(), itb[:m2].cpu().numpy()
+            live2 = og2 != 2
+            same2 = all(np.array_equal(sg2[e, : min(ng2[e], first_pass)].view(np.uint64), sc2[e, : min(nc2[e], first_pass)].view(np.uint64))
+                        for e in range(m2) if live2[e])
+            res["bulk"]["parity_vs_det_oracle"] = {"edges": int(live2.sum()), "bit_identical": bool(
+                same2 and np.array_equal(ng2[live2], nc2[live2]) and np.array_equal(og2[live2], okc2[live2]) and np.array_equal(ig2[live2], itc2[live2]))}
+        except Exception as e:
+            res["bulk"] = {"error": repr(e)}
         try:
             # the CPU path beside it: the glibc build of the oracle — what the reference's loop would call — on
             # the first 4096 of the same edges with every usable core (lists of 64), and growTree's five edges on one thread

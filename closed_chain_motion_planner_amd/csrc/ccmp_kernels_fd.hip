@@ -628,7 +628,8 @@ __device__ __forceinline__ double geo_interpolate(double fr, double tg, double t
 }
 
 template <bool STOCK>
-__global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_kernel(
+__global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_kernel( // (no occupancy bound: 181 registers, no scratch, 1-2 % slower)
+   
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from, const double *__restrict__ to,
     unsigned long long E, int max_states, double *__restrict__ states, int *__restrict__ n_states, uint8_t *__restrict__ ok_out,
     int *__restrict__ newton_iters, unsigned long long *queue, const unsigned int *__restrict__ order,

@@ -66,7 +66,7 @@ def test_bench_line_contract():
     # SURVEY.md section 8(d) are repeated there, flat
     for k in FLAT_CONFIG:
         assert k in j["config"] and isinstance(j["config"][k], (int, float, bool)), k
-    for k in ("c1_bitwise", "c2_bitwise", "c4_bitwise", "extend_bitwise"):
+    for k in ("c1_bitwise", "c2_bitwise", "c4_bitwise", "extend_bitwise", "extend_bulk_bitwise"):
         assert j["config"][k] is True, k
     assert j["config"]["c2_batch4096_per_s"] == sec["batch4096_projections_per_s"] and j["config"]["extend_complete_ms"] == g["complete_ms"]
     for k in ("fp64_algorithmic_frac",):
@@ -82,7 +82,7 @@ FLAT_CONFIG = ("c1_dumbbell_cpu_single_thread_per_s", "c1_dumbbell_gpu_per_s", "
                "c4_stefan_per_s", "c4_stefan_tight_per_s", "c4_bitwise", "extend_first_pass_edges_per_s", "extend_first_pass_ms",
                "extend_unfinished_edges", "extend_complete_ms", "extend_bitwise", "growtree_5_edges_ms", "single_project_us",
                "single_project_near_manifold_us", "host_buffer_pageable_per_s", "host_buffer_pinned_per_s", "analytic_mode_per_s",
-               "proxy_clearance_states_per_s", "extend_cpu_edges_per_s", "extend_cpu_threads", "growtree_5_edges_cpu_single_thread_ms",
+               "proxy_clearance_states_per_s", "extend_bulk_65536_edges_per_s", "extend_bulk_65536_ms", "extend_bulk_bitwise", "extend_cpu_edges_per_s", "extend_cpu_threads", "growtree_5_edges_cpu_single_thread_ms",
                "single_project_cpu_us", "single_project_near_manifold_cpu_us")
 FLAT_CPU = ("det_bit_identical", "det_samples", "libm_samples", "libm_n_gt_1e-6", "libm_max_abs_dq", "libm_iter_diffs_gt1", "libm_ok_mismatches")
 
@@ -108,6 +108,7 @@ def test_flat_keys_are_first_level_scalars():
             "stefan_batch%d_tol_5e-4_2.5e-3" % B: {"projections_per_s": 9.0e6, "parity_vs_det_oracle": par},
             "discrete_geodesic": {"edges_per_s": 10.7e6, "ms": 1.52, "overflowed_edges": 29, "complete_ms": 42.8, "growtree_5_edges_ms": 0.41,
                                   "cpu": {"edges_per_s": 9000.0, "threads": 16, "growtree_5_edges_single_thread_ms": 7.5},
+                                  "bulk": {"edges_per_s": 15.9e6, "ms": 4.1, "parity_vs_det_oracle": {"bit_identical": True}},
                                   "parity_vs_det_oracle": {"bit_identical": True, "continued_edges": {"bit_identical": True}}},
             "proxy_clearance": {"states_per_s": 6.6e8},
             "host_buffer": {"pageable": {"projections_per_s": 14.5e6}, "pinned": {"projections_per_s": 13.2e6}},
