@@ -1065,7 +1065,7 @@ hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double
                                       unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
                                       hipStream_t st)
 {
-  if (K->stock)
+  if (K->stock && K->twin_arms) // the STOCK instantiation also assumes twin arms on diag(+-1) base frames (chain_rows), like project_fd_kernel's
     hipLaunchKernelGGL(geodesic_group_kernel<true>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
                        max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget);
   else

@@ -128,6 +128,26 @@ for obj, tol, seed, mode, N, variant in cases:
             m = min(int(nst[e]), maxs)
             same_edges += int(nst[e] == nc[e] and gok[e] == okc[e] and gits[e] == itc[e]
                               and np.array_equal(st[e, :m].view(np.uint64), sc[e, :m].view(np.uint64)))
+    # the extend step's bulk form (late round 4): a call with a round budget over tens of thousands of edges runs its short edges ten to
+    # a wavefront on the throughput layout (geodesic_group_kernel) beside latency blocks for the long ones — forced here whatever the
+    # edge count; every edge the budget did not suspend against the oracle's bounded traversal
+    if mode == 0:
+        nb = min(49152, good.shape[0])
+        fb = good[:nb].contiguous()
+        tb, _, _, _ = c.sample_near_project_batch(seed + 0x300, 0, fb, 0.6, nb, want_iters=False)
+        ctx.set_option("geodesic_group_min", 0)
+        sb, nbs, okb, itb, _ = c.discrete_geodesic_batch(fb, tb, 16, want_carry=True, round_budget=128)
+        ctx.set_option("geodesic_group_min", 40960)
+        sb, nbs, okb, itb = sb.cpu().numpy(), nbs.cpu().numpy(), okb.cpu().numpy(), itb.cpu().numpy()
+        scb, ncb, okcb, itcb = orc.discrete_geodesic_batch(P, fb.cpu().numpy(), tb.cpu().numpy(), 16, NCPU)
+        liveb = okb != 2
+        bulk_same = sum(int(nbs[e] == ncb[e] and okb[e] == okcb[e] and itb[e] == itcb[e]
+                            and np.array_equal(sb[e, : min(int(nbs[e]), 16)].view(np.uint64), scb[e, : min(int(ncb[e]), 16)].view(np.uint64)))
+                        for e in range(nb) if liveb[e])
+        entry["bulk_extend_edges"] = int(liveb.sum())
+        entry["bulk_extend_edges_bit_identical"] = bulk_same
+        entry["bulk_extend_edges_suspended_by_the_budget"] = int((~liveb).sum())
+        assert bulk_same == int(liveb.sum())
     # proxy clearance (the pre-filter ahead of the host's validity test) on the projected states: default scene, both
     # kernels (64-state tiles for the whole batch, one block per state for its first 4096 states)
     if mode == 0:

@@ -550,24 +550,32 @@ def test_geodesic_flavours_are_bitwise_identical(gpu_ctx, oracle_det):
         assert np.array_equal(got[0][E - 128 + k, :m].cpu().numpy().view(np.uint64), s_cpu[k, :m].view(np.uint64))
 
 
-@pytest.mark.parametrize("calibrated", [False, True])
-def test_bulk_extend_hybrid_is_bitwise_identical(gpu_ctx, oracle_det, calibrated):
+@pytest.mark.parametrize("variant", [None, "calibrated", "tilted"])
+def test_bulk_extend_hybrid_is_bitwise_identical(gpu_ctx, oracle_det, variant):
     """Bulk extend calls (round budget, scout order) put their short edges on the throughput layout — geodesic_group_kernel, ten
     edges per wavefront — and the front of the scout's order on latency blocks beside them.  Forced at a size the CPU checks in
     seconds: everything on the group kernel, a mixed split, a split by share of the predicted work, nearly everything on the front —
     states, counts, flags (list full, budget spent, arrived, given up), Newton counts and carries equal the latency kernel's alone
     and, on a slice, the oracle's; then every edge that stopped short is continued and equals the oracle's uninterrupted traversal.
-    With calibrated arms the kernels' general instantiations run (the stock Panda's exact-zero structure is gone)."""
+    With calibrated arms, and with stock arms on a tilted base (no twin arms: the rows-per-lane chains do not apply), the kernels'
+    general instantiations run."""
     import ctypes as C
 
     import torch
     from closed_chain_motion_planner_amd import _lib
 
     c = _constraint("Wine_Bottle", gpu_ctx)
-    if calibrated:
+    if variant == "calibrated":
         dh = (C.c_double * 28)(*[1e-3 * ((7 * i) % 5 - 2) for i in range(28)])
         assert _lib.lib().ccmp_set_calibration(C.byref(c.problem), 0, dh) == 0
         assert _lib.lib().ccmp_set_calibration(C.byref(c.problem), 1, dh) == 0
+    elif variant == "tilted":
+        a, b = 0.3, -0.7
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Rz = np.array([[np.cos(b), -np.sin(b), 0], [np.sin(b), np.cos(b), 0], [0, 0, 1]])
+        for k, v in enumerate((Rz @ Rx).reshape(-1)):
+            c.problem.base_R[9 + k] = float(v)
+        c.setInitialPosition(np.array(c.problem.start_joint[:]))
     P = _oracle_problem(oracle_det, c)
     E = 8 * gpu_ctx.num_cus + 1200
     q, ok, _, _ = c.sample_project_batch(0x6F5, 0, 8 * E, want_iters=False)
