@@ -302,13 +302,13 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
     if (value < 0) return CCMP_EINVAL;
     ctx->geodesic_group_min = (size_t)value;
   } else if (!strcmp(name, "geodesic_group_pred")) { // predicted Newton rounds from which an edge goes to the latency blocks
-    if (value < 1 || value > 1023) return CCMP_EINVAL;
+    if ((value < 1 && value != -1) || value > 1023) return CCMP_EINVAL;
     ctx->geodesic_group_pred = (int)value;
   } else if (!strcmp(name, "geodesic_group_permille")) { // share of the predicted work the front must carry (0 = cut at geodesic_group_pred)
     if (value < 0 || value > 1000) return CCMP_EINVAL;
     ctx->geodesic_group_permille = (int)value;
   } else if (!strcmp(name, "geodesic_group_front_per_cu")) {
-    if (value < 1 || value > 8) return CCMP_EINVAL;
+    if ((value < 1 && value != -1) || value > 8) return CCMP_EINVAL;
     ctx->geodesic_group_front_per_cu = (int)value;
   } else if (!strcmp(name, "geodesic_group_waves_per_cu")) {
     if (value < 1 || value > 10) return CCMP_EINVAL;
@@ -739,14 +739,17 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     unsigned long long *gq = ctx->queue + kGeoGroupWords; // [0] group kernel's ticket (starts behind the front), [4] front length, [5] front's ticket
     unsigned int *hist = (unsigned int *)((char *)ctx->lpt_buf + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
     HIP_TRY(ccmp_launch_clear_words(gq, 16, st));
+    const bool high = E >= kGeoGroupHighCut;
+    const int cut = ctx->geodesic_group_pred > 0 ? ctx->geodesic_group_pred : (high ? 64 : 40);
+    const int front_per_cu = ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : (high ? 6 : 8);
     if (ctx->geodesic_group_permille > 0)
-      HIP_TRY(ccmp_launch_geo_split(hist, 8, ctx->geodesic_group_pred, ctx->geodesic_group_permille, gq, st));
+      HIP_TRY(ccmp_launch_geo_split(hist, 8, cut, ctx->geodesic_group_permille, gq, st));
     else
-      HIP_TRY(ccmp_launch_fd_split(hist, ctx->geodesic_group_pred, 0xffffffffu, gq, st));
+      HIP_TRY(ccmp_launch_fd_split(hist, cut, 0xffffffffu, gq, st));
     HIP_TRY(hipEventRecord(ctx->fork, st));
     HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
     HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, 0,
-                                 ctx->num_cus * ctx->geodesic_group_front_per_cu, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, ctx->side));
+                                 ctx->num_cus * front_per_cu, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, ctx->side));
     HIP_TRY(hipEventRecord(ctx->join, ctx->side));
     size_t waves = (E + 9) / 10;
     const size_t cap = (size_t)ctx->num_cus * (size_t)ctx->geodesic_group_waves_per_cu;

@@ -59,6 +59,7 @@ struct DeviceGuard {
 // 16384: 1.917 | 1.677; stefan 12288: 2.324 | 2.753, 14336: 2.663 | 2.887, 16384: 3.028 | 3.029, 20480: 3.706 | 3.302)
 constexpr size_t kDefaultSmallBatch = 10240; // (14336 before the wide split launch: profiles/r04_hybrid_launch_sweep.log)
 constexpr size_t kSplitWideMax = 24576;
+constexpr size_t kGeoGroupHighCut = 49152;  // bulk extend calls: from this many edges on the cut of the order is the scout's cap (ccmp_ctx: geodesic_group*)
 constexpr int kGeoGroupWords = 8 + 64 + 4; // ctx->queue: first of the 8 words of the extend step's bulk form (behind the analytic kernels')     // split launch: up to here two latency blocks per CU (ccmp_ctx: fd_split*)
 constexpr size_t kDefaultLatencyOrderMin = 3072;
 constexpr size_t kDefaultLptMinBatch = 16384;  // from here on the scout pays (round 3: its predictions also sort the hand-over into two classes
@@ -129,14 +130,17 @@ struct ccmp_ctx {
   // geodesic_group_pred Newton rounds run on geodesic_group_kernel (ten edges per wavefront, ccmp_kernels_fd.hip: ~1 250 instead of
   // ~2 700 wave-instructions per round and edge), the others — at the default: the edges the scout's cap of 64 rounds cut off — on
   // geodesic_flat_kernel blocks on the side stream, both from the start.  The slow-per-round layout sets a floor of (cut x ~47 us)
-  // ~ 3 ms under a call, so it pays from ~40 000 edges.  tools/geo_group_ab.py, lists of 16 + 128 rounds, ms, latency kernel alone |
+  // ~ 3 ms under a call (~2 ms at a cut of 40), so it pays from ~32 000 edges.  tools/geo_group_ab.py, lists of 16 + 128 rounds, ms, latency kernel alone |
   // hybrid (profiles/r04_bulk_extend_ab.log): Wine_Bottle 40960: 3.14 | 3.04   65536: 4.96 | 4.00   131072: 9.79 | 7.92
-  //   stefan 40960: 4.47 | 4.06   65536: 7.08 | 6.07   131072: 13.98 | 11.72;  32768 and below: slower (+5..+60 %)
+  //   stefan 40960: 4.47 | 4.06   65536: 7.08 | 6.07   131072: 13.98 | 11.72.  Between 32768 and 49152 edges a cut of 40 rounds (floor ~2 ms)
+  //   and eight front blocks per CU: Wine_Bottle 32768: 2.55 | 2.27   40960: 3.14 | 2.70   stefan 32768: 3.63 | 3.60   40960: 4.48 | 4.36;
+  //   24576 and below: slower for at least one object whatever the cut (16384: +2..+100 %)
   int geodesic_group = 1;
-  size_t geodesic_group_min = 40960;
-  int geodesic_group_pred = 64;          // cut of the order: edges predicted this many rounds or more go to the latency blocks ...
+  size_t geodesic_group_min = 32768;
+  int geodesic_group_pred = -1;          // cut of the order: edges predicted this many rounds or more go to the latency blocks (-1: 40 below
+                                         // kGeoGroupHighCut edges — a lower floor — and the scout's cap, 64, from there on) ...
   int geodesic_group_permille = 0;       // ... or, > 0: the largest cut <= geodesic_group_pred whose front carries this share of the predicted work
-  int geodesic_group_front_per_cu = 6;   // latency blocks per CU for the front
+  int geodesic_group_front_per_cu = -1;  // latency blocks per CU for the front (-1: 8 below kGeoGroupHighCut edges, 6 from there on)
   int geodesic_group_waves_per_cu = 8;   // group kernel's wavefronts per CU at most (10 fit by LDS; the front's blocks need room)
   size_t latency_order_min = kDefaultLatencyOrderMin; // latency kernel alone (batches <= small_batch): FP32 scout order from this many samples on
   // FP32 scouts on LANE PAIRS (round 4, ccmp_kernels_scout.hip): the even lane takes arm 0, the odd lane arm 1 — half the chain

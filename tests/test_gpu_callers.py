@@ -621,7 +621,7 @@ def test_bulk_extend_hybrid_is_bitwise_identical(gpu_ctx, oracle_det, variant):
             assert got_e.shape == st_cpu.shape and np.array_equal(np.ascontiguousarray(got_e).view(np.uint64), st_cpu.view(np.uint64)), e
             assert bool(ok_e) == ok_cpu and its_e == its_cpu, e
     finally:
-        for name, val in zip(opts, (1, 40960, 64, 0, 6144)):
+        for name, val in zip(opts, (1, 32768, -1, 0, 6144)):
             gpu_ctx.set_option(name, val)
 
 
