@@ -87,6 +87,34 @@ def test_sample_filter_compact_and_extend_replay_from_a_graph(gpu_ctx):
     assert int(ok.sum().item()) > 0 and int(ns.max().item()) > 1
 
 
+def test_bulk_extend_call_replays_from_a_graph(gpu_ctx):
+    """a roadmap built in bulk: the extend step's hybrid form (scout, cut of its order, latency blocks on the context's side stream,
+    ten-edges-per-wavefront kernel on the caller's) forks and joins through events — capturable, and every replay redoes all of it"""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    E = 8 * gpu_ctx.num_cus + 900
+    q, ok, _, _ = c.sample_project_batch(0x57EB, 0, 8 * E, want_iters=False)
+    frm = q[ok == 1][:E].contiguous()
+    to = c.sample_near_project_batch(0x57EC, 0, frm, 0.6, E, want_iters=False)[0]
+    slot = torch.arange(8, device="cuda")[None, :, None]
+
+    def extend():
+        st, ns, okf, its, carry = c.discrete_geodesic_batch(frm, to, 8, want_carry=True, round_budget=40)
+        return torch.where(slot < ns[:, None, None], st, 0.0), ns, okf, its, carry
+
+    try:
+        gpu_ctx.set_option("geodesic_scout_min", 0)
+        gpu_ctx.set_option("geodesic_group_min", 0)
+        gpu_ctx.set_option("geodesic_group_pred", 14)  # a front and a rest of comparable size
+        st, ns, okf, its, carry = _capture_and_replay(extend)
+        assert int((okf == 2).sum().item()) > 0 and int((okf == 1).sum().item()) > 0 and int(ns.max().item()) == 9
+    finally:
+        gpu_ctx.set_option("geodesic_scout_min", 6144)
+        gpu_ctx.set_option("geodesic_group_min", 32768)
+        gpu_ctx.set_option("geodesic_group_pred", -1)
+
+
 def test_two_contexts_on_two_streams_run_side_by_side(gpu_ctx):
     """"use one context per stream for concurrency" (include/ccmp.h): two contexts of one device, each on its own stream,
     launched back to back without synchronising in between — reference arithmetic with scout and hand-over on one, the
