@@ -67,15 +67,17 @@ hipError_t ccmp_launch_t_wo(const ccmp_consts *K, const double *q, int q_stride,
 hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr, hipStream_t st);
+                                const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr,
+                                const double *pool, const unsigned long long *pool_count, hipStream_t st);
 hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                     size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                     int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                    const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr, hipStream_t st);
+                                    const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr,
+                                const double *pool, const unsigned long long *pool_count, hipStream_t st);
 hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
                                       int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
                                       unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
-                                      hipStream_t st);
+                                      double *pool, unsigned long long *pool_count, int handover_pct, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -196,6 +198,7 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx)
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->geo_pool) (void)hipFree(ctx->geo_pool);
   if (ctx->queue) (void)hipFree(ctx->queue);
   if (ctx->pool) (void)hipFree(ctx->pool);
   if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
@@ -307,6 +310,9 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "geodesic_group_permille")) { // share of the predicted work the front must carry (0 = cut at geodesic_group_pred)
     if (value < 0 || value > 1000) return CCMP_EINVAL;
     ctx->geodesic_group_permille = (int)value;
+  } else if (!strcmp(name, "geodesic_group_handover_pct")) {
+    if (value < 0 || value > 100) return CCMP_EINVAL;
+    ctx->geodesic_group_handover_pct = (int)value;
   } else if (!strcmp(name, "geodesic_group_front_per_cu")) {
     if ((value < 1 && value != -1) || value > 8) return CCMP_EINVAL;
     ctx->geodesic_group_front_per_cu = (int)value;
@@ -740,8 +746,8 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     unsigned int *hist = (unsigned int *)((char *)ctx->lpt_buf + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
     HIP_TRY(ccmp_launch_clear_words(gq, 16, st));
     const bool high = E >= kGeoGroupHighCut;
-    const int cut = ctx->geodesic_group_pred > 0 ? ctx->geodesic_group_pred : (high ? 64 : 40);
-    const int front_per_cu = ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : (high ? 6 : 8);
+    const int cut = ctx->geodesic_group_pred > 0 ? ctx->geodesic_group_pred : (high ? 64 : 48);
+    const int front_per_cu = ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : 8;
     if (ctx->geodesic_group_permille > 0)
       HIP_TRY(ccmp_launch_geo_split(hist, 8, cut, ctx->geodesic_group_permille, gq, st));
     else
@@ -749,19 +755,33 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     HIP_TRY(hipEventRecord(ctx->fork, st));
     HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
     HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, 0,
-                                 ctx->num_cus * front_per_cu, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, ctx->side));
+                                 ctx->num_cus * front_per_cu, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, nullptr, nullptr, ctx->side));
     HIP_TRY(hipEventRecord(ctx->join, ctx->side));
     size_t waves = (E + 9) / 10;
     const size_t cap = (size_t)ctx->num_cus * (size_t)ctx->geodesic_group_waves_per_cu;
     if (waves > cap) waves = cap;
+    const int pct = ctx->geodesic_group_handover_pct;
+    if (pct > 0 && ctx->geo_pool_cap < waves * 10) { // (grows outside any stream capture: the first call at a size is never captured)
+      if (ctx->geo_pool) (void)hipFree(ctx->geo_pool);
+      ctx->geo_pool = nullptr;
+      ctx->geo_pool_cap = 0;
+      HIP_TRY(hipMalloc((void **)&ctx->geo_pool, waves * 10 * kGeoPoolDoubles * sizeof(double)));
+      ctx->geo_pool_cap = waves * 10;
+    }
     HIP_TRY(ccmp_launch_geodesic_group(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, (int)waves, gq, order,
-                                       carry_out, round_budget, st));
+                                       carry_out, round_budget, pct > 0 ? ctx->geo_pool : nullptr, gq + 6, pct, st));
+    if (pct > 0) { // the handed-over edges: latency blocks behind the group kernel; the pool's fill count is read on the device
+      const size_t lat = (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
+      HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, 0,
+                                   (int)(waves * 10 < lat ? waves * 10 : lat), gq + 7, nullptr, nullptr, carry_out, round_budget, nullptr, ctx->geo_pool,
+                                   gq + 6, st));
+    }
     HIP_TRY(hipStreamWaitEvent(st, ctx->join, 0));
     return CCMP_OK;
   }
   HIP_TRY((latency_flavour ? ccmp_launch_geodesic_lat : ccmp_launch_geodesic)(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok,
                                                                              newton_iters, check_target, (int)nb, queue, order, carry_in, carry_out,
-                                                                             round_budget, nullptr, st));
+                                                                             round_budget, nullptr, nullptr, nullptr, st));
   return CCMP_OK;
 }
 

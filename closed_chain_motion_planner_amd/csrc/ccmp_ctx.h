@@ -59,7 +59,8 @@ struct DeviceGuard {
 // 16384: 1.917 | 1.677; stefan 12288: 2.324 | 2.753, 14336: 2.663 | 2.887, 16384: 3.028 | 3.029, 20480: 3.706 | 3.302)
 constexpr size_t kDefaultSmallBatch = 10240; // (14336 before the wide split launch: profiles/r04_hybrid_launch_sweep.log)
 constexpr size_t kSplitWideMax = 24576;
-constexpr size_t kGeoGroupHighCut = 49152;  // bulk extend calls: from this many edges on the cut of the order is the scout's cap (ccmp_ctx: geodesic_group*)
+constexpr size_t kGeoGroupHighCut = 20480;  // bulk extend calls: from this many edges on the cut of the order is the scout's cap (ccmp_ctx: geodesic_group*)
+constexpr int kGeoPoolDoubles = 40;  // = kGeoPoolEntry (ccmp_fd_common.h): one handed-over edge of the extend step's bulk form
 constexpr int kGeoGroupWords = 8 + 64 + 4; // ctx->queue: first of the 8 words of the extend step's bulk form (behind the analytic kernels')     // split launch: up to here two latency blocks per CU (ccmp_ctx: fd_split*)
 constexpr size_t kDefaultLatencyOrderMin = 3072;
 constexpr size_t kDefaultLptMinBatch = 16384;  // from here on the scout pays (round 3: its predictions also sort the hand-over into two classes
@@ -126,21 +127,25 @@ struct ccmp_ctx {
   int fd_split_front = -1;               // ... on this many latency blocks ...
   long long fd_split_samples = -1;       // ... at most this many samples (0 = one per block); more: the blocks go on with the next-longest
   int fd_split_group_cut = -1;           // throughput wavefronts per CU the split launch leaves out
-  // Bulk extend calls (round budget + scout order, geodesic_group_min edges or more): the edges predicted shorter than
-  // geodesic_group_pred Newton rounds run on geodesic_group_kernel (ten edges per wavefront, ccmp_kernels_fd.hip: ~1 250 instead of
-  // ~2 700 wave-instructions per round and edge), the others — at the default: the edges the scout's cap of 64 rounds cut off — on
-  // geodesic_flat_kernel blocks on the side stream, both from the start.  The slow-per-round layout sets a floor of (cut x ~47 us)
-  // ~ 3 ms under a call (~2 ms at a cut of 40), so it pays from ~32 000 edges.  tools/geo_group_ab.py, lists of 16 + 128 rounds, ms, latency kernel alone |
-  // hybrid (profiles/r04_bulk_extend_ab.log): Wine_Bottle 40960: 3.14 | 3.04   65536: 4.96 | 4.00   131072: 9.79 | 7.92
-  //   stefan 40960: 4.47 | 4.06   65536: 7.08 | 6.07   131072: 13.98 | 11.72.  Between 32768 and 49152 edges a cut of 40 rounds (floor ~2 ms)
-  //   and eight front blocks per CU: Wine_Bottle 32768: 2.55 | 2.27   40960: 3.14 | 2.70   stefan 32768: 3.63 | 3.60   40960: 4.48 | 4.36;
-  //   24576 and below: slower for at least one object whatever the cut (16384: +2..+100 %)
+  // Bulk extend calls (round budget + scout order, geodesic_group_min edges or more): the edges predicted shorter than the cut run on
+  // geodesic_group_kernel (ten edges per wavefront, ccmp_kernels_fd.hip: ~1 250 instead of ~2 700 wave-instructions per round and
+  // edge, at twelve times the latency per round), the others on geodesic_flat_kernel blocks on the side stream, both from the start;
+  // once the ticket queue is dry and the group kernel's live edges fill less than geodesic_group_handover_pct % of its slots it hands
+  // them — in the middle of their projections — to latency blocks launched behind it.  tools/geo_group_ab.py, lists of 16 + 128
+  // rounds, ms, latency kernel alone | hybrid (profiles/r04_bulk_extend_ab.log, calls 10-13):
+  //   Wine_Bottle 16384: 1.36 | 1.29   24576: 1.97 | 1.60   32768: 2.57 | 1.91   65536: 5.00 | 3.49   131072: 9.86 | 6.69
+  //   stefan      16384: 1.93 | 1.70   24576: 2.78 | 2.26   32768: 3.65 | 2.98   65536: 7.12 | 5.57   131072: 14.1 | 10.8
+  //   12288 and below: slower (Wine_Bottle +5..+40 %).  Without the hand-over the group kernel's longest TRUE edge sets a floor of
+  //   2-3 ms under a call and the hybrid only paid from 32768 edges (calls 1-9).
   int geodesic_group = 1;
-  size_t geodesic_group_min = 32768;
-  int geodesic_group_pred = -1;          // cut of the order: edges predicted this many rounds or more go to the latency blocks (-1: 40 below
-                                         // kGeoGroupHighCut edges — a lower floor — and the scout's cap, 64, from there on) ...
+  size_t geodesic_group_min = 16384;
+  int geodesic_group_pred = -1;          // cut of the order: edges predicted this many rounds or more go to the latency blocks (-1: 48 below
+                                         // kGeoGroupHighCut edges, the scout's cap, 64, from there on) ...
   int geodesic_group_permille = 0;       // ... or, > 0: the largest cut <= geodesic_group_pred whose front carries this share of the predicted work
-  int geodesic_group_front_per_cu = -1;  // latency blocks per CU for the front (-1: 8 below kGeoGroupHighCut edges, 6 from there on)
+  int geodesic_group_front_per_cu = 8;   // latency blocks per CU for the front
+  int geodesic_group_handover_pct = 50;  // hand the group kernel's live edges to latency blocks once the queue is dry and they fill less than this share of its slots (0 = never)
+  double *geo_pool = nullptr;            // ... through this pool (kGeoPoolDoubles per edge)
+  size_t geo_pool_cap = 0;
   int geodesic_group_waves_per_cu = 8;   // group kernel's wavefronts per CU at most (10 fit by LDS; the front's blocks need room)
   size_t latency_order_min = kDefaultLatencyOrderMin; // latency kernel alone (batches <= small_batch): FP32 scout order from this many samples on
   // FP32 scouts on LANE PAIRS (round 4, ccmp_kernels_scout.hip): the even lane takes arm 0, the odd lane arm 1 — half the chain

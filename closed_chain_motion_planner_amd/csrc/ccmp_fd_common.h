@@ -11,6 +11,8 @@
 
 namespace ccmp {
 
+constexpr int kGeoPoolEntry = 40; // (= kGeoPoolDoubles, ccmp_ctx.h) extend step, hand-over of an edge in the middle of a projection: x[14], previous[14], dist, total, maxd,
+                                  // edge, (n, its), (rounds, iter), updates, norm1, norm2 (geodesic_group_kernel -> geodesic_flat_kernel)
 constexpr int kPoolEntry = 18; // straggler hand-over record: x[14], idx, (iter,updates), norm1, norm2
 
 __device__ __forceinline__ double shfl_f64(double v, int src_lane)

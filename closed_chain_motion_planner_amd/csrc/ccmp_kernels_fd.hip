@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from, const double *__restrict__ to,
     unsigned long long E, int max_states, double *__restrict__ states, int *__restrict__ n_states, uint8_t *__restrict__ ok_out,
     int *__restrict__ newton_iters, unsigned long long *queue, const unsigned int *__restrict__ order,
-    double *__restrict__ carry_out, int round_budget)
+    double *__restrict__ carry_out, int round_budget, double *__restrict__ pool, unsigned long long *pool_count, int handover_pct)
 {
   __shared__ double lds[kGroupsPerWave * kRecG];
   const int lane = threadIdx.x;
@@ -701,6 +701,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
             ok_out[edge] = (uint8_t)(dist <= delta);
             if (newton_iters) newton_iters[edge] = 0;
             if (carry_out) { carry_out[2ull * edge] = total; carry_out[2ull * edge + 1ull] = maxd; }
+            if (pool) atomicAdd(queue + 3, 1ull); // finished edges: what the hand-over rule below counts down from
           }
         } else drained = true;
       }
@@ -710,6 +711,42 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
       continue;                                                          // edges that needed no traversal: take the next tickets
     }
     __syncthreads();
+    // ---- hand-over (as project_fd_kernel's): once the ticket queue is dry and the edges still in flight — E minus the finished
+    // count in queue[3], which starts at the front's length — no longer fill handover_pct % of this launch's group slots, every
+    // wavefront dumps its live edges at the loop top — iterate, previous state, running distances, counters: the next thing that
+    // happens to them is function(x) + the loop test, where geodesic_flat_kernel's Newton routine starts — and retires; latency
+    // blocks launched behind this kernel finish them.  A wavefront whose ten edges are of similar predicted length empties all at
+    // once; what is left near the end are stragglers on mostly idle wavefronts, at a twelfth of the latency kernel's pace.
+    if (pool != nullptr) {
+      unsigned long long head = 0, fin_count = 0;
+      if (lane == 0) {
+        head = __hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin_count = __hip_atomic_load(queue + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      head = shfl_u64(head, 0);
+      fin_count = shfl_u64(fin_count, 0);
+      const unsigned long long in_flight = E - fin_count, slots = (unsigned long long)gridDim.x * kGroupsPerWave;
+      if (head >= E && in_flight * 100ull < slots * (unsigned long long)handover_pct) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(active && r == 0);
+        unsigned long long base = 0;
+        if (lane == 0 && m) base = atomicAdd(pool_count, (unsigned long long)__builtin_popcountll(m));
+        base = shfl_u64(base, 0);
+        if (active) {
+          double *ent = pool + (base + (unsigned long long)__builtin_popcountll(m & ((1ull << leader) - 1ull))) * (unsigned long long)kGeoPoolEntry;
+          for (int e = r; e < 14; e += kGroup) { ent[e] = rec[kX + e]; ent[14 + e] = rec[kGPrev + e]; }
+          if (r == 0) {
+            const int *cnt = reinterpret_cast<const int *>(rec + kGCnt);
+            ent[28] = rec[kGDist]; ent[29] = rec[kGDist + 1]; ent[30] = rec[kGDist + 2];
+            ent[31] = __longlong_as_double((long long)edge);
+            ent[32] = __hiloint2double(cnt[0], cnt[1]);   // states listed, Newton updates of the finished projections
+            ent[33] = __hiloint2double(cnt[2], iter);     // Newton rounds of the finished projections, loop counter of this one
+            ent[34] = __hiloint2double(0, updates);
+            ent[35] = norm1; ent[36] = norm2;
+          }
+        }
+        break;
+      }
+    }
 
     // ---- phase 1: function(x) — sines/cosines, both chains, residual (project_fd_kernel's) -------------------------------
     for (int e = r; e < 14; e += kGroup) {
@@ -805,6 +842,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
             ok_out[edge] = suspended ? (uint8_t)2 : (uint8_t)(fits && dist <= delta);
             if (newton_iters) newton_iters[edge] = its;
             if (carry_out) { carry_out[2ull * edge] = total; carry_out[2ull * edge + 1ull] = maxd; }
+            if (pool) atomicAdd(queue + 3, 1ull);
           }
           active = false;
         } else { // the accepted state becomes `previous`; the next scratch state is interpolated towards the target
@@ -1063,14 +1101,14 @@ extern "C" {
 hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
                                       int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
                                       unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
-                                      hipStream_t st)
+                                      double *pool, unsigned long long *pool_count, int handover_pct, hipStream_t st)
 {
   if (K->stock && K->twin_arms) // the STOCK instantiation also assumes twin arms on diag(+-1) base frames (chain_rows), like project_fd_kernel's
     hipLaunchKernelGGL(geodesic_group_kernel<true>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget);
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct);
   else
     hipLaunchKernelGGL(geodesic_group_kernel<false>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget);
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct);
   return hipGetLastError();
 }
 

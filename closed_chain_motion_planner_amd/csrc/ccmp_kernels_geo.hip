@@ -53,7 +53,8 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,
     unsigned long long *queue, const unsigned int *__restrict__ order, const double *__restrict__ carry_in,
-    double *__restrict__ carry_out, int round_budget, const unsigned long long *__restrict__ total_ptr)
+    double *__restrict__ carry_out, int round_budget, const unsigned long long *__restrict__ total_ptr,
+    const double *__restrict__ pool, const unsigned long long *__restrict__ pool_count)
 {
   __shared__ __attribute__((aligned(16))) double lds[gRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -79,20 +80,32 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     }
     // total_ptr (bulk calls, ccmp_api.cpp: geodesic_common): this launch takes the first *total_ptr tickets of the order — the
     // edges the scout predicts longest — beside geodesic_group_kernel, which takes the rest
-    if (tk >= (total_ptr ? *total_ptr : E)) break;
-    const unsigned long long t = order ? (unsigned long long)order[tk] : tk;
+    if (tk >= (pool ? *pool_count : (total_ptr ? *total_ptr : E))) break;
+    // pool (bulk calls): the edges geodesic_group_kernel handed over in the middle of a projection — iterate, previous state,
+    // running distances and counters — go on here exactly where they stood
+    // (the ticket is block-uniform: a scalar address keeps the entry out of the vector registers this kernel has none to spare of)
+    const unsigned long long tks = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(tk >> 32)) << 32) |
+                                   (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+    const double *ent = pool ? pool + tks * (unsigned long long)kGeoPoolEntry : nullptr;
+    const unsigned long long t = ent ? (unsigned long long)__double_as_longlong(ent[31]) : (order ? (unsigned long long)order[tk] : tk);
 #ifdef CCMP_GEO_TRACE
     if (tid == 0 && t < 65536) { g_geo_trace[3 * t] = wall_clock64(); g_geo_trace[3 * t + 2] = ((unsigned long long)blockIdx.x << 32) | tk; }
 #endif
     double *out = states + t * (unsigned long long)max_states * 14ull;
     if (tid < 14) {
-      const double a = from[t * 14 + tid];
-      rec[gPrev + tid] = a;
+      if (ent) {
+        rec[fX + tid] = ent[tid];
+        rec[gPrev + tid] = ent[14 + tid];
+      } else {
+        const double a = from[t * 14 + tid];
+        rec[gPrev + tid] = a;
+        if (max_states > 0) out[tid] = a; // geodesic->push_back(cloneState(from))
+      }
       rec[gTo + tid] = to[t * 14 + tid];
-      if (max_states > 0) out[tid] = a; // geodesic->push_back(cloneState(from))
     }
     __syncthreads();
     int n = 1, its = 0, rounds = 0;
+    bool resume = ent != nullptr; // the first pass through the loop below skips the interpolation and takes the projection's counters from the entry
     bool suspended = false; // the edge used up the call's budget of Newton rounds: it stops between two states (ok = 2)
     bool fits = true; // false: an accepted state found the list full — the edge stops there and reports max_states + 1
     bool target_ok = true;
@@ -111,6 +124,11 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     }
     double dist = lds_distance(rec + gPrev, rec + gTo), total = 0.0, total_before = 0.0;
     double maxd = dist * lambda;
+    if (ent) { // (dist is the value the group kernel held: the distance of `previous` to the target, from the same operands)
+      dist = ent[28]; total = ent[29]; maxd = ent[30];
+      n = __double2hiint(ent[32]); its = __double2loint(ent[32]);
+      rounds = __double2hiint(ent[33]);
+    }
     // a continuation is in the middle of the reference's do-while: it re-enters on the loop's own condition
     // (dist >= delta) with the running length and the bound of the first call
     bool enter = dist > delta;
@@ -119,6 +137,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
       maxd = carry_in[2 * t + 1];
       enter = dist >= delta;
     }
+    if (ent) enter = true; // in the middle of the reference's loop
     if (target_ok && enter) {
       // Between two projections every thread does the reference's bookkeeping for itself, in ONE pass over the 14 joints
       // and without a barrier (round 3; before: jointValid through a ballot and two barriers, then the distances one
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
       double x_own = 0.0, to_own = 0.0; // this thread's joint of the accepted state / of the target (tid < 14)
       if (tid < 14) { x_own = rec[gPrev + tid]; to_own = rec[gTo + tid]; }
       for (int guard = 0; guard < 1000000; guard++) { // the reference loop ends by itself; guard bounds a non-finite input
-        if (tid < 14) { // WrapperStateSpace::interpolate(previous, to, delta_ / dist, scratch)
+        if (tid < 14 && !resume) { // WrapperStateSpace::interpolate(previous, to, delta_ / dist, scratch)
           const double tt = delta / dist;
           const double fr = x_own;
           double diff = to_own - fr, v;
@@ -147,6 +166,11 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
         __syncthreads();
         int iter = 0, updates = 0;
         double norm1 = 0.0, norm2 = 0.0;
+        if (resume) { // the handed-over projection's own counters, read where they are needed
+          iter = __double2loint(ent[33]); updates = __double2loint(ent[34]);
+          norm1 = ent[35]; norm2 = ent[36];
+          resume = false;
+        }
         const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2, K.max_iter);
         its += updates;
         rounds += updates + 1;
@@ -252,14 +276,15 @@ extern "C" {
 hipError_t CCMP_LAUNCH_GEODESIC(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
-                                const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr, hipStream_t st)
+                                const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr,
+                                const double *pool, const unsigned long long *pool_count, hipStream_t st)
 {
   if (K->stock)
     hipLaunchKernelGGL(geodesic_flat_kernel<true>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count);
   else
     hipLaunchKernelGGL(geodesic_flat_kernel<false>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count);
   return hipGetLastError();
 }
 

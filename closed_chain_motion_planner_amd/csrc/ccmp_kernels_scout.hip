@@ -846,7 +846,7 @@ __global__ __launch_bounds__(64) void geo_split_kernel(const unsigned int *__res
     const unsigned long long front = n[P];
     queue[4] = front;
     queue[0] = front;
-    queue[3] = (unsigned long long)P; // for inspection (ccmp_ctx_debug): the cut that was taken
+    queue[3] = front; // the group kernel's count of finished edges starts there (its hand-over rule)
   }
 }
 

@@ -161,10 +161,11 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
  * stream beside the throughput kernel, which gives up "fd_split_group_cut" wavefronts per CU; the four follow the batch size
  * when left at -1, the default: up to 24576 samples two blocks per CU, predictions >= 40, four samples per CU, a cut of 3;
  * above one block per CU, >= 56, three to four samples per CU, a cut of 2; 0 = off);
- * bulk extend calls: "geodesic_group" (1 = calls with a round budget over "geodesic_group_min" edges or more, default 32768, run their
- * short edges — predicted fewer than "geodesic_group_pred" Newton rounds; -1, the default: 40 below 49152 edges, 64 from there on —
- * ten to a wavefront on the throughput layout and the others on "geodesic_group_front_per_cu" latency blocks per CU (-1: 8 / 6) beside
- * them; default 1; same results bit for bit);
+ * bulk extend calls: "geodesic_group" (1 = calls with a round budget over "geodesic_group_min" edges or more, default 16384, run their
+ * short edges — predicted fewer than "geodesic_group_pred" Newton rounds; -1, the default: 48 below 20480 edges, 64 from there on —
+ * ten to a wavefront on the throughput layout and the others on "geodesic_group_front_per_cu" latency blocks per CU, default 8, beside
+ * them; what is still in flight when the short edges fill less than "geodesic_group_handover_pct" % of their slots, default 50, goes to
+ * latency blocks too; default 1; same results bit for bit);
  * the FP32 scouts: "scout_pairs" (1 = two lanes per sample / edge,
  * one arm each, where lanes are plentiful — projector batches of up to 128 x "scout_pair_blocks_per_cu" (default 1) x CUs samples,
  * extend-step batches of up to "scout_pair_max_edges" (default 131072) edges; stock twin arms only; default 1);

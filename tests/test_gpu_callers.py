@@ -594,15 +594,17 @@ def test_bulk_extend_hybrid_is_bitwise_identical(gpu_ctx, oracle_det, variant):
         assert int((ref[2] == 2).sum()) > 50 and int((ref[1] > cap).sum()) > 50 and int((ref[1] == 1).sum()) >= 24
         gpu_ctx.set_option("geodesic_group", 1)
         gpu_ctx.set_option("geodesic_group_min", 0)
-        for pred, permille in ((1023, 0), (12, 0), (64, 300), (1, 0)):
+        # (cut of the order, cut by work share, hand-over of the group kernel's live edges below this occupancy)
+        for pred, permille, handover in ((1023, 0, 0), (12, 0, 0), (64, 300, 0), (1023, 0, 100), (20, 0, 60), (1, 0, 0)):
             gpu_ctx.set_option("geodesic_group_pred", pred)
             gpu_ctx.set_option("geodesic_group_permille", permille)
+            gpu_ctx.set_option("geodesic_group_handover_pct", handover)
             for _ in range(2):  # twice: queue words and events are reused
                 got = c.discrete_geodesic_batch(frm, to, cap, want_carry=True, round_budget=budget)
                 torch.cuda.synchronize()
                 for k in (1, 2, 3, 4):
-                    assert torch.equal(got[k], ref[k]), (pred, permille, k)
-                assert torch.equal(got[0][live], ref[0][live]), (pred, permille)
+                    assert torch.equal(got[k], ref[k]), (pred, permille, handover, k)
+                assert torch.equal(got[0][live], ref[0][live]), (pred, permille, handover)
         # the last setting's result against the oracle: first pass on a slice, then the continued edges whole
         st, n, okf, its, carry = got
         sl = slice(0, 160)
@@ -621,8 +623,9 @@ def test_bulk_extend_hybrid_is_bitwise_identical(gpu_ctx, oracle_det, variant):
             assert got_e.shape == st_cpu.shape and np.array_equal(np.ascontiguousarray(got_e).view(np.uint64), st_cpu.view(np.uint64)), e
             assert bool(ok_e) == ok_cpu and its_e == its_cpu, e
     finally:
-        for name, val in zip(opts, (1, 32768, -1, 0, 6144)):
+        for name, val in zip(opts, (1, 16384, -1, 0, 6144)):
             gpu_ctx.set_option(name, val)
+        gpu_ctx.set_option("geodesic_group_handover_pct", 50)
 
 
 def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):

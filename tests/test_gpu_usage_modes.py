@@ -111,7 +111,7 @@ def test_bulk_extend_call_replays_from_a_graph(gpu_ctx):
         assert int((okf == 2).sum().item()) > 0 and int((okf == 1).sum().item()) > 0 and int(ns.max().item()) == 9
     finally:
         gpu_ctx.set_option("geodesic_scout_min", 6144)
-        gpu_ctx.set_option("geodesic_group_min", 32768)
+        gpu_ctx.set_option("geodesic_group_min", 16384)
         gpu_ctx.set_option("geodesic_group_pred", -1)
 
 

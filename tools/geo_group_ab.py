@@ -45,20 +45,22 @@ for obj in sys.argv[1:] or ["Wine_Bottle", "stefan"]:
         for rnd in range(2):
             for cfg in [None] + CFGS:
                 ctx.set_option("geodesic_group", 0 if cfg is None else 1)
-                ctx.set_option("geodesic_group_min", 32768 if cfg and cfg[0] == -1 else 0)  # "-1,-1,8" = the default policy
+                ctx.set_option("geodesic_group_min", 16384 if cfg and cfg[0] == -1 else 0)  # "-1,-1,8" = the default policy
                 if cfg:
                     ctx.set_option("geodesic_group_pred", cfg[0])
                     ctx.set_option("geodesic_group_front_per_cu", cfg[1])
                     ctx.set_option("geodesic_group_waves_per_cu", cfg[2])
                     ctx.set_option("geodesic_group_permille", cfg[3] if len(cfg) > 3 else 0)
+                    ctx.set_option("geodesic_group_handover_pct", cfg[4] if len(cfg) > 4 else (50 if cfg[0] == -1 else 0))
                 got = call()
                 torch.cuda.synchronize()
                 same = all(torch.equal(got[i], ref[i]) for i in (1, 2, 3, 4)) and torch.equal(got[0][live], ref[0][live])
                 assert same, (obj, E, cfg, [bool(torch.equal(got[i], ref[i])) for i in (1, 2, 3, 4)])
-                name = "flat alone" if cfg is None else ("default" if cfg[0] == -1 else "p%d/f%d/w%d" % cfg[:3]) + ("/m%d" % cfg[3] if len(cfg) > 3 else "")
+                name = "flat alone" if cfg is None else ("default" if cfg[0] == -1 else "p%d/f%d/w%d" % cfg[:3]) + ("/m%d" % cfg[3] if len(cfg) > 3 and cfg[3] else "") + ("/h%d" % cfg[4] if len(cfg) > 4 else "")
                 best[name] = min(best.get(name, 1e9), mean(call))
         base = best["flat alone"]
         print("%-11s E=%6d ms  %s" % (obj, E, "  ".join("%s %.3f (%+.1f %%)" % (k, v, 100 * (v / base - 1)) for k, v in best.items())), flush=True)
 ctx.set_option("geodesic_group", 1)
 for name in ("geodesic_group_pred", "geodesic_group_front_per_cu"):
     ctx.set_option(name, -1)
+ctx.set_option("geodesic_group_handover_pct", 50)
