@@ -378,8 +378,8 @@ def run(argv):
     elif what == "flat1":
         x = c.ambient_uniform_batch(0xC1, 0, 64).cpu().numpy()
         fn = lambda: [c.project(x[i].copy()) for i in range(64)]
-    elif what == "geodesic":
-        frm, to = near_edges(c, 16384)
+    elif what.startswith("geodesic"):  # geodesic (16384 edges: bench.py's first pass), geodesic65536 (a bulk call) ...
+        frm, to = near_edges(c, int(what[8:] or 16384))
         fn = lambda: c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128)  # bench.py's first pass
     elif what == "analytic":
         c.setJacobianMode(1)
