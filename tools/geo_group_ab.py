@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Bulk extend calls (lists of 16, 128 rounds per edge): geodesic_flat_kernel alone against the hybrid — short edges on the
 throughput layout (geodesic_group_kernel), the front of the scout's order on latency blocks beside it.  Interleaved on one device;
-every output compared bit for bit.  GEO_CFGS="pred,front_per_cu,waves_per_cu;..." and GEO_SIZES override.  GPU box."""
+every output compared bit for bit.  GEO_CFGS="pred,front_per_cu,waves_per_cu[,permille[,handover_pct]];..." ("-1,-1,8" = the default
+policy) and GEO_SIZES override.  GPU box."""
 import os
 import sys
 
