@@ -33,6 +33,8 @@ CFGS = [(32, 4, 8), (24, 4, 8), (16, 4, 8), (48, 4, 8), (32, 2, 10), (32, 4, 6)]
 if os.environ.get("GEO_CFGS"):
     CFGS = [tuple(int(v) for v in c.split(",")) for c in os.environ["GEO_CFGS"].split(";")]
 SIZES = [int(v) for v in os.environ.get("GEO_SIZES", "8192,16384,32768,65536").split(",")]
+if os.environ.get("GEO_SCOUT_ROUNDS"):  # the scout's cap of predicted rounds (default 64) — applies to every variant, the baseline too
+    ctx.set_option("geodesic_scout_rounds", int(os.environ["GEO_SCOUT_ROUNDS"]))
 for obj in sys.argv[1:] or ["Wine_Bottle", "stefan"]:
     c = KinematicChainConstraint.from_yaml("tests/golden/config/%s.yaml" % obj, ctx=ctx)
     for E in SIZES:
