@@ -603,13 +603,14 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
 // reference's bookkeeping between two projections — jointValid, the four break tests, the state list, the next
 // interpolated state (geodesic_flat_kernel's, statement for statement: ccmp_kernels_geo.hip) — instead.  A Newton round
 // costs this layout ~1 250 wave-instructions per edge against the latency kernel's ~2 700, and ~12 times the latency: it
-// (the two phases are written out again rather than shared through functions: factored, the general instantiations of BOTH kernels
-// came out with 2.3 KB of scratch instead of 0.1-0.2 — the register allocator loses the scoping of the pose arrays.)  It
 // serves the SHORT edges of a bulk call (round budget, thousands of edges), beside geodesic_flat_kernel, which takes the
 // front of the FP32 scout's longest-first order on the side stream (ccmp_api.cpp: geodesic_common).  interpolate == true
 // semantics; first calls only (carry_out / round_budget as in the latency kernel; no carry_in, no check_target form).
 // Per-edge state lives in the group's LDS record behind the projector's 165 doubles: previous accepted state (14), dist,
 // running length, bound (3), and three counters — 185 doubles per group, 10 wavefronts per CU.
+// (The two halves of the Newton iteration are written out again here rather than shared with project_fd_kernel through functions:
+// factored, the general instantiations of BOTH kernels came out with 2.3 KB of scratch instead of 0.1-0.2 KB — the register
+// allocator loses the scoping of the pose arrays.)
 constexpr int kGPrev = kRec, kGDist = kRec + 14, kGCnt = kRec + 17, kRecG = kRec + 20; // odd stride like kRec
 static_assert(kRecG % 2 == 1, "odd record stride: the ten groups stay on distinct LDS banks");
 
