@@ -77,7 +77,7 @@ hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double l
 hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
                                       int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
                                       unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
-                                      double *pool, unsigned long long *pool_count, int handover_pct, hipStream_t st);
+                                      double *pool, unsigned long long *pool_count, int handover_pct, const uint8_t *target_ok, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -481,7 +481,7 @@ static int ensure_lpt_buffers(ccmp_ctx *ctx, size_t B)
   if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
   ctx->lpt_buf = nullptr;
   ctx->lpt_cap = 0;
-  HIP_TRY(hipMalloc(&ctx->lpt_buf, ((B * 2 + 255) & ~(size_t)255) + 4096 + B * 4)); // pred u16 | hist 1024 x u32 | order u32
+  HIP_TRY(hipMalloc(&ctx->lpt_buf, ((B * 2 + 255) & ~(size_t)255) + 4096 + B * 4 + B)); // pred u16 | hist 1024 x u32 | order u32 | flags u8 (bulk checkMotion)
   ctx->lpt_cap = B;
   return CCMP_OK;
 }
@@ -741,10 +741,16 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   // Bulk calls (round budget, thousands of edges, scout order): the SHORT edges run on the throughput layout — ten edges per
   // wavefront, geodesic_group_kernel, less than half the instructions per Newton round — and the front of the order, the edges
   // predicted to need geodesic_group_pred rounds or more, on this kernel's blocks on the side stream, both from the start.
-  if (scouted && round_budget > 0 && !check_target && !carry_in && ctx->geodesic_group && E >= ctx->geodesic_group_min) {
+  if (scouted && round_budget > 0 && !carry_in && ctx->geodesic_group && E >= ctx->geodesic_group_min) {
     unsigned long long *gq = ctx->queue + kGeoGroupWords; // [0] group kernel's ticket (starts behind the front), [4] front length, [5] front's ticket
     unsigned int *hist = (unsigned int *)((char *)ctx->lpt_buf + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
     HIP_TRY(ccmp_launch_clear_words(gq, 16, st));
+    // checkMotion: isSatisfied(to) of every edge up front (one lane per edge) for the group kernel; the front's blocks test their own
+    uint8_t *target_ok = nullptr;
+    if (check_target) {
+      target_ok = (uint8_t *)hist + 4096 + ctx->lpt_cap * 4;
+      HIP_TRY(ccmp_launch_is_satisfied(&K, to, target_ok, E, nullptr, 0, st));
+    }
     const bool high = E >= kGeoGroupHighCut;
     const int cut = ctx->geodesic_group_pred > 0 ? ctx->geodesic_group_pred : (high ? 64 : 48);
     const int front_per_cu = ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : 8;
@@ -754,7 +760,7 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
       HIP_TRY(ccmp_launch_fd_split(hist, cut, 0xffffffffu, gq, st));
     HIP_TRY(hipEventRecord(ctx->fork, st));
     HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
-    HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, 0,
+    HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target,
                                  ctx->num_cus * front_per_cu, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, nullptr, nullptr, ctx->side));
     HIP_TRY(hipEventRecord(ctx->join, ctx->side));
     size_t waves = (E + 9) / 10;
@@ -769,7 +775,7 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
       ctx->geo_pool_cap = waves * 10;
     }
     HIP_TRY(ccmp_launch_geodesic_group(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, (int)waves, gq, order,
-                                       carry_out, round_budget, pct > 0 ? ctx->geo_pool : nullptr, gq + 6, pct, st));
+                                       carry_out, round_budget, pct > 0 ? ctx->geo_pool : nullptr, gq + 6, pct, target_ok, st));
     if (pct > 0) { // the handed-over edges: latency blocks behind the group kernel; the pool's fill count is read on the device
       const size_t lat = (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
       HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, 0,

@@ -605,7 +605,8 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
 // costs this layout ~1 250 wave-instructions per edge against the latency kernel's ~2 700, and ~12 times the latency: it
 // serves the SHORT edges of a bulk call (round budget, thousands of edges), beside geodesic_flat_kernel, which takes the
 // front of the FP32 scout's longest-first order on the side stream (ccmp_api.cpp: geodesic_common).  interpolate == true
-// semantics; first calls only (carry_out / round_budget as in the latency kernel; no carry_in, no check_target form).
+// semantics; first calls only (carry_out / round_budget as in the latency kernel; no carry_in); checkMotion's isSatisfied(to) comes from
+// a launch in front of this one (target_ok).
 // Per-edge state lives in the group's LDS record behind the projector's 165 doubles: previous accepted state (14), dist,
 // running length, bound (3), and three counters — 185 doubles per group, 10 wavefronts per CU.
 // (The two halves of the Newton iteration are written out again here rather than shared with project_fd_kernel through functions:
@@ -636,7 +637,8 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from, const double *__restrict__ to,
     unsigned long long E, int max_states, double *__restrict__ states, int *__restrict__ n_states, uint8_t *__restrict__ ok_out,
     int *__restrict__ newton_iters, unsigned long long *queue, const unsigned int *__restrict__ order,
-    double *__restrict__ carry_out, int round_budget, double *__restrict__ pool, unsigned long long *pool_count, int handover_pct)
+    double *__restrict__ carry_out, int round_budget, double *__restrict__ pool, unsigned long long *pool_count, int handover_pct,
+    const uint8_t *__restrict__ target_ok)
 {
   __shared__ double lds[kGroupsPerWave * kRecG];
   const int lane = threadIdx.x;
@@ -682,7 +684,10 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
           }
           const double dist = ccmp_sqrt(acc);
           const double total = 0.0, maxd = dist * lambda;
-          const bool enter = dist > delta; // (continuations — carry_in — are few edges and stay on geodesic_flat_kernel)
+          // target_ok (checkMotion, src/planner/stefanBiPRM.cpp:397-398): isSatisfied(to) of every edge, tested by a launch in front of
+          // this one — an edge whose target fails is not traversed (n = 1, ok = 0), as in geodesic_flat_kernel
+          const bool tgt = target_ok == nullptr || target_ok[edge] != 0;
+          const bool enter = tgt && dist > delta; // (continuations — carry_in — are few edges and stay on geodesic_flat_kernel)
           const double tt = delta / dist;
           for (int e = r; e < 14; e += kGroup) {
             const double a = fr[e];
@@ -701,7 +706,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
             active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
           } else if (r == 0) { // within delta already (or a continuation that has arrived): nothing to traverse
             n_states[edge] = 1;
-            ok_out[edge] = (uint8_t)(dist <= delta);
+            ok_out[edge] = (uint8_t)(tgt && dist <= delta);
             if (newton_iters) newton_iters[edge] = 0;
             if (carry_out) { carry_out[2ull * edge] = total; carry_out[2ull * edge + 1ull] = maxd; }
             if (pool) atomicAdd(queue + 3, 1ull); // finished edges: what the hand-over rule below counts down from
@@ -1104,14 +1109,14 @@ extern "C" {
 hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
                                       int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
                                       unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
-                                      double *pool, unsigned long long *pool_count, int handover_pct, hipStream_t st)
+                                      double *pool, unsigned long long *pool_count, int handover_pct, const uint8_t *target_ok, hipStream_t st)
 {
   if (K->stock && K->twin_arms) // the STOCK instantiation also assumes twin arms on diag(+-1) base frames (chain_rows), like project_fd_kernel's
     hipLaunchKernelGGL(geodesic_group_kernel<true>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct);
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok);
   else
     hipLaunchKernelGGL(geodesic_group_kernel<false>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct);
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok);
   return hipGetLastError();
 }
 

@@ -605,7 +605,25 @@ def test_bulk_extend_hybrid_is_bitwise_identical(gpu_ctx, oracle_det, variant):
                 for k in (1, 2, 3, 4):
                     assert torch.equal(got[k], ref[k]), (pred, permille, handover, k)
                 assert torch.equal(got[0][live], ref[0][live]), (pred, permille, handover)
-        # the last setting's result against the oracle: first pass on a slice, then the continued edges whole
+        # checkMotion in bulk (check_target): isSatisfied(to) first — targets off the manifold among them — then the same traversal
+        to_cm = to.clone()
+        to_cm[24:64] = c.ambient_uniform_batch(0x6F7, 0, 40)  # not satisfied: such an edge is not traversed (n = 1, ok = 0)
+        gpu_ctx.set_option("geodesic_group", 0)
+        ref_cm = c.discrete_geodesic_batch(frm, to_cm, cap, check_target=True, want_carry=True, round_budget=budget)
+        torch.cuda.synchronize()
+        assert int((ref_cm[1][24:64] == 1).sum()) == 40 and int(ref_cm[2][24:64].sum()) == 0
+        live_cm = torch.arange(cap, device=frm.device)[None, :] < ref_cm[1].clamp(max=cap)[:, None]
+        gpu_ctx.set_option("geodesic_group", 1)
+        for pred, handover in ((1023, 50), (20, 50), (1, 0)):
+            gpu_ctx.set_option("geodesic_group_pred", pred)
+            gpu_ctx.set_option("geodesic_group_permille", 0)
+            gpu_ctx.set_option("geodesic_group_handover_pct", handover)
+            got_cm = c.discrete_geodesic_batch(frm, to_cm, cap, check_target=True, want_carry=True, round_budget=budget)
+            torch.cuda.synchronize()
+            for k in (1, 2, 3, 4):
+                assert torch.equal(got_cm[k], ref_cm[k]), ("check_target", pred, handover, k)
+            assert torch.equal(got_cm[0][live_cm], ref_cm[0][live_cm]), ("check_target", pred, handover)
+        # the last plain setting's result against the oracle: first pass on a slice, then the continued edges whole
         st, n, okf, its, carry = got
         sl = slice(0, 160)
         for e in range(sl.start, sl.stop):
