@@ -42,6 +42,7 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned int done_seq, size_t pool_records, const unsigned int *order,
                                     const unsigned long long *total_ptr, hipStream_t st);
 hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st);
+hipError_t ccmp_launch_geo_split2(const unsigned int *hist, int p_low, int p_high, int permille, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_geo_split(const unsigned int *hist, int p_min, int p_max, int permille, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
@@ -310,6 +311,12 @@ int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value)
   } else if (!strcmp(name, "geodesic_group_permille")) { // share of the predicted work the front must carry (0 = cut at geodesic_group_pred)
     if (value < 0 || value > 1000) return CCMP_EINVAL;
     ctx->geodesic_group_permille = (int)value;
+  } else if (!strcmp(name, "geodesic_group_low_cut")) {
+    if ((value < 1 && value != -1) || value > 64) return CCMP_EINVAL;
+    ctx->geodesic_group_low_cut = (int)value;
+  } else if (!strcmp(name, "geodesic_group_heavy_permille")) {
+    if (value < 0 || value > 1001) return CCMP_EINVAL;
+    ctx->geodesic_group_heavy_permille = (int)value;
   } else if (!strcmp(name, "geodesic_group_handover_pct")) {
     if (value < 0 || value > 100) return CCMP_EINVAL;
     ctx->geodesic_group_handover_pct = (int)value;
@@ -751,13 +758,16 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
       target_ok = (uint8_t *)hist + 4096 + ctx->lpt_cap * 4;
       HIP_TRY(ccmp_launch_is_satisfied(&K, to, target_ok, E, nullptr, 0, st));
     }
-    const bool high = E >= kGeoGroupHighCut;
-    const int cut = ctx->geodesic_group_pred > 0 ? ctx->geodesic_group_pred : (high ? 64 : 48);
+    // the cut of the order: by default one of two, by what the batch looks like (geo_split2_kernel) — at the scout's cap where the edges
+    // beyond it carry a tenth of the predicted work (stefan, dumbbell), lower where they do not (Wine_Bottle)
+    const int low_cut = ctx->geodesic_group_low_cut > 0 ? ctx->geodesic_group_low_cut : (E < kGeoGroupHighCut ? 40 : 48);
     const int front_per_cu = ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : 8;
     if (ctx->geodesic_group_permille > 0)
-      HIP_TRY(ccmp_launch_geo_split(hist, 8, cut, ctx->geodesic_group_permille, gq, st));
+      HIP_TRY(ccmp_launch_geo_split(hist, 8, ctx->geodesic_group_pred > 0 ? ctx->geodesic_group_pred : 64, ctx->geodesic_group_permille, gq, st));
+    else if (ctx->geodesic_group_pred <= 0)
+      HIP_TRY(ccmp_launch_geo_split2(hist, low_cut, 64, ctx->geodesic_group_heavy_permille, gq, st));
     else
-      HIP_TRY(ccmp_launch_fd_split(hist, cut, 0xffffffffu, gq, st));
+      HIP_TRY(ccmp_launch_fd_split(hist, ctx->geodesic_group_pred, 0xffffffffu, gq, st));
     HIP_TRY(hipEventRecord(ctx->fork, st));
     HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->fork, 0));
     HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target,

@@ -59,7 +59,7 @@ struct DeviceGuard {
 // 16384: 1.917 | 1.677; stefan 12288: 2.324 | 2.753, 14336: 2.663 | 2.887, 16384: 3.028 | 3.029, 20480: 3.706 | 3.302)
 constexpr size_t kDefaultSmallBatch = 10240; // (14336 before the wide split launch: profiles/r04_hybrid_launch_sweep.log)
 constexpr size_t kSplitWideMax = 24576;
-constexpr size_t kGeoGroupHighCut = 20480;  // bulk extend calls: from this many edges on the cut of the order is the scout's cap (ccmp_ctx: geodesic_group*)
+constexpr size_t kGeoGroupHighCut = 20480;  // bulk extend calls: the low cut of the order is 40 rounds below this many edges, 48 from there on (ccmp_ctx: geodesic_group*)
 constexpr int kGeoPoolDoubles = 40;  // = kGeoPoolEntry (ccmp_fd_common.h): one handed-over edge of the extend step's bulk form
 constexpr int kGeoGroupWords = 8 + 64 + 4; // ctx->queue: first of the 8 words of the extend step's bulk form (behind the analytic kernels')     // split launch: up to here two latency blocks per CU (ccmp_ctx: fd_split*)
 constexpr size_t kDefaultLatencyOrderMin = 3072;
@@ -139,8 +139,10 @@ struct ccmp_ctx {
   //   2-3 ms under a call and the hybrid only paid from 32768 edges (calls 1-9).
   int geodesic_group = 1;
   size_t geodesic_group_min = 16384;
-  int geodesic_group_pred = -1;          // cut of the order: edges predicted this many rounds or more go to the latency blocks (-1: 48 below
-                                         // kGeoGroupHighCut edges, the scout's cap, 64, from there on) ...
+  int geodesic_group_pred = -1;          // cut of the order: edges predicted this many rounds or more go to the latency blocks (-1: by the batch,
+                                         // see geodesic_group_low_cut) ...
+  int geodesic_group_low_cut = -1, geodesic_group_heavy_permille = 100; // pred = -1: cut at the scout's cap (64) if the edges beyond it carry
+                                         // this share of the predicted work, else at the low cut (-1: 40 below kGeoGroupHighCut edges, 48 from there on)
   int geodesic_group_permille = 0;       // ... or, > 0: the largest cut <= geodesic_group_pred whose front carries this share of the predicted work
   int geodesic_group_front_per_cu = 8;   // latency blocks per CU for the front
   int geodesic_group_handover_pct = 50;  // hand the group kernel's live edges to latency blocks once the queue is dry and they fill less than this share of its slots (0 = never)

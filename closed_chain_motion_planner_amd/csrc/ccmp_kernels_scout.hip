@@ -820,6 +820,35 @@ __global__ void fd_split_kernel(const unsigned int *__restrict__ hist, int pred_
   }
 }
 
+// Bulk extend calls of about one fill of the group kernel (ccmp_api.cpp: geodesic_common): one of TWO cuts, by what the batch looks
+// like.  Where the edges the scout's cap cut off (predicted >= p_high rounds) already carry permille / 1000 of the predicted work —
+// stefan, dumbbell: 17 % — they are the front; where they do not — Wine_Bottle: 5 % — the front starts at p_low rounds, or its blocks
+// would idle while the group kernel's longest edges run at a twelfth of their pace.  Words as fd_split_kernel leaves them.
+__global__ __launch_bounds__(64) void geo_split2_kernel(const unsigned int *__restrict__ hist, int p_low, int p_high, int permille,
+                                                        unsigned long long *__restrict__ queue)
+{
+  // hist[k] = edges predicted >= k rounds: the predicted work is sum_{j >= 1} hist[j], that of the edges predicted >= P is
+  // P * hist[P] + sum_{j > P} hist[j].  One wavefront, sixteen bins per lane, two shuffle reductions.
+  if (p_high > kBins - 1) p_high = kBins - 1;
+  unsigned long long all = 0, above = 0;
+  for (int j = threadIdx.x; j < kBins; j += 64) {
+    const unsigned long long v = j >= 1 ? hist[j] : 0u;
+    all += v;
+    if (j > p_high) above += v;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    all += __shfl_down(all, off);
+    above += __shfl_down(above, off);
+  }
+  if (threadIdx.x == 0) {
+    const bool heavy = ((unsigned long long)p_high * hist[p_high] + above) * 1000ull >= all * (unsigned long long)permille;
+    const unsigned long long front = hist[heavy ? p_high : p_low];
+    queue[4] = front;
+    queue[0] = front;
+    queue[3] = front;
+  }
+}
+
 // Bulk extend calls (ccmp_api.cpp: geodesic_common): where to cut the scout's descending order between the latency blocks (front)
 // and the throughput layout (rest).  hist[k] = number of edges predicted >= k rounds (hist[0] = all), so the predicted work of
 // the edges predicted >= P is P * hist[P] + sum_{j > P} hist[j] and all of it is sum_{j >= 1} hist[j].  The cut is the LARGEST
@@ -853,6 +882,12 @@ __global__ __launch_bounds__(64) void geo_split_kernel(const unsigned int *__res
 } // namespace
 
 extern "C" hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st); // ccmp_kernels_fd.hip
+
+extern "C" hipError_t ccmp_launch_geo_split2(const unsigned int *hist, int p_low, int p_high, int permille, unsigned long long *queue, hipStream_t st)
+{
+  hipLaunchKernelGGL(geo_split2_kernel, dim3(1), dim3(64), 0, st, hist, p_low, p_high, permille, queue);
+  return hipGetLastError();
+}
 
 extern "C" hipError_t ccmp_launch_geo_split(const unsigned int *hist, int p_min, int p_max, int permille, unsigned long long *queue, hipStream_t st)
 {

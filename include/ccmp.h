@@ -162,7 +162,8 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
  * when left at -1, the default: up to 24576 samples two blocks per CU, predictions >= 40, four samples per CU, a cut of 3;
  * above one block per CU, >= 56, three to four samples per CU, a cut of 2; 0 = off);
  * bulk extend calls: "geodesic_group" (1 = calls with a round budget over "geodesic_group_min" edges or more, default 16384, run their
- * short edges — predicted fewer than "geodesic_group_pred" Newton rounds; -1, the default: 48 below 20480 edges, 64 from there on —
+ * short edges — predicted fewer than "geodesic_group_pred" Newton rounds; -1, the default: 64, the scout's cap, where the edges beyond it
+ * carry a tenth of the predicted work, else 40 (below 20480 edges) or 48 —
  * ten to a wavefront on the throughput layout and the others on "geodesic_group_front_per_cu" latency blocks per CU, default 8, beside
  * them; what is still in flight when the short edges fill less than "geodesic_group_handover_pct" % of their slots, default 50, goes to
  * latency blocks too; default 1; same results bit for bit);
