@@ -178,3 +178,49 @@ def test_analytic_default_policy_at_full_size_is_bitwise_the_oracle(gpu_ctx, ora
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64)), rep
         assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu), rep
+
+
+@pytest.mark.parametrize("obj,n_edges", [("Wine_Bottle", 65536), ("stefan", 40000), ("dumbbell", 17000)])
+def test_bulk_extend_at_full_size(gpu_ctx, oracle_det, obj, n_edges):
+    """The extend step's bulk form at sizes the oracle cannot follow in seconds, under the DEFAULT policy (ten-edges-per-wavefront
+    kernel + latency blocks + hand-over; the cut of the scout's order decided on the device), through what does not depend on size:
+    the same lists, counts, flags, Newton counts and carries as the latency kernel alone; every listed state satisfies the
+    constraint; consecutive states are no further apart than lambda * delta; an edge that reports `reached` ends within delta of its
+    target; a spot-check of 96 edges against the oracle."""
+    import torch
+
+    c = _constraint(obj, gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    q, ok, _, _ = c.sample_project_batch(0x6FA, 0, 8 * n_edges, want_iters=False)
+    frm = q[ok == 1][:n_edges].contiguous()
+    assert frm.shape[0] == n_edges
+    to, _, _, _ = c.sample_near_project_batch(0x6FB, 0, frm, 0.6, n_edges, want_iters=False)
+    cap, budget = 16, 128
+    try:
+        gpu_ctx.set_option("geodesic_group", 0)
+        ref = c.discrete_geodesic_batch(frm, to, cap, want_carry=True, round_budget=budget)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_option("geodesic_group", 1)
+    got = c.discrete_geodesic_batch(frm, to, cap, want_carry=True, round_budget=budget)
+    torch.cuda.synchronize()
+    st, n, okf, its, carry = got
+    listed = torch.arange(cap, device=frm.device)[None, :] < n.clamp(max=cap)[:, None]
+    for k in (1, 2, 3, 4):
+        assert torch.equal(got[k], ref[k]), k
+    assert torch.equal(st[listed], ref[0][listed])
+    states = st[listed]
+    assert bool(c.is_satisfied_batch(states).all())  # every state the traversal accepted is on the manifold
+    step = (st[:, 1:] - st[:, :-1]).norm(dim=2)
+    pair = listed[:, 1:] & listed[:, :-1]
+    assert float(step[pair].max()) <= P.lambda_ * P.delta * (1 + 1e-12)
+    last = st[torch.arange(n_edges, device=frm.device), n.clamp(max=cap) - 1]
+    reached = okf == 1
+    assert int(reached.sum()) > 0.4 * n_edges and float((last - to).norm(dim=1)[reached].max()) <= P.delta
+    sel = np.random.default_rng(0x6FC).choice(n_edges, 96, replace=False)
+    for e in sel:
+        ok_e, st_e, n_e, its_e, carry_e = oracle_det.discrete_geodesic_ex(P, frm[e].cpu().numpy(), to[e].cpu().numpy(), cap)
+        if int(okf[e]) == 2:
+            continue
+        assert int(n[e]) == n_e and bool(okf[e]) == bool(ok_e) and int(its[e]) == its_e, e
+        assert np.array_equal(st[e, : min(n_e, cap)].cpu().numpy().view(np.uint64), st_e.view(np.uint64)), e
