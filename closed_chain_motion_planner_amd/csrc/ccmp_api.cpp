@@ -587,6 +587,10 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   const unsigned int *order = ctx->order;
   bool fd_split = false;
   int group_blocks = pl.group_blocks;
+  if (pl.handover) { // (workspace first: nothing of this call is in flight yet if an allocation fails)
+    int rc = ensure_pool(ctx, (size_t)pl.group_blocks * 10);
+    if (rc != CCMP_OK) return rc;
+  }
   if (pl.scout) { // FP32 scout pass -> predicted iteration counts -> descending counting sort -> processing order
     int rc = ensure_lpt_buffers(ctx, B);
     if (rc != CCMP_OK) return rc;
@@ -617,10 +621,6 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       const int room = ctx->num_cus * ((ctx->waves_per_cu > 0 ? ctx->waves_per_cu : 12) - sh.cut);
       if (group_blocks > room) group_blocks = room;
     }
-  }
-  if (pl.handover) {
-    int rc = ensure_pool(ctx, (size_t)pl.group_blocks * 10);
-    if (rc != CCMP_OK) return rc;
   }
   // hand-over in two classes (scout's prediction minus the iterations done): the pool is filled from both ends and the
   // latency kernel takes the long samples first; only with the scout's predictions and the default latency kernel
@@ -749,6 +749,18 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   // wavefront, geodesic_group_kernel, less than half the instructions per Newton round — and the front of the order, the edges
   // predicted to need geodesic_group_pred rounds or more, on this kernel's blocks on the side stream, both from the start.
   if (scouted && round_budget > 0 && !carry_in && ctx->geodesic_group && E >= ctx->geodesic_group_min) {
+    // (workspace first: nothing of this call is in flight yet if the allocation fails)
+    size_t waves = (E + 9) / 10;
+    const size_t cap = (size_t)ctx->num_cus * (size_t)ctx->geodesic_group_waves_per_cu;
+    if (waves > cap) waves = cap;
+    const int pct = ctx->geodesic_group_handover_pct;
+    if (pct > 0 && ctx->geo_pool_cap < waves * 10) { // (grows outside any stream capture: the first call at a size is never captured)
+      if (ctx->geo_pool) (void)hipFree(ctx->geo_pool);
+      ctx->geo_pool = nullptr;
+      ctx->geo_pool_cap = 0;
+      HIP_TRY(hipMalloc((void **)&ctx->geo_pool, waves * 10 * kGeoPoolDoubles * sizeof(double)));
+      ctx->geo_pool_cap = waves * 10;
+    }
     unsigned long long *gq = ctx->queue + kGeoGroupWords; // [0] group kernel's ticket (starts behind the front), [4] front length, [5] front's ticket
     unsigned int *hist = (unsigned int *)((char *)ctx->lpt_buf + ((ctx->lpt_cap * 2 + 255) & ~(size_t)255));
     HIP_TRY(ccmp_launch_clear_words(gq, 16, st));
@@ -773,17 +785,6 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     HIP_TRY(ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target,
                                  ctx->num_cus * front_per_cu, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, nullptr, nullptr, ctx->side));
     HIP_TRY(hipEventRecord(ctx->join, ctx->side));
-    size_t waves = (E + 9) / 10;
-    const size_t cap = (size_t)ctx->num_cus * (size_t)ctx->geodesic_group_waves_per_cu;
-    if (waves > cap) waves = cap;
-    const int pct = ctx->geodesic_group_handover_pct;
-    if (pct > 0 && ctx->geo_pool_cap < waves * 10) { // (grows outside any stream capture: the first call at a size is never captured)
-      if (ctx->geo_pool) (void)hipFree(ctx->geo_pool);
-      ctx->geo_pool = nullptr;
-      ctx->geo_pool_cap = 0;
-      HIP_TRY(hipMalloc((void **)&ctx->geo_pool, waves * 10 * kGeoPoolDoubles * sizeof(double)));
-      ctx->geo_pool_cap = waves * 10;
-    }
     HIP_TRY(ccmp_launch_geodesic_group(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, (int)waves, gq, order,
                                        carry_out, round_budget, pct > 0 ? ctx->geo_pool : nullptr, gq + 6, pct, target_ok, st));
     if (pct > 0) { // the handed-over edges: latency blocks behind the group kernel; the pool's fill count is read on the device
