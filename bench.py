@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets several ranks share one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
+    ap.add_argument("--one-process", type=int, default=0,
+                    help="internal: this process is the ONE-process child — it drives that many GPUs through the C ABI's sharded entry "
+                         "points (SURVEY.md section 8(e): 'implement both, report both') and prints its own JSON line")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, rendezvous over gloo on the CPU, print the launch facts and exit (no GPU work: "
                          "checks the launcher on a box without GPUs)")
@@ -115,6 +118,86 @@ def launch_ranks(n):
     if rc != 0:
         print("bench.py: %s; the other ranks were stopped" % why, file=sys.stderr)
         sys.exit(rc)
+
+
+# ---- one process, n GPUs: the reference's own shape (src/main.cpp:27-63 is a single process) ---------------------------------------
+def one_process_child(args):
+    """The child started after the ranks are done (run_one_process below): ONE process, one context per GPU, the batch
+    sharded inside the C ABI — `direct`: ccmp_sample_project_sharded_host, every GPU returns its shard straight to the host, no
+    collective; `rccl`: ccmp_sample_project_sharded, ncclCommInitAll over the devices + one ncclAllGather of the compacted
+    valid states.  262 144 samples per GPU and call (BASELINE configs[4]'s shard), results in HOST memory as the host tree
+    consumes them, so these rates include the download that `value` (device-resident, one process per GPU) does not.
+    Prints one JSON line; the direct form's result is flushed to --one-process-out before the collective is touched."""
+    import numpy as np
+    import torch  # noqa: F401  (loads the HIP runtime the library binds to)
+
+    from closed_chain_motion_planner_amd import Communicator, Context, KinematicChainConstraint
+
+    n = args.one_process
+    devs = [args.force_device] * n if args.force_device >= 0 else list(range(n))
+    ctxs = [Context(d) for d in devs]
+    c = KinematicChainConstraint.from_yaml(os.path.join(ROOT, "tests", "golden", "config", args.obj + ".yaml"), ctx=ctxs[0])
+    B = args.batch * n
+    out = {"gpus": n, "devices": devs, "samples_per_call": B, "samples_per_gpu": args.batch, "results_in": "host memory (pageable)"}
+
+    def timed(fn, reps=5, warm=2):
+        for _ in range(warm):
+            r = fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), r
+
+    sec, (q, ok, it) = timed(lambda: c.sample_project_sharded_host(0xC5, 0, B, ctxs))
+    launch_ms, start_ms = c.sharded_host_last_timing(ctxs)
+    out["direct"] = {"entry": "ccmp_sample_project_sharded_host", "collective": "none", "shards": n, "ms_per_call": sec * 1e3,
+                     "projections_per_s": B / sec, "ok_fraction": float(ok.mean()), "shard_launch_ms": launch_ms, "shard_start_ms_on_gpu": start_ms}
+    ref_ok = ok.copy()
+    print(json.dumps(out), flush=True)  # (a first line: kept by the parent if the collective below never returns)
+    if len(set(devs)) == n:  # RCCL wants distinct devices: a rehearsal with two contexts on one card has no collective form
+        try:
+            comm = Communicator(ctxs)
+            sec, (valid, counts, full) = timed(lambda: c.sample_project_sharded(0xC5, 0, B, comm, block_rows=max(1, args.batch // 2)))
+            kernel_ms, gather_ms = comm.last_timing()
+            out["rccl"] = {"entry": "ccmp_sample_project_sharded", "collective": "ncclAllGather of fixed-capacity blocks of valid states",
+                           "ranks": n, "ms_per_call": sec * 1e3, "projections_per_s": B / sec, "valid_states": int(sum(counts)),
+                           "kernel_ms_per_gpu": kernel_ms, "gather_ms_per_gpu": gather_ms,
+                           "same_flags_as_direct": bool(np.array_equal(full[1], ref_ok))}
+        except Exception as e:
+            out["rccl"] = {"error": repr(e)}
+    else:
+        out["rccl"] = {"skipped": "the contexts share a device (rehearsal): RCCL needs one device per rank"}
+    print(json.dumps(out), flush=True)
+
+
+def run_one_process(args, n):
+    """starts the one-process child (a fresh process: never an exec of one that has touched a GPU) with a deadline, and
+    returns its last JSON line — {"error": ...} if it produced none"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--one-process", str(n), "--batch", str(args.batch), "--obj", args.obj]
+    if args.force_device >= 0:
+        cmd += ["--force-device", str(args.force_device)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "CCMP_BENCH_CHILD")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = p.communicate(timeout=float(os.environ.get("CCMP_ONE_PROCESS_TIMEOUT", "240")))
+    except subprocess.TimeoutExpired:
+        p.kill()  # this child only, by handle
+        so, se = p.communicate()
+        se = (se or "") + "\n[deadline passed: child stopped]"
+    lines = [ln for ln in (so or "").splitlines() if ln.startswith("{")]
+    if lines:
+        try:
+            res = json.loads(lines[-1])
+            if p.returncode not in (0, None):
+                res["child_exit_code"] = p.returncode
+                res["child_stderr_tail"] = (se or "")[-400:]
+            return res
+        except Exception:
+            pass
+    return {"error": "the one-process child produced no result (exit code %s)" % p.returncode, "stderr_tail": (se or "")[-600:]}
 
 
 # ---- host cores -----------------------------------------------------------------------------------------------------------
@@ -274,6 +357,8 @@ def gather_probe(c, vg, rank, world, torch, dist, n=4096, seed=0xC5):
 
 def main():
     args = parse()
+    if args.one_process:
+        return one_process_child(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         return launch_ranks(args.gpus)  # before anything touches a GPU
@@ -395,7 +480,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kms = sum(a.elapsed_time(b) for a, b in kernel_ms) / max(1, len(kernel_ms))
+    kms_steps = [a.elapsed_time(b) for a, b in kernel_ms]
+    kms = sum(kms_steps) / max(1, len(kms_steps))
     sum_iters = float(it.to(torch.float64).sum().item())
     ok_frac = float(ok.to(torch.float64).mean().item())
     gathered = None
@@ -421,6 +507,8 @@ def main():
         n_valid = int(cnt.item())
     rccl_ranks = dist.get_world_size() if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)
 
+    if world > 1:
+        dist.barrier()  # every rank is through its measurements: what follows on rank 0 has the GPUs to itself
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -429,13 +517,18 @@ def main():
     value = world * B * args.steps / elapsed
     kernel = "project_fd_kernel+project_fd_flat_kernel+scout_kernel" if args.mode == "fd" else "project_fast_kernel"
     achieved_gbs = BYTES_PER_PROJECTION * B / (kms * 1e-3) / 1e9
-    traffic, valu, executed = None, None, None
+    traffic, valu, executed, profile_kernel = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):  # PMC numbers come from separate rocprofv3 --pmc passes (tools/profile.sh), not from this run
         try:
             tj = json.load(open(tpath))
             if tj.get("kernel") == kernel and tj.get("batch") == B:
                 traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("kernel_median_ms"):  # the committed rocprofv3 summary's own figure for the dominant kernel (median over
+                    # its profiled dispatches): must agree with what this run measures live (tests/test_bench_contract.py)
+                    profile_kernel = {"ms": tj["kernel_median_ms"], "q1_ms": tj.get("kernel_q1_ms"), "q3_ms": tj.get("kernel_q3_ms"),
+                                      "dispatches": tj.get("kernel_profiled_dispatches"), "kernel": tj.get("dominant_kernel"),
+                                      "source": "profiles/%s_summary.md" % tj.get("tag")}
                 if tj.get("executed_fp64_flop_per_launch"):
                     ef = tj["executed_fp64_flop_per_launch"]
                     executed = {"achieved": ef / (kms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -469,7 +562,9 @@ def main():
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_ratio": (traffic / (BYTES_PER_PROJECTION * B)) if traffic else None,
-            "kernel": kernel, "kernel_ms": kms,
+            "kernel": kernel, "kernel_ms": kms, "kernel_ms_median": sorted(kms_steps)[len(kms_steps) // 2] if kms_steps else None,
+            "kernel_ms_per_step": kms_steps,
+            "profile_kernel_ms": profile_kernel["ms"] if profile_kernel else None, "profile_kernel": profile_kernel,
             "note": "metric asks for %HBM; the kernel is FP64-VALU bound (see fp64); traffic above the algorithmic bytes comes from "
                     "scattered 112-B rows in longest-first order and partial-sector flag writes, harmless at this fraction of HBM",
             "fp64": {"achieved": fp64_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -493,10 +588,20 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.obj, seed, gpu_check)
         except Exception as e:  # the oracle is a checker; its absence must not fail the GPU bench
             line["cpu_baseline"] = {"error": repr(e)}
-    flatten_for_the_driver(line, B)
-    print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not args.no_secondary and args.mode == "fd":
+        # the other multi-GPU form SURVEY.md section 8(e) names: ONE process driving all the GPUs through the C ABI (a fresh child,
+        # started when every rank is done; with a deadline, and never allowed to take this line down with it)
+        if world > 1:
+            time.sleep(1.0)  # the other ranks are on their way out
+        try:
+            one = run_one_process(args, world)
+        except Exception as e:
+            one = {"error": repr(e)}
+        line.setdefault("secondary", {})["one_process"] = one
+    flatten_for_the_driver(line, B)
+    print(json.dumps(line), flush=True)
 
 
 def flatten_for_the_driver(line, B):
@@ -547,6 +652,9 @@ def flatten_for_the_driver(line, B):
             "host_buffer_pinned_per_s": get(sec, "host_buffer", "pinned", "projections_per_s"),
             "analytic_mode_per_s": sec.get("analytic_mode_projections_per_s"),
             "proxy_clearance_states_per_s": get(sec, "proxy_clearance", "states_per_s"),
+            "one_process_gpus": get(sec, "one_process", "gpus"),
+            "one_process_direct_per_s": get(sec, "one_process", "direct", "projections_per_s"),
+            "one_process_rccl_per_s": get(sec, "one_process", "rccl", "projections_per_s"),
         }
         cfgd.update(flat)
     if cb and "error" not in cb:

@@ -4,7 +4,7 @@ Only the projector hot path of jkw0701/closed_chain_motion_planner: 
 `libccmp.so` (include/ccmp.h, csrc/) and this thin host mirror of the reference's constraint
 interface.  Importing the package needs neither a GPU nor the built library; using it does.
 """
-from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem  # noqa: F401
+from ._lib import CCMP_JAC_ANALYTIC, CCMP_JAC_FD, CcmpError, CcmpProblem, describe, get_option, option_table  # noqa: F401
 from .constraint import ArmModel, Communicator, Context, KinematicChainConstraint, load_config  # noqa: F401
 
 from .space import (check_motion, format_graphml, format_graphviz, format_path_matrix, geodesic_interpolate,  # noqa: F401
@@ -13,4 +13,4 @@ from .space import (check_motion, format_graphml, format_graphviz, format_path_m
 
 from .scene import ProxyScene, ProxyValidityChecker, default_allowed, skeleton_spheres  # noqa: F401
 
-__version__ = "0.4.0"
+__version__ = "0.5.0"

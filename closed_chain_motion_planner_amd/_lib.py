@@ -64,7 +64,7 @@ CCMP_JAC_ANALYTIC = 1
 # every symbol include/ccmp.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ccmp_problem_from_yaml", "ccmp_problem_init", "ccmp_set_arms", "ccmp_set_base_frame", "ccmp_set_start", "ccmp_set_tolerance", "ccmp_set_calibration",
-    "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_set_schedule", "ccmp_ctx_set_option", "ccmp_ctx_set_lpt", "ccmp_ctx_device", "ccmp_ctx_num_cus",
+    "ccmp_ctx_create", "ccmp_ctx_destroy", "ccmp_ctx_set_waves_per_cu", "ccmp_ctx_set_schedule", "ccmp_ctx_set_option", "ccmp_ctx_get_option", "ccmp_ctx_option_info", "ccmp_ctx_describe", "ccmp_ctx_set_lpt", "ccmp_ctx_device", "ccmp_ctx_num_cus",
     "ccmp_function_batch", "ccmp_project_batch", "ccmp_is_satisfied_batch", "ccmp_joint_valid_batch",
     "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
     "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_check_motion_batch", "ccmp_geodesic_batch_ex", "ccmp_geodesic_host_ex", "ccmp_check_motion_host", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid", "ccmp_compact_valid_capped",
@@ -112,6 +112,10 @@ def lib():
         "ccmp_ctx_set_waves_per_cu": ([vp, C.c_int], C.c_int),
         "ccmp_ctx_set_schedule": ([vp, C.c_int, C.c_size_t], C.c_int),
         "ccmp_ctx_set_option": ([vp, C.c_char_p, C.c_long], C.c_int),
+        "ccmp_ctx_get_option": ([vp, C.c_char_p, C.POINTER(C.c_long)], C.c_int),
+        "ccmp_ctx_option_info": ([C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long),
+                                  C.POINTER(C.c_char_p)], C.c_int),
+        "ccmp_ctx_describe": ([vp, C.c_int, C.c_size_t, C.c_char_p, C.c_size_t], C.c_int),
         "ccmp_ctx_set_lpt": ([vp, C.c_int, C.c_size_t], C.c_int),
         "ccmp_ctx_device": ([vp], C.c_int),
         "ccmp_ctx_num_cus": ([vp], C.c_int),
@@ -172,6 +176,40 @@ def lib():
         raise ImportError("ccmp_problem layout mismatch between libccmp.so and the Python binding")
     _lib = L
     return L
+
+
+CALL_PROJECT, CALL_SAMPLE_PROJECT, CALL_PROJECT_ANALYTIC, CALL_GEODESIC, CALL_GEODESIC_BUDGET = range(5)  # ccmp.h: CCMP_CALL_*
+
+
+def option_table():
+    """every tuning option of a context as the library itself states it (ccmp_ctx_option_info): name, built-in default, range,
+    meaning — no device needed"""
+    L = lib()
+    out, i = [], 0
+    while True:
+        name, doc = C.c_char_p(), C.c_char_p()
+        d, lo, hi = C.c_long(), C.c_long(), C.c_long()
+        if L.ccmp_ctx_option_info(i, C.byref(name), C.byref(d), C.byref(lo), C.byref(hi), C.byref(doc)) != 0:
+            return out
+        out.append({"name": name.value.decode(), "default": d.value, "lo": lo.value, "hi": hi.value, "doc": doc.value.decode()})
+        i += 1
+
+
+def get_option(ctx_handle, name):
+    """ccmp_ctx_get_option; ctx_handle None = the built-in default"""
+    v = C.c_long()
+    check(lib().ccmp_ctx_get_option(ctx_handle, name.encode(), C.byref(v)), "ccmp_ctx_get_option(%s)" % name)
+    return v.value
+
+
+def describe(ctx_handle, call_kind, n):
+    """ccmp_ctx_describe: one line naming the kernels and thresholds the policy takes for a call of n samples / edges
+    (ctx_handle None = the built-in policy on a 256-CU device)"""
+    buf = C.create_string_buffer(2048)
+    rc = lib().ccmp_ctx_describe(ctx_handle, int(call_kind), int(n), buf, len(buf))
+    if rc < 0:
+        check(rc, "ccmp_ctx_describe")
+    return buf.value.decode()
 
 
 def _strerror(code):

@@ -9,7 +9,10 @@ Translation units with deliberately different flags:
                          like the flat unit (throughput flavour) and -DCCMP_GEO_LATENCY with machine LICM and a 256-register
                          budget (latency flavour)
   ccmp_problem.cpp       -ffp-contract=off -DCCMP_USE_FMA   host set-up (problem, constants) in the same rounding model
-  ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   context, scheduling, launches
+  ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   context, launches
+  ccmp_policy.cpp                                           option table (set / get / info), scheduling plans, ccmp_ctx_describe
+  ccmp_resident.cpp                                         opt-in resident service kernel for single-state calls (host side)
+  ccmp_kernels_resident.hip -ffp-contract=off -DCCMP_USE_FMA  ... its device side, on the latency flavour's Newton routine
   ccmp_host_io.cpp                                          *_host conveniences (staging, pinned block, page-locked caller buffers), sharded host calls
   ccmp_comm.cpp                                             one process / several GPUs: RCCL communicator and sharded entry points
   ccmp_kernels_fast.hip  -ffp-contract=off -DCCMP_USE_FMA   analytic fast mode, bit-identical to the oracle's analytic mode
@@ -46,16 +49,20 @@ _UNITS = [
     ("ccmp_kernels_geo.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     ("ccmp_kernels_geo.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_GEO_LATENCY", "-DCCMP_SUMS_IN_LANE", "-DCCMP_FLAT_MIN_WAVES=2", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
      "ccmp_kernels_geo_lat.hip.o"),
+    # the resident service kernel: one block alone on its SIMDs — the latency flavour's flags (registers are free, fewest instructions per round)
+    ("ccmp_kernels_resident.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_SUMS_IN_LANE", "-DCCMP_FLAT_MIN_WAVES=2", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_problem.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
+    ("ccmp_policy.cpp", ["-O2", "-x", "hip"]),
+    ("ccmp_resident.cpp", ["-O2", "-x", "hip"]),
     ("ccmp_host_io.cpp", ["-O2", "-x", "hip"]),
     ("ccmp_comm.cpp", ["-O2", "-x", "hip"]),
     ("ccmp_kernels_scene.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT"]),
     ("ccmp_scene.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]
-_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_flat_newton.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_flat_newton.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_policy.h", "ccmp_resident.h", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
 
 
 def hipcc_path():
@@ -72,6 +79,85 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
 
 
+# ---- build-time check of the kernels' register allocation (round 5) ------------------------------------------------------------
+# Every device unit is compiled with -Rpass-analysis=kernel-resource-usage; the remarks are kept beside the object
+# (build/<unit>.resources.json) and checked against the bounds below — a build whose hot kernels have started to spill FAILS
+# instead of shipping a silently slower library.  Scratch is in bytes per lane.
+#   * the STOCK instantiations (template argument `true`: both arms carry the uncalibrated Panda's exact zeros — what the
+#     reference ships, ConstrainedPlanningCommon.cpp:97 has the calibration commented out) of the projector kernels and of the
+#     extend step's latency kernel: NO scratch;
+#   * geodesic_group_kernel<true>: at most 96 B — with the occupancy bound of three wavefronts per SIMD (168 registers) the
+#     allocator parks ten loop-invariant values in scratch: 13 stores in the prologue, 12 reloads in a 7 000-instruction loop body
+#     (one Newton round = ~12 500 issued instructions).  Without the bound: 181 registers, no scratch, and 5 % SLOWER at
+#     16 384 - 32 768 edges (interleaved A/B, profiles/r05_bulk_live_ab.log: the front's latency blocks lose the register space);
+#   * the general instantiations (calibrated arms, tilted bases): at most 200 B, except the fused-sampler throughput kernel
+#     project_fd_kernel<1,false>, which spills 2.3 KB (its sampler prologue and the general chain's pose arrays overlap; the
+#     path is the fused sampler x a calibrated model, which nothing in the reference's configuration reaches);
+#   * everything else (scouts, small per-lane kernels, analytic mode, scene): at most 64 B unless listed.
+_SCRATCH_RULES = [  # (regex on the demangled name, bound); first match wins
+    (r"project_fd_kernel<1, false>", 2400),
+    (r"geodesic_group_kernel<true>", 96),
+    (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?)<(\d+, )?true>", 0),
+    (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel)<(\d+, )?false>", 200),
+    (r"scout_|project_fast|project_rows|clearance", 400),
+    (r".", 64),
+]
+
+
+def _demangle(names):
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", shutil.which("c++filt")):
+        if tool and os.path.exists(tool):
+            out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+            return dict(zip(names, out))
+    return {n: n for n in names}
+
+
+def parse_resource_remarks(stderr_text):
+    """[{name, vgprs, agprs, sgprs, scratch, occupancy, lds, vgpr_spill, sgpr_spill}] from -Rpass-analysis=kernel-resource-usage"""
+    import re
+
+    kernels, cur = [], None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+            "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds"}
+    for line in stderr_text.splitlines():
+        m = re.search(r"remark: (?:\s*)([A-Za-z \[\]/]+): (\S+) \[-Rpass-analysis", line)
+        if not m:
+            continue
+        k, v = m.group(1).strip(), m.group(2)
+        if k == "Function Name":
+            cur = {"mangled": v}
+            kernels.append(cur)
+        elif cur is not None and k in keys:
+            cur[keys[k]] = int(v)
+    dm = _demangle([k["mangled"] for k in kernels])
+    for k in kernels:
+        k["name"] = dm[k["mangled"]].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+    return kernels
+
+
+def check_resources(kernels, unit):
+    """raises RuntimeError when a kernel of `unit` exceeds its scratch bound"""
+    import re
+
+    bad = []
+    for k in kernels:
+        bound = next(b for rx, b in _SCRATCH_RULES if re.search(rx, k["name"]))
+        k["scratch_bound"] = bound
+        if k.get("scratch", 0) > bound:
+            bad.append("%s: %d B/lane of scratch (bound %d), %d VGPRs, %d spilled" % (k["name"], k["scratch"], bound, k.get("vgprs", -1), k.get("vgpr_spill", -1)))
+    if bad and not os.environ.get("CCMP_ALLOW_SPILLS"):
+        raise RuntimeError("register allocation of %s regressed (closed_chain_motion_planner_amd/build.py: _SCRATCH_RULES; CCMP_ALLOW_SPILLS=1 "
+                           "builds anyway):\n  " % unit + "\n  ".join(bad))
+
+
+def resource_report():
+    """{unit object: [kernel records]} of the last build (build/*.resources.json)"""
+    import glob
+    import json
+
+    return {os.path.basename(f)[:-len(".resources.json")]: json.load(open(f)) for f in sorted(glob.glob(os.path.join(HERE, "build", "*.resources.json")))}
+
+
 def build_library(force=False, verbose=False):
     """Compile (if stale) and return the path of libccmp.so."""
     os.makedirs(LIBDIR, exist_ok=True)
@@ -86,14 +172,29 @@ def build_library(force=False, verbose=False):
         op = os.path.join(objdir, obj[0] if obj else src + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + headers):
-            jobs.append([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags + ["-c", sp, "-o", op])
+            jobs.append([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags +
+                        (["-Rpass-analysis=kernel-resource-usage"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op])
     if jobs:  # the units are independent: compile them side by side (hipcc is one process per unit)
+        import json
         from concurrent.futures import ThreadPoolExecutor
 
         def run(cmd):
             if verbose:
                 print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            rest = "\n".join(ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln)
+            if rest.strip():
+                print(rest)
+            if r.returncode != 0:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            if "-Rpass-analysis=kernel-resource-usage" in cmd:
+                kernels = parse_resource_remarks(r.stderr)
+                try:
+                    check_resources(kernels, os.path.basename(cmd[-1]))
+                except RuntimeError:
+                    os.remove(cmd[-1])  # a failed check must not leave an object that looks up to date
+                    raise
+                json.dump(kernels, open(cmd[-1][:-2] + ".resources.json", "w"), indent=1)
 
         workers = max(1, min(len(jobs), int(os.environ.get("CCMP_BUILD_JOBS", "0")) or min(4, os.cpu_count() or 1)))
         with ThreadPoolExecutor(workers) as pool:

@@ -56,6 +56,15 @@ class Context:
         "_front", "_cap"), "clearance_per_state_max"; results never change"""
         check(_lib.lib().ccmp_ctx_set_option(self._h, name.encode(), int(value)), "ccmp_ctx_set_option(%s)" % name)
 
+    def get_option(self, name):
+        """ccmp_ctx_get_option: the value in force (also "num_cus", "side_stream_busy", "resident")"""
+        return _lib.get_option(self._h, name)
+
+    def describe(self, call_kind, n):
+        """ccmp_ctx_describe: which kernels and thresholds the policy takes for a call of n samples / edges (call_kind:
+        _lib.CALL_PROJECT, CALL_SAMPLE_PROJECT, CALL_PROJECT_ANALYTIC, CALL_GEODESIC, CALL_GEODESIC_BUDGET)"""
+        return _lib.describe(self._h, call_kind, n)
+
     def set_lpt(self, mode=1, min_batch=None):
         """0 = index order, 1 = FP32 scout + longest-predicted-first (default), 2 = the same without hand-over;
         min_batch None = the library default"""

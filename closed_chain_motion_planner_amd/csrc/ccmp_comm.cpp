@@ -237,9 +237,12 @@ static int comm_phase3(int g, void *arg)
   const CommShard &S = (*A.sh)[(size_t)g];
   ccmp_ctx *ctx = c->ctxs[g];
   DeviceGuard guard(ctx->device);
-  int rc = CCMP_OK;
+  // without the device current the copies below would be issued against whichever device this shard thread happens to have:
+  // report that — but still wait for the shard's stream (a stream handle can be synchronised from any device context), so the
+  // caller's buffers are idle when the call returns
+  int rc = guard.ok ? CCMP_OK : CCMP_ENODEV;
   hipError_t e = hipSuccess;
-  if (g == 0) {
+  if (rc == CCMP_OK && g == 0) {
     e = hipMemcpyAsync(c->host_recv, c->recv[0], (c->cap + 1) * 14 * sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, ctx->stream);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(D2H gathered blocks)");
   }
@@ -260,8 +263,9 @@ static int comm_sync_one(int g, void *arg)
 {
   ccmp_comm *c = ((CommArgs *)arg)->c;
   DeviceGuard guard(c->ctxs[g]->device);
-  (void)hipStreamSynchronize(c->ctxs[g]->stream);
-  return CCMP_OK;
+  const hipError_t e = hipStreamSynchronize(c->ctxs[g]->stream); // (attempted whether or not the device could be made current)
+  if (!guard.ok) return CCMP_ENODEV;
+  return e == hipSuccess ? CCMP_OK : hip_fail(e, "hipStreamSynchronize(shard, error path)");
 }
 
 static int comm_project_common(ccmp_comm *c, const ccmp_problem *p, int mode, const double *q_in, uint64_t seed, uint64_t first_index,

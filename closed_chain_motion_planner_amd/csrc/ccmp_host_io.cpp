@@ -14,6 +14,7 @@
 
 #include "../../include/ccmp.h"
 #include "ccmp_ctx.h"
+#include "ccmp_resident.h"
 
 using ccmp_host::DeviceGuard;
 using ccmp_host::ensure_stage;
@@ -25,6 +26,7 @@ namespace ccmp_host {
 int ensure_stage(ccmp_ctx *ctx, size_t bytes)
 {
   if (ctx->stage_cap >= bytes) return CCMP_OK;
+  quiesce(ctx); // (hipFree waits for the whole device: a resident service kernel must be gone first)
   if (ctx->stage) (void)hipFree(ctx->stage);
   ctx->stage = nullptr;
   ctx->stage_cap = 0;
@@ -36,15 +38,24 @@ int ensure_stage(ccmp_ctx *ctx, size_t bytes)
 void *pinned_alias(const void *host, size_t bytes)
 {
   if (!host || bytes == 0) return nullptr;
-  hipPointerAttribute_t a, b;
+  hipPointerAttribute_t a;
   memset(&a, 0, sizeof a);
-  memset(&b, 0, sizeof b);
   // an unregistered (pageable) pointer is reported as an error by older runtimes and as hipMemoryTypeUnregistered by newer
   // ones; the error is sticky for hipGetLastError only and is cleared here
   if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
-  if (hipPointerGetAttributes(&b, (const char *)host + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  if (b.type != hipMemoryTypeHost || (const char *)b.devicePointer != (const char *)a.devicePointer + (bytes - 1)) return nullptr;
+  // the mapping must be this device's: page-locked memory of another device's context is only usable here when it was
+  // allocated portable, which the attributes do not tell — such a buffer takes the staged path
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || a.device != dev) return nullptr;
+  // [host, host + bytes) must lie inside ONE page-locked allocation.  (Round 4 tested the first and the last byte only: with
+  // hipHostRegister the device address equals the host address, so two separately registered regions with a pageable gap
+  // between them passed, and the kernels then touched the gap — a GPU page fault instead of a fall-back.)
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  const char *lo = (const char *)a.devicePointer, *b0 = (const char *)base;
+  if (!base || lo < b0 || bytes > size || (size_t)(lo - b0) > size - bytes) return nullptr;
   return a.devicePointer;
 }
 
@@ -97,6 +108,7 @@ struct HostIO {
   {
     if (bytes <= kPinData) {
       if (!ctx->pin) {
+        ccmp_host::quiesce(ctx);
         HIP_TRY(hipHostMalloc(&ctx->pin, kPinBytes, hipHostMallocMapped | hipHostMallocCoherent));
         memset(ctx->pin, 0, kPinBytes);
         hipError_t e = hipHostGetDevicePointer(&ctx->pin_dev, ctx->pin, 0);
@@ -195,6 +207,10 @@ int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, 
   if (!q_in || !q_out || !ok) return CCMP_EINVAL;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
+  if (B == 1 && ctx->resident_on) { // the resident service kernel (opt-in): no launch on the call path
+    const int rc = ccmp_host::resident_call(ctx, p, ccmp_host::ResidentCall{kResProject, q_in, q_out, nullptr, ok, iters});
+    if (rc != ccmp_host::kResidentFallBack) return rc;
+  }
   const size_t qb = B * 14 * sizeof(double);
   if (qb > kPinData && ctx->host_zero_copy) {
     const int done = project_host_pinned(ctx, p, q_in, q_out, ok, iters, B);
@@ -223,6 +239,10 @@ int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, do
   if (!q || !f) return CCMP_EINVAL;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
+  if (B == 1 && ctx->resident_on) {
+    const int rc = ccmp_host::resident_call(ctx, p, ccmp_host::ResidentCall{kResFunction, q, nullptr, f, nullptr, nullptr});
+    if (rc != ccmp_host::kResidentFallBack) return rc;
+  }
   const size_t qb = B * 14 * sizeof(double);
   const size_t off_f = (qb + 255) & ~(size_t)255;
   HostIO io(ctx);
@@ -243,6 +263,10 @@ int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
   if (!q || !ok) return CCMP_EINVAL;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
+  if (B == 1 && ctx->resident_on) {
+    const int rc = ccmp_host::resident_call(ctx, p, ccmp_host::ResidentCall{kResIsSatisfied, q, nullptr, nullptr, ok, nullptr});
+    if (rc != ccmp_host::kResidentFallBack) return rc;
+  }
   const size_t qb = B * 14 * sizeof(double);
   const size_t off_ok = (qb + 255) & ~(size_t)255;
   HostIO io(ctx);
@@ -263,6 +287,10 @@ int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q,
   if (!q || !ok) return CCMP_EINVAL;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
+  if (B == 1 && ctx->resident_on) {
+    const int rc = ccmp_host::resident_call(ctx, p, ccmp_host::ResidentCall{kResJointValid, q, nullptr, nullptr, ok, nullptr});
+    if (rc != ccmp_host::kResidentFallBack) return rc;
+  }
   const size_t qb = B * 14 * sizeof(double);
   const size_t off_ok = (qb + 255) & ~(size_t)255;
   HostIO io(ctx);

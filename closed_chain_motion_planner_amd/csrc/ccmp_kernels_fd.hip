@@ -631,14 +631,16 @@ __device__ __forceinline__ double geo_interpolate(double fr, double tg, double t
   return v;
 }
 
+#ifndef CCMP_GEO_GROUP_WAVES_PER_SIMD
+#define CCMP_GEO_GROUP_WAVES_PER_SIMD CCMP_FD_WAVES_PER_SIMD
+#endif
 template <bool STOCK>
-__global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_kernel( // (no occupancy bound: 181 registers, no scratch, 1-2 % slower)
-   
+__global__ __launch_bounds__(64, CCMP_GEO_GROUP_WAVES_PER_SIMD) void geodesic_group_kernel(
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from, const double *__restrict__ to,
     unsigned long long E, int max_states, double *__restrict__ states, int *__restrict__ n_states, uint8_t *__restrict__ ok_out,
     int *__restrict__ newton_iters, unsigned long long *queue, const unsigned int *__restrict__ order,
     double *__restrict__ carry_out, int round_budget, double *__restrict__ pool, unsigned long long *pool_count, int handover_pct,
-    const uint8_t *__restrict__ target_ok)
+    const uint8_t *__restrict__ target_ok, unsigned int *__restrict__ pool_flags, int retire_active)
 {
   __shared__ double lds[kGroupsPerWave * kRecG];
   const int lane = threadIdx.x;
@@ -658,6 +660,19 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
     bp_lane = arm_l ? (row_l == 0 ? K.base_p[1][0] : (row_l == 1 ? K.base_p[1][1] : K.base_p[1][2]))
                     : (row_l == 0 ? K.base_p[0][0] : (row_l == 1 ? K.base_p[0][1] : K.base_p[0][2]));
   }
+  // The lane's address offsets into from / to / states and its bit masks never change either, but they are NOT held across the
+  // Newton loop: under the bound of three wavefronts per SIMD the allocator parked them in scratch.  They are recomputed where they
+  // are used — once per edge or projection — from a lane index the optimiser cannot see through, which keeps it from hoisting them
+  // back out of the loop.
+#ifndef CCMP_GEO_GROUP_OPAQUE
+#define CCMP_GEO_GROUP_OPAQUE 1
+#endif
+  auto lane_opaque = [](int v) {
+#if CCMP_GEO_GROUP_OPAQUE
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+  };
 
   unsigned long long edge = 0;
   int iter = 0, updates = 0;
@@ -689,7 +704,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
           const bool tgt = target_ok == nullptr || target_ok[edge] != 0;
           const bool enter = tgt && dist > delta; // (continuations — carry_in — are few edges and stay on geodesic_flat_kernel)
           const double tt = delta / dist;
-          for (int e = r; e < 14; e += kGroup) {
+          for (int e = lane_opaque(r); e < 14; e += kGroup) {
             const double a = fr[e];
             rec[kGPrev + e] = a;
             if (max_states > 0) out[e] = a; // geodesic->push_back(cloneState(from))
@@ -734,23 +749,43 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
       head = shfl_u64(head, 0);
       fin_count = shfl_u64(fin_count, 0);
       const unsigned long long in_flight = E - fin_count, slots = (unsigned long long)gridDim.x * kGroupsPerWave;
-      if (head >= E && in_flight * 100ull < slots * (unsigned long long)handover_pct) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(active && r == 0);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(active && r == 0);
+      // Live hand-over (round 5, pool_flags != NULL: latency blocks take entries while this kernel runs): with the queue dry a
+      // wavefront no longer waits for the whole launch to thin out — it gives its edges up as soon as retire_active or fewer of
+      // its ten groups are busy (below half full the layout pays more instructions per edge and round than the latency kernel)
+      if (head >= E && (in_flight * 100ull < slots * (unsigned long long)handover_pct ||
+                        (pool_flags != nullptr && __builtin_popcountll(m) <= retire_active))) {
         unsigned long long base = 0;
-        if (lane == 0 && m) base = atomicAdd(pool_count, (unsigned long long)__builtin_popcountll(m));
+        if (lane == 0 && m) {
+          base = atomicAdd(pool_count, (unsigned long long)__builtin_popcountll(m));
+          if (pool_flags) atomicAdd(queue + 3, (unsigned long long)__builtin_popcountll(m)); // given up = no longer in flight HERE
+        }
         base = shfl_u64(base, 0);
+        const unsigned long long slot = base + (unsigned long long)__builtin_popcountll(m & ((1ull << lane_opaque(leader)) - 1ull));
+        // live: agent-scope atomic stores — they are written through to where every XCD reads them, so the flag behind them needs
+        // no cache write-back (a release fence at agent scope writes the whole L2 back: seen as a chip-wide slowdown)
+        const bool through = pool_flags != nullptr;
+        auto put = [through](double *p, double v) {
+          if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *p = v;
+        };
         if (active) {
-          double *ent = pool + (base + (unsigned long long)__builtin_popcountll(m & ((1ull << leader) - 1ull))) * (unsigned long long)kGeoPoolEntry;
-          for (int e = r; e < 14; e += kGroup) { ent[e] = rec[kX + e]; ent[14 + e] = rec[kGPrev + e]; }
+          double *ent = pool + slot * (unsigned long long)kGeoPoolEntry;
+          for (int e = lane_opaque(r); e < 14; e += kGroup) { put(ent + e, rec[kX + e]); put(ent + 14 + e, rec[kGPrev + e]); }
           if (r == 0) {
             const int *cnt = reinterpret_cast<const int *>(rec + kGCnt);
-            ent[28] = rec[kGDist]; ent[29] = rec[kGDist + 1]; ent[30] = rec[kGDist + 2];
-            ent[31] = __longlong_as_double((long long)edge);
-            ent[32] = __hiloint2double(cnt[0], cnt[1]);   // states listed, Newton updates of the finished projections
-            ent[33] = __hiloint2double(cnt[2], iter);     // Newton rounds of the finished projections, loop counter of this one
-            ent[34] = __hiloint2double(0, updates);
-            ent[35] = norm1; ent[36] = norm2;
+            put(ent + 28, rec[kGDist]); put(ent + 29, rec[kGDist + 1]); put(ent + 30, rec[kGDist + 2]);
+            put(ent + 31, __longlong_as_double((long long)edge));
+            put(ent + 32, __hiloint2double(cnt[0], cnt[1]));   // states listed, Newton updates of the finished projections
+            put(ent + 33, __hiloint2double(cnt[2], iter));     // Newton rounds of the finished projections, loop counter of this one
+            put(ent + 34, __hiloint2double(0, updates));
+            put(ent + 35, norm1); put(ent + 36, norm2);
           }
+        }
+        if (pool_flags) { // the entries — all of them acknowledged — then their flags, then the takers' semaphore
+          __builtin_amdgcn_s_waitcnt(0);
+          if (active && r == 0) __hip_atomic_store(pool_flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0 && m) atomicAdd(queue + 8, (unsigned long long)__builtin_popcountll(m));
         }
         break;
       }
@@ -838,7 +873,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
           if (newDist >= dist) break;                      // no closer than before
           if (n >= max_states) { fits = false; n = max_states + 1; total = total_before; its -= updates; break; } // list full
           dist = newDist;
-          for (int e = r; e < 14; e += kGroup) out[(unsigned long long)n * 14ull + e] = rec[kX + e];
+          for (int e = lane_opaque(r); e < 14; e += kGroup) out[(unsigned long long)n * 14ull + e] = rec[kX + e];
           n++;
           if (!(dist >= delta)) break;                     // arrived
           if (round_budget > 0 && rounds >= round_budget) { suspended = true; break; } // this call's share of the edge is spent
@@ -855,7 +890,7 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
           active = false;
         } else { // the accepted state becomes `previous`; the next scratch state is interpolated towards the target
           const double tt = delta / dist;
-          for (int e = r; e < 14; e += kGroup) {
+          for (int e = lane_opaque(r); e < 14; e += kGroup) {
             const double a = rec[kX + e];
             rec[kGPrev + e] = a;
             rec[kX + e] = geo_interpolate(a, tg[e], tt);
@@ -906,6 +941,11 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void geodesic_group_ker
       }
     }
     __syncthreads();
+  }
+  // live hand-over: this wavefront has left (queue[1]); when all have, the pool's count is final and waiting consumers go home
+  if (pool_flags != nullptr) {
+    __builtin_amdgcn_s_waitcnt(0); // (what this wavefront added to the semaphore is there before it is counted out)
+    if (lane == 0) __hip_atomic_fetch_add(queue + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1109,14 +1149,17 @@ extern "C" {
 hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
                                       int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
                                       unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
-                                      double *pool, unsigned long long *pool_count, int handover_pct, const uint8_t *target_ok, hipStream_t st)
+                                      double *pool, unsigned long long *pool_count, int handover_pct, const uint8_t *target_ok,
+                                      unsigned int *pool_flags, int retire_active, hipStream_t st)
 {
   if (K->stock && K->twin_arms) // the STOCK instantiation also assumes twin arms on diag(+-1) base frames (chain_rows), like project_fd_kernel's
     hipLaunchKernelGGL(geodesic_group_kernel<true>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok);
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok,
+                       pool_flags, retire_active);
   else
     hipLaunchKernelGGL(geodesic_group_kernel<false>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok);
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok,
+                       pool_flags, retire_active);
   return hipGetLastError();
 }
 

@@ -1,0 +1,133 @@
+// ccmp_kernels_resident.hip — the resident service kernel (ccmp_resident.h: what it is for, what keeps it from hanging anything).
+// One persistent 128-thread block on the latency kernels' Newton routine (ccmp_flat_newton.h, built like the extend step's
+// latency flavour: machine LICM on, 256-register budget — the block is alone on its CU's SIMDs, registers are free).
+// Same arithmetic, same rounding model (-ffp-contract=off -DCCMP_USE_FMA): project / function / isSatisfied / jointValid through
+// it are bit-identical to the launched kernels (tests/test_gpu_resident.py).
+#include "ccmp_flat_newton.h"
+#include "ccmp_resident.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void sys_store(unsigned long long *p, unsigned long long v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long lane_word(unsigned long long v, int src_lane) // wave-uniform broadcast of one lane's word
+{
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), src_lane);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), src_lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool STOCK>
+__global__ __launch_bounds__(128, 1) void resident_service_kernel(unsigned long long *box, unsigned long long last_tag,
+                                                                 unsigned long long idle_ticks /* of the 100 MHz wall clock */)
+{
+  __shared__ __attribute__((aligned(16))) double lds[fRec];
+  __shared__ double ktab[kConstsDoubles + 1];
+  __shared__ __attribute__((aligned(16))) double steptab[kStepTab];
+  __shared__ unsigned long long s_tag;
+  __shared__ int s_cmd;
+  __shared__ unsigned int s_consts;
+  const int tid = threadIdx.x;
+  const unsigned long long *consts = box + kResConstsOff / 8;
+  const unsigned long long *req = box + kResReqOff / 8;
+  unsigned long long *resp = box + kResRespOff / 8;
+  unsigned long long *state = box + kResStateOff / 8;
+  const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
+  double *rec = lds;
+  unsigned int my_consts = ~0u; // nothing loaded yet: the first request brings its constants
+  if (tid == 0) sys_store(state, (unsigned long long)kResRunning);
+  unsigned long long idle_since = wall_clock64();
+
+  for (;;) {
+    // ---- wait for a request: the first 24 lanes read the three request lines, eight bytes each, over the link -------------------
+    bool fresh = false;
+    if (tid < 64) { // wave 0
+      unsigned long long w = 0;
+      if (tid < kResReqWords) w = sys_load(req + tid);
+      const unsigned long long ta = lane_word(w, 7), tb = lane_word(w, 15), te = lane_word(w, 23);
+      fresh = ta == tb && tb == te && te != last_tag;
+      if (fresh) {
+        // x sits in lanes 0..6 and 8..14 of this very read: straight into the Newton routine's record
+        if (tid < 7) rec[fX + tid] = __longlong_as_double((long long)w);
+        else if (tid >= 8 && tid < 15) rec[fX + tid - 1] = __longlong_as_double((long long)w);
+        if (tid == 0) {
+          const unsigned long long head = lane_word(w, 16);
+          s_cmd = (int)(head & 0xffffffffull);
+          s_consts = (unsigned int)(head >> 32);
+          s_tag = te;
+        }
+        last_tag = te;
+      } else if (tid == 0) {
+        s_cmd = (wall_clock64() - idle_since > idle_ticks) ? kResStop : kResNone; // nobody has asked for a while: leave by itself
+      }
+    }
+    __syncthreads();
+    const int cmd = s_cmd;
+    if (cmd == kResNone) {
+      __syncthreads(); // (s_cmd is rewritten at the top)
+      continue;
+    }
+    if (cmd == kResStop) break;
+    if (tid >= 64) last_tag = s_tag; // wave 1 follows (it never polls, but keeps the value coherent for clarity)
+    // ---- the problem in force: its constants are reloaded when the host says they changed ----------------------------------------
+    if (s_consts != my_consts) {
+      __syncthreads();
+      for (int k = tid; k < kConstsDoubles; k += 128) ktab[k] = __longlong_as_double((long long)sys_load(consts + k));
+      __syncthreads();
+      stage_step_table(KL, steptab, tid);
+      my_consts = s_consts;
+      __syncthreads();
+    }
+    // ---- the call ------------------------------------------------------------------------------------------------------------------
+    int iter = 0, updates = 0;
+    double norm1 = 0.0, norm2 = 0.0;
+    bool ok = false;
+    if (cmd == kResProject) {
+      // KinematicChainConstraint::project (ConstraintFunction.h:57-82): project_fd_flat_kernel's sequence
+      const bool conv = flat_newton<STOCK>(KL, KL, steptab, rec, tid, iter, updates, norm1, norm2, KL.max_iter);
+      const bool jv = flat_joint_valid(KL, rec, tid);
+      ok = jv && conv;
+      if (tid < 14) sys_store(resp + kResRespQ + tid, (unsigned long long)__double_as_longlong(rec[fX + tid]));
+    } else if (cmd == kResJointValid) {
+      ok = flat_joint_valid(KL, rec, tid); // ConstraintFunction.h:43-55
+    } else {
+      // function(x) through one evaluation pass of the Newton routine (iteration cap 0: no update), as checkMotion's isSatisfied(to)
+      // in geodesic_flat_kernel; KinematicChainConstraint::isSatisfied's test on it (ConstraintFunction.h:114-120)
+      (void)flat_newton<STOCK>(KL, KL, steptab, rec, tid, iter, updates, norm1, norm2, 0);
+      const double f0 = rec[fF], f1 = rec[fF + 1];
+      ok = (f0 - f0 == 0.0) && (f1 - f1 == 0.0) && f0 <= KL.tol_pos && f1 <= KL.tol_rot;
+      if (tid < 2) sys_store(resp + kResRespF + tid, (unsigned long long)__double_as_longlong(tid ? f1 : f0));
+      updates = 0;
+    }
+    if (tid == 0) sys_store(resp + kResRespFlags, (unsigned long long)(ok ? 1u : 0u) | ((unsigned long long)(unsigned int)updates << 32));
+    // every wavefront's result words are on their way before the tag is: system fence, block barrier, then the tag
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(resp + kResRespDone, s_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      idle_since = wall_clock64();
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __threadfence_system();
+    __hip_atomic_store(state, (unsigned long long)kResExited, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+} // namespace
+
+extern "C" hipError_t ccmp_launch_resident(int stock, void *box_dev, unsigned long long last_tag, unsigned long long idle_ticks, hipStream_t st)
+{
+  if (stock)
+    hipLaunchKernelGGL(resident_service_kernel<true>, dim3(1), dim3(128), 0, st, (unsigned long long *)box_dev, last_tag, idle_ticks);
+  else
+    hipLaunchKernelGGL(resident_service_kernel<false>, dim3(1), dim3(128), 0, st, (unsigned long long *)box_dev, last_tag, idle_ticks);
+  return hipGetLastError();
+}

@@ -1,0 +1,204 @@
+// ccmp_resident.cpp — host side of the opt-in resident service kernel (ccmp_resident.h: purpose, mailbox, and the five rules that
+// keep a never-ending kernel from hanging anything).
+#include "ccmp_resident.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <new>
+
+#include "ccmp_ctx.h"
+#include "ccmp_host.h"
+
+using ccmp_host::DeviceGuard;
+using ccmp_host::hip_fail;
+
+extern "C" hipError_t ccmp_launch_resident(int stock, void *box_dev, unsigned long long last_tag, unsigned long long idle_ticks, hipStream_t st);
+
+struct ccmp_resident {
+  char *box = nullptr;      // pinned, device-mapped, coherent
+  void *box_dev = nullptr;
+  hipStream_t stream = nullptr;
+  bool launched = false;    // a kernel was put on `stream` and has not been waited for
+  int stock = -1;           // which instantiation runs
+  unsigned long long tag = 0;
+  unsigned int consts_seq = 0;
+  bool have_problem = false;
+  ccmp_problem problem;     // the problem whose constants the mailbox holds
+  int stock_kernels = -1;   // ... under this setting of the option
+};
+
+namespace {
+
+inline volatile unsigned long long *word(ccmp_resident *r, size_t byte_off) { return reinterpret_cast<volatile unsigned long long *>(r->box + byte_off); }
+
+double now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// waits for the kernel on the service's stream to be gone (it has been told to stop, or stopped by itself)
+void drain(ccmp_resident *r)
+{
+  if (!r->launched) return;
+  (void)hipStreamSynchronize(r->stream);
+  r->launched = false;
+}
+
+void stop(ccmp_resident *r)
+{
+  if (!r || !r->launched) return;
+  if (__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) != (unsigned long long)kResExited) {
+    // a request whose command is "stop": payload first, the three tags last (ccmp_resident.h)
+    const unsigned long long tag = ++r->tag;
+    volatile unsigned long long *req = word(r, kResReqOff);
+    req[16] = (unsigned long long)kResStop;
+    __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
+    __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
+    __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
+  }
+  drain(r);
+}
+
+int start(ccmp_ctx *ctx, ccmp_resident *r, int stock)
+{
+  if (!r->box) {
+    HIP_TRY(hipHostMalloc((void **)&r->box, kResBoxBytes, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(r->box, 0, kResBoxBytes);
+    hipError_t e = hipHostGetDevicePointer(&r->box_dev, r->box, 0);
+    if (e != hipSuccess) { (void)hipHostFree(r->box); r->box = nullptr; return hip_fail(e, "hipHostGetDevicePointer(resident mailbox)"); }
+  }
+  if (!r->stream) {
+    // lowest priority: a stream of its own priority has a hardware queue of its own — nothing else is ever queued behind the kernel
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e == hipSuccess && least != greatest) e = hipStreamCreateWithPriority(&r->stream, hipStreamNonBlocking, least);
+    else e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate(resident)");
+  }
+  drain(r); // (a kernel that left by itself)
+  __atomic_store_n(word(r, kResStateOff), (unsigned long long)kResStarting, __ATOMIC_RELEASE);
+  const unsigned long long idle_ticks = (unsigned long long)ctx->resident_idle_ms * 100000ull; // wall_clock64: 100 MHz
+  HIP_TRY(ccmp_launch_resident(stock, r->box_dev, r->tag, idle_ticks, r->stream));
+  r->launched = true;
+  r->stock = stock;
+  return CCMP_OK;
+}
+
+}  // namespace
+
+namespace ccmp_host {
+
+void quiesce(ccmp_ctx *ctx)
+{
+  if (ctx && ctx->resident) stop(ctx->resident);
+}
+
+void resident_destroy(ccmp_ctx *ctx)
+{
+  ccmp_resident *r = ctx ? ctx->resident : nullptr;
+  if (!r) return;
+  stop(r);
+  if (r->stream) (void)hipStreamDestroy(r->stream);
+  if (r->box) (void)hipHostFree(r->box);
+  delete r;
+  ctx->resident = nullptr;
+}
+
+int resident_set(ccmp_ctx *ctx, long on)
+{
+  if (!ctx || (on != 0 && on != 1)) return CCMP_EINVAL;
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return CCMP_ENODEV;
+  if (!on) {
+    resident_destroy(ctx);
+    ctx->resident_on = 0;
+    return CCMP_OK;
+  }
+  if (!ctx->resident) {
+    ctx->resident = new (std::nothrow) ccmp_resident();
+    if (!ctx->resident) return CCMP_ENOMEM;
+  }
+  ctx->resident_on = 1; // started by the first single-state call: it brings the problem the kernel is instantiated for
+  return CCMP_OK;
+}
+
+int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call)
+{
+  ccmp_resident *r = ctx->resident;
+  if (!ctx->resident_on || !r || !p || p->jacobian_mode != CCMP_JAC_FD) return kResidentFallBack; // reference arithmetic only
+  // the problem in force: its kernel constants go into the mailbox when it changes (a planner sets its problem up once)
+  if (!r->have_problem || r->stock_kernels != ctx->stock_kernels || memcmp(&r->problem, p, sizeof *p) != 0) {
+    if (!(p->tol_pos > 0) || !(p->tol_rot > 0) || p->max_iter < 0 || p->max_iter > 65535) return CCMP_EINVAL;
+    ccmp_consts K;
+    make_consts(*p, K);
+    if (!ctx->stock_kernels) K.stock = K.twin_arms = 0;
+    if (r->launched && r->stock != (K.stock ? 1 : 0)) stop(r); // the other instantiation of the kernel
+    static_assert(sizeof(ccmp_consts) <= kResStateOff, "the constants fit in front of the state word");
+    if (!r->box) { // (first use: the mailbox comes with the first start)
+      int rc = start(ctx, r, K.stock ? 1 : 0);
+      if (rc != CCMP_OK) return rc;
+    }
+    memcpy(r->box + kResConstsOff, &K, sizeof K);
+    r->consts_seq++;
+    r->problem = *p;
+    r->have_problem = true;
+    r->stock_kernels = ctx->stock_kernels;
+    if (!r->launched) r->stock = K.stock ? 1 : 0;
+  }
+  // (re)start: never started, stopped by quiesce(), or left by itself after its idle time
+  if (!r->launched || __atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) == (unsigned long long)kResExited) {
+    int rc = start(ctx, r, r->stock);
+    if (rc != CCMP_OK) return rc;
+  }
+  // ---- the request: payloads, then the three tags -------------------------------------------------------------------------------
+  const unsigned long long tag = ++r->tag;
+  volatile unsigned long long *req = word(r, kResReqOff);
+  volatile unsigned long long *resp = word(r, kResRespOff);
+  for (int i = 0; i < 7; i++) {
+    unsigned long long a, b;
+    memcpy(&a, call.x + i, 8);
+    memcpy(&b, call.x + 7 + i, 8);
+    req[i] = a;
+    req[8 + i] = b;
+  }
+  req[16] = (unsigned long long)(unsigned int)call.cmd | ((unsigned long long)r->consts_seq << 32);
+  __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
+  __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
+  __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
+  // ---- the answer: bounded.  A kernel that left by itself between our look at its state and our request never answers: the state
+  // word says so, and this one call takes the launch path (the next one starts the service again).
+  bool done = false;
+  const double t0 = now_ms();
+  for (long spin = 0;; spin++) {
+    if (__atomic_load_n(&resp[kResRespDone], __ATOMIC_ACQUIRE) == tag) { done = true; break; }
+    if ((spin & 1023) == 1023) {
+      if (__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) == (unsigned long long)kResExited) {
+        // one more look: the answer may have been written just before the kernel left
+        if (__atomic_load_n(&resp[kResRespDone], __ATOMIC_ACQUIRE) == tag) { done = true; break; }
+        drain(r);
+        return kResidentFallBack;
+      }
+      if (now_ms() - t0 > 2000.0) break; // 250 Newton rounds are under a millisecond
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (!done) {
+    snprintf(g_hip_err, sizeof g_hip_err, "resident service kernel: no answer within 2 s (state %llu)",
+             (unsigned long long)__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE));
+    return CCMP_EHIP;
+  }
+  const unsigned long long flags = resp[kResRespFlags];
+  if (call.q_out)
+    for (int i = 0; i < 14; i++) { const unsigned long long v = resp[kResRespQ + i]; memcpy(call.q_out + i, &v, 8); }
+  if (call.f)
+    for (int i = 0; i < 2; i++) { const unsigned long long v = resp[kResRespF + i]; memcpy(call.f + i, &v, 8); }
+  if (call.ok) *call.ok = (uint8_t)(flags & 1ull);
+  if (call.iters) *call.iters = (uint16_t)(flags >> 32);
+  return CCMP_OK;
+}
+
+}  // namespace ccmp_host

@@ -1,0 +1,66 @@
+/* ccmp_resident.h — the opt-in resident service kernel of a context (option "resident"): layout of its mailbox, shared by the
+ * device side (ccmp_kernels_resident.hip) and the host side (ccmp_resident.cpp).  Not part of the public ABI.
+ *
+ * What it is for.  The unchanged planner calls the constraint one state at a time — project(State*), isSatisfied(State*)
+ * (src/base/jy_ProjectedStateSpace.cpp:13,20,27,65; src/planner/stefanBiPRM.cpp:397-398) — and a single-state call is a kernel
+ * launch plus a completion poll: ~17 us of fixed cost around 38-105 us of Newton rounds, 70 % of an isSatisfied.  With the option
+ * on, ONE persistent 128-thread block waits on a mailbox in pinned, device-mapped host memory: the host writes the state and a
+ * tag, the block — already running — finds it with its next read over the link, computes with the latency kernel's Newton
+ * routine (ccmp_flat_newton.h: the same bits), writes the result and the tag back.  No launch on the call path.
+ *
+ * What keeps it from hanging anything.  A kernel that never ends blocks whatever waits for the device — hipDeviceSynchronize
+ * (torch.cuda.synchronize), hipFree, anything queued behind it on its hardware queue.  So (1) it ends by itself after idle_ticks
+ * without a request (default 10 ms; the next single-state call starts it again: one launch), (2) the library stops it — mailbox
+ * command, then a stream wait — before every hipFree / hipMalloc / device-wide synchronise of its own (ccmp_host::quiesce) and in
+ * ccmp_ctx_destroy, (3) it is never started under stream capture (only the synchronous *_host entry points start it), (4) every
+ * wait on the host is bounded: no answer within the bound = CCMP_EHIP, and (5) while it is stopped the calls take the launch path.
+ * Its stream has the LOWEST priority: streams of one priority share a few hardware queues and a stream queued behind a resident
+ * kernel would wait for its idle exit; a priority of its own is a queue of its own (DESIGN_experiments.md §10.8). */
+#ifndef CCMP_RESIDENT_H
+#define CCMP_RESIDENT_H
+#include <stddef.h>
+#include <stdint.h>
+
+/* commands (low 32 bits of word 0 of request line E) */
+enum { kResNone = 0, kResProject = 1, kResFunction = 2, kResIsSatisfied = 3, kResJointValid = 4, kResStop = 5 };
+/* states (kResStateOff) */
+enum { kResStarting = 0, kResRunning = 1, kResExited = 2 };
+
+/* The mailbox: one pinned, device-mapped, coherent host allocation.
+ *   [0, 2304)            ccmp_consts of the problem in force (the host rewrites it when the problem changes and bumps consts_seq)
+ *   [2304, 2312)         state word, written by the device
+ *   [4096, 4096 + 192)   request, three 64-byte lines; a line = 7 payload words + its tag (the request's sequence number) LAST:
+ *                          line A: x[0..6] | tag      line B: x[7..13] | tag
+ *                          line E: (cmd | consts_seq << 32), 6 spare words | tag
+ *                        the host fills the payloads, then the three tags; a 64-byte line is read as one snapshot, x86 stores become
+ *                        visible in program order, so a line whose tag is new carries its new payload — the device acts when all
+ *                        three tags agree and differ from the last request it served
+ *   [4608, 4608 + 192)   response: q_out[14], f[2], (ok | iters << 32), 6 spare words, done tag LAST (behind a system fence) */
+constexpr size_t kResConstsOff = 0, kResStateOff = 2304, kResReqOff = 4096, kResRespOff = 4608, kResBoxBytes = 8192;
+constexpr int kResReqWords = 24;  /* words the polling lanes read */
+constexpr int kResRespQ = 0, kResRespF = 14, kResRespFlags = 16, kResRespDone = 23; /* word indices in the response */
+
+#include "../../include/ccmp.h"
+
+struct ccmp_ctx;
+namespace ccmp_host {
+struct ResidentCall {
+  int cmd;
+  const double *x;  /* 14 */
+  double *q_out;    /* 14, project */
+  double *f;        /* 2, function */
+  uint8_t *ok;      /* project / isSatisfied / jointValid */
+  uint16_t *iters;  /* project (nullable) */
+};
+constexpr int kResidentFallBack = 1; /* the service is off, stopped or cannot serve this problem right now: take the launch path */
+/* one single-state call through the service; CCMP_OK, kResidentFallBack, or an error */
+int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call);
+/* stops the service and waits for its stream (before hipFree / hipMalloc / device-wide synchronisation; idempotent, cheap when
+ * nothing runs); the next single-state call starts it again if the option is still on */
+void quiesce(ccmp_ctx *ctx);
+/* option "resident": 1 = on (started lazily by the first single-state *_host call), 0 = stop and release */
+int resident_set(ccmp_ctx *ctx, long on);
+/* ccmp_ctx_destroy */
+void resident_destroy(ccmp_ctx *ctx);
+}  // namespace ccmp_host
+#endif /* CCMP_RESIDENT_H */

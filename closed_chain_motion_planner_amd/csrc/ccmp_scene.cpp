@@ -6,6 +6,7 @@
 
 #include "ccmp_ctx.h"
 #include "ccmp_host.h"
+#include "ccmp_resident.h"
 #include "ccmp_scene.h"
 
 using namespace ccmp_host;
@@ -107,6 +108,7 @@ int ccmp_scene_create(ccmp_ctx *ctx, const ccmp_sphere *spheres, int n_spheres, 
   H.n_pairs = np;
   DeviceGuard guard(ctx->device);
   if (!guard.ok) { delete sc; return CCMP_ENODEV; }
+  ccmp_host::quiesce(ctx);
   hipError_t e = hipMalloc((void **)&sc->dev, sizeof(scene_dev));
   if (e == hipSuccess) e = hipMemcpy(sc->dev, &H, sizeof(scene_dev), hipMemcpyHostToDevice);
   if (e != hipSuccess) {

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CCMP_VERSION 400
+#define CCMP_VERSION 500
 
 enum {
   CCMP_OK = 0,
@@ -125,61 +125,126 @@ int ccmp_set_calibration(ccmp_problem *p, int arm_slot, const double dh_offsets[
 typedef struct ccmp_ctx ccmp_ctx;
 int ccmp_ctx_create(int device, ccmp_ctx **out);
 void ccmp_ctx_destroy(ccmp_ctx *ctx);
-/* persistent waves per CU for the projector kernels (0 = built-in default) */
+/* persistent waves per CU for the projector kernels (0 = built-in default); = option "waves_per_cu" */
 int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
-/* projector scheduling: hand_over 0 = throughput kernel (10 samples per wavefront) only, 1 = that kernel until the
- * sample queue drains, then the latency kernel on the samples still in flight (default), 2 = latency kernel only;
- * batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = built-in default, 14336), from
- * "latency_order_min" samples on (option, default 3072) in the FP32 scout's longest-predicted-first order.
- * Results are bit-identical under every setting. */
+/* projector scheduling (= options "hand_over", "small_batch"): hand_over 0 = throughput kernel (10 samples per wavefront) only,
+ * 1 = that kernel until the sample queue drains, then the latency kernel on the samples still in flight (default), 2 = latency
+ * kernel only; batches of at most small_batch samples always use the latency kernel (CCMP_DEFAULT = the built-in default of the
+ * table below).  Results are bit-identical under every setting. */
 #define CCMP_DEFAULT ((size_t)-1)
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
-/* tuning knobs (results never change): "handover_threshold" (-1 = automatic; 0..10: hand a wave's samples to the
- * latency kernel once the queue is dry and at most this many of its 10 groups are busy; 11..110: occupancy-driven —
- * all waves hand over together once the samples in flight fill less than (value - 10) per cent of the launch's group slots), "flat_kernel" (latency
- * work — small batches, single states, handed-over samples: 1 = one sample per 128-thread block with every
- * evaluation of an iteration in one round (default), 0 = one wavefront per sample), "stock_kernels" (1 = when both arms
- * carry the exact-zero structure of the uncalibrated Panda, run kernels that skip the products with those zeros —
- * same bits, fewer operations (default); 0 = always the general kernels); analytic mode: "analytic_small_batch" (at or below:
- * the six-lanes-per-sample kernel alone; default 16384), "analytic_cap" (samples past this many iterations are handed from
- * the one-lane kernel to it; default 96, 0 = never), "analytic_handover_max" (hand-over for batches up to this size;
- * default 131072), "analytic_split" (1 = batches of analytic_split_min..analytic_split_max samples, default 100000..300000,
- * are ordered longest-predicted-first by the FP32 scout and the samples predicted past "analytic_split_pred" iterations
- * (default 90) run on "analytic_split_front" wavefronts (default 128) of the six-lane kernel on a side stream BESIDE the
- * one-lane kernel, which hands over past "analytic_split_cap" iterations (default 160); 0 = off); proxy clearance: "clearance_per_state_max" (batches up to this many states run one block per state,
- * larger ones 64-state tiles; default 8192); latency work: "latency_blocks_per_cu" (persistent blocks of the latency kernel
- * per CU, default 8 = what is resident), "pool_long_remaining" (hand-over in two classes: samples the scout predicts to need
- * at least this many more iterations are taken first; default 24, 0 = one class); extend step: "geodesic_order" (0 = edges in
- * index order, 1 = far-apart edges first, 2 = FP32 scout order from "geodesic_scout_min" edges on, default), "geodesic_order_min"
- * (no ordering pass below this many edges; default 4096), "geodesic_long_steps" (order 1: edges longer than this many delta steps
- * count as long; default 12), "geodesic_scout_min" (default 6144), "geodesic_scout_rounds" (cap of the scout's traversal; default
- * 64), "geodesic_flavour" (the extend step is built twice from one source — same bits: 0 = throughput build for calls with a
- * round budget and more edges than the latency build has blocks, latency build otherwise (default); 1 / 2 = always the throughput
- * / latency build), "geodesic_blocks_per_cu" (persistent blocks of the latency build per CU; default 4); reference arithmetic, mid-size batches: "fd_split" (1 = split
- * launch, default: for batches above small_batch and up to "fd_split_max" samples, default 90112, the samples the FP32 scout predicts
- * to need at least "fd_split_pred" iterations — at most "fd_split_samples" — run on "fd_split_front" latency blocks on a side
- * stream beside the throughput kernel, which gives up "fd_split_group_cut" wavefronts per CU; the four follow the batch size
- * when left at -1, the default: up to 24576 samples two blocks per CU, predictions >= 40, four samples per CU, a cut of 3;
- * above one block per CU, >= 56, three to four samples per CU, a cut of 2; 0 = off);
- * bulk extend calls: "geodesic_group" (1 = calls with a round budget over "geodesic_group_min" edges or more, default 16384, run their
- * short edges — predicted fewer than "geodesic_group_pred" Newton rounds; -1, the default: 64, the scout's cap, where the edges beyond it
- * carry a tenth of the predicted work, else 40 (below 20480 edges) or 48 —
- * ten to a wavefront on the throughput layout and the others on "geodesic_group_front_per_cu" latency blocks per CU, default 8, beside
- * them; what is still in flight when the short edges fill less than "geodesic_group_handover_pct" % of their slots, default 50, goes to
- * latency blocks too; default 1; same results bit for bit);
- * the FP32 scouts: "scout_pairs" (1 = two lanes per sample / edge,
- * one arm each, where lanes are plentiful — projector batches of up to 128 x "scout_pair_blocks_per_cu" (default 1) x CUs samples,
- * extend-step batches of up to "scout_pair_max_edges" (default 131072) edges; stock twin arms only; default 1);
- * host entry points: "host_zero_copy"
- * (see ccmp_project_host).  None of these changes a
- * result bit.  CCMP_EINVAL for unknown names. */
-int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
-/* longest-predicted-first scheduling of large reference-arithmetic batches: mode 0 = process samples in index
- * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is
- * processed longest first, straggler hand-over kept up to 120000 samples and dropped above (default); 2 = the same
- * without hand-over at any size.  Used for batches of at least min_batch samples (CCMP_DEFAULT = built-in default, 26624).  Results are bit-identical under
- * every setting. */
+/* longest-predicted-first scheduling of large reference-arithmetic batches (= options "lpt", "lpt_min_batch"): mode 0 = index
+ * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is processed longest
+ * first, straggler hand-over kept up to 120000 samples and dropped above (default); 2 = the same without hand-over at any size.
+ * Used for batches of at least min_batch samples (CCMP_DEFAULT = the built-in default of the table below). */
 int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch);
+/* Tuning options, by name.  NONE of them changes a result bit: they choose which kernels a call runs on and where the regimes
+ * meet.  ccmp_ctx_set_option: CCMP_EINVAL for an unknown name or a value outside the range.  ccmp_ctx_get_option: the value in
+ * force; with ctx == NULL the built-in default (no device needed); besides the table it answers "num_cus", "resident" and
+ * "side_stream_busy" (1 while the context's side stream still holds unfinished work).  ccmp_ctx_option_info enumerates the table
+ * (index 0 .. until CCMP_EINVAL; any out-pointer may be NULL).  The table below is GENERATED from the library's
+ * (tools/gen_option_docs.py) and compared with it by the CPU test suite, so a default stated here is the default in the code.
+ * "resident" (0 / 1, default 0; not in the table: it starts and stops something) — see "resident service kernel" below. */
+int ccmp_ctx_set_option(ccmp_ctx *ctx, const char *name, long value);
+int ccmp_ctx_get_option(const ccmp_ctx *ctx, const char *name, long *value);
+int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, long *hi, const char **doc);
+/* BEGIN OPTION TABLE (generated from csrc/ccmp_policy.cpp: python tools/gen_option_docs.py --write)
+ *   name                            default   range         meaning
+ *   "hand_over"                     1         0..2          0 = throughput kernel (10 samples per wavefront) only, 1 = that kernel until its queue
+ *                                                           drains, then the latency kernel on what is in flight, 2 = latency kernel only (=
+ *                                                           ccmp_ctx_set_schedule)
+ *   "small_batch"                   10240     0..max        batches of at most this many samples run on the latency kernel alone (=
+ *                                                           ccmp_ctx_set_schedule)
+ *   "waves_per_cu"                  0         0..32         persistent wavefronts of the throughput kernels per CU, 0 = 12 (=
+ *                                                           ccmp_ctx_set_waves_per_cu)
+ *   "lpt"                           1         0..2          0 = index order, 1 = FP32 scout + longest-predicted-first, hand-over kept below 120000
+ *                                                           samples, 2 = the same without hand-over (= ccmp_ctx_set_lpt)
+ *   "lpt_min_batch"                 16384     0..max        the scout's order from this many samples on (= ccmp_ctx_set_lpt)
+ *   "latency_order_min"             3072      0..max        latency kernel alone: tickets through the scout's order from this many samples on
+ *   "flat_kernel"                   1         0..1          latency work: 1 = one sample per 128-thread block, an iteration's evaluations in one
+ *                                                           round, 0 = one wavefront per sample
+ *   "stock_kernels"                 1         0..1          1 = kernels that skip the exact zeros of the uncalibrated Panda when both arms carry them
+ *                                                           (same bits), 0 = always the general kernels
+ *   "handover_threshold"            -1        -1..110       -1 = automatic; 0..10: a wavefront hands over once the queue is dry and at most this many
+ *                                                           of its 10 groups are busy; 11..110: all hand over once the samples in flight fill less
+ *                                                           than (value - 10) % of the group slots
+ *   "pool_long_remaining"           24        0..1000       hand-over in two classes: samples predicted to need at least this many more iterations
+ *                                                           are taken first (0 = one class)
+ *   "latency_blocks_per_cu"         8         1..32         persistent blocks of the latency kernel per CU (8 are resident)
+ *   "fd_split"                      1         0..1          1 = split launch: above small_batch, the predicted-longest samples run on latency blocks
+ *                                                           on a side stream beside the throughput kernel
+ *   "fd_split_min"                  0         0..max        split launch from this many samples ...
+ *   "fd_split_max"                  90112     0..max        ... up to this many
+ *   "fd_split_pred"                 -1        -1..1023      predicted iterations from which a sample belongs to the front (-1: 40 up to 24576
+ *                                                           samples, 56 above)
+ *   "fd_split_front"                -1        -1..4096      latency blocks of the front (-1: two per CU up to 24576 samples, one above; 0 = no split)
+ *   "fd_split_samples"              -1        -1..2147483647 samples of the front at most (-1: four per CU up to 24576 samples, three to four above;
+ *                                                            0 = one per block)
+ *   "fd_split_group_cut"            -1        -1..8         throughput wavefronts per CU left out for the front's blocks (-1: 3 up to 24576 samples,
+ *                                                           2 above)
+ *   "analytic_small_batch"          16384     0..max        analytic mode: at or below, the six-lanes-per-sample kernel alone
+ *   "analytic_cap"                  96        0..65535      analytic mode: samples past this many iterations leave the one-lane kernel for the six-
+ *                                                           lane kernel (0 = never)
+ *   "analytic_handover_max"         131072    0..max        analytic mode: that hand-over for batches up to this size
+ *   "analytic_split"                1         0..1          analytic mode: 1 = scout order + six-lane kernel beside the one-lane kernel for large
+ *                                                           batches
+ *   "analytic_split_min"            100000    0..max        ... from this many samples
+ *   "analytic_split_max"            300000    0..max        ... up to this many
+ *   "analytic_split_pred"           90        1..1023       ... samples predicted past this many iterations go to the six-lane kernel
+ *   "analytic_split_front"          128       1..512        ... which gets this many wavefronts
+ *   "analytic_split_cap"            160       1..65535      ... and the one-lane kernel hands over past this many iterations
+ *   "scout_pairs"                   1         0..1          1 = two lanes per sample / edge, one arm each, where lanes are plentiful (stock twin
+ *                                                           arms)
+ *   "scout_pair_blocks_per_cu"      1         1..64         ... projector: up to 128 x this x CUs samples
+ *   "scout_pair_max_edges"          131072    0..max        ... extend step: up to this many edges
+ *   "geodesic_flavour"              0         0..2          two builds, same bits: 0 = throughput build for calls with a round budget beyond the
+ *                                                           latency build's blocks, latency build otherwise; 1 / 2 = always the throughput / latency
+ *                                                           build
+ *   "geodesic_blocks_per_cu"        4         1..32         persistent blocks of the latency build per CU (4 are resident)
+ *   "geodesic_order"                2         0..2          batches beyond the resident blocks: 0 = index order, 1 = far-apart edges first, 2 = FP32
+ *                                                           scout order from geodesic_scout_min edges on
+ *   "geodesic_order_min"            4096      0..max        no ordering pass below this many edges
+ *   "geodesic_long_steps"           12        0..max        order 1: edges further apart than this many delta count as long
+ *   "geodesic_scout_min"            6144      0..max        the scout from this many edges on
+ *   "geodesic_scout_rounds"         64        1..1023       the scout stops an edge after this many Newton rounds
+ *   "geodesic_group"                1         0..1          1 = bulk calls (round budget, scout order): short edges ten to a wavefront on the
+ *                                                           throughput layout, the front of the order on latency blocks beside them
+ *   "geodesic_group_min"            16384     0..max        ... from this many edges
+ *   "geodesic_group_pred"           -1        -1..1023      ... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it
+ *                                                           carry geodesic_group_heavy_permille of the work, else geodesic_group_low_cut)
+ *   "geodesic_group_low_cut"        -1        -1..64        ... (-1: 40 below 20480 edges, 48 from there on)
+ *   "geodesic_group_heavy_permille" 100       0..1001       ... see geodesic_group_pred
+ *   "geodesic_group_permille"       0         0..1000       ... > 0: instead, the largest cut whose front carries this share of the predicted work
+ *   "geodesic_group_front_per_cu"   8         -1..8         ... latency blocks per CU launched for the front (-1 = 8)
+ *   "geodesic_group_waves_per_cu"   8         1..10         ... wavefronts of the throughput layout per CU at most
+ *   "geodesic_group_handover_pct"   50        0..100        ... with the queue dry, every wavefront gives its edges to latency blocks once those in
+ *                                                           flight fill less than this share of the slots (0 = never)
+ *   "geodesic_group_live"           1         0..1          ... 1 = the front's blocks take given-up edges while the group kernel runs, 0 = only a
+ *                                                           launch behind it does
+ *   "geodesic_group_retire"         5         0..10         ... live: a wavefront gives up as soon as the queue is dry and this many of its ten
+ *                                                           groups or fewer are busy (0 = only by the occupancy rule)
+ *   "geodesic_group_pollers_per_cu" 2         0..4          ... live: latency blocks per CU that may wait for entries at one time
+ *   "geodesic_group_poll_limit"     65536     0..16777216   ... live: polls a waiting block spends before it leaves (a backstop)
+ *   "clearance_per_state_max"       8192      0..max        proxy clearance: one block per state up to this many states, 64-state tiles above
+ *   "host_zero_copy"                2         0..2          *_host calls on page-locked caller buffers: 0 = staged, 1 = q_out written in place, 2 =
+ *                                                           q_in read in place too
+ *   "resident_idle_ms"              10        1..10000      the resident service kernel (option "resident") leaves by itself after this many
+ *                                                           milliseconds without a request
+ *   "fail_after_fork"               0         0..2          debug: the split launches report a failure in front of (1) / behind (2) their side-stream
+ *                                                           part
+ * END OPTION TABLE */
+/* What the policy does with a call: writes ONE line into buf (NUL-terminated, truncated to cap) naming the kernels a call of
+ * kind call_kind over n samples / edges runs on under the context's present settings, and the thresholds that delimit that
+ * regime — computed by the same functions the launches use (csrc/ccmp_policy.cpp), so it cannot disagree with them.  ctx == NULL:
+ * the built-in policy on a 256-CU device.  Returns the length of the whole line (snprintf's convention) or CCMP_EINVAL. */
+enum {
+  CCMP_CALL_PROJECT = 0,          /* ccmp_project_batch, reference arithmetic          */
+  CCMP_CALL_SAMPLE_PROJECT = 1,   /* ccmp_sample_project_batch                         */
+  CCMP_CALL_PROJECT_ANALYTIC = 2, /* ccmp_project_batch with CCMP_JAC_ANALYTIC         */
+  CCMP_CALL_GEODESIC = 3,         /* ccmp_geodesic_batch / _ex without a round budget  */
+  CCMP_CALL_GEODESIC_BUDGET = 4   /* ccmp_geodesic_batch_ex with round_budget > 0      */
+};
+int ccmp_ctx_describe(const ccmp_ctx *ctx, int call_kind, size_t n, char *buf, size_t cap);
 int ccmp_ctx_device(const ccmp_ctx *ctx);
 int ccmp_ctx_num_cus(const ccmp_ctx *ctx);
 

@@ -143,7 +143,7 @@ def test_latency_kernels_agree_and_repeat(gpu_ctx, obj, seed):
                                    ("stefan", 30000), ("Wine_Bottle", 50000), ("stefan", 60000), ("Wine_Bottle", 95000)])
 def test_default_policy_at_mid_sizes_is_bitwise_the_oracle(gpu_ctx, oracle_det, obj, n):
     """the default scheduling policy where its regimes meet — the latency kernel alone in index order (< 3 072 samples) and in
-    the FP32 scout's longest-first order (up to 14 336); above that scout + throughput kernel with the predicted-longest
+    the FP32 scout's longest-first order (up to 10 240 = small_batch); above that scout + throughput kernel with the predicted-longest
     samples on latency blocks beside it (split launch, up to 90 112) and the occupancy-driven hand-over (all waves hand over
     together once the samples in flight fill < 70 % of the group slots, up to 53 248; at once above) — against the oracle,
     every sample, bit for bit"""

@@ -26,7 +26,7 @@ def test_exports_every_declared_symbol(L, ccmp_built):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ccmp_version() == 400
+    assert L.ccmp_version() == 500
 
 
 def test_library_does_not_link_rccl(ccmp_built):
@@ -220,3 +220,82 @@ def test_every_sampler_gets_its_own_seed(monkeypatch):
     monkeypatch.setattr(sp, "_seed_counter", __import__("itertools").count())
     assert sp.next_sampler_seed() == sp.splitmix64(0x5EED) and sp.next_sampler_seed() == sp.splitmix64(0x5EEE)
     assert sp.splitmix64(0) == 0xE220A8397B1DCDAF  # published first output of SplitMix64 seeded with 0
+
+
+# ---- the option table, its getter and the policy's own description (round 5: the header had drifted from the code) ----------------
+def test_header_option_table_is_the_librarys(L):
+    """the table of defaults and ranges in include/ccmp.h is generated from the library's own (csrc/ccmp_policy.cpp) — and is
+    re-generated here: a default stated in the header IS the default in the code"""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_option_docs
+
+    hdr = open(os.path.join(ROOT, "include", "ccmp.h")).read()
+    a, b = hdr.index(gen_option_docs.BEGIN), hdr.index(gen_option_docs.END) + len(gen_option_docs.END) + 1
+    assert hdr[a:b] == gen_option_docs.block(), "include/ccmp.h is stale: python tools/gen_option_docs.py --write"
+    # and nothing outside the table states a number for the two defaults that had drifted
+    rest = hdr[:a] + hdr[b:]
+    assert "14336" not in rest and "26624" not in rest
+
+
+def test_get_option_reports_the_defaults_without_a_device(L):
+    from closed_chain_motion_planner_amd import get_option, option_table
+
+    table = option_table()
+    names = [o["name"] for o in table]
+    assert len(names) == len(set(names)) and len(names) >= 50
+    for o in table:
+        assert o["lo"] <= o["default"] <= o["hi"], o
+        assert get_option(None, o["name"]) == o["default"]
+        assert o["doc"]
+    # the defaults the previous header stated wrongly, as the code has them
+    assert get_option(None, "small_batch") == 10240 and get_option(None, "lpt_min_batch") == 16384
+    assert get_option(None, "num_cus") == 256 and get_option(None, "resident") == 0
+    v = C.c_long()
+    assert L.ccmp_ctx_get_option(None, b"no_such_option", C.byref(v)) == -1
+    assert L.ccmp_ctx_get_option(None, b"small_batch", None) == -1
+    assert L.ccmp_ctx_get_option(None, b"side_stream_busy", C.byref(v)) == -1  # a fact of a live context only
+    assert L.ccmp_ctx_set_option(None, b"small_batch", 1) == -1
+    assert L.ccmp_ctx_option_info(len(table), None, None, None, None, None) == -1 and L.ccmp_ctx_option_info(-1, None, None, None, None, None) == -1
+    assert L.ccmp_ctx_option_info(0, None, None, None, None, None) == 0
+
+
+def test_describe_names_the_regime_on_both_sides_of_every_boundary(L):
+    """ccmp_ctx_describe (the built-in policy on a 256-CU device: no context needed) at every size boundary of the policy; the
+    line comes from the functions the launches use (csrc/ccmp_policy.cpp)"""
+    from closed_chain_motion_planner_amd import describe
+    from closed_chain_motion_planner_amd._lib import CALL_GEODESIC, CALL_GEODESIC_BUDGET, CALL_PROJECT, CALL_PROJECT_ANALYTIC, CALL_SAMPLE_PROJECT
+
+    d = lambda n, kind=CALL_PROJECT: describe(None, kind, n)
+    # projector, reference arithmetic
+    assert "latency kernel alone" in d(1) and "one per sample" in d(2048) and "ticket queue" in d(2049)
+    assert "scout" not in d(3071) and "longest-predicted-first" in d(3072)                       # latency_order_min
+    assert "latency kernel alone" in d(10240) and "split launch" in d(10241)                     # small_batch
+    assert "predicted >= 40" in d(24576) and "512 project_fd_flat_kernel" in d(24576)            # wide split up to kSplitWideMax
+    assert "predicted >= 56" in d(24577) and "256 project_fd_flat_kernel" in d(24577)
+    assert "(<= 768)" in d(40959) and "(<= 1024)" in d(40960)                                    # samples of the front per CU: 3 -> 4
+    assert "below 70 % occupancy" in d(53247) and "per wavefront at <= 10 busy groups" in d(53248)
+    assert "split launch" in d(90112) and "split launch" not in d(90113)                         # fd_split_max
+    assert "hand-over" in d(119999) and "no hand-over" in d(120000)
+    assert d(4096, CALL_SAMPLE_PROJECT).startswith("sample_project B=4096")
+    # analytic mode
+    a = lambda n: d(n, CALL_PROJECT_ANALYTIC)
+    assert "six-lanes-per-sample kernel alone" in a(16384) and "samples past 96" in a(16385)
+    assert "FP32 scout order" in a(100000) and "FP32 scout order" in a(300000) and "one sample per lane" in a(300001)
+    # extend step
+    g, gb = (lambda n: d(n, CALL_GEODESIC)), (lambda n: d(n, CALL_GEODESIC_BUDGET))
+    assert "geodesic_flat_kernel_lat x 1024 blocks, one per edge" in g(1024) and "ticket queue" in g(1025)
+    assert "geodesic_flat_kernel_lat" in gb(1024) and "geodesic_flat_kernel x 1025 blocks, one per edge" in gb(1025)
+    assert "one per edge" in gb(2048) and "ticket queue" in gb(2049)
+    assert "first" not in gb(4095) and "far-apart edges first" in gb(4096)                       # geodesic_order_min
+    assert "far-apart" in gb(6143) and "FP32 scout on lane pairs" in gb(6144)                    # geodesic_scout_min
+    assert "bulk form" not in gb(16383) and "bulk form" in gb(16384) and "bulk form" not in g(16384)
+    assert "else >= 40" in gb(20479) and "else >= 48" in gb(20480)                               # kGeoGroupHighCut
+    assert "x 1639 wavefronts" in gb(16384) and "x 2048 wavefronts" in gb(65536)
+    assert "lane pairs" in gb(131072) and "lane pairs" not in gb(131073)
+    # truncation follows snprintf: the return value is the whole length, the buffer holds what fits
+    buf = C.create_string_buffer(16)
+    n = L.ccmp_ctx_describe(None, CALL_PROJECT, 4096, buf, 16)
+    assert n > 16 and len(buf.value) == 15 and d(4096).startswith(buf.value.decode())
+    assert L.ccmp_ctx_describe(None, 99, 4096, buf, 16) == -1

@@ -363,7 +363,7 @@ def clearance(argv):
 def run(argv):
     """fixed workloads for the profiler: one kernel family each, `reps` launches"""
     what = argv[0]
-    reps = int(argv[1]) if len(argv) > 1 else 3
+    reps = int(argv[1]) if len(argv) > 1 else 12
     ctx = Context(0)
     c = KinematicChainConstraint.from_yaml(CFG % ("stefan" if what == "stefan" else "Wine_Bottle"), ctx=ctx)
     if what in ("c3", "stefan"):
@@ -393,13 +393,26 @@ def run(argv):
         fn = lambda: sc.clearance_batch(q, 0.0)
     else:
         raise SystemExit(__doc__)
-    fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    # >= 3 warm-up calls (the profile's summary drops their dispatches), then `reps` calls, each bracketed by HIP events on the
+    # launch stream (a call that forks to the context's side stream joins it back before it returns, so the second event is behind
+    # everything) and followed by a synchronise — the idle gap that tells two calls apart in the kernel trace.  The per-call times
+    # are printed as JSON: under `--kernel-trace` alone they are the call's wall time with its kernels overlapping as they do in
+    # production; under `--pmc` they show what counter collection does to that overlap.
+    import json
+
+    warm = int(argv[2]) if len(argv) > 2 else 3
+    for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    print("%s: %.3f ms per repetition" % (what, (time.perf_counter() - t0) / reps * 1e3))
+        torch.cuda.synchronize()
+    calls = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        calls.append(e0.elapsed_time(e1))
+    print("CALL_MS " + json.dumps({"workload": what, "warmup_calls": warm, "call_ms": calls}))
 
 
 if __name__ == "__main__":

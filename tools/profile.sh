@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over one workload; run on the GPU box from the repo root:
 #   bash tools/profile.sh <tag>                      bench.py at its default configuration (C3)
-#   bash tools/profile.sh <tag> <workload> [reps]    tools/measure.py run <workload>: flat4096 | flat1 | geodesic | analytic | stefan | clearance
+#   bash tools/profile.sh <tag> <workload> [reps]    tools/measure.py run <workload>: flat4096 | flat1 | geodesic | geodesic65536 | analytic | stefan | clearance (reps: profiled calls, default 12, behind 3 warm-ups)
 # -> gpurun_out/prof_<tag>/{trace,pmc_*}/...; condense with: python tools/summarize_profile.py <tag> <kernel,...> <units per launch>
 # The program after `--` is python3 itself (no env / bash -c / launcher hop: the profiler's library initialises the GPU
 # before the program starts).  Counters are collected in their own passes, never together with a trace domain other
@@ -11,7 +11,10 @@ TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-if [ -n "$2" ]; then ARGS="$ROOT/tools/measure.py run $2 ${3:-3}"; else ARGS="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary ${BENCH_ARGS}"; fi
+# >= 10 profiled calls behind >= 3 warm-up calls (a 4-call mean with a cold outlier was thin evidence); the summary
+# reports median and quartiles over the profiled calls only
+REPS=${3:-12}
+if [ -n "$2" ]; then ARGS="$ROOT/tools/measure.py run $2 $REPS 3"; else ARGS="$ROOT/bench.py --steps $REPS --warmup 3 --no-cpu-baseline --no-secondary ${BENCH_ARGS}"; fi
 cd $ROOT && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
