@@ -648,6 +648,13 @@ def flatten_for_the_driver(line, B):
             "single_project_near_manifold_us": get(sec, "single_project_c_abi", "near_manifold_median_us"),
             "single_project_cpu_us": get(sec, "single_project_c_abi", "uniform_sample_cpu_median_us"),
             "single_project_near_manifold_cpu_us": get(sec, "single_project_c_abi", "near_manifold_cpu_median_us"),
+            "single_project_resident_us": get(sec, "single_project_c_abi", "uniform_sample_resident_median_us"),
+            "single_project_near_manifold_resident_us": get(sec, "single_project_c_abi", "near_manifold_resident_median_us"),
+            "single_is_satisfied_us": get(sec, "single_project_c_abi", "is_satisfied_median_us"),
+            "single_is_satisfied_resident_us": get(sec, "single_project_c_abi", "is_satisfied_resident_median_us"),
+            "single_function_us": get(sec, "single_project_c_abi", "function_median_us"),
+            "single_function_resident_us": get(sec, "single_project_c_abi", "function_resident_median_us"),
+            "single_resident_bitwise": get(sec, "single_project_c_abi", "resident_bit_identical_to_launched"),
             "host_buffer_pageable_per_s": get(sec, "host_buffer", "pageable", "projections_per_s"),
             "host_buffer_pinned_per_s": get(sec, "host_buffer", "pinned", "projections_per_s"),
             "analytic_mode_per_s": sec.get("analytic_mode_projections_per_s"),
@@ -740,18 +747,43 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         rng = np.random.default_rng(0xC7)
         near = valid + rng.uniform(-0.05, 0.05, valid.shape)
         out = {}
-        for name, xs in (("uniform_sample", far), ("near_manifold", near)):
-            ts, its = [], []
+
+        def time_calls(xs, resident):
+            """median us of ccmp_project_host / ccmp_is_satisfied_host / ccmp_function_host over the states, results kept for the
+            bitwise comparison of the two paths"""
+            c.ctx.set_option("resident", 1 if resident else 0)
+            tp, ts_, tf, its, res = [], [], [], [], []
+            fb = (C.c_double * 2)()
             for i in range(xs.shape[0]):
                 xi, xo = np.ascontiguousarray(xs[i]), np.zeros(14)
                 it = (C.c_uint16 * 1)()
                 a, b = xi.ctypes.data_as(dp), xo.ctypes.data_as(dp)
                 t0 = time.perf_counter()
                 L.ccmp_project_host(c.ctx.handle, C.byref(c.problem), a, b, okb, it, 1)
-                ts.append(time.perf_counter() - t0)
+                t1 = time.perf_counter()
+                L.ccmp_is_satisfied_host(c.ctx.handle, C.byref(c.problem), b, okb, 1)
+                t2 = time.perf_counter()
+                L.ccmp_function_host(c.ctx.handle, C.byref(c.problem), a, fb, 1)
+                t3 = time.perf_counter()
+                tp.append(t1 - t0), ts_.append(t2 - t1), tf.append(t3 - t2)
                 its.append(int(it[0]))
-            out[name + "_median_us"] = float(np.median(ts[8:]) * 1e6)
-            out[name + "_median_newton_iters"] = float(np.median(its[8:]))
+                res.append((xo.tobytes(), int(it[0]), int(okb[0]), bytes(fb)))
+            c.ctx.set_option("resident", 0)
+            med = lambda v: float(np.median(v[8:]) * 1e6)
+            return med(tp), med(ts_), med(tf), float(np.median(its[8:])), res
+
+        same = True
+        for name, xs in (("uniform_sample", far), ("near_manifold", near)):
+            p0, s0, f0, its, r0 = time_calls(xs, False)
+            out[name + "_median_us"] = p0
+            out[name + "_median_newton_iters"] = its
+            # the opt-in resident service kernel (ccmp_ctx_set_option "resident"): the same calls with no launch on the call path
+            p1, s1, f1, _, r1 = time_calls(xs, True)
+            out[name + "_resident_median_us"] = p1
+            same = same and r0 == r1
+            if name == "near_manifold":
+                out.update(is_satisfied_median_us=s0, function_median_us=f0, is_satisfied_resident_median_us=s1, function_resident_median_us=f1)
+        out["resident_bit_identical_to_launched"] = bool(same)
         try:
             # the CPU path beside it: the same states through the glibc build of the oracle, one call at a time on one thread
             sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -62,7 +62,7 @@ _UNITS = [
     ("ccmp_kernels_scene.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT"]),
     ("ccmp_scene.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]
-_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_flat_newton.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_policy.h", "ccmp_resident.h", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_flat_newton.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_policy.h", "ccmp_resident.h", "ccmp_fd_newton_phase1.inc", "ccmp_fd_newton_phase2.inc", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
 
 
 def hipcc_path():
@@ -84,21 +84,20 @@ def _stale(target, sources):
 # (build/<unit>.resources.json) and checked against the bounds below — a build whose hot kernels have started to spill FAILS
 # instead of shipping a silently slower library.  Scratch is in bytes per lane.
 #   * the STOCK instantiations (template argument `true`: both arms carry the uncalibrated Panda's exact zeros — what the
-#     reference ships, ConstrainedPlanningCommon.cpp:97 has the calibration commented out) of the projector kernels and of the
-#     extend step's latency kernel: NO scratch;
-#   * geodesic_group_kernel<true>: at most 96 B — with the occupancy bound of three wavefronts per SIMD (168 registers) the
-#     allocator parks ten loop-invariant values in scratch: 13 stores in the prologue, 12 reloads in a 7 000-instruction loop body
-#     (one Newton round = ~12 500 issued instructions).  Without the bound: 181 registers, no scratch, and 5 % SLOWER at
-#     16 384 - 32 768 edges (interleaved A/B, profiles/r05_bulk_live_ab.log: the front's latency blocks lose the register space);
+#     reference ships, ConstrainedPlanningCommon.cpp:97 has the calibration commented out) of the projector kernels, of the extend
+#     step's kernels (geodesic_flat_kernel both builds, geodesic_group_kernel) and of the resident service kernel: NO scratch.
+#     (geodesic_group_kernel<true> had 64-76 B until round 5: ten loop-invariant per-lane values the allocator parked in scratch
+#     under the bound of three wavefronts per SIMD; they are now recomputed where they are used or kept in LDS.  Without the bound
+#     the kernel takes 181 registers, no scratch, and is 5 % SLOWER at 16 384 - 32 768 edges — profiles/r05_bulk_live_ab.log, B/r4
+#     of version 1: the front's latency blocks lose the register space.)
 #   * the general instantiations (calibrated arms, tilted bases): at most 200 B, except the fused-sampler throughput kernel
 #     project_fd_kernel<1,false>, which spills 2.3 KB (its sampler prologue and the general chain's pose arrays overlap; the
 #     path is the fused sampler x a calibrated model, which nothing in the reference's configuration reaches);
 #   * everything else (scouts, small per-lane kernels, analytic mode, scene): at most 64 B unless listed.
 _SCRATCH_RULES = [  # (regex on the demangled name, bound); first match wins
     (r"project_fd_kernel<1, false>", 2400),
-    (r"geodesic_group_kernel<true>", 96),
-    (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?)<(\d+, )?true>", 0),
-    (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel)<(\d+, )?false>", 200),
+    (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel|resident_service_kernel)<(\d+, )?true>", 0),
+    (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel|resident_service_kernel)<(\d+, )?false>", 200),
     (r"scout_|project_fast|project_rows|clearance", 400),
     (r".", 64),
 ]

@@ -15,7 +15,6 @@
 #include "ccmp_host.h"
 #include "ccmp_policy.h"
 #include "ccmp_resident.h"
-#include "ccmp_fd_common.h"
 #include "ccmp_kin.h"
 
 using ccmp_host::AnalyticPlan;
@@ -77,17 +76,16 @@ hipError_t ccmp_launch_geodesic(const ccmp_consts *K, double delta, double lambd
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
                                 const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr,
-                                const double *pool, const unsigned long long *pool_count, const ccmp_geo_live *live, hipStream_t st);
+                                const double *pool, const unsigned long long *pool_count, hipStream_t st);
 hipError_t ccmp_launch_geodesic_lat(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to,
                                     size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                     int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
                                     const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr,
-                                    const double *pool, const unsigned long long *pool_count, const ccmp_geo_live *live, hipStream_t st);
+                                    const double *pool, const unsigned long long *pool_count, hipStream_t st);
 hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
                                       int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
                                       unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
-                                      double *pool, unsigned long long *pool_count, int handover_pct, const uint8_t *target_ok,
-                                      unsigned int *pool_flags, int retire_active, hipStream_t st);
+                                      double *pool, unsigned long long *pool_count, int handover_pct, const uint8_t *target_ok, hipStream_t st);
 hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size_t E, double long_dist, unsigned int *counters,
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
@@ -213,7 +211,7 @@ int ccmp_ctx_create(int device, ccmp_ctx **out)
   ctx->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate"); }
-  e = hipMalloc((void **)&ctx->queue, (kGeoGroupWords + 16) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64 + 3: analytic kernels; 1: split count
+  e = hipMalloc((void **)&ctx->queue, (kGeoGroupWords + 8) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64 + 3: analytic kernels; 1: split count
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return hip_fail(e, "hipMalloc(queue)"); }
   // side stream of the analytic mode's split launches (latency kernel beside the throughput kernel) and the two events
   // that order it against the caller's stream
@@ -558,11 +556,8 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     if (ctx->geo_pool) (void)hipFree(ctx->geo_pool);
     ctx->geo_pool = nullptr;
     ctx->geo_pool_cap = 0;
-    // entries, then one flag word per entry (live hand-over: set behind an entry, cleared by whoever takes it — all zero between calls)
-    const size_t entries = pl.group_waves * 10 * kGeoPoolDoubles * sizeof(double);
-    HIP_TRY(hipMalloc((void **)&ctx->geo_pool, entries + pl.group_waves * 10 * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc((void **)&ctx->geo_pool, pl.group_waves * 10 * kGeoPoolDoubles * sizeof(double)));
     ctx->geo_pool_cap = pl.group_waves * 10;
-    HIP_TRY(hipMemsetAsync((char *)ctx->geo_pool + entries, 0, pl.group_waves * 10 * sizeof(unsigned int), st));
   }
   if (pl.queued) {
     queue = ctx->queue + 3; // word 3: ticket; word 4: the two counters of the ordering pass
@@ -584,11 +579,10 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   // wavefront, geodesic_group_kernel, less than half the instructions per Newton round — and the front of the order on this
   // kernel's blocks on the side stream, both from the start.
   if (pl.bulk) {
-    unsigned long long *gq = ctx->queue + kGeoGroupWords; // the sixteen words of the bulk form (ccmp_fd_common.h: ccmp_geo_live)
+    unsigned long long *gq = ctx->queue + kGeoGroupWords; // [0] group kernel's ticket (starts behind the front), [3] finished edges, [4] front length, [5] front's ticket, [6] pool count, [7] pool ticket
     const ScoutBuffers sb(ctx);
-    unsigned int *flags = ctx->geo_pool ? (unsigned int *)((char *)ctx->geo_pool + ctx->geo_pool_cap * kGeoPoolDoubles * sizeof(double)) : nullptr;
     const int pct = pl.handover_pct;
-    HIP_TRY(ccmp_launch_clear_words(gq, 32, st));
+    HIP_TRY(ccmp_launch_clear_words(gq, 16, st));
     // checkMotion: isSatisfied(to) of every edge up front (one lane per edge) for the group kernel; the front's blocks test their own
     uint8_t *target_ok = nullptr;
     if (check_target) {
@@ -607,28 +601,22 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     // caller's stream first (an early return left the side stream's kernels writing the caller's buffers unordered against
     // `st`), then the first error is reported.
     ForkJoin fj(ctx, st);
-    // live hand-over (round 5): the front's launch stays — as at most max_pollers waiting blocks — until the group kernel's last
-    // wavefront has left, and takes what that kernel gives up as it is given up; the launch behind the group kernel drains the rest
-    const ccmp_geo_live front_live = {gq, flags, (int)pl.group_waves, ctx->num_cus * ctx->geodesic_group_pollers_per_cu, ctx->geodesic_group_poll_limit};
-    const ccmp_geo_live drain_live = {gq, flags, 0, 0, 0};
     fj.fork();
     if (ctx->fail_after_fork == 1) fj.fail(hipErrorLaunchFailure, "fail_after_fork (debug option)");
     FJ_STEP(fj, ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target,
-                                     pl.front_blocks, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, pl.live ? ctx->geo_pool : nullptr, nullptr,
-                                     pl.live ? &front_live : nullptr, ctx->side));
+                                     pl.front_blocks, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, nullptr, nullptr, ctx->side));
     fj.side_done();
     if (ctx->fail_after_fork == 2) fj.fail(hipErrorLaunchFailure, "fail_after_fork (debug option)");
     FJ_STEP(fj, ccmp_launch_geodesic_group(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, (int)pl.group_waves, gq,
-                                           order, carry_out, round_budget, pct > 0 ? ctx->geo_pool : nullptr, gq + 6, pct, target_ok,
-                                           pl.live ? flags : nullptr, pl.retire, st));
+                                           order, carry_out, round_budget, pct > 0 ? ctx->geo_pool : nullptr, gq + 6, pct, target_ok, st));
     if (pct > 0) // the handed-over edges: latency blocks behind the group kernel; the pool's fill count is read on the device
       FJ_STEP(fj, ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, 0, pl.drain_blocks, gq + 7,
-                                       nullptr, nullptr, carry_out, round_budget, nullptr, ctx->geo_pool, gq + 6, pl.live ? &drain_live : nullptr, st));
+                                       nullptr, nullptr, carry_out, round_budget, nullptr, ctx->geo_pool, gq + 6, st));
     return fj.join();
   }
   HIP_TRY((pl.latency_flavour ? ccmp_launch_geodesic_lat : ccmp_launch_geodesic)(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok,
                                                                                 newton_iters, check_target, (int)pl.blocks, queue, order, carry_in,
-                                                                                carry_out, round_budget, nullptr, nullptr, nullptr, nullptr, st));
+                                                                                carry_out, round_budget, nullptr, nullptr, nullptr, st));
   return CCMP_OK;
 }
 

@@ -50,11 +50,11 @@ constexpr size_t kSplitWideMax = 24576;            // split launch: up to here t
 constexpr size_t kGeoGroupHighCut = 20480;         // bulk extend calls: the low cut of the order is 40 rounds below this many edges, 48 from here on
 constexpr int kGeoPoolDoubles = 40;                // = kGeoPoolEntry (ccmp_fd_common.h): one handed-over edge of the extend step's bulk form
 constexpr int kGeoGroupWords = 8 + 64 + 4;         // ctx->queue: first of the 8 words of the extend step's bulk form (behind the analytic kernels')
-constexpr size_t kDefaultLatencyOrderMin = 3072;   // latency kernel alone: FP32 scout order from this many samples on
+constexpr size_t kDefaultLatencyOrderMin = 2049;   // latency kernel alone: FP32 scout order as soon as the blocks take tickets (more samples than blocks)
 constexpr size_t kDefaultLptMinBatch = 16384;      // throughput kernel: the scout's order pays from here on
 constexpr size_t kOccupancyHandoverBelow = 53248;  // below: the throughput kernel hands over by occupancy, from here on at once
 constexpr int kOccupancyHandoverValue = 10 + 70;   // "handover_threshold" encoding of that rule: 10 + per cent of the group slots (70 %)
-constexpr size_t kNoHandoverFrom = 120000;         // ordered batches of this size or more end on their shortest samples: no hand-over
+constexpr size_t kNoHandoverFrom = 131072;         // ordered batches of this size or more end on their shortest samples: no hand-over
 
 // One execution context (include/ccmp.h).  The tuning members are reached by name through the option table of ccmp_policy.cpp
 // (ccmp_ctx_set_option / ccmp_ctx_get_option / ccmp_ctx_option_info), which also holds their ranges and one-line meanings; their
@@ -70,7 +70,7 @@ struct ccmp_ctx {
   size_t pool_cap = 0;                 // in records
   void *lpt_buf = nullptr;             // pred (u16 x B) | hist (u32 x 1024) | order (u32 x B) | flags (u8 x B, bulk checkMotion)
   size_t lpt_cap = 0;                  // in samples
-  double *geo_pool = nullptr;          // bulk extend hand-over: kGeoPoolDoubles per edge, then one flag word per edge
+  double *geo_pool = nullptr;          // bulk extend hand-over: kGeoPoolDoubles per edge
   size_t geo_pool_cap = 0;
   unsigned int *scan = nullptr;        // compaction block counts
   size_t scan_cap = 0;
@@ -114,14 +114,13 @@ struct ccmp_ctx {
   int scout_pairs = 1, scout_pair_blocks_per_cu = 1;
   size_t scout_pair_max_edges = 131072;
   int geodesic_blocks_per_cu = 4, geodesic_flavour = 0, geodesic_order = 2;
-  size_t geodesic_order_min = 4096, geodesic_scout_min = 6144;
+  size_t geodesic_order_min = 4096, geodesic_scout_min = 4096;
   int geodesic_scout_rounds = 64;
   double geodesic_long_steps = 12.0;
   int geodesic_group = 1;
-  size_t geodesic_group_min = 16384;
+  size_t geodesic_group_min = 13312;  // (16384 until round 5: tools/policy_check.py found the bulk form 10-12 % ahead at 15872 edges; crossover at 13312, profiles/r05_bulk_crossover.log)
   int geodesic_group_pred = -1, geodesic_group_low_cut = -1, geodesic_group_heavy_permille = 100, geodesic_group_permille = 0;
   int geodesic_group_front_per_cu = 8, geodesic_group_waves_per_cu = 8, geodesic_group_handover_pct = 50;
-  int geodesic_group_live = 1, geodesic_group_retire = 5, geodesic_group_pollers_per_cu = 2, geodesic_group_poll_limit = 1 << 16;
   size_t clearance_per_state_max = 8192;
   int host_zero_copy = 2;
   int resident_idle_ms = 10;           // the resident service kernel leaves by itself after this long without a request

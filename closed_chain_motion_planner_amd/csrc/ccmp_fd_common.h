@@ -9,24 +9,6 @@
 #include "ccmp_kin.h"
 #include "ccmp_solve.h"
 
-/* Bulk extend calls with the LIVE hand-over (round 5; ccmp_api.cpp: geodesic_common): geodesic_group_kernel's wavefronts publish the
- * edges they give up WHILE the kernel runs, and the front's geodesic_flat_kernel blocks — once the front of the order is taken —
- * pick them up from the pool instead of leaving.  words = the 64-bit words of the bulk form (sixteen are reserved):
- *   [0] group kernel's ticket   [1] group wavefronts that have left   [2] blocks waiting for entries   [3] edges finished or given up
- *   [4] front length            [5] front's ticket                    [6] pool entries reserved        [7] pool entries claimed
- *   [8] entries published and not yet taken (a counting semaphore)
- * A producer reserves its entries ([6] += n), writes them, fences, flags them and then adds n to [8]; a taker subtracts one from [8]
- * (and puts it back if there was none), takes the next ticket of [7] — which is then below [6] — waits for THAT entry's flag (its
- * producer is a running wavefront between its reservation and its flag: a few hundred cycles) and clears it again — every call
- * leaves the flags as it found them, all zero, which is what makes a captured call replayable. */
-struct ccmp_geo_live {
-  unsigned long long *words; /* NULL: not a live call */
-  unsigned int *flags;       /* one per pool entry */
-  int group_waves;           /* producers: the grid of geodesic_group_kernel; 0 = none are running (the launch behind it): drain and leave */
-  int max_pollers;           /* blocks that may wait for entries at one time (the others leave: the launch behind the group kernel drains what is left) */
-  int poll_limit;            /* polls a block spends waiting once the group kernel is seen running (a backstop, not a schedule) */
-};
-
 namespace ccmp {
 
 constexpr int kGeoPoolEntry = 40; // (= kGeoPoolDoubles, ccmp_ctx.h) extend step, hand-over of an edge in the middle of a projection: x[14], previous[14], dist, total, maxd,

@@ -475,47 +475,8 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
       break;
     }
 
-    // ---- phase 1: function(x) — sines/cosines, both chains, residual ---------------------------
-    for (int e = r; e < 14; e += kGroup) {
-      double s, c;
-      ccmp_sincos(rec[kX + e], &s, &c);
-      if (live) { rec[kSC + 2 * e] = s; rec[kSC + 2 * e + 1] = c; }
-    }
-    __syncthreads();
-    bool cont = false;
-    double f0, f1;
-    {
-      double T0[12], T1[12], f[2];
-      if constexpr (STOCK && CCMP_FD_ROWS) {
-        // both chains and both tool poses, one matrix row per lane; arm 0's prefix frames stay in LDS for its columns
-        chain_rows<true>(K, rec, arm_l, row_l, live, 0, d_lane, bp_lane);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 12; k++) { T0[k] = rec[kEE + k]; T1[k] = rec[kEE + 12 + k]; }
-      } else {
-        chain_at_x<1, false, STOCK>(K, rec, writer, T1);
-        if (writer) {
-#pragma unroll
-          for (int k = 0; k < 12; k++) rec[kEE + 12 + k] = T1[k];
-        }
-        chain_at_x<0, true, STOCK>(K, rec, writer, T0); // arm 0's prefix frames stay in LDS for its columns
-        if (writer) {
-#pragma unroll
-          for (int k = 0; k < 12; k++) rec[kEE + k] = T0[k];
-        }
-      }
-      chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
-      f0 = f[0]; f1 = f[1];
-      // ---- loop condition of ConstraintFunction.h:68, quirks included -------------------------
-      // while (((norm1 = f[0] > tol1) || (norm2 = f[1]) > tol2) && iter++ < maxIterations)
-      if (active) {
-        const bool c1 = f[0] > K.tol_pos;
-        norm1 = c1 ? 1.0 : 0.0;
-        bool resid = c1;
-        if (!c1) { norm2 = f[1]; resid = f[1] > K.tol_rot; }
-        if (resid) { cont = iter < K.max_iter; iter++; }
-      }
-    }
+#define CCMP_FD_BP bp_lane
+#include "ccmp_fd_newton_phase1.inc"
     // ---- finished groups: jointValid, write-back --------------------------------------------
     {
       const bool fin = active && !cont;
@@ -556,47 +517,12 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
     if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue; // nobody iterates: straight to refill
     __syncthreads(); // prefix frames / tool poses written by the writer lane are visible to the group
 
-    // ---- phase 2: OMPL's default Constraint::jacobian, one column per step --------------------
-    jacobian_columns<0, STOCK>(K, rec, live, r, plus, nstep);
-    __syncthreads();
-    stencil_combine<0>(rec, r, live);
-    __syncthreads();
-    if constexpr (STOCK && CCMP_FD_ROWS) {
-      chain_rows<false>(K, rec, arm_l, row_l, live, 1, d_lane, bp_lane); // re-run by rows: arm 1's lanes stage ITS prefix frames
-    } else {
-      double T1[12];
-      chain_at_x<1, true, STOCK>(K, rec, writer, T1); // re-run arm 1's chain to stage ITS prefix frames
-    }
-    __syncthreads();
-    jacobian_columns<1, STOCK>(K, rec, live, r, plus, nstep);
-    __syncthreads();
-    stencil_combine<1>(rec, r, live);
-    __syncthreads();
-
-    // ---- Newton update: x -= 0.30 * J.jacobiSvd().solve(f) --------------------------------------
-    {
-      double Jr[28], dx[14];
-#pragma unroll
-      for (int j = 0; j < 7; j++) {
-        Jr[j] = rec[kJ0 + 2 * j];
-        Jr[14 + j] = rec[kJ0 + 2 * j + 1];
-        Jr[7 + j] = rec[kSC + 2 * j];
-        Jr[21 + j] = rec[kSC + 2 * j + 1];
-      }
-      solve_minnorm(Jr, f0, f1, dx);
-      if (cont) {
-#pragma unroll
-        for (int e = 0; e < 14; e++)
-          if (e % kGroup == r) rec[kX + e] = CCMP_FMA(-K.step, dx[e], rec[kX + e]);
-        updates++;
-      }
-    }
-    __syncthreads();
+#include "ccmp_fd_newton_phase2.inc"
+#undef CCMP_FD_BP
   }
 }
 
 
-// ------------------------------------------------------------------------------------------------------------------------
 // geodesic_group_kernel — the extend step (jy_ProjectedStateSpace::discreteGeodesic, src/base/jy_ProjectedStateSpace.cpp:
 // 32-96) on the THROUGHPUT layout: ten edges x six lanes per wavefront, the Newton iteration of project_fd_kernel (the same
 // device functions in the same order: same bits), and at the point where that kernel writes a finished sample back, the
@@ -609,9 +535,10 @@ __global__ __launch_bounds__(64, CCMP_FD_WAVES_PER_SIMD) void project_fd_kernel(
 // a launch in front of this one (target_ok).
 // Per-edge state lives in the group's LDS record behind the projector's 165 doubles: previous accepted state (14), dist,
 // running length, bound (3), and three counters — 185 doubles per group, 10 wavefronts per CU.
-// (The two halves of the Newton iteration are written out again here rather than shared with project_fd_kernel through functions:
-// factored, the general instantiations of BOTH kernels came out with 2.3 KB of scratch instead of 0.1-0.2 KB — the register
-// allocator loses the scoping of the pose arrays.)
+// (The two halves of the Newton round are ONE text, included into both kernels' loops: ccmp_fd_newton_phase1.inc / _phase2.inc.  Shared
+// through functions instead, the general instantiations of both kernels came out with 2.3 KB of scratch — the allocator lost the
+// scoping of the pose arrays; textual inclusion leaves both allocations as they were: 167 / 168 registers, no scratch for the stock
+// instantiations.  What does spill is listed, and bounded at build time, in build.py: _SCRATCH_RULES.)
 constexpr int kGPrev = kRec, kGDist = kRec + 14, kGCnt = kRec + 17, kRecG = kRec + 20; // odd stride like kRec
 static_assert(kRecG % 2 == 1, "odd record stride: the ten groups stay on distinct LDS banks");
 
@@ -640,9 +567,10 @@ __global__ __launch_bounds__(64, CCMP_GEO_GROUP_WAVES_PER_SIMD) void geodesic_gr
     unsigned long long E, int max_states, double *__restrict__ states, int *__restrict__ n_states, uint8_t *__restrict__ ok_out,
     int *__restrict__ newton_iters, unsigned long long *queue, const unsigned int *__restrict__ order,
     double *__restrict__ carry_out, int round_budget, double *__restrict__ pool, unsigned long long *pool_count, int handover_pct,
-    const uint8_t *__restrict__ target_ok, unsigned int *__restrict__ pool_flags, int retire_active)
+    const uint8_t *__restrict__ target_ok)
 {
   __shared__ double lds[kGroupsPerWave * kRecG];
+  __shared__ double lane_bp[64]; // the lane's base-frame offset (bp_lane below): parked here instead of in scratch
   const int lane = threadIdx.x;
   const int g = lane / kGroup;
   const int r = lane - kGroup * g;
@@ -660,6 +588,7 @@ __global__ __launch_bounds__(64, CCMP_GEO_GROUP_WAVES_PER_SIMD) void geodesic_gr
     bp_lane = arm_l ? (row_l == 0 ? K.base_p[1][0] : (row_l == 1 ? K.base_p[1][1] : K.base_p[1][2]))
                     : (row_l == 0 ? K.base_p[0][0] : (row_l == 1 ? K.base_p[0][1] : K.base_p[0][2]));
   }
+  lane_bp[lane] = bp_lane;
   // The lane's address offsets into from / to / states and its bit masks never change either, but they are NOT held across the
   // Newton loop: under the bound of three wavefronts per SIMD the allocator parked them in scratch.  They are recomputed where they
   // are used — once per edge or projection — from a lane index the optimiser cannot see through, which keeps it from hoisting them
@@ -749,86 +678,30 @@ __global__ __launch_bounds__(64, CCMP_GEO_GROUP_WAVES_PER_SIMD) void geodesic_gr
       head = shfl_u64(head, 0);
       fin_count = shfl_u64(fin_count, 0);
       const unsigned long long in_flight = E - fin_count, slots = (unsigned long long)gridDim.x * kGroupsPerWave;
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(active && r == 0);
-      // Live hand-over (round 5, pool_flags != NULL: latency blocks take entries while this kernel runs): with the queue dry a
-      // wavefront no longer waits for the whole launch to thin out — it gives its edges up as soon as retire_active or fewer of
-      // its ten groups are busy (below half full the layout pays more instructions per edge and round than the latency kernel)
-      if (head >= E && (in_flight * 100ull < slots * (unsigned long long)handover_pct ||
-                        (pool_flags != nullptr && __builtin_popcountll(m) <= retire_active))) {
+      if (head >= E && in_flight * 100ull < slots * (unsigned long long)handover_pct) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(active && r == 0);
         unsigned long long base = 0;
-        if (lane == 0 && m) {
-          base = atomicAdd(pool_count, (unsigned long long)__builtin_popcountll(m));
-          if (pool_flags) atomicAdd(queue + 3, (unsigned long long)__builtin_popcountll(m)); // given up = no longer in flight HERE
-        }
+        if (lane == 0 && m) base = atomicAdd(pool_count, (unsigned long long)__builtin_popcountll(m));
         base = shfl_u64(base, 0);
-        const unsigned long long slot = base + (unsigned long long)__builtin_popcountll(m & ((1ull << lane_opaque(leader)) - 1ull));
-        // live: agent-scope atomic stores — they are written through to where every XCD reads them, so the flag behind them needs
-        // no cache write-back (a release fence at agent scope writes the whole L2 back: seen as a chip-wide slowdown)
-        const bool through = pool_flags != nullptr;
-        auto put = [through](double *p, double v) {
-          if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *p = v;
-        };
         if (active) {
-          double *ent = pool + slot * (unsigned long long)kGeoPoolEntry;
-          for (int e = lane_opaque(r); e < 14; e += kGroup) { put(ent + e, rec[kX + e]); put(ent + 14 + e, rec[kGPrev + e]); }
+          double *ent = pool + (base + (unsigned long long)__builtin_popcountll(m & ((1ull << lane_opaque(leader)) - 1ull))) * (unsigned long long)kGeoPoolEntry;
+          for (int e = lane_opaque(r); e < 14; e += kGroup) { ent[e] = rec[kX + e]; ent[14 + e] = rec[kGPrev + e]; }
           if (r == 0) {
             const int *cnt = reinterpret_cast<const int *>(rec + kGCnt);
-            put(ent + 28, rec[kGDist]); put(ent + 29, rec[kGDist + 1]); put(ent + 30, rec[kGDist + 2]);
-            put(ent + 31, __longlong_as_double((long long)edge));
-            put(ent + 32, __hiloint2double(cnt[0], cnt[1]));   // states listed, Newton updates of the finished projections
-            put(ent + 33, __hiloint2double(cnt[2], iter));     // Newton rounds of the finished projections, loop counter of this one
-            put(ent + 34, __hiloint2double(0, updates));
-            put(ent + 35, norm1); put(ent + 36, norm2);
+            ent[28] = rec[kGDist]; ent[29] = rec[kGDist + 1]; ent[30] = rec[kGDist + 2];
+            ent[31] = __longlong_as_double((long long)edge);
+            ent[32] = __hiloint2double(cnt[0], cnt[1]);   // states listed, Newton updates of the finished projections
+            ent[33] = __hiloint2double(cnt[2], iter);     // Newton rounds of the finished projections, loop counter of this one
+            ent[34] = __hiloint2double(0, updates);
+            ent[35] = norm1; ent[36] = norm2;
           }
-        }
-        if (pool_flags) { // the entries — all of them acknowledged — then their flags, then the takers' semaphore
-          __builtin_amdgcn_s_waitcnt(0);
-          if (active && r == 0) __hip_atomic_store(pool_flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (lane == 0 && m) atomicAdd(queue + 8, (unsigned long long)__builtin_popcountll(m));
         }
         break;
       }
     }
 
-    // ---- phase 1: function(x) — sines/cosines, both chains, residual (project_fd_kernel's) -------------------------------
-    for (int e = r; e < 14; e += kGroup) {
-      double s, c;
-      ccmp_sincos(rec[kX + e], &s, &c);
-      if (live) { rec[kSC + 2 * e] = s; rec[kSC + 2 * e + 1] = c; }
-    }
-    __syncthreads();
-    bool cont = false;
-    double f0, f1;
-    {
-      double T0[12], T1[12], f[2];
-      if constexpr (STOCK && CCMP_FD_ROWS) {
-        chain_rows<true>(K, rec, arm_l, row_l, live, 0, d_lane, bp_lane);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 12; k++) { T0[k] = rec[kEE + k]; T1[k] = rec[kEE + 12 + k]; }
-      } else {
-        chain_at_x<1, false, STOCK>(K, rec, writer, T1);
-        if (writer) {
-#pragma unroll
-          for (int k = 0; k < 12; k++) rec[kEE + 12 + k] = T1[k];
-        }
-        chain_at_x<0, true, STOCK>(K, rec, writer, T0);
-        if (writer) {
-#pragma unroll
-          for (int k = 0; k < 12; k++) rec[kEE + k] = T0[k];
-        }
-      }
-      chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, nullptr, nullptr);
-      f0 = f[0]; f1 = f[1];
-      if (active) { // loop condition of ConstraintFunction.h:68, quirks included
-        const bool c1 = f[0] > K.tol_pos;
-        norm1 = c1 ? 1.0 : 0.0;
-        bool resid = c1;
-        if (!c1) { norm2 = f[1]; resid = f[1] > K.tol_rot; }
-        if (resid) { cont = iter < K.max_iter; iter++; }
-      }
-    }
+#define CCMP_FD_BP lane_bp[lane_opaque(lane)]
+#include "ccmp_fd_newton_phase1.inc"
     // ---- a projection has ended: the reference's bookkeeping between two projections (jy_ProjectedStateSpace.cpp:65-90) --
     {
       const bool fin = active && !cont;
@@ -866,7 +739,9 @@ __global__ __launch_bounds__(64, CCMP_GEO_GROUP_WAVES_PER_SIMD) void geodesic_gr
         do {
           if (!(conv && jv)) break;                        // not on manifold
           const double step = ccmp_sqrt(s_acc), newDist = ccmp_sqrt(d_acc);
-          if (step > lambda * delta) break;                // deviated
+          double delta_o = delta; // (opaque: the product below is otherwise formed once, in front of the loop, and parked in scratch)
+          asm volatile("" : "+v"(delta_o));
+          if (step > lambda * delta_o) break;              // deviated
           const double total_before = total;
           total += step;
           if (total > maxd) break;                         // wandered too far
@@ -907,45 +782,8 @@ __global__ __launch_bounds__(64, CCMP_GEO_GROUP_WAVES_PER_SIMD) void geodesic_gr
     if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue; // nobody iterates: back to the top (refill, next function(x))
     __syncthreads();
 
-    // ---- phase 2: OMPL's default Constraint::jacobian; Newton update (project_fd_kernel's) --------------------------------
-    jacobian_columns<0, STOCK>(K, rec, live, r, plus, nstep);
-    __syncthreads();
-    stencil_combine<0>(rec, r, live);
-    __syncthreads();
-    if constexpr (STOCK && CCMP_FD_ROWS) {
-      chain_rows<false>(K, rec, arm_l, row_l, live, 1, d_lane, bp_lane);
-    } else {
-      double T1[12];
-      chain_at_x<1, true, STOCK>(K, rec, writer, T1);
-    }
-    __syncthreads();
-    jacobian_columns<1, STOCK>(K, rec, live, r, plus, nstep);
-    __syncthreads();
-    stencil_combine<1>(rec, r, live);
-    __syncthreads();
-    {
-      double Jr[28], dx[14];
-#pragma unroll
-      for (int j = 0; j < 7; j++) {
-        Jr[j] = rec[kJ0 + 2 * j];
-        Jr[14 + j] = rec[kJ0 + 2 * j + 1];
-        Jr[7 + j] = rec[kSC + 2 * j];
-        Jr[21 + j] = rec[kSC + 2 * j + 1];
-      }
-      solve_minnorm(Jr, f0, f1, dx);
-      if (cont) {
-#pragma unroll
-        for (int e = 0; e < 14; e++)
-          if (e % kGroup == r) rec[kX + e] = CCMP_FMA(-K.step, dx[e], rec[kX + e]);
-        updates++;
-      }
-    }
-    __syncthreads();
-  }
-  // live hand-over: this wavefront has left (queue[1]); when all have, the pool's count is final and waiting consumers go home
-  if (pool_flags != nullptr) {
-    __builtin_amdgcn_s_waitcnt(0); // (what this wavefront added to the semaphore is there before it is counted out)
-    if (lane == 0) __hip_atomic_fetch_add(queue + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#include "ccmp_fd_newton_phase2.inc"
+#undef CCMP_FD_BP
   }
 }
 
@@ -1149,17 +987,14 @@ extern "C" {
 hipError_t ccmp_launch_geodesic_group(const ccmp_consts *K, double delta, double lambda, const double *from, const double *to, size_t E,
                                       int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters, int nblocks,
                                       unsigned long long *queue, const unsigned int *order, double *carry_out, int round_budget,
-                                      double *pool, unsigned long long *pool_count, int handover_pct, const uint8_t *target_ok,
-                                      unsigned int *pool_flags, int retire_active, hipStream_t st)
+                                      double *pool, unsigned long long *pool_count, int handover_pct, const uint8_t *target_ok, hipStream_t st)
 {
   if (K->stock && K->twin_arms) // the STOCK instantiation also assumes twin arms on diag(+-1) base frames (chain_rows), like project_fd_kernel's
     hipLaunchKernelGGL(geodesic_group_kernel<true>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok,
-                       pool_flags, retire_active);
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok);
   else
     hipLaunchKernelGGL(geodesic_group_kernel<false>, dim3(nblocks), dim3(64), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok,
-                       pool_flags, retire_active);
+                       max_states, states, n_states, ok, newton_iters, queue, order, carry_out, round_budget, pool, pool_count, handover_pct, target_ok);
   return hipGetLastError();
 }
 

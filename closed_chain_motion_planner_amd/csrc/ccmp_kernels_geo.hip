@@ -54,22 +54,17 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,
     unsigned long long *queue, const unsigned int *__restrict__ order, const double *__restrict__ carry_in,
     double *__restrict__ carry_out, int round_budget, const unsigned long long *__restrict__ total_ptr,
-    const double *pool, const unsigned long long *__restrict__ pool_count, const ccmp_geo_live live)
+    const double *__restrict__ pool, const unsigned long long *__restrict__ pool_count)
 {
   __shared__ __attribute__((aligned(16))) double lds[gRec];
   __shared__ double ktab[kConstsDoubles + 1];
   __shared__ __attribute__((aligned(16))) double steptab[kStepTab];
   __shared__ unsigned long long ticket;
-  __shared__ int ticket_kind;
-  __shared__ double ent_l[kGeoPoolEntry]; // a pool entry, staged: every later read of it is an LDS read
-  __shared__ ccmp_geo_live live_s;        // the live words (see below)
-  __shared__ int front_dry;               // (thread 0, live calls) the front of the order is taken
   const int tid = threadIdx.x;
   {
     const double *src = reinterpret_cast<const double *>(&K);
     for (int k = tid; k < kConstsDoubles; k += 128) ktab[k] = src[k];
   }
-  if (tid == 0) { live_s = live; front_dry = 0; }
   stage_step_table(K, steptab, tid);
   __syncthreads();
   const ccmp_consts &KL = *reinterpret_cast<const ccmp_consts *>(ktab);
@@ -78,128 +73,43 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
 
   unsigned long long tk = blockIdx.x;
   for (;;) {
-    bool from_pool = pool != nullptr;
-    if (live_s.words) {
-      // Live hand-over (round 5): this launch takes the front of the order (kind 1) and then, instead of leaving, the edges the
-      // group kernel's wavefronts give up while that kernel is still running (kind 2).  Thread 0 finds the block's next piece of
-      // work; the others are parked at the barrier.
-      if (tid == 0) {
-        // (the live words come from LDS, where the block's first instructions put them: as kernel arguments they would sit in
-        // scalar registers across the Newton loop, and this kernel has none to spare — it started to spill)
-        unsigned long long *const words = live_s.words;
-        int kind = 0;
-        unsigned long long t = 0;
-        if (!front_dry && total_ptr) {
-          t = atomicAdd(words + 5, 1ull);
-          if (t < *total_ptr) kind = 1;
-          else front_dry = 1;
-        }
-        if (kind == 0) {
-          bool poller = false;
-          int polls = 0;
-          for (;;) {
-            // words[8] is a counting semaphore of published entries (its producers add, a taker subtracts one and puts it back if
-            // there was none: plain atomic adds — a compare-and-swap loop on one claim word lets ONE of two thousand contending
-            // blocks through per round trip, measured: 15 us per entry, 125 ms per call); whoever got a unit takes the next ticket
-            // of words[7], which is then below the number of entries reserved, and waits for THAT entry's flag
-            if ((long long)__hip_atomic_load(words + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
-              if ((long long)atomicAdd(words + 8, ~0ull) > 0) { t = atomicAdd(words + 7, 1ull); kind = 2; break; }
-              atomicAdd(words + 8, 1ull);
-              continue;
-            }
-            // nothing to take right now.  Producers all gone: what the semaphore shows BEHIND that observation is final.
-            // (relaxed loads throughout: on this chip an ACQUIRE at agent scope invalidates the XCD's L2 — a polling loop of them,
-            // or one per entry taken, slowed every other wavefront on the chip: the first live version was 40 % slower than none)
-            const unsigned long long gone = __hip_atomic_load(words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gone >= (unsigned long long)live_s.group_waves) {
-              if ((long long)__hip_atomic_load(words + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
-              break;
-            }
-            // wait — as one of at most max_pollers blocks (waiting blocks hold registers and LDS the group kernel's wavefronts may
-            // still need: a bounded number of them can never keep that kernel from finishing), and not for ever: until the group
-            // kernel is seen running (its ticket word has moved past the front) only briefly — if the two streams ever shared a
-            // hardware queue this launch would run in FRONT of it (DESIGN_experiments.md §10.8) and must not wait for it
-            if (!poller) {
-              if (atomicAdd(words + 2, 1ull) >= (unsigned long long)live_s.max_pollers) { atomicAdd(words + 2, ~0ull); break; }
-              poller = true;
-            }
-            const bool running = __hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
-                                 __hip_atomic_load(words + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++polls > (running ? live_s.poll_limit : 256)) break;
-            __builtin_amdgcn_s_sleep(32);
-          }
-          if (poller) atomicAdd(words + 2, ~0ull);
-          if (kind == 2) { // the entry's producer reserved it before it wrote it: wait for the flag behind the entry, and leave it cleared
-            // (bounded like every wait in this kernel — ~1 s: a flag that never comes would be a bug, and a wrong result that
-            // the parity tests catch is better than a grid that never drains)
-            int spins = 0;
-            while (__hip_atomic_load(live_s.flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
-            __hip_atomic_store(live_s.flags + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        ticket = t;
-        ticket_kind = kind;
-      }
+    if (queue) {
+      if (tid == 0) ticket = atomicAdd(queue, 1ull);
       __syncthreads();
       tk = ticket;
-      const int kind = ticket_kind;
-      if (kind == 0) break;
-      from_pool = kind == 2;
-    } else {
-      if (queue) {
-        if (tid == 0) ticket = atomicAdd(queue, 1ull);
-        __syncthreads();
-        tk = ticket;
-      }
-      // total_ptr (bulk calls, ccmp_api.cpp: geodesic_common): this launch takes the first *total_ptr tickets of the order — the
-      // edges the scout predicts longest — beside geodesic_group_kernel, which takes the rest
-      if (tk >= (pool ? *pool_count : (total_ptr ? *total_ptr : E))) break;
     }
+    // total_ptr (bulk calls, ccmp_api.cpp: geodesic_common): this launch takes the first *total_ptr tickets of the order — the
+    // edges the scout predicts longest — beside geodesic_group_kernel, which takes the rest
+    if (tk >= (pool ? *pool_count : (total_ptr ? *total_ptr : E))) break;
     // pool (bulk calls): the edges geodesic_group_kernel handed over in the middle of a projection — iterate, previous state,
     // running distances and counters — go on here exactly where they stood
     // (the ticket is block-uniform: a scalar address keeps the entry out of the vector registers this kernel has none to spare of)
     const unsigned long long tks = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(tk >> 32)) << 32) |
                                    (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
-    // Live calls: the producer wrote the entry with agent-scope atomic stores (they go through to the point every XCD sees) and
-    // set the flag behind them; it is read here the same way — agent-scope atomic loads, one double per thread — so that neither
-    // side needs a cache write-back or invalidation, and never through the scalar cache.
-    if (from_pool) {
-      if (tid < kGeoPoolEntry) {
-        // (the thread index made opaque: hoisted out of the edge loop, `pool + tid` is one more 64-bit value held — in scratch, there
-        // being no register left — across the Newton loop for a load that happens once per edge)
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));
-        const double *src = pool + tks * (unsigned long long)kGeoPoolEntry + tid_o;
-        ent_l[tid] = live_s.words ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
-      }
-      __syncthreads();
-    }
-    const double *const ent = ent_l; // (valid where from_pool holds)
-    const unsigned long long t = from_pool ? (unsigned long long)__double_as_longlong(ent[31]) : (order ? (unsigned long long)order[tk] : tk);
+    const double *ent = pool ? pool + tks * (unsigned long long)kGeoPoolEntry : nullptr;
+    const unsigned long long t = ent ? (unsigned long long)__double_as_longlong(ent[31]) : (order ? (unsigned long long)order[tk] : tk);
 #ifdef CCMP_GEO_TRACE
     if (tid == 0 && t < 65536) { g_geo_trace[3 * t] = wall_clock64(); g_geo_trace[3 * t + 2] = ((unsigned long long)blockIdx.x << 32) | tk; }
 #endif
     double *out = states + t * (unsigned long long)max_states * 14ull;
     if (tid < 14) {
-      int tid_o = tid; // (opaque, as above: `from + tid` / `to + tid` are not worth a register pair across the Newton loop)
-      asm volatile("" : "+v"(tid_o));
-      if (from_pool) {
+      if (ent) {
         rec[fX + tid] = ent[tid];
         rec[gPrev + tid] = ent[14 + tid];
       } else {
-        const double a = from[t * 14 + tid_o];
+        const double a = from[t * 14 + tid];
         rec[gPrev + tid] = a;
         if (max_states > 0) out[tid] = a; // geodesic->push_back(cloneState(from))
       }
-      rec[gTo + tid] = to[t * 14 + tid_o];
+      rec[gTo + tid] = to[t * 14 + tid];
     }
     __syncthreads();
     int n = 1, its = 0, rounds = 0;
-    bool resume = from_pool; // the first pass through the loop below skips the interpolation and takes the projection's counters from the entry
+    bool resume = ent != nullptr; // the first pass through the loop below skips the interpolation and takes the projection's counters from the entry
     bool suspended = false; // the edge used up the call's budget of Newton rounds: it stops between two states (ok = 2)
     bool fits = true; // false: an accepted state found the list full — the edge stops there and reports max_states + 1
     bool target_ok = true;
-    if (check_target && !from_pool) { // (an edge from the pool had its target tested before the group kernel took it)
+    if (check_target) {
       // ConstrainedMotionValidator::checkMotion (src/planner/stefanBiPRM.cpp:397-398): isSatisfied(s2) first —
       // function(to) through one evaluation pass of the Newton routine (iteration cap 0: no update), then
       // KinematicChainConstraint::isSatisfied's test (finite, f0 <= tol1, f1 <= tol2; ConstraintFunction.h:114-120)
@@ -214,7 +124,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     }
     double dist = lds_distance(rec + gPrev, rec + gTo), total = 0.0, total_before = 0.0;
     double maxd = dist * lambda;
-    if (from_pool) { // (dist is the value the group kernel held: the distance of `previous` to the target, from the same operands)
+    if (ent) { // (dist is the value the group kernel held: the distance of `previous` to the target, from the same operands)
       dist = ent[28]; total = ent[29]; maxd = ent[30];
       n = __double2hiint(ent[32]); its = __double2loint(ent[32]);
       rounds = __double2hiint(ent[33]);
@@ -227,7 +137,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
       maxd = carry_in[2 * t + 1];
       enter = dist >= delta;
     }
-    if (from_pool) enter = true; // in the middle of the reference's loop
+    if (ent) enter = true; // in the middle of the reference's loop
     if (target_ok && enter) {
       // Between two projections every thread does the reference's bookkeeping for itself, in ONE pass over the 14 joints
       // and without a barrier (round 3; before: jointValid through a ballot and two barriers, then the distances one
@@ -367,16 +277,14 @@ hipError_t CCMP_LAUNCH_GEODESIC(const ccmp_consts *K, double delta, double lambd
                                 size_t E, int max_states, double *states, int *n_states, uint8_t *ok, int *newton_iters,
                                 int check_target, int nblocks, unsigned long long *queue, const unsigned int *order,
                                 const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr,
-                                const double *pool, const unsigned long long *pool_count, const ccmp_geo_live *live, hipStream_t st)
+                                const double *pool, const unsigned long long *pool_count, hipStream_t st)
 {
-  ccmp_geo_live lv = {nullptr, nullptr, 0, 0, 0};
-  if (live) lv = *live;
   if (K->stock)
     hipLaunchKernelGGL(geodesic_flat_kernel<true>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count, lv);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count);
   else
     hipLaunchKernelGGL(geodesic_flat_kernel<false>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count, lv);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count);
   return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ const OptionDesc kOptions[] = {
     OPT("hand_over", wave_kernel, kInt, 0, 2, 0, "0 = throughput kernel (10 samples per wavefront) only, 1 = that kernel until its queue drains, then the latency kernel on what is in flight, 2 = latency kernel only (= ccmp_ctx_set_schedule)"),
     OPT("small_batch", small_batch, kSize, 0, LONG_MAX, 0, "batches of at most this many samples run on the latency kernel alone (= ccmp_ctx_set_schedule)"),
     OPT("waves_per_cu", waves_per_cu, kInt, 0, 32, 0, "persistent wavefronts of the throughput kernels per CU, 0 = 12 (= ccmp_ctx_set_waves_per_cu)"),
-    OPT("lpt", lpt, kInt, 0, 2, 0, "0 = index order, 1 = FP32 scout + longest-predicted-first, hand-over kept below 120000 samples, 2 = the same without hand-over (= ccmp_ctx_set_lpt)"),
+    OPT("lpt", lpt, kInt, 0, 2, 0, "0 = index order, 1 = FP32 scout + longest-predicted-first, hand-over kept below 131072 samples, 2 = the same without hand-over (= ccmp_ctx_set_lpt)"),
     OPT("lpt_min_batch", lpt_min_batch, kSize, 0, LONG_MAX, 0, "the scout's order from this many samples on (= ccmp_ctx_set_lpt)"),
     OPT("latency_order_min", latency_order_min, kSize, 0, LONG_MAX, 0, "latency kernel alone: tickets through the scout's order from this many samples on"),
     OPT("flat_kernel", flat_kernel, kInt, 0, 1, 0, "latency work: 1 = one sample per 128-thread block, an iteration's evaluations in one round, 0 = one wavefront per sample"),
@@ -76,10 +76,6 @@ const OptionDesc kOptions[] = {
     OPT("geodesic_group_front_per_cu", geodesic_group_front_per_cu, kInt, -1, 8, kNotZero, "... latency blocks per CU launched for the front (-1 = 8)"),
     OPT("geodesic_group_waves_per_cu", geodesic_group_waves_per_cu, kInt, 1, 10, 0, "... wavefronts of the throughput layout per CU at most"),
     OPT("geodesic_group_handover_pct", geodesic_group_handover_pct, kInt, 0, 100, 0, "... with the queue dry, every wavefront gives its edges to latency blocks once those in flight fill less than this share of the slots (0 = never)"),
-    OPT("geodesic_group_live", geodesic_group_live, kInt, 0, 1, 0, "... 1 = the front's blocks take given-up edges while the group kernel runs, 0 = only a launch behind it does"),
-    OPT("geodesic_group_retire", geodesic_group_retire, kInt, 0, 10, 0, "... live: a wavefront gives up as soon as the queue is dry and this many of its ten groups or fewer are busy (0 = only by the occupancy rule)"),
-    OPT("geodesic_group_pollers_per_cu", geodesic_group_pollers_per_cu, kInt, 0, 4, 0, "... live: latency blocks per CU that may wait for entries at one time"),
-    OPT("geodesic_group_poll_limit", geodesic_group_poll_limit, kInt, 0, 1 << 24, 0, "... live: polls a waiting block spends before it leaves (a backstop)"),
     // other
     OPT("clearance_per_state_max", clearance_per_state_max, kSize, 0, LONG_MAX, 0, "proxy clearance: one block per state up to this many states, 64-state tiles above"),
     OPT("host_zero_copy", host_zero_copy, kInt, 0, 2, 0, "*_host calls on page-locked caller buffers: 0 = staged, 1 = q_out written in place, 2 = q_in read in place too"),
@@ -279,8 +275,6 @@ GeoPlan plan_geodesic(const ccmp_ctx *ctx, size_t E, int round_budget, bool cont
     pl.front_blocks = ctx->num_cus * (ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : 8);
     pl.low_cut = ctx->geodesic_group_low_cut > 0 ? ctx->geodesic_group_low_cut : (E < kGeoGroupHighCut ? 40 : 48);
     pl.handover_pct = ctx->geodesic_group_handover_pct;
-    pl.live = pl.handover_pct > 0 && ctx->geodesic_group_live; // (the live form needs the pool: a hand-over percentage of 0 means none)
-    pl.retire = pl.live ? ctx->geodesic_group_retire : 0;
     if (pl.handover_pct > 0) {
       const size_t lat = (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
       pl.drain_blocks = (int)(pl.group_waves * 10 < lat ? pl.group_waves * 10 : lat);
@@ -418,8 +412,7 @@ int ccmp_ctx_describe(const ccmp_ctx *ctx_in, int call_kind, size_t n, char *buf
               ctx->geodesic_group_heavy_permille, pl.low_cut, pl.front_blocks, pl.group_waves);
         if (ctx->geodesic_group_pred > 0) L.add(" (cut fixed at %d)", ctx->geodesic_group_pred);
         if (pl.handover_pct > 0)
-          L.add("; hand-over below %d %% occupancy%s to %d blocks behind it", pl.handover_pct, pl.live ? "" : " (not live)", pl.drain_blocks);
-        if (pl.live) L.add(", live: a wavefront gives up at <= %d busy groups and the front's blocks take its edges at once", pl.retire);
+          L.add("; hand-over below %d %% occupancy to %d blocks behind it", pl.handover_pct, pl.drain_blocks);
       } else {
         L.add("%s x %zu blocks%s", pl.latency_flavour ? "geodesic_flat_kernel_lat" : "geodesic_flat_kernel", pl.blocks, pl.queued ? ", ticket queue" : ", one per edge");
       }

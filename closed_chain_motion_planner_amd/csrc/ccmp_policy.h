@@ -51,8 +51,6 @@ struct GeoPlan {
   int front_blocks = 0;         // grid of the front's launch
   int low_cut = 0;              // cut of the order where the edges beyond the scout's cap carry little work
   int handover_pct = 0;         // occupancy below which the group kernel gives up everything (0 = never)
-  bool live = false;            // hand-over while the group kernel runs
-  int retire = 0;               // ... a wavefront gives up with this many busy groups or fewer
   int drain_blocks = 0;         // grid of the launch behind the group kernel
 };
 GeoPlan plan_geodesic(const ccmp_ctx *ctx, size_t E, int round_budget, bool continuation);

@@ -135,7 +135,7 @@ int ccmp_ctx_set_waves_per_cu(ccmp_ctx *ctx, int waves_per_cu);
 int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
 /* longest-predicted-first scheduling of large reference-arithmetic batches (= options "lpt", "lpt_min_batch"): mode 0 = index
  * order; 1 = an FP32 analytic-Jacobian scout pass predicts each sample's iteration count and the batch is processed longest
- * first, straggler hand-over kept up to 120000 samples and dropped above (default); 2 = the same without hand-over at any size.
+ * first, straggler hand-over kept below 131072 samples and dropped from there on (default); 2 = the same without hand-over at any size.
  * Used for batches of at least min_batch samples (CCMP_DEFAULT = the built-in default of the table below). */
 int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch);
 /* Tuning options, by name.  NONE of them changes a result bit: they choose which kernels a call runs on and where the regimes
@@ -157,10 +157,10 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *                                                           ccmp_ctx_set_schedule)
  *   "waves_per_cu"                  0         0..32         persistent wavefronts of the throughput kernels per CU, 0 = 12 (=
  *                                                           ccmp_ctx_set_waves_per_cu)
- *   "lpt"                           1         0..2          0 = index order, 1 = FP32 scout + longest-predicted-first, hand-over kept below 120000
+ *   "lpt"                           1         0..2          0 = index order, 1 = FP32 scout + longest-predicted-first, hand-over kept below 131072
  *                                                           samples, 2 = the same without hand-over (= ccmp_ctx_set_lpt)
  *   "lpt_min_batch"                 16384     0..max        the scout's order from this many samples on (= ccmp_ctx_set_lpt)
- *   "latency_order_min"             3072      0..max        latency kernel alone: tickets through the scout's order from this many samples on
+ *   "latency_order_min"             2049      0..max        latency kernel alone: tickets through the scout's order from this many samples on
  *   "flat_kernel"                   1         0..1          latency work: 1 = one sample per 128-thread block, an iteration's evaluations in one
  *                                                           round, 0 = one wavefront per sample
  *   "stock_kernels"                 1         0..1          1 = kernels that skip the exact zeros of the uncalibrated Panda when both arms carry them
@@ -205,11 +205,11 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *                                                           scout order from geodesic_scout_min edges on
  *   "geodesic_order_min"            4096      0..max        no ordering pass below this many edges
  *   "geodesic_long_steps"           12        0..max        order 1: edges further apart than this many delta count as long
- *   "geodesic_scout_min"            6144      0..max        the scout from this many edges on
+ *   "geodesic_scout_min"            4096      0..max        the scout from this many edges on
  *   "geodesic_scout_rounds"         64        1..1023       the scout stops an edge after this many Newton rounds
  *   "geodesic_group"                1         0..1          1 = bulk calls (round budget, scout order): short edges ten to a wavefront on the
  *                                                           throughput layout, the front of the order on latency blocks beside them
- *   "geodesic_group_min"            16384     0..max        ... from this many edges
+ *   "geodesic_group_min"            13312     0..max        ... from this many edges
  *   "geodesic_group_pred"           -1        -1..1023      ... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it
  *                                                           carry geodesic_group_heavy_permille of the work, else geodesic_group_low_cut)
  *   "geodesic_group_low_cut"        -1        -1..64        ... (-1: 40 below 20480 edges, 48 from there on)
@@ -219,12 +219,6 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "geodesic_group_waves_per_cu"   8         1..10         ... wavefronts of the throughput layout per CU at most
  *   "geodesic_group_handover_pct"   50        0..100        ... with the queue dry, every wavefront gives its edges to latency blocks once those in
  *                                                           flight fill less than this share of the slots (0 = never)
- *   "geodesic_group_live"           1         0..1          ... 1 = the front's blocks take given-up edges while the group kernel runs, 0 = only a
- *                                                           launch behind it does
- *   "geodesic_group_retire"         5         0..10         ... live: a wavefront gives up as soon as the queue is dry and this many of its ten
- *                                                           groups or fewer are busy (0 = only by the occupancy rule)
- *   "geodesic_group_pollers_per_cu" 2         0..4          ... live: latency blocks per CU that may wait for entries at one time
- *   "geodesic_group_poll_limit"     65536     0..16777216   ... live: polls a waiting block spends before it leaves (a backstop)
  *   "clearance_per_state_max"       8192      0..max        proxy clearance: one block per state up to this many states, 64-state tiles above
  *   "host_zero_copy"                2         0..2          *_host calls on page-locked caller buffers: 0 = staged, 1 = q_out written in place, 2 =
  *                                                           q_in read in place too

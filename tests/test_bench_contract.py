@@ -53,6 +53,9 @@ def test_bench_line_contract():
     assert c1["parity_vs_det_oracle"]["bit_identical"] is True and c1["same_ambient_samples_on_both_sides"] is True
     sp = sec["single_project_c_abi"]  # ccmp_project_host as the C++ adapter calls it: from a uniform sample and near the manifold
     assert 10 < sp["near_manifold_median_us"] < sp["uniform_sample_median_us"] < 1000
+    # the opt-in resident service kernel beside it: the same calls, the same bits, no launch on the call path
+    assert sp["resident_bit_identical_to_launched"] is True and sp["near_manifold_resident_median_us"] < sp["near_manifold_median_us"]
+    assert sp["is_satisfied_resident_median_us"] < sp["is_satisfied_median_us"] and sp["function_resident_median_us"] < sp["function_median_us"]
     assert sp["near_manifold_median_newton_iters"] < sp["uniform_sample_median_newton_iters"]
     g = sec["discrete_geodesic"]  # the complete operation is timed, overflowing edges are counted
     assert set(g) >= {"edges_per_s", "overflowed_edges", "complete_ms", "complete_edges_per_s", "growtree_5_edges_ms", "max_states_first_pass"}
@@ -107,7 +110,9 @@ FLAT_CONFIG = ("c1_dumbbell_cpu_single_thread_per_s", "c1_dumbbell_gpu_per_s", "
                "extend_unfinished_edges", "extend_complete_ms", "extend_bitwise", "growtree_5_edges_ms", "single_project_us",
                "single_project_near_manifold_us", "host_buffer_pageable_per_s", "host_buffer_pinned_per_s", "analytic_mode_per_s",
                "proxy_clearance_states_per_s", "extend_bulk_65536_edges_per_s", "extend_bulk_65536_ms", "extend_bulk_bitwise", "extend_cpu_edges_per_s", "extend_cpu_threads", "growtree_5_edges_cpu_single_thread_ms",
-               "single_project_cpu_us", "single_project_near_manifold_cpu_us", "one_process_gpus", "one_process_direct_per_s", "one_process_rccl_per_s")
+               "single_project_cpu_us", "single_project_near_manifold_cpu_us", "single_project_resident_us", "single_project_near_manifold_resident_us",
+               "single_is_satisfied_us", "single_is_satisfied_resident_us", "single_function_us", "single_function_resident_us", "single_resident_bitwise",
+               "one_process_gpus", "one_process_direct_per_s", "one_process_rccl_per_s")
 FLAT_CPU = ("det_bit_identical", "det_samples", "libm_samples", "libm_n_gt_1e-6", "libm_max_abs_dq", "libm_iter_diffs_gt1", "libm_ok_mismatches")
 
 
@@ -126,7 +131,9 @@ def test_flat_keys_are_first_level_scalars():
         "secondary": {
             "batch4096_projections_per_s": 5.1e6, "batch4096": {"parity_vs_det_oracle": par}, "batch32768_projections_per_s": 11.4e6,
             "single_project_c_abi": {"uniform_sample_median_us": 122.0, "near_manifold_median_us": 54.7, "uniform_sample_cpu_median_us": 1100.0,
-                                     "near_manifold_cpu_median_us": 350.0},
+                                     "near_manifold_cpu_median_us": 350.0, "uniform_sample_resident_median_us": 110.0,
+                                     "near_manifold_resident_median_us": 45.0, "is_satisfied_median_us": 21.0, "is_satisfied_resident_median_us": 8.0,
+                                     "function_median_us": 21.0, "function_resident_median_us": 8.0, "resident_bit_identical_to_launched": True},
             "analytic_mode_projections_per_s": 1.4e8,
             "stefan_batch%d_tol_1e-3_5e-3" % B: {"projections_per_s": 9.9e6, "parity_vs_det_oracle": par},
             "stefan_batch%d_tol_5e-4_2.5e-3" % B: {"projections_per_s": 9.0e6, "parity_vs_det_oracle": par},

@@ -211,6 +211,74 @@ def test_split_launch_is_bitwise_identical(gpu_ctx, oracle_det, obj, pred, front
             gpu_ctx.set_option(name, val)
 
 
+@pytest.mark.parametrize("wpc,cut", [(2, -1), (1, -1), (3, 3), (2, 8), (12, 8)])
+def test_split_launch_with_few_waves_per_cu(gpu_ctx, oracle_det, wpc, cut):
+    """waves_per_cu (an option, 1..32) at or below the split launch's cut of throughput wavefronts per CU (default 3 / 2, option up
+    to 8): round 4 computed `CUs x (waves_per_cu - cut)` blocks for the throughput kernel — zero or negative — BEHIND a front that
+    was already running.  The plan now decides the split before anything is launched: without one throughput wavefront
+    per CU left beside the front there is no split.  Bit-identical to the oracle either way, twice in a row."""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    P = _oracle_problem(oracle_det, c)
+    B = 16384
+    q = oracle_det.ambient_uniform_batch(P, 0x61 + wpc, 0, B)
+    q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q, NCPU)
+    gpu_ctx.set_waves_per_cu(wpc)
+    gpu_ctx.set_option("fd_split_group_cut", cut)
+    try:
+        from closed_chain_motion_planner_amd._lib import CALL_PROJECT
+
+        line = gpu_ctx.describe(CALL_PROJECT, B)
+        eff_cut = cut if cut >= 0 else 3
+        assert ("split launch" in line) == (wpc - eff_cut >= 1), line
+        for _ in range(2):
+            q_gpu, ok_gpu, it_gpu = c.project_batch(torch.as_tensor(q).cuda())
+            torch.cuda.synchronize()
+            assert np.array_equal(q_gpu.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
+            assert np.array_equal(ok_gpu.cpu().numpy(), ok_cpu) and np.array_equal(it_gpu.cpu().numpy().astype(np.int32), it_cpu)
+    finally:
+        gpu_ctx.set_waves_per_cu(0)
+        gpu_ctx.set_option("fd_split_group_cut", -1)
+
+
+@pytest.mark.parametrize("where", [1, 2])
+def test_a_failure_behind_the_fork_still_joins_the_side_stream(gpu_ctx, where):
+    """VERDICT r4 #8 / ADVICE r4: a HIP failure after work had been queued on the context's side stream returned at once — the
+    caller's stream was never ordered behind the side stream, whose kernels went on writing the caller's buffers.  With the debug
+    option "fail_after_fork" the projector's split launch and the extend step's bulk form report a failure in front of (1) /
+    behind (2) their side-stream part: the call returns CCMP_EHIP, and once the CALLER'S stream is idle the side stream is too."""
+    import torch
+
+    from closed_chain_motion_planner_amd import CcmpError
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    q = c.ambient_uniform_batch(0x77, 0, 20000)
+    qs, oks, _, _ = c.sample_project_batch(0x6F5, 0, 8 * 16384, want_iters=False)  # growTree-shaped edges, as the extend-step tests make them
+    frm = qs[oks == 1][:16384].contiguous()
+    to, _, _, _ = c.sample_near_project_batch(0x6F6, 0, frm, 0.6, 16384, want_iters=False)
+    c.project_batch(q)  # (workspaces grown, nothing pending)
+    c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128)
+    torch.cuda.synchronize()
+    gpu_ctx.set_option("fail_after_fork", where)
+    try:
+        for call in (lambda: c.project_batch(q), lambda: c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128)):
+            with pytest.raises(CcmpError) as e:
+                call()
+            assert e.value.code == -2 and "fail_after_fork" in str(e.value)
+            torch.cuda.current_stream().synchronize()  # the caller's stream ONLY
+            assert gpu_ctx.get_option("side_stream_busy") == 0
+    finally:
+        gpu_ctx.set_option("fail_after_fork", 0)
+    # and the context is usable again
+    a = c.project_batch(q)
+    gpu_ctx.set_option("fd_split", 0)
+    b = c.project_batch(q)
+    gpu_ctx.set_option("fd_split", 1)
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
 def test_sample_project_bitwise(gpu_ctx, oracle_det):
     c = _constraint("Wine_Bottle", gpu_ctx)
     P = _oracle_problem(oracle_det, c)

@@ -1,5 +1,6 @@
 """The scheduling policy's size boundaries, re-timed on the box the suite runs on (tools/policy_check.py)."""
 import os
+import subprocess
 import sys
 
 import pytest
@@ -9,17 +10,19 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_every_policy_boundary_pays_on_this_box(gpu_ctx):
+def test_every_policy_boundary_pays_on_this_box():
     """+/-512 around each boundary, default policy against the neighbouring regime forced through ccmp_ctx_set_option, both
     objects: the default must not be > 5 % slower than the neighbour on both objects, and the time per sample / edge must not
-    jump by > 12 % across a boundary.  Timing on a shared box is noisy: a boundary that fails is measured once more, longer,
-    before the test fails.  The log (every timed call with ccmp_ctx_describe's account of its regime) is kept."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import policy_check
-
+    rise by > 12 % across a boundary.  Run as the tool is run — a process of its own (in the suite's process dozens of contexts
+    have lived and died, and which hardware queue a context's side stream shares decides 10 % of a forked launch).  Timing on a
+    shared box is noisy: a failing check is repeated once, longer, before the test fails.  The log (every timed call with
+    ccmp_ctx_describe's account of its regime) is kept under gpurun_out/ and copied to profiles/."""
     out_dir = os.path.join(ROOT, "gpurun_out")
-    log = os.path.join(out_dir, "r05_policy_check.log") if os.path.isdir(out_dir) else None
-    bad, _ = policy_check.run(reps=6, rounds=2, log=log, out=lambda s: None)
-    if bad:
-        bad, lines = policy_check.run(reps=10, rounds=4, log=log, out=lambda s: None)
-        assert not bad, "\n".join([ln for ln in lines if "<--" in ln] + bad)
+    os.makedirs(out_dir, exist_ok=True)
+    log = os.path.join(out_dir, "r05_policy_check.log")
+    tool = os.path.join(ROOT, "tools", "policy_check.py")
+    r = subprocess.run([sys.executable, tool, "--log", log, "--reps", "6", "--rounds", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    if r.returncode != 0:
+        r = subprocess.run([sys.executable, tool, "--log", log, "--reps", "10", "--rounds", "4"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    tail = "\n".join(ln for ln in r.stdout.splitlines() if "<--" in ln or ln.startswith("RESULT"))
+    assert r.returncode == 0, tail + r.stderr[-1500:]

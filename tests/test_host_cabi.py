@@ -269,15 +269,15 @@ def test_describe_names_the_regime_on_both_sides_of_every_boundary(L):
 
     d = lambda n, kind=CALL_PROJECT: describe(None, kind, n)
     # projector, reference arithmetic
-    assert "latency kernel alone" in d(1) and "one per sample" in d(2048) and "ticket queue" in d(2049)
-    assert "scout" not in d(3071) and "longest-predicted-first" in d(3072)                       # latency_order_min
+    assert "latency kernel alone" in d(1) and "one per sample" in d(2048) and "scout" not in d(2048)
+    assert "ticket queue" in d(2049) and "longest-predicted-first" in d(2049)                    # latency_order_min: as soon as blocks take tickets
     assert "latency kernel alone" in d(10240) and "split launch" in d(10241)                     # small_batch
     assert "predicted >= 40" in d(24576) and "512 project_fd_flat_kernel" in d(24576)            # wide split up to kSplitWideMax
     assert "predicted >= 56" in d(24577) and "256 project_fd_flat_kernel" in d(24577)
     assert "(<= 768)" in d(40959) and "(<= 1024)" in d(40960)                                    # samples of the front per CU: 3 -> 4
     assert "below 70 % occupancy" in d(53247) and "per wavefront at <= 10 busy groups" in d(53248)
     assert "split launch" in d(90112) and "split launch" not in d(90113)                         # fd_split_max
-    assert "hand-over" in d(119999) and "no hand-over" in d(120000)
+    assert "hand-over" in d(131071) and "no hand-over" not in d(131071) and "no hand-over" in d(131072)  # kNoHandoverFrom
     assert d(4096, CALL_SAMPLE_PROJECT).startswith("sample_project B=4096")
     # analytic mode
     a = lambda n: d(n, CALL_PROJECT_ANALYTIC)
@@ -288,9 +288,8 @@ def test_describe_names_the_regime_on_both_sides_of_every_boundary(L):
     assert "geodesic_flat_kernel_lat x 1024 blocks, one per edge" in g(1024) and "ticket queue" in g(1025)
     assert "geodesic_flat_kernel_lat" in gb(1024) and "geodesic_flat_kernel x 1025 blocks, one per edge" in gb(1025)
     assert "one per edge" in gb(2048) and "ticket queue" in gb(2049)
-    assert "first" not in gb(4095) and "far-apart edges first" in gb(4096)                       # geodesic_order_min
-    assert "far-apart" in gb(6143) and "FP32 scout on lane pairs" in gb(6144)                    # geodesic_scout_min
-    assert "bulk form" not in gb(16383) and "bulk form" in gb(16384) and "bulk form" not in g(16384)
+    assert "first" not in gb(4095) and "FP32 scout on lane pairs" in gb(4096)                    # geodesic_order_min = geodesic_scout_min
+    assert "bulk form" not in gb(13311) and "bulk form" in gb(13312) and "bulk form" not in g(16384)     # geodesic_group_min
     assert "else >= 40" in gb(20479) and "else >= 48" in gb(20480)                               # kGeoGroupHighCut
     assert "x 1639 wavefronts" in gb(16384) and "x 2048 wavefronts" in gb(65536)
     assert "lane pairs" in gb(131072) and "lane pairs" not in gb(131073)
@@ -299,3 +298,24 @@ def test_describe_names_the_regime_on_both_sides_of_every_boundary(L):
     n = L.ccmp_ctx_describe(None, CALL_PROJECT, 4096, buf, 16)
     assert n > 16 and len(buf.value) == 15 and d(4096).startswith(buf.value.decode())
     assert L.ccmp_ctx_describe(None, 99, 4096, buf, 16) == -1
+
+
+def test_stock_kernels_do_not_spill(ccmp_built):
+    """build.py keeps the compiler's own account of every kernel (-Rpass-analysis=kernel-resource-usage -> build/*.resources.json)
+    and FAILS the build when a kernel exceeds its scratch bound; here the record is read back: the stock instantiations of the
+    projector kernels, of the extend step's kernels and of the resident service kernel use no scratch at all, the general ones stay
+    under 200 B per lane — except the one instantiation DESIGN.md names (fused sampler x calibrated model: 2.3 KB)."""
+    from closed_chain_motion_planner_amd.build import check_resources, resource_report
+
+    rep = resource_report()
+    assert {"ccmp_kernels_fd.hip", "ccmp_kernels_flat.hip", "ccmp_kernels_geo.hip", "ccmp_kernels_geo_lat.hip", "ccmp_kernels_resident.hip"} <= set(rep)
+    by_name = {k["name"]: k for ks in rep.values() for k in ks}
+    for name in ("project_fd_kernel<0, true>", "project_fd_kernel<1, true>", "geodesic_group_kernel<true>", "project_fd_flat_kernel<0, true>",
+                 "geodesic_flat_kernel<true>", "geodesic_flat_kernel_lat<true>", "resident_service_kernel<true>"):
+        assert by_name[name]["scratch"] == 0 and by_name[name]["scratch_bound"] == 0, (name, by_name[name])
+    assert by_name["project_fd_kernel<0, true>"]["vgprs"] <= 168 and by_name["geodesic_group_kernel<true>"]["vgprs"] <= 168  # three wavefronts per SIMD
+    assert by_name["project_fd_flat_kernel<0, true>"]["vgprs"] <= 128 and by_name["geodesic_flat_kernel<true>"]["vgprs"] <= 128  # four
+    spill = {n: k["scratch"] for n, k in by_name.items() if k["scratch"] > 200 and "project_fast" not in n}  # (analytic mode, general arms: 236 B, opt-in extra)
+    assert set(spill) == {"project_fd_kernel<1, false>"}, spill
+    with pytest.raises(RuntimeError):  # and the check itself bites
+        check_resources([{"name": "project_fd_kernel<0, true>", "scratch": 8, "vgprs": 168, "vgpr_spill": 2}], "ccmp_kernels_fd.hip.o")
