@@ -114,7 +114,7 @@ struct ccmp_ctx {
   int scout_pairs = 1, scout_pair_blocks_per_cu = 1;
   size_t scout_pair_max_edges = 131072;
   int geodesic_blocks_per_cu = 4, geodesic_flavour = 0, geodesic_order = 2;
-  size_t geodesic_order_min = 4096, geodesic_scout_min = 4096;
+  size_t geodesic_order_min = 2049, geodesic_scout_min = 2049; // (4096 / 6144 until round 5: the scout's order pays as soon as the blocks take tickets — tools/policy_check.py)
   int geodesic_scout_rounds = 64;
   double geodesic_long_steps = 12.0;
   int geodesic_group = 1;

@@ -36,14 +36,19 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
   // order / total_ptr (SRC 0, 1; the split launch of mid-size batches, ccmp_api.cpp): the block's tickets run through the
   // first *total_ptr entries of a processing order — the samples the scout predicts longest — beside the throughput kernel
   const unsigned long long total = (SRC == 2) ? n_front + (pool_records ? pool_count[5] : 0ull) : (total_ptr ? *total_ptr : B);
+  // The first ticket of every block is its own index — no atomic: a fetch-add on ONE word costs 12 ns chip-wide whoever issues it
+  // (tools/ubench/atomic_rate.hip), so 2 048 blocks taking their first ticket from the queue word stood in line for up to 25 us
+  // before the last of them had a sample; the queue word hands out the tickets behind the grid's.
   unsigned long long t = blockIdx.x;
+  bool first = true;
 
   for (;;) {
-    if (queue) {
-      if (tid == 0) ticket = atomicAdd(queue, 1ull);
+    if (queue && !first) {
+      if (tid == 0) ticket = (unsigned long long)gridDim.x + atomicAdd(queue, 1ull);
       __syncthreads();
       t = ticket;
     }
+    first = false;
     if (t >= total) break;
     unsigned long long idx;
     int iter = 0, updates = 0;

@@ -71,13 +71,17 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
   double *rec = lds;
   const double pi = 3.14159265358979323846;
 
+  // (the first ticket of every block is its own index, the queue word hands out those behind the grid's: a fetch-add on one word
+  // costs 12 ns chip-wide, tools/ubench/atomic_rate.hip — 2 048 blocks stood in line for up to 25 us for their first edge)
   unsigned long long tk = blockIdx.x;
+  bool first = true;
   for (;;) {
-    if (queue) {
-      if (tid == 0) ticket = atomicAdd(queue, 1ull);
+    if (queue && !first) {
+      if (tid == 0) ticket = (unsigned long long)gridDim.x + atomicAdd(queue, 1ull);
       __syncthreads();
       tk = ticket;
     }
+    first = false;
     // total_ptr (bulk calls, ccmp_api.cpp: geodesic_common): this launch takes the first *total_ptr tickets of the order — the
     // edges the scout predicts longest — beside geodesic_group_kernel, which takes the rest
     if (tk >= (pool ? *pool_count : (total_ptr ? *total_ptr : E))) break;

@@ -203,9 +203,9 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "geodesic_blocks_per_cu"        4         1..32         persistent blocks of the latency build per CU (4 are resident)
  *   "geodesic_order"                2         0..2          batches beyond the resident blocks: 0 = index order, 1 = far-apart edges first, 2 = FP32
  *                                                           scout order from geodesic_scout_min edges on
- *   "geodesic_order_min"            4096      0..max        no ordering pass below this many edges
+ *   "geodesic_order_min"            2049      0..max        no ordering pass below this many edges
  *   "geodesic_long_steps"           12        0..max        order 1: edges further apart than this many delta count as long
- *   "geodesic_scout_min"            4096      0..max        the scout from this many edges on
+ *   "geodesic_scout_min"            2049      0..max        the scout from this many edges on
  *   "geodesic_scout_rounds"         64        1..1023       the scout stops an edge after this many Newton rounds
  *   "geodesic_group"                1         0..1          1 = bulk calls (round budget, scout order): short edges ten to a wavefront on the
  *                                                           throughput layout, the front of the order on latency blocks beside them
@@ -227,6 +227,17 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "fail_after_fork"               0         0..2          debug: the split launches report a failure in front of (1) / behind (2) their side-stream
  *                                                           part
  * END OPTION TABLE */
+/* Resident service kernel (option "resident", 0 / 1, default 0): with it on, the single-state calls the unchanged planner makes —
+ * ccmp_project_host, ccmp_function_host, ccmp_is_satisfied_host, ccmp_joint_valid_host with B == 1, reference arithmetic: the
+ * reference's project(State*) / isSatisfied(State*), src/base/jy_ProjectedStateSpace.cpp:13,20,27,65, src/planner/stefanBiPRM.cpp:
+ * 397-398 — are served by ONE persistent 128-thread block that waits on a mailbox in pinned host memory, instead of a kernel launch
+ * and a completion poll each: the same bits, ~10 us less per call.  Started by the first such call, never under stream capture.
+ * What a kernel that stays on the device asks of the caller: the LIBRARY stops it before every hipFree / hipMalloc / device-wide
+ * synchronise of its own and in ccmp_ctx_destroy (and takes the launch path while it is stopped), so every entry point of this
+ * header can be mixed with resident calls; the APPLICATION's own hipDeviceSynchronize / hipFree waits until the service leaves by
+ * itself, after "resident_idle_ms" (default 10) without a request — bounded, never for ever; the next call starts it again.  Its
+ * stream has the lowest priority (a hardware queue of its own).  Every host-side wait is bounded: CCMP_EHIP after 2 s without an
+ * answer. */
 /* What the policy does with a call: writes ONE line into buf (NUL-terminated, truncated to cap) naming the kernels a call of
  * kind call_kind over n samples / edges runs on under the context's present settings, and the thresholds that delimit that
  * regime — computed by the same functions the launches use (csrc/ccmp_policy.cpp), so it cannot disagree with them.  ctx == NULL:

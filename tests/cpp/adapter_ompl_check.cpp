@@ -221,6 +221,21 @@ int main(int argc, char **argv)
       direct.sampleUniform(b);
       print_hex("uniform3", xb.values, 14);
     }
+    // the same single-state calls through the context's resident service kernel (opt-in): the same bits, no launch on the call path
+    {
+      constraint->setResident(true);
+      ob::State *r = space->allocState();
+      auto &xr = *r->as<ob::ConstrainedStateSpace::StateType>();
+      for (int i = 0; i < 14; i++) xr[i] = start[i] + 0.05 * ((i % 3) - 1);
+      const bool okr = constraint->project(r);
+      std::printf("resident project %d satisfied %d\n", okr ? 1 : 0, constraint->isSatisfied(r) ? 1 : 0);
+      print_hex("xr", xr.values, 14);
+      Eigen::VectorXd fr(2);
+      constraint->function(xr, fr);
+      print_hex("fr", fr.data(), 2);
+      constraint->setResident(false);
+      space->freeState(r);
+    }
     space->freeState(a);
     space->freeState(b);
   } catch (const std::exception &e) {

@@ -227,6 +227,10 @@ def test_part2_control_flow_matches_oracle(ccmp_built, oracle_det):
     # the sampler's two-argument constructor: third sampler of the space, its own stream
     exp3, _, _ = oracle_det.sample_project_batch(P, splitmix64(space_seed + 2), 0, 1, 1)
     assert np.array_equal(_hex_row(out[k + 7], "uniform3").view(np.uint64), exp3[0].view(np.uint64))
+    # the adapter's opt-in setResident(true): project(State*) / isSatisfied / function through the resident service kernel
+    assert out[k + 8] == "resident project %d satisfied %d" % (int(ok_a), int(oracle_det.is_satisfied(P, xa)))
+    assert np.array_equal(_hex_row(out[k + 9], "xr").view(np.uint64), xa.view(np.uint64))
+    assert np.array_equal(_hex_row(out[k + 10], "fr"), oracle_det.function(P, xa))
 
 
 # ---- the drop-in recipe of INTEGRATION.md section 2, compiled: both replacement headers, two translation units --------------

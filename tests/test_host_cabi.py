@@ -287,8 +287,8 @@ def test_describe_names_the_regime_on_both_sides_of_every_boundary(L):
     g, gb = (lambda n: d(n, CALL_GEODESIC)), (lambda n: d(n, CALL_GEODESIC_BUDGET))
     assert "geodesic_flat_kernel_lat x 1024 blocks, one per edge" in g(1024) and "ticket queue" in g(1025)
     assert "geodesic_flat_kernel_lat" in gb(1024) and "geodesic_flat_kernel x 1025 blocks, one per edge" in gb(1025)
-    assert "one per edge" in gb(2048) and "ticket queue" in gb(2049)
-    assert "first" not in gb(4095) and "FP32 scout on lane pairs" in gb(4096)                    # geodesic_order_min = geodesic_scout_min
+    assert "one per edge" in gb(2048) and "first" not in gb(2048)
+    assert "ticket queue" in gb(2049) and "FP32 scout on lane pairs" in gb(2049)                 # geodesic_order_min = geodesic_scout_min: as soon as blocks take tickets
     assert "bulk form" not in gb(13311) and "bulk form" in gb(13312) and "bulk form" not in g(16384)     # geodesic_group_min
     assert "else >= 40" in gb(20479) and "else >= 48" in gb(20480)                               # kGeoGroupHighCut
     assert "x 1639 wavefronts" in gb(16384) and "x 2048 wavefronts" in gb(65536)

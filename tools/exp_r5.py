@@ -177,6 +177,51 @@ def two_contexts_report(argv):
                   (int(r["End_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
 
 
+def resident_ab(argv):
+    """single-state calls through the resident service kernel of two builds (lib/libccmp.so, lib/libccmp_B.so — tools/ab.py build with
+    AB_UNIT=ccmp_kernels_resident.hip), launched path beside them: median us of ccmp_project_host / ccmp_is_satisfied_host"""
+    import time
+
+    LB = C.CDLL(os.environ.get("R5_LIBB", os.path.join("closed_chain_motion_planner_amd", "lib", "libccmp_B.so")))
+    LA = _lib.lib()
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    far = c.ambient_uniform_batch(0xC1, 0, 72).cpu().numpy()
+    q, ok, _ = c.project_batch(c.ambient_uniform_batch(0xC7, 0, 2048))
+    near = q[ok == 1][:72].cpu().numpy() + np.random.default_rng(0xC7).uniform(-0.05, 0.05, (72, 14))
+    torch.cuda.synchronize()
+    dp = C.POINTER(C.c_double)
+    res = {}
+    for rnd in range(3):
+        for name, L in (("A", LA), ("B", LB)):
+            L.ccmp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+            L.ccmp_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+            L.ccmp_project_host.argtypes = [vp, vp, dp, dp, vp, vp, C.c_size_t]
+            L.ccmp_is_satisfied_host.argtypes = [vp, vp, dp, vp, C.c_size_t]
+            L.ccmp_ctx_destroy.argtypes = [vp]
+            h = vp()
+            assert L.ccmp_ctx_create(0, C.byref(h)) == 0
+            for on in (0, 1):
+                assert L.ccmp_ctx_set_option(h, b"resident", on) == 0
+                for kind, xs in (("uniform", far), ("near", near)):
+                    tp, ts = [], []
+                    okb = (C.c_uint8 * 1)()
+                    for x in xs:
+                        xi, xo = np.ascontiguousarray(x), np.zeros(14)
+                        t0 = time.perf_counter()
+                        L.ccmp_project_host(h, C.byref(c.problem), xi.ctypes.data_as(dp), xo.ctypes.data_as(dp), okb, None, 1)
+                        t1 = time.perf_counter()
+                        L.ccmp_is_satisfied_host(h, C.byref(c.problem), xo.ctypes.data_as(dp), okb, 1)
+                        t2 = time.perf_counter()
+                        tp.append(t1 - t0), ts.append(t2 - t1)
+                    key = (name, "resident" if on else "launched", kind)
+                    res.setdefault(key, []).append((float(np.median(tp[8:]) * 1e6), float(np.median(ts[8:]) * 1e6)))
+            L.ccmp_ctx_set_option(h, b"resident", 0)
+            L.ccmp_ctx_destroy(h)
+    for key in sorted(res):
+        print("%s %-9s %-8s project %6.1f us   isSatisfied %5.1f us" % (key + (min(v[0] for v in res[key]), min(v[1] for v in res[key]))))
+
+
 def timeline_report(argv):
     files = sorted(glob.glob(os.path.join(argv[0], "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(files[-1])))
@@ -196,4 +241,4 @@ def timeline_report(argv):
 
 if __name__ == "__main__":
     {"geo_rounds": geo_rounds, "bulk_ab": bulk_ab, "timeline": timeline, "timeline_report": timeline_report, "two_contexts": two_contexts,
-     "two_contexts_report": two_contexts_report}[sys.argv[1]](sys.argv[2:])
+     "two_contexts_report": two_contexts_report, "resident_ab": resident_ab}[sys.argv[1]](sys.argv[2:])

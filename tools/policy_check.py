@@ -46,7 +46,7 @@ def boundaries(cus):
         ("fd_split_max", "p", D("fd_split_max"), {"fd_split_max": 0}, {"fd_split_max": BIG}),
         ("end of the hand-over (kNoHandoverFrom)", "p", 131072, {"lpt": 2}, {"handover_threshold": 10}),
         ("latency build's capacity", "g", 4 * cus, {"geodesic_flavour": 1}, {"geodesic_flavour": 2}),
-        ("geodesic_order_min = geodesic_scout_min", "g", D("geodesic_scout_min"), {"geodesic_order_min": 0, "geodesic_scout_min": 0},
+        ("geodesic_order_min = geodesic_scout_min", "g", max(D("geodesic_scout_min"), 3072), {"geodesic_order_min": 0, "geodesic_scout_min": 0},
          {"geodesic_order_min": BIG, "geodesic_scout_min": BIG}),
         ("geodesic_group_min", "g", D("geodesic_group_min"), {"geodesic_group_min": 0}, {"geodesic_group_min": BIG}),
         ("low cut (kGeoGroupHighCut)", "g", 20480, {"geodesic_group_low_cut": 48}, {"geodesic_group_low_cut": 40}),
