@@ -89,6 +89,7 @@ struct ccmp_ctx {
   // resident service kernel (opt-in, option "resident"; ccmp_resident.h)
   struct ccmp_resident *resident = nullptr;
   int resident_on = 0;
+  int resident_gave_up = 0;            // the service kernel did not get to run within 2 ms of a start (its queue is shared): option turned off
 
   // ---- tuning (option table: ccmp_policy.cpp) ----------------------------------------------------------------------------
   int waves_per_cu = 0;                // persistent wavefronts of the throughput kernels per CU (0 = 12)

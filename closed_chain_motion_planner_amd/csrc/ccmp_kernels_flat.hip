@@ -15,7 +15,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
     uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
     unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
     const unsigned long long *__restrict__ pool_count, int wrap_output, unsigned int *done_flag, unsigned int done_seq,
-    unsigned long long pool_records, const unsigned int *__restrict__ order, const unsigned long long *__restrict__ total_ptr)
+    unsigned long long pool_records, const unsigned int *__restrict__ order, const unsigned long long *__restrict__ total_ptr, int static_first)
 {
   __shared__ __attribute__((aligned(16))) double lds[fRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -36,15 +36,19 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void project_fd_flat_kern
   // order / total_ptr (SRC 0, 1; the split launch of mid-size batches, ccmp_api.cpp): the block's tickets run through the
   // first *total_ptr entries of a processing order — the samples the scout predicts longest — beside the throughput kernel
   const unsigned long long total = (SRC == 2) ? n_front + (pool_records ? pool_count[5] : 0ull) : (total_ptr ? *total_ptr : B);
-  // The first ticket of every block is its own index — no atomic: a fetch-add on ONE word costs 12 ns chip-wide whoever issues it
-  // (tools/ubench/atomic_rate.hip), so 2 048 blocks taking their first ticket from the queue word stood in line for up to 25 us
-  // before the last of them had a sample; the queue word hands out the tickets behind the grid's.
+  // static_first (launches that have the chip to themselves with no more blocks than are resident at once: the latency kernel
+  // alone): the first ticket of every block is its own index — no atomic: a fetch-add on ONE word costs 12 ns chip-wide whoever
+  // issues it (tools/ubench/atomic_rate.hip), so 2 048 blocks taking their first ticket from the queue word stood in line for up to
+  // 25 us before the last of them had a sample; the queue word hands out the tickets behind the grid's.  NOT where part of the
+  // grid may have to wait for room (beside a throughput kernel, behind a hand-over): a block that is not resident yet would hold
+  // its ticket — one of the LONGEST samples of a longest-first order — until a resident block leaves, which is at the very end
+  // (measured: bulk extend calls 5-6 % slower with it).
   unsigned long long t = blockIdx.x;
-  bool first = true;
+  bool first = static_first != 0;
 
   for (;;) {
     if (queue && !first) {
-      if (tid == 0) ticket = (unsigned long long)gridDim.x + atomicAdd(queue, 1ull);
+      if (tid == 0) ticket = (static_first ? (unsigned long long)gridDim.x : 0ull) + atomicAdd(queue, 1ull);
       __syncthreads();
       t = ticket;
     }
@@ -115,11 +119,13 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned int done_seq, size_t pool_records, const unsigned int *order,
                                     const unsigned long long *total_ptr, hipStream_t st)
 {
+  // the latency kernel alone (no pool, no front of a split launch): the whole grid is resident at once — static first tickets
+  const int static_first = (src != 2 && total_ptr == nullptr) ? 1 : 0;
   if (nblocks != 1) done_flag = nullptr; // the completion word is written by the one block of a single-state call
 #define CCMP_LAUNCH_FLAT(SRC, STOCK)                                                                                             \
   hipLaunchKernelGGL((project_fd_flat_kernel<SRC, STOCK>), dim3(nblocks), dim3(128), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
                      (unsigned long long)B, queue_head, seed, first, pool, pool_count, wrap_output, done_flag, done_seq, \
-                     (unsigned long long)pool_records, order, total_ptr)
+                     (unsigned long long)pool_records, order, total_ptr, static_first)
   if (src == 0) {
     if (K->stock) CCMP_LAUNCH_FLAT(0, true);
     else CCMP_LAUNCH_FLAT(0, false);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,
     unsigned long long *queue, const unsigned int *__restrict__ order, const double *__restrict__ carry_in,
     double *__restrict__ carry_out, int round_budget, const unsigned long long *__restrict__ total_ptr,
-    const double *__restrict__ pool, const unsigned long long *__restrict__ pool_count)
+    const double *__restrict__ pool, const unsigned long long *__restrict__ pool_count, int static_first)
 {
   __shared__ __attribute__((aligned(16))) double lds[gRec];
   __shared__ double ktab[kConstsDoubles + 1];
@@ -71,13 +71,14 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
   double *rec = lds;
   const double pi = 3.14159265358979323846;
 
-  // (the first ticket of every block is its own index, the queue word hands out those behind the grid's: a fetch-add on one word
-  // costs 12 ns chip-wide, tools/ubench/atomic_rate.hip — 2 048 blocks stood in line for up to 25 us for their first edge)
+  // static_first (a launch that has the chip to itself: not the front or the hand-over of a bulk call, whose blocks are not all
+  // resident at once — ccmp_kernels_flat.hip says why): the first ticket of every block is its own index, the queue word hands out
+  // those behind the grid's — a fetch-add on one word costs 12 ns chip-wide, 2 048 blocks stood in line for up to 25 us
   unsigned long long tk = blockIdx.x;
-  bool first = true;
+  bool first = static_first != 0;
   for (;;) {
     if (queue && !first) {
-      if (tid == 0) ticket = (unsigned long long)gridDim.x + atomicAdd(queue, 1ull);
+      if (tid == 0) ticket = (static_first ? (unsigned long long)gridDim.x : 0ull) + atomicAdd(queue, 1ull);
       __syncthreads();
       tk = ticket;
     }
@@ -283,12 +284,13 @@ hipError_t CCMP_LAUNCH_GEODESIC(const ccmp_consts *K, double delta, double lambd
                                 const double *carry_in, double *carry_out, int round_budget, const unsigned long long *total_ptr,
                                 const double *pool, const unsigned long long *pool_count, hipStream_t st)
 {
+  const int static_first = (pool == nullptr && total_ptr == nullptr) ? 1 : 0; // alone on the chip: neither front nor hand-over of a bulk call
   if (K->stock)
     hipLaunchKernelGGL(geodesic_flat_kernel<true>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count, static_first);
   else
     hipLaunchKernelGGL(geodesic_flat_kernel<false>, dim3(nblocks), dim3(128), 0, st, *K, delta, lambda, from, to, (unsigned long long)E,
-                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count);
+                       max_states, states, n_states, ok, newton_iters, check_target, queue, order, carry_in, carry_out, round_budget, total_ptr, pool, pool_count, static_first);
   return hipGetLastError();
 }
 

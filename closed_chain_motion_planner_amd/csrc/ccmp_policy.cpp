@@ -332,6 +332,7 @@ int ccmp_ctx_get_option(const ccmp_ctx *ctx, const char *name, long *value)
     return CCMP_OK;
   }
   if (!strcmp(name, "resident")) { *value = ctx ? ctx->resident_on : 0; return CCMP_OK; }
+  if (!strcmp(name, "resident_gave_up")) { *value = ctx ? ctx->resident_gave_up : 0; return CCMP_OK; } // 1: its queue was shared, the option turned itself off
   const OptionDesc *o = find_option(name);
   if (!o) return CCMP_EINVAL;
   *value = read_option(ctx ? ctx : &ccmp_host::default_ctx(), *o);

@@ -83,6 +83,27 @@ int start(ccmp_ctx *ctx, ccmp_resident *r, int stock)
   HIP_TRY(ccmp_launch_resident(stock, r->box_dev, r->tag, idle_ticks, r->stream));
   r->launched = true;
   r->stock = stock;
+  // The kernel reports itself running with its first instructions (~20 us behind the launch).  If it does not within 2 ms its
+  // stream is queued behind something that does not end — another context's resident kernel on the same hardware queue (streams
+  // of one priority share a few) — and every start would wait for that one's idle exit: this context then gives the option up
+  // (the kernel, told to stop, leaves as soon as it gets to run) and its calls take the launch path.
+  const double t0 = now_ms();
+  while (__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) == (unsigned long long)kResStarting) {
+    if (now_ms() - t0 > 2.0) {
+      const unsigned long long tag = ++r->tag;
+      volatile unsigned long long *req = word(r, kResReqOff);
+      req[16] = (unsigned long long)kResStop;
+      __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
+      __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
+      __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
+      ctx->resident_on = 0;
+      ctx->resident_gave_up = 1;
+      return ccmp_host::kResidentFallBack;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
   return CCMP_OK;
 }
 
@@ -138,7 +159,7 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
     static_assert(sizeof(ccmp_consts) <= kResStateOff, "the constants fit in front of the state word");
     if (!r->box) { // (first use: the mailbox comes with the first start)
       int rc = start(ctx, r, K.stock ? 1 : 0);
-      if (rc != CCMP_OK) return rc;
+      if (rc != CCMP_OK) return rc; // (kResidentFallBack: the service could not get a queue of its own)
     }
     memcpy(r->box + kResConstsOff, &K, sizeof K);
     r->consts_seq++;

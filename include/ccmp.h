@@ -140,8 +140,8 @@ int ccmp_ctx_set_schedule(ccmp_ctx *ctx, int hand_over, size_t small_batch);
 int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch);
 /* Tuning options, by name.  NONE of them changes a result bit: they choose which kernels a call runs on and where the regimes
  * meet.  ccmp_ctx_set_option: CCMP_EINVAL for an unknown name or a value outside the range.  ccmp_ctx_get_option: the value in
- * force; with ctx == NULL the built-in default (no device needed); besides the table it answers "num_cus", "resident" and
- * "side_stream_busy" (1 while the context's side stream still holds unfinished work).  ccmp_ctx_option_info enumerates the table
+ * force; with ctx == NULL the built-in default (no device needed); besides the table it answers "num_cus", "resident",
+ * "resident_gave_up" and "side_stream_busy" (1 while the context's side stream still holds unfinished work).  ccmp_ctx_option_info enumerates the table
  * (index 0 .. until CCMP_EINVAL; any out-pointer may be NULL).  The table below is GENERATED from the library's
  * (tools/gen_option_docs.py) and compared with it by the CPU test suite, so a default stated here is the default in the code.
  * "resident" (0 / 1, default 0; not in the table: it starts and stops something) — see "resident service kernel" below. */
@@ -236,8 +236,10 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  * synchronise of its own and in ccmp_ctx_destroy (and takes the launch path while it is stopped), so every entry point of this
  * header can be mixed with resident calls; the APPLICATION's own hipDeviceSynchronize / hipFree waits until the service leaves by
  * itself, after "resident_idle_ms" (default 10) without a request — bounded, never for ever; the next call starts it again.  Its
- * stream has the lowest priority (a hardware queue of its own).  Every host-side wait is bounded: CCMP_EHIP after 2 s without an
- * answer. */
+ * stream has the lowest priority (a hardware queue of its own); should the kernel not get to run within 2 ms of a start — its queue
+ * is shared with something that does not end, e.g. another context's service — the context turns the option off by itself
+ * ("resident_gave_up" reads 1) and its calls take the launch path.  Every host-side wait is bounded: CCMP_EHIP after 2 s without
+ * an answer. */
 /* What the policy does with a call: writes ONE line into buf (NUL-terminated, truncated to cap) naming the kernels a call of
  * kind call_kind over n samples / edges runs on under the context's present settings, and the thresholds that delimit that
  * regime — computed by the same functions the launches use (csrc/ccmp_policy.cpp), so it cannot disagree with them.  ctx == NULL:

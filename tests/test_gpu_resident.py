@@ -147,3 +147,31 @@ def test_resident_latency_is_reported():
     for name in ("project(uniform)", "project(near)", "isSatisfied", "function"):
         print("%-18s launched %6.1f us   resident %6.1f us" % (name, min(res[(name, 0)]), min(res[(name, 1)])))
     assert min(res[("isSatisfied", 1)]) < min(res[("isSatisfied", 0)])
+
+
+def test_two_contexts_with_a_service_each():
+    """two constraints, two contexts, both resident, called in turn (a planner with a second constraint object): each service has
+    its own low-priority stream; either they get hardware queues of their own — then no call waits for the other's idle exit — or
+    a context that finds its kernel queued behind the other's gives the option up by itself ("resident_gave_up") and goes on on
+    the launch path.  Either way: the same bits, and no call anywhere near the idle time."""
+    import torch
+
+    (ca, xa), (cb, xb) = _constraint(), _constraint("stefan")
+    for ctx in (xa, xb):
+        ctx.set_option("resident_idle_ms", 200)  # long enough that waiting for the other's idle exit would show
+    xs = ca.ambient_uniform_batch(0x4E9, 0, 12).cpu().numpy()
+    want_a, want_b = _single_calls(ca, xs), _single_calls(cb, xs)
+    xa.set_option("resident", 1)
+    xb.set_option("resident", 1)
+    worst = 0.0
+    for k in range(6):
+        for c, want in ((ca, want_a), (cb, want_b)):
+            t0 = time.perf_counter()
+            got = _single_calls(c, xs[2 * k: 2 * k + 2])
+            worst = max(worst, time.perf_counter() - t0)
+            assert _same(want[2 * k: 2 * k + 2], got)
+    print("two services: worst batch of 14 single-state calls %.2f ms; gave up: %d %d" % (worst * 1e3, xa.get_option("resident_gave_up"), xb.get_option("resident_gave_up")))
+    assert worst < 0.05, worst  # 14 calls of ~0.1 ms; a wait for the other service's idle exit would be 200 ms
+    xa.set_option("resident", 0)
+    xb.set_option("resident", 0)
+    torch.cuda.synchronize()
