@@ -655,6 +655,8 @@ def flatten_for_the_driver(line, B):
             "single_function_us": get(sec, "single_project_c_abi", "function_median_us"),
             "single_function_resident_us": get(sec, "single_project_c_abi", "function_resident_median_us"),
             "single_resident_bitwise": get(sec, "single_project_c_abi", "resident_bit_identical_to_launched"),
+            "one_edge_check_motion_us": get(sec, "single_project_c_abi", "one_edge_check_motion_median_us"),
+            "one_edge_check_motion_resident_us": get(sec, "single_project_c_abi", "one_edge_check_motion_resident_median_us"),
             "host_buffer_pageable_per_s": get(sec, "host_buffer", "pageable", "projections_per_s"),
             "host_buffer_pinned_per_s": get(sec, "host_buffer", "pinned", "projections_per_s"),
             "analytic_mode_per_s": sec.get("analytic_mode_projections_per_s"),
@@ -783,6 +785,29 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             same = same and r0 == r1
             if name == "near_manifold":
                 out.update(is_satisfied_median_us=s0, function_median_us=f0, is_satisfied_resident_median_us=s1, function_resident_median_us=f1)
+        # ONE edge of checkMotion — isSatisfied(to) && discreteGeodesic(from, to), as the unchanged planner asks for them, one pair at a
+        # time (src/planner/stefanBiPRM.cpp:397-398; the adapter's ccmp_geodesic_host_ex with E == 1): launched and through the service
+        tos = near.copy()
+        for i in range(tos.shape[0]):
+            c.project(tos[i])
+        st, nb, cb = np.zeros((64, 14)), (C.c_int32 * 1)(), np.zeros(2)
+        edge_res = {}
+        for on in (0, 1):
+            c.ctx.set_option("resident", on)
+            ts, rs = [], []
+            for i in range(valid.shape[0]):
+                a, b = np.ascontiguousarray(valid[i]), np.ascontiguousarray(tos[i])
+                t0 = time.perf_counter()
+                L.ccmp_geodesic_host_ex(c.ctx.handle, C.byref(c.problem), a.ctypes.data_as(dp), b.ctypes.data_as(dp), 1, 64, st.ctypes.data_as(dp), nb, okb, None,
+                                        cb.ctypes.data_as(dp), 0, 1)
+                ts.append(time.perf_counter() - t0)
+                rs.append((int(nb[0]), int(okb[0]), st[: min(int(nb[0]), 64)].tobytes()))
+            edge_res[on] = (float(np.median(ts[8:]) * 1e6), rs)
+        c.ctx.set_option("resident", 0)
+        out["one_edge_check_motion_median_us"] = edge_res[0][0]
+        out["one_edge_check_motion_resident_median_us"] = edge_res[1][0]
+        out["one_edge_median_states"] = float(np.median([r[0] for r in edge_res[0][1]]))
+        same = same and edge_res[0][1] == edge_res[1][1]
         out["resident_bit_identical_to_launched"] = bool(same)
         try:
             # the CPU path beside it: the same states through the glibc build of the oracle, one call at a time on one thread

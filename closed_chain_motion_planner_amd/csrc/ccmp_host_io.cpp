@@ -391,6 +391,20 @@ static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const doub
   if ((carry_in || carry_out || round_budget > 0) && max_states < 2) return CCMP_EINVAL; // as geodesic_common: before any buffer is touched
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return CCMP_ENODEV;
+  // ONE edge, as the unchanged planner asks for them (discreteGeodesic / checkMotion of a single pair, src/planner/stefanBiPRM.cpp:
+  // 315-318,397-398): through the resident service kernel when the option is on — no launch on the call path
+  if (E == 1 && ctx->resident_on && !carry_in && max_states <= kResMaxStates && p->delta > 0 && p->lambda > 0) {
+    ccmp_host::ResidentCall call{kResGeodesic, from, nullptr, nullptr, ok, nullptr};
+    call.to = to;
+    call.max_states = max_states;
+    call.round_budget = round_budget;
+    call.check_target = check_target;
+    call.states = states;
+    call.n_states = n_states;
+    call.carry_out = carry_out;
+    const int rc = ccmp_host::resident_call(ctx, p, call);
+    if (rc != ccmp_host::kResidentFallBack) return rc;
+  }
   const size_t eb = E * 14 * sizeof(double);
   const size_t sb = E * (size_t)max_states * 14 * sizeof(double);
   const size_t cb = E * 2 * sizeof(double);

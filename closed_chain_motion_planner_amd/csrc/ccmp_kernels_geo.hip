@@ -10,6 +10,7 @@
 //    2.55 -> 2.13 ms on this flavour; with 128 rounds per edge 1.51 ms on the throughput flavour and 1.85 ms on this one.
 // Same source, same arithmetic (-ffp-contract=off): the two produce the same bits.
 #include "ccmp_flat_newton.h"
+#include "ccmp_geo_edge.h"
 #ifdef CCMP_GEO_LATENCY
 #define geodesic_flat_kernel geodesic_flat_kernel_lat // its own name in kernel traces
 #endif
@@ -31,22 +32,6 @@ namespace {
 // lambda * dist(from, to); a later call with carry_in resumes it from its last stored state (passed as `from`): `dist`
 // is then the distance of that state to the target, recomputed from the same operands as the value the first call held,
 // so first call + continuation produce the states, flags and counts of one uninterrupted traversal bit for bit.
-constexpr int gPrev = fRec, gTo = fRec + 14, gRec = fRec + 28;
-
-
-// RealVectorStateSpace::distance over the 14 joints (plain Euclidean, KinematicChainSpace does not override it),
-// summed serially in the canonical order; every thread computes it from LDS.
-__device__ __forceinline__ double lds_distance(const double *a, const double *b)
-{
-  double dist = 0.0;
-#pragma unroll
-  for (int i = 0; i < 14; i++) {
-    const double diff = a[i] - b[i];
-    dist = CCMP_FMA(diff, diff, dist);
-  }
-  return ccmp_sqrt(dist);
-}
-
 template <bool STOCK>
 __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel(
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
@@ -96,140 +81,7 @@ __global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel
 #ifdef CCMP_GEO_TRACE
     if (tid == 0 && t < 65536) { g_geo_trace[3 * t] = wall_clock64(); g_geo_trace[3 * t + 2] = ((unsigned long long)blockIdx.x << 32) | tk; }
 #endif
-    double *out = states + t * (unsigned long long)max_states * 14ull;
-    if (tid < 14) {
-      if (ent) {
-        rec[fX + tid] = ent[tid];
-        rec[gPrev + tid] = ent[14 + tid];
-      } else {
-        const double a = from[t * 14 + tid];
-        rec[gPrev + tid] = a;
-        if (max_states > 0) out[tid] = a; // geodesic->push_back(cloneState(from))
-      }
-      rec[gTo + tid] = to[t * 14 + tid];
-    }
-    __syncthreads();
-    int n = 1, its = 0, rounds = 0;
-    bool resume = ent != nullptr; // the first pass through the loop below skips the interpolation and takes the projection's counters from the entry
-    bool suspended = false; // the edge used up the call's budget of Newton rounds: it stops between two states (ok = 2)
-    bool fits = true; // false: an accepted state found the list full — the edge stops there and reports max_states + 1
-    bool target_ok = true;
-    if (check_target) {
-      // ConstrainedMotionValidator::checkMotion (src/planner/stefanBiPRM.cpp:397-398): isSatisfied(s2) first —
-      // function(to) through one evaluation pass of the Newton routine (iteration cap 0: no update), then
-      // KinematicChainConstraint::isSatisfied's test (finite, f0 <= tol1, f1 <= tol2; ConstraintFunction.h:114-120)
-      if (tid < 14) rec[fX + tid] = rec[gTo + tid];
-      __syncthreads();
-      int iter0 = 0, upd0 = 0;
-      double n1 = 0.0, n2 = 0.0;
-      (void)flat_newton<STOCK>(K, KL, steptab, rec, tid, iter0, upd0, n1, n2, 0);
-      const double f0 = rec[fF], f1 = rec[fF + 1];
-      target_ok = (f0 - f0 == 0.0) && (f1 - f1 == 0.0) && f0 <= K.tol_pos && f1 <= K.tol_rot;
-      __syncthreads();
-    }
-    double dist = lds_distance(rec + gPrev, rec + gTo), total = 0.0, total_before = 0.0;
-    double maxd = dist * lambda;
-    if (ent) { // (dist is the value the group kernel held: the distance of `previous` to the target, from the same operands)
-      dist = ent[28]; total = ent[29]; maxd = ent[30];
-      n = __double2hiint(ent[32]); its = __double2loint(ent[32]);
-      rounds = __double2hiint(ent[33]);
-    }
-    // a continuation is in the middle of the reference's do-while: it re-enters on the loop's own condition
-    // (dist >= delta) with the running length and the bound of the first call
-    bool enter = dist > delta;
-    if (carry_in) {
-      total = carry_in[2 * t];
-      maxd = carry_in[2 * t + 1];
-      enter = dist >= delta;
-    }
-    if (ent) enter = true; // in the middle of the reference's loop
-    if (target_ok && enter) {
-      // Between two projections every thread does the reference's bookkeeping for itself, in ONE pass over the 14 joints
-      // and without a barrier (round 3; before: jointValid through a ballot and two barriers, then the distances one
-      // after the other — per state about as long as a Newton round): jointValid(x), step = |previous - x| and
-      // newDist = |x - to| are accumulated side by side (two independent serial sums, the canonical order each), the
-      // tests then run in the reference's order.  The joints' owners (tid < 14) keep x, previous and to in registers and
-      // write the next interpolated state themselves: two block barriers per state instead of five.
-      double x_own = 0.0, to_own = 0.0; // this thread's joint of the accepted state / of the target (tid < 14)
-      if (tid < 14) { x_own = rec[gPrev + tid]; to_own = rec[gTo + tid]; }
-      for (int guard = 0; guard < 1000000; guard++) { // the reference loop ends by itself; guard bounds a non-finite input
-        if (tid < 14 && !resume) { // WrapperStateSpace::interpolate(previous, to, delta_ / dist, scratch)
-          const double tt = delta / dist;
-          const double fr = x_own;
-          double diff = to_own - fr, v;
-          if (ccmp_abs(diff) <= pi) v = CCMP_FMA(diff, tt, fr);
-          else {
-            if (diff > 0.0) diff = 2.0 * pi - diff;
-            else diff = -2.0 * pi - diff;
-            v = CCMP_FMA(-diff, tt, fr);
-            if (v > pi) v -= 2.0 * pi;
-            else if (v < -pi) v += 2.0 * pi;
-          }
-          rec[fX + tid] = v;
-          rec[gPrev + tid] = fr; // previous := the accepted state (unchanged on the first pass)
-        }
-        __syncthreads();
-        int iter = 0, updates = 0;
-        double norm1 = 0.0, norm2 = 0.0;
-        if (resume) { // the handed-over projection's own counters, read where they are needed
-          iter = __double2loint(ent[33]); updates = __double2loint(ent[34]);
-          norm1 = ent[35]; norm2 = ent[36];
-          resume = false;
-        }
-        const bool conv = flat_newton<STOCK>(K, KL, steptab, rec, tid, iter, updates, norm1, norm2, K.max_iter);
-        its += updates;
-        rounds += updates + 1;
-        // flat_newton leaves through a block barrier behind which nobody writes x any more: every thread reads the final
-        // iterate, previous and the target straight from LDS
-        bool jv = true;
-        double s_acc = 0.0, d_acc = 0.0;
-#pragma unroll
-        for (int i = 0; i < 14; i++) {
-          const double xi = rec[fX + i];
-          const int jj = i < 7 ? i : i - 7;
-          if (xi < K.lbe[jj]) jv = false; // KinematicChainConstraint::jointValid (ConstraintFunction.h:43-55)
-          if (xi > K.ube[jj]) jv = false;
-          const double ds = rec[gPrev + i] - xi, dd = xi - rec[gTo + i];
-          s_acc = CCMP_FMA(ds, ds, s_acc); // distance(previous, scratch)
-          d_acc = CCMP_FMA(dd, dd, d_acc); // distance(scratch, to)
-        }
-        if (!(conv && jv)) break;                        // not on manifold
-        const double step = ccmp_sqrt(s_acc), newDist = ccmp_sqrt(d_acc);
-        if (step > lambda * delta) break;                // deviated
-        total_before = total;
-        total += step;
-        if (total > maxd) break;                         // wandered too far
-        if (newDist >= dist) break;                      // no closer than before
-        // an edge that creeps (hundreds of accepted states, each a hair closer: seen at 1 in 16384 near-neighbour edges,
-        // 952 states) must not hold the whole launch: when the list is full the edge stops and says so
-        // (its running length and Newton count go back to what they were before this state: a continuation projects it again)
-        if (n >= max_states) { fits = false; n = max_states + 1; total = total_before; its -= updates; break; }
-        dist = newDist;
-        if (tid < 14) {
-          x_own = rec[fX + tid];
-          out[(unsigned long long)n * 14ull + tid] = x_own;
-        }
-        n++;
-        if (!(dist >= delta)) break;
-        // A call bounds the serial work it spends on one edge: past round_budget Newton rounds the edge stops HERE — between
-        // two states, where the reference's do-while has just found dist >= delta — and reports ok = 2; a continuation
-        // from its last stored state with carry_out goes on exactly where this one stops (nothing is projected twice).
-        // 16 384 near-neighbour edges, lists of 16: everything but one edge is through after 1.46 ms, that one creeping
-        // edge needs 545 rounds for its 15 states and held the launch until 2.1 ms (profiles/r03_extend_timeline.log).
-        if (round_budget > 0 && rounds >= round_budget) { suspended = true; break; }
-        __syncthreads(); // everybody has read x and previous: their owners may overwrite them (top of the loop)
-      }
-    }
-    if (tid == 0) {
-      n_states[t] = n;
-      ok_out[t] = suspended ? (uint8_t)2 : (uint8_t)(target_ok && fits && dist <= delta);
-      if (newton_iters) newton_iters[t] = its;
-      if (carry_out) { carry_out[2 * t] = total; carry_out[2 * t + 1] = maxd; }
-#ifdef CCMP_GEO_TRACE
-      if (t < 65536) g_geo_trace[3 * t + 1] = wall_clock64();
-#endif
-    }
-    __syncthreads();
+#include "ccmp_geo_edge_body.inc"
     if (!queue) tk += gridDim.x;
   }
 }

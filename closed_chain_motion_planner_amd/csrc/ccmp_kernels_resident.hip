@@ -1,9 +1,11 @@
 // ccmp_kernels_resident.hip — the resident service kernel (ccmp_resident.h: what it is for, what keeps it from hanging anything).
 // One persistent 128-thread block on the latency kernels' Newton routine (ccmp_flat_newton.h, built like the extend step's
 // latency flavour: machine LICM on, 256-register budget — the block is alone on its CU's SIMDs, registers are free).
-// Same arithmetic, same rounding model (-ffp-contract=off -DCCMP_USE_FMA): project / function / isSatisfied / jointValid through
-// it are bit-identical to the launched kernels (tests/test_gpu_resident.py).
+// Same arithmetic, same rounding model (-ffp-contract=off -DCCMP_USE_FMA): project / function / isSatisfied / jointValid and ONE edge
+// of discreteGeodesic / checkMotion (the per-edge body of geodesic_flat_kernel, included: ccmp_geo_edge_body.inc) through it are
+// bit-identical to the launched kernels (tests/test_gpu_resident.py).
 #include "ccmp_flat_newton.h"
+#include "ccmp_geo_edge.h"
 #include "ccmp_resident.h"
 
 namespace {
@@ -27,7 +29,9 @@ template <bool STOCK>
 __global__ __launch_bounds__(128, 1) void resident_service_kernel(unsigned long long *box, unsigned long long last_tag,
                                                                  unsigned long long idle_ticks /* of the 100 MHz wall clock */)
 {
-  __shared__ __attribute__((aligned(16))) double lds[fRec];
+  __shared__ __attribute__((aligned(16))) double lds[gRec]; // the Newton routine's record + an edge's previous state and target
+  __shared__ double edge_ft[28];                            // an edge's `from` and `to`, as the request brought them
+  __shared__ double s_par[4];                               // an edge's parameters: (max_states | round_budget), check_target, delta, lambda
   __shared__ double ktab[kConstsDoubles + 1];
   __shared__ __attribute__((aligned(16))) double steptab[kStepTab];
   __shared__ unsigned long long s_tag;
@@ -45,19 +49,25 @@ __global__ __launch_bounds__(128, 1) void resident_service_kernel(unsigned long 
   unsigned long long idle_since = wall_clock64();
 
   for (;;) {
-    // ---- wait for a request: the first 24 lanes read the three request lines, eight bytes each, over the link -------------------
+    // ---- wait for a request: the first 40 lanes read the five request lines, eight bytes each, over the link ---------------------
     bool fresh = false;
     if (tid < 64) { // wave 0
       unsigned long long w = 0;
       if (tid < kResReqWords) w = sys_load(req + tid);
-      const unsigned long long ta = lane_word(w, 7), tb = lane_word(w, 15), te = lane_word(w, 23);
-      fresh = ta == tb && tb == te && te != last_tag;
+      const unsigned long long ta = lane_word(w, 7), tb = lane_word(w, 15), tc = lane_word(w, 23), td = lane_word(w, 31), te = lane_word(w, 39);
+      fresh = ta == tb && tb == tc && tc == td && td == te && te != last_tag;
       if (fresh) {
-        // x sits in lanes 0..6 and 8..14 of this very read: straight into the Newton routine's record
-        if (tid < 7) rec[fX + tid] = __longlong_as_double((long long)w);
-        else if (tid >= 8 && tid < 15) rec[fX + tid - 1] = __longlong_as_double((long long)w);
+        // the state sits in lanes 0..6 and 8..14 of this very read: straight into the Newton routine's record (and, for an edge,
+        // `from` and `to` — lanes 16..22, 24..30 — into their staging)
+        const double v = __longlong_as_double((long long)w);
+        const int line = tid >> 3, col = tid & 7;
+        if (col < 7) {
+          if (line < 2) { rec[fX + 7 * line + col] = v; edge_ft[7 * line + col] = v; }
+          else if (line < 4) edge_ft[14 + 7 * (line - 2) + col] = v;
+          else if (line == 4 && col >= 1 && col <= 4) s_par[col - 1] = v; // words 33..36 (bit patterns; the integers are unpacked below)
+        }
         if (tid == 0) {
-          const unsigned long long head = lane_word(w, 16);
+          const unsigned long long head = lane_word(w, 32);
           s_cmd = (int)(head & 0xffffffffull);
           s_consts = (unsigned int)(head >> 32);
           s_tag = te;
@@ -96,6 +106,32 @@ __global__ __launch_bounds__(128, 1) void resident_service_kernel(unsigned long 
       if (tid < 14) sys_store(resp + kResRespQ + tid, (unsigned long long)__double_as_longlong(rec[fX + tid]));
     } else if (cmd == kResJointValid) {
       ok = flat_joint_valid(KL, rec, tid); // ConstraintFunction.h:43-55
+    } else if (cmd == kResGeodesic) {
+      // ONE edge of jy_ProjectedStateSpace::discreteGeodesic / checkMotion: geodesic_flat_kernel's per-edge body, the same text
+      // (ccmp_geo_edge_body.inc), with its inputs and outputs pointed at the mailbox
+      const ccmp_consts &K = KL;
+      const double pi = 3.14159265358979323846;
+      const unsigned long long pk = (unsigned long long)__double_as_longlong(s_par[0]);
+      const int max_states = (int)(pk & 0xffffffffull), round_budget = (int)(pk >> 32);
+      const int check_target = (int)(unsigned long long)__double_as_longlong(s_par[1]);
+      const double delta = s_par[2], lambda = s_par[3];
+      const unsigned long long t = 0;
+      const double *from = edge_ft, *to = edge_ft + 14, *carry_in = nullptr, *ent = nullptr;
+      double *states = reinterpret_cast<double *>(box + kResStatesOff / 8);
+      int *n_states = reinterpret_cast<int *>(resp + kResRespN), *newton_iters = reinterpret_cast<int *>(resp + kResRespIts);
+      uint8_t *ok_out = reinterpret_cast<uint8_t *>(resp + kResRespFlags);
+      double *carry_out = reinterpret_cast<double *>(resp + kResRespCarry);
+      if (tid == 0) sys_store(resp + kResRespFlags, 0ull); // (the body writes the flag as one byte)
+      __syncthreads();
+#include "ccmp_geo_edge_body.inc"
+      __threadfence_system();
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(resp + kResRespDone, s_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        idle_since = wall_clock64();
+      }
+      __syncthreads();
+      continue;
     } else {
       // function(x) through one evaluation pass of the Newton routine (iteration cap 0: no update), as checkMotion's isSatisfied(to)
       // in geodesic_flat_kernel; KinematicChainConstraint::isSatisfied's test on it (ConstraintFunction.h:114-120)

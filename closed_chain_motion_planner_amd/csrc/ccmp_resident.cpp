@@ -53,10 +53,12 @@ void stop(ccmp_resident *r)
     // a request whose command is "stop": payload first, the three tags last (ccmp_resident.h)
     const unsigned long long tag = ++r->tag;
     volatile unsigned long long *req = word(r, kResReqOff);
-    req[16] = (unsigned long long)kResStop;
+    req[32] = (unsigned long long)kResStop;
     __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
     __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
     __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
+    __atomic_store_n(&req[31], tag, __ATOMIC_RELEASE);
+    __atomic_store_n(&req[39], tag, __ATOMIC_RELEASE);
   }
   drain(r);
 }
@@ -92,10 +94,12 @@ int start(ccmp_ctx *ctx, ccmp_resident *r, int stock)
     if (now_ms() - t0 > 2.0) {
       const unsigned long long tag = ++r->tag;
       volatile unsigned long long *req = word(r, kResReqOff);
-      req[16] = (unsigned long long)kResStop;
+      req[32] = (unsigned long long)kResStop;
       __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
       __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
       __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
+      __atomic_store_n(&req[31], tag, __ATOMIC_RELEASE);
+      __atomic_store_n(&req[39], tag, __ATOMIC_RELEASE);
       ctx->resident_on = 0;
       ctx->resident_gave_up = 1;
       return ccmp_host::kResidentFallBack;
@@ -184,10 +188,28 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
     req[i] = a;
     req[8 + i] = b;
   }
-  req[16] = (unsigned long long)(unsigned int)call.cmd | ((unsigned long long)r->consts_seq << 32);
+  req[32] = (unsigned long long)(unsigned int)call.cmd | ((unsigned long long)r->consts_seq << 32);
+  if (call.cmd == kResGeodesic) {
+    for (int i = 0; i < 7; i++) {
+      unsigned long long a, b;
+      memcpy(&a, call.to + i, 8);
+      memcpy(&b, call.to + 7 + i, 8);
+      req[16 + i] = a;
+      req[24 + i] = b;
+    }
+    unsigned long long d, l;
+    memcpy(&d, &p->delta, 8);
+    memcpy(&l, &p->lambda, 8);
+    req[33] = (unsigned long long)(unsigned int)call.max_states | ((unsigned long long)(unsigned int)call.round_budget << 32);
+    req[34] = (unsigned long long)(unsigned int)call.check_target;
+    req[35] = d;
+    req[36] = l;
+  }
   __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
   __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
   __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
+  __atomic_store_n(&req[31], tag, __ATOMIC_RELEASE);
+  __atomic_store_n(&req[39], tag, __ATOMIC_RELEASE);
   // ---- the answer: bounded.  A kernel that left by itself between our look at its state and our request never answers: the state
   // word says so, and this one call takes the launch path (the next one starts the service again).
   bool done = false;
@@ -213,6 +235,18 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
     return CCMP_EHIP;
   }
   const unsigned long long flags = resp[kResRespFlags];
+  if (call.cmd == kResGeodesic) {
+    const unsigned long long nw = resp[kResRespN];
+    int32_t n;
+    memcpy(&n, &nw, 4);
+    if (call.n_states) *call.n_states = n;
+    if (call.ok) *call.ok = (uint8_t)(flags & 0xffull); // 0 / 1 / 2 (round budget spent)
+    const int rows = n > call.max_states ? call.max_states : (n < 0 ? 0 : n);
+    memcpy(call.states, r->box + kResStatesOff, (size_t)rows * 14 * sizeof(double));
+    if (call.carry_out)
+      for (int i = 0; i < 2; i++) { const unsigned long long v = resp[kResRespCarry + i]; memcpy(call.carry_out + i, &v, 8); }
+    return CCMP_OK;
+  }
   if (call.q_out)
     for (int i = 0; i < 14; i++) { const unsigned long long v = resp[kResRespQ + i]; memcpy(call.q_out + i, &v, 8); }
   if (call.f)

@@ -22,23 +22,27 @@
 #include <stdint.h>
 
 /* commands (low 32 bits of word 0 of request line E) */
-enum { kResNone = 0, kResProject = 1, kResFunction = 2, kResIsSatisfied = 3, kResJointValid = 4, kResStop = 5 };
+enum { kResNone = 0, kResProject = 1, kResFunction = 2, kResIsSatisfied = 3, kResJointValid = 4, kResStop = 5, kResGeodesic = 6 };
 /* states (kResStateOff) */
 enum { kResStarting = 0, kResRunning = 1, kResExited = 2 };
 
 /* The mailbox: one pinned, device-mapped, coherent host allocation.
  *   [0, 2304)            ccmp_consts of the problem in force (the host rewrites it when the problem changes and bumps consts_seq)
  *   [2304, 2312)         state word, written by the device
- *   [4096, 4096 + 192)   request, three 64-byte lines; a line = 7 payload words + its tag (the request's sequence number) LAST:
- *                          line A: x[0..6] | tag      line B: x[7..13] | tag
- *                          line E: (cmd | consts_seq << 32), 6 spare words | tag
- *                        the host fills the payloads, then the three tags; a 64-byte line is read as one snapshot, x86 stores become
+ *   [4096, 4096 + 320)   request, five 64-byte lines; a line = 7 payload words + its tag (the request's sequence number) LAST:
+ *                          line A: x[0..6] | tag      line B: x[7..13] | tag          (the state; `from` of an edge)
+ *                          line C: to[0..6] | tag     line D: to[7..13] | tag         (an edge's target)
+ *                          line E: (cmd | consts_seq << 32), (max_states | round_budget << 32), check_target, delta, lambda, 2 spare | tag
+ *                        the host fills the payloads, then the five tags; a 64-byte line is read as one snapshot, x86 stores become
  *                        visible in program order, so a line whose tag is new carries its new payload — the device acts when all
- *                        three tags agree and differ from the last request it served
- *   [4608, 4608 + 192)   response: q_out[14], f[2], (ok | iters << 32), 6 spare words, done tag LAST (behind a system fence) */
-constexpr size_t kResConstsOff = 0, kResStateOff = 2304, kResReqOff = 4096, kResRespOff = 4608, kResBoxBytes = 8192;
-constexpr int kResReqWords = 24;  /* words the polling lanes read */
-constexpr int kResRespQ = 0, kResRespF = 14, kResRespFlags = 16, kResRespDone = 23; /* word indices in the response */
+ *                        five tags agree and differ from the last request it served
+ *   [4608, 4608 + 192)   response: q_out[14], f[2], (ok | iters << 32), n_states, newton_iters, carry[2], 2 spare, done tag LAST
+ *                        (behind a system fence)
+ *   [8192, 8192 + 7168)  the states of an edge: kResMaxStates x 14 doubles */
+constexpr size_t kResConstsOff = 0, kResStateOff = 2304, kResReqOff = 4096, kResRespOff = 4608, kResStatesOff = 8192, kResBoxBytes = 16384;
+constexpr int kResMaxStates = 64;
+constexpr int kResReqWords = 40;  /* words the polling lanes read */
+constexpr int kResRespQ = 0, kResRespF = 14, kResRespFlags = 16, kResRespN = 17, kResRespIts = 18, kResRespCarry = 19, kResRespDone = 23; /* word indices in the response */
 
 #include "../../include/ccmp.h"
 
@@ -46,11 +50,17 @@ struct ccmp_ctx;
 namespace ccmp_host {
 struct ResidentCall {
   int cmd;
-  const double *x;  /* 14 */
+  const double *x;  /* 14: the state; `from` of an edge */
   double *q_out;    /* 14, project */
   double *f;        /* 2, function */
-  uint8_t *ok;      /* project / isSatisfied / jointValid */
+  uint8_t *ok;      /* project / isSatisfied / jointValid / geodesic */
   uint16_t *iters;  /* project (nullable) */
+  /* kResGeodesic — one edge of discreteGeodesic / checkMotion (ccmp_geodesic_host_ex with E == 1, no carry_in) */
+  const double *to = nullptr; /* 14 */
+  int max_states = 0, round_budget = 0, check_target = 0;
+  double *states = nullptr;   /* [max_states][14]: the rows the traversal listed are written, the others left alone */
+  int32_t *n_states = nullptr;
+  double *carry_out = nullptr; /* 2, nullable */
 };
 constexpr int kResidentFallBack = 1; /* the service is off, stopped or cannot serve this problem right now: take the launch path */
 /* one single-state call through the service; CCMP_OK, kResidentFallBack, or an error */

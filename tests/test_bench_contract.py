@@ -112,7 +112,7 @@ FLAT_CONFIG = ("c1_dumbbell_cpu_single_thread_per_s", "c1_dumbbell_gpu_per_s", "
                "proxy_clearance_states_per_s", "extend_bulk_65536_edges_per_s", "extend_bulk_65536_ms", "extend_bulk_bitwise", "extend_cpu_edges_per_s", "extend_cpu_threads", "growtree_5_edges_cpu_single_thread_ms",
                "single_project_cpu_us", "single_project_near_manifold_cpu_us", "single_project_resident_us", "single_project_near_manifold_resident_us",
                "single_is_satisfied_us", "single_is_satisfied_resident_us", "single_function_us", "single_function_resident_us", "single_resident_bitwise",
-               "one_process_gpus", "one_process_direct_per_s", "one_process_rccl_per_s")
+               "one_edge_check_motion_us", "one_edge_check_motion_resident_us", "one_process_gpus", "one_process_direct_per_s", "one_process_rccl_per_s")
 FLAT_CPU = ("det_bit_identical", "det_samples", "libm_samples", "libm_n_gt_1e-6", "libm_max_abs_dq", "libm_iter_diffs_gt1", "libm_ok_mismatches")
 
 
@@ -133,7 +133,8 @@ def test_flat_keys_are_first_level_scalars():
             "single_project_c_abi": {"uniform_sample_median_us": 122.0, "near_manifold_median_us": 54.7, "uniform_sample_cpu_median_us": 1100.0,
                                      "near_manifold_cpu_median_us": 350.0, "uniform_sample_resident_median_us": 110.0,
                                      "near_manifold_resident_median_us": 45.0, "is_satisfied_median_us": 21.0, "is_satisfied_resident_median_us": 8.0,
-                                     "function_median_us": 21.0, "function_resident_median_us": 8.0, "resident_bit_identical_to_launched": True},
+                                     "function_median_us": 21.0, "function_resident_median_us": 8.0, "resident_bit_identical_to_launched": True,
+                                     "one_edge_check_motion_median_us": 150.0, "one_edge_check_motion_resident_median_us": 130.0},
             "analytic_mode_projections_per_s": 1.4e8,
             "stefan_batch%d_tol_1e-3_5e-3" % B: {"projections_per_s": 9.9e6, "parity_vs_det_oracle": par},
             "stefan_batch%d_tol_5e-4_2.5e-3" % B: {"projections_per_s": 9.0e6, "parity_vs_det_oracle": par},

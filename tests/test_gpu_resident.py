@@ -175,3 +175,61 @@ def test_two_contexts_with_a_service_each():
     xa.set_option("resident", 0)
     xb.set_option("resident", 0)
     torch.cuda.synchronize()
+
+
+def test_single_edges_through_the_service_are_bitwise_the_launched_ones():
+    """discreteGeodesic / checkMotion of ONE pair — how the unchanged planner asks for them (src/planner/stefanBiPRM.cpp:315-318,
+    397-398; the adapter's ccmp_geodesic_host_ex with E == 1) — through the resident service kernel: the per-edge body of
+    geodesic_flat_kernel, included into it.  States, counts, flags and carries bit for bit the launched kernel's: arriving edges,
+    edges that give up, a target that fails isSatisfied, a list too short (n = max_states + 1), a round budget spent (ok = 2)."""
+    import torch
+
+    from closed_chain_motion_planner_amd import _lib
+
+    c, ctx = _constraint()
+    L, dp = _lib.lib(), C.POINTER(C.c_double)
+    q, ok, _ = c.project_batch(c.ambient_uniform_batch(0x4EA, 0, 2048))
+    good = q[ok == 1].cpu().numpy()
+    frm = good[:24]
+    to = np.array([c.sample_near_project_batch(0x4EB, 0, torch.as_tensor(frm).cuda(), 0.6, len(frm), want_iters=False)[0].cpu().numpy()][0])
+    to[3] = good[100]           # far apart: many states or a give-up
+    to[4] = to[4] + 0.3         # off the manifold: checkMotion's isSatisfied(to) fails
+    torch.cuda.synchronize()
+    cases = [(64, 0, 0), (64, 0, 1), (3, 0, 0), (16, 8, 0)]  # (max_states, round_budget, check_target)
+
+    def run(on):
+        ctx.set_option("resident", on)
+        out = []
+        for ms, budget, chk in cases:
+            for a, b in zip(frm, to):
+                st, n, okb, carry = np.full((ms, 14), 7.0), (C.c_int32 * 1)(), (C.c_uint8 * 1)(), np.zeros(2)
+                rc = L.ccmp_geodesic_host_ex(ctx.handle, C.byref(c.problem), a.ctypes.data_as(dp), b.ctypes.data_as(dp), 1, ms, st.ctypes.data_as(dp), n, okb, None,
+                                             carry.ctypes.data_as(dp), budget, chk)
+                assert rc == 0
+                rows = min(int(n[0]), ms)
+                out.append((int(n[0]), int(okb[0]), st[:rows].tobytes(), carry.tobytes()))
+        return out
+
+    want = run(0)
+    got = run(1)
+    ctx.set_option("resident", 0)
+    assert [w[:2] for w in want] == [g[:2] for g in got]
+    assert want == got
+    flags = {w[1] for w in want}
+    assert {0, 1, 2} <= flags and any(w[0] == 4 for w in want[2 * len(frm): 3 * len(frm)])  # every kind of ending was in the sample
+    # latency of one pair, launched against resident
+    res = {}
+    for on in (0, 1, 0, 1):
+        ctx.set_option("resident", on)
+        ts = []
+        st, n, okb, carry = np.zeros((64, 14)), (C.c_int32 * 1)(), (C.c_uint8 * 1)(), np.zeros(2)
+        for a, b in list(zip(frm, to)) * 3:
+            t0 = time.perf_counter()
+            L.ccmp_geodesic_host_ex(ctx.handle, C.byref(c.problem), a.ctypes.data_as(dp), b.ctypes.data_as(dp), 1, 64, st.ctypes.data_as(dp), n, okb, None,
+                                    carry.ctypes.data_as(dp), 0, 1)
+            ts.append(time.perf_counter() - t0)
+        res.setdefault(on, []).append(float(np.median(ts[8:]) * 1e6))
+    ctx.set_option("resident", 0)
+    print("checkMotion of one pair: launched %.1f us   resident %.1f us" % (min(res[0]), min(res[1])))
+    assert min(res[1]) < min(res[0])
+    torch.cuda.synchronize()
