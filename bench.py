@@ -787,7 +787,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
                 out.update(is_satisfied_median_us=s0, function_median_us=f0, is_satisfied_resident_median_us=s1, function_resident_median_us=f1)
         # ONE edge of checkMotion — isSatisfied(to) && discreteGeodesic(from, to), as the unchanged planner asks for them, one pair at a
         # time (src/planner/stefanBiPRM.cpp:397-398; the adapter's ccmp_geodesic_host_ex with E == 1): launched and through the service
-        tos = near.copy()
+        tos = valid + rng.uniform(-0.25, 0.25, valid.shape)  # a few delta-steps away, like growTree's neighbours
         for i in range(tos.shape[0]):
             c.project(tos[i])
         st, nb, cb = np.zeros((64, 14)), (C.c_int32 * 1)(), np.zeros(2)

@@ -6,7 +6,9 @@
  * launch plus a completion poll: ~17 us of fixed cost around 38-105 us of Newton rounds, 70 % of an isSatisfied.  With the option
  * on, ONE persistent 128-thread block waits on a mailbox in pinned, device-mapped host memory: the host writes the state and a
  * tag, the block — already running — finds it with its next read over the link, computes with the latency kernel's Newton
- * routine (ccmp_flat_newton.h: the same bits), writes the result and the tag back.  No launch on the call path.
+ * routine (ccmp_flat_newton.h: the same bits), writes the result and the tag back.  No launch on the call path.  The same for ONE
+ * edge of discreteGeodesic / checkMotion (stefanBiPRM.cpp:315-318,397-398 ask for them one pair at a time): the per-edge body of
+ * geodesic_flat_kernel, included (ccmp_geo_edge_body.inc); the edge's states land in the mailbox.
  *
  * What keeps it from hanging anything.  A kernel that never ends blocks whatever waits for the device — hipDeviceSynchronize
  * (torch.cuda.synchronize), hipFree, anything queued behind it on its hardware queue.  So (1) it ends by itself after idle_ticks

@@ -227,11 +227,12 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "fail_after_fork"               0         0..2          debug: the split launches report a failure in front of (1) / behind (2) their side-stream
  *                                                           part
  * END OPTION TABLE */
-/* Resident service kernel (option "resident", 0 / 1, default 0): with it on, the single-state calls the unchanged planner makes —
- * ccmp_project_host, ccmp_function_host, ccmp_is_satisfied_host, ccmp_joint_valid_host with B == 1, reference arithmetic: the
- * reference's project(State*) / isSatisfied(State*), src/base/jy_ProjectedStateSpace.cpp:13,20,27,65, src/planner/stefanBiPRM.cpp:
- * 397-398 — are served by ONE persistent 128-thread block that waits on a mailbox in pinned host memory, instead of a kernel launch
- * and a completion poll each: the same bits, ~10 us less per call.  Started by the first such call, never under stream capture.
+/* Resident service kernel (option "resident", 0 / 1, default 0): with it on, the one-at-a-time calls the unchanged planner makes —
+ * ccmp_project_host, ccmp_function_host, ccmp_is_satisfied_host, ccmp_joint_valid_host with B == 1, and ccmp_geodesic_host /
+ * ccmp_geodesic_host_ex / ccmp_check_motion_host with E == 1 (no carry_in, max_states <= 64), reference arithmetic: the reference's
+ * project(State*) / isSatisfied(State*) / discreteGeodesic and checkMotion of one pair, src/base/jy_ProjectedStateSpace.cpp:13,20,27,
+ * 32-96, src/planner/stefanBiPRM.cpp:315-318,397-398 — are served by ONE persistent 128-thread block that waits on a mailbox in pinned host memory, instead of a kernel launch
+ * and a completion poll each: the same bits, ~10-13 us less per call.  Started by the first such call, never under stream capture.
  * What a kernel that stays on the device asks of the caller: the LIBRARY stops it before every hipFree / hipMalloc / device-wide
  * synchronise of its own and in ccmp_ctx_destroy (and takes the launch path while it is stopped), so every entry point of this
  * header can be mixed with resident calls; the APPLICATION's own hipDeviceSynchronize / hipFree waits until the service leaves by
