@@ -54,13 +54,25 @@ __global__ __launch_bounds__(128, 1) void resident_service_kernel(unsigned long 
     if (tid < 64) { // wave 0
       unsigned long long w = 0;
       if (tid < kResReqWords) w = sys_load(req + tid);
-      const unsigned long long ta = lane_word(w, 7), tb = lane_word(w, 15), tc = lane_word(w, 23), td = lane_word(w, 31), te = lane_word(w, 39);
-      fresh = ta == tb && tb == tc && tc == td && td == te && te != last_tag;
+      // A line's tag = the request's sequence number (low half) and a checksum of the line's seven payload words (high half):
+      // whether this read returned each 64-byte line as ONE snapshot is the memory system's business — a line whose payload
+      // words and tag are not of one request (read in pieces while the host was writing) fails its checksum and is polled again.
+      const int col = tid & 7;
+      unsigned long long h = 0;
+      if (col < 7) { const int r = 7 * col + 1; h = (w << r) | (w >> (64 - r)); }
+      h ^= __shfl_xor(h, 1);
+      h ^= __shfl_xor(h, 2);
+      h ^= __shfl_xor(h, 4); // every lane of a line holds the line's checksum
+      const bool torn = col == 7 && tid < kResReqWords && (unsigned int)(w >> 32) != (unsigned int)(h ^ (h >> 32));
+      const bool clean = __builtin_amdgcn_ballot_w64(torn) == 0ull;
+      const unsigned int ta = (unsigned int)lane_word(w, 7), tb = (unsigned int)lane_word(w, 15), tc = (unsigned int)lane_word(w, 23),
+                         td = (unsigned int)lane_word(w, 31), te = (unsigned int)lane_word(w, 39);
+      fresh = clean && ta == tb && tb == tc && tc == td && td == te && te != (unsigned int)last_tag;
       if (fresh) {
         // the state sits in lanes 0..6 and 8..14 of this very read: straight into the Newton routine's record (and, for an edge,
         // `from` and `to` — lanes 16..22, 24..30 — into their staging)
         const double v = __longlong_as_double((long long)w);
-        const int line = tid >> 3, col = tid & 7;
+        const int line = tid >> 3;
         if (col < 7) {
           if (line < 2) { rec[fX + 7 * line + col] = v; edge_ft[7 * line + col] = v; }
           else if (line < 4) edge_ft[14 + 7 * (line - 2) + col] = v;
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(128, 1) void resident_service_kernel(unsigned long 
           const unsigned long long head = lane_word(w, 32);
           s_cmd = (int)(head & 0xffffffffull);
           s_consts = (unsigned int)(head >> 32);
-          s_tag = te;
+          s_tag = (unsigned long long)te;
         }
         last_tag = te;
       } else if (tid == 0) {

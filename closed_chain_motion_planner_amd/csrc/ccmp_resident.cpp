@@ -22,7 +22,7 @@ struct ccmp_resident {
   hipStream_t stream = nullptr;
   bool launched = false;    // a kernel was put on `stream` and has not been waited for
   int stock = -1;           // which instantiation runs
-  unsigned long long tag = 0;
+  unsigned int tag = 0;     // sequence number of the last request
   unsigned int consts_seq = 0;
   bool have_problem = false;
   ccmp_problem problem;     // the problem whose constants the mailbox holds
@@ -38,6 +38,24 @@ double now_ms()
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// a request line's tag: the request's sequence number (low half) and a checksum of the line's seven payload words (high half) — the
+// device accepts a line only when the two belong together (ccmp_kernels_resident.hip)
+unsigned long long line_tag(unsigned int seq, const volatile unsigned long long *w7)
+{
+  unsigned long long h = 0;
+  for (int i = 0; i < 7; i++) {
+    const unsigned long long v = w7[i];
+    const int r = 7 * i + 1;
+    h ^= (v << r) | (v >> (64 - r));
+  }
+  return (unsigned long long)seq | ((unsigned long long)(unsigned int)(h ^ (h >> 32)) << 32);
+}
+// payloads are in place: the five tags, last
+void post(volatile unsigned long long *req, unsigned int seq)
+{
+  for (int line = 0; line < 5; line++) __atomic_store_n(&req[8 * line + 7], line_tag(seq, req + 8 * line), __ATOMIC_RELEASE);
+}
+
 // waits for the kernel on the service's stream to be gone (it has been told to stop, or stopped by itself)
 void drain(ccmp_resident *r)
 {
@@ -50,15 +68,11 @@ void stop(ccmp_resident *r)
 {
   if (!r || !r->launched) return;
   if (__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) != (unsigned long long)kResExited) {
-    // a request whose command is "stop": payload first, the three tags last (ccmp_resident.h)
-    const unsigned long long tag = ++r->tag;
+    // a request whose command is "stop": payload first, the five tags last (ccmp_resident.h)
+    const unsigned int tag = ++r->tag;
     volatile unsigned long long *req = word(r, kResReqOff);
     req[32] = (unsigned long long)kResStop;
-    __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
-    __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
-    __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
-    __atomic_store_n(&req[31], tag, __ATOMIC_RELEASE);
-    __atomic_store_n(&req[39], tag, __ATOMIC_RELEASE);
+    post(req, tag);
   }
   drain(r);
 }
@@ -92,14 +106,10 @@ int start(ccmp_ctx *ctx, ccmp_resident *r, int stock)
   const double t0 = now_ms();
   while (__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) == (unsigned long long)kResStarting) {
     if (now_ms() - t0 > 2.0) {
-      const unsigned long long tag = ++r->tag;
+      const unsigned int tag = ++r->tag;
       volatile unsigned long long *req = word(r, kResReqOff);
       req[32] = (unsigned long long)kResStop;
-      __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
-      __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
-      __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
-      __atomic_store_n(&req[31], tag, __ATOMIC_RELEASE);
-      __atomic_store_n(&req[39], tag, __ATOMIC_RELEASE);
+      post(req, tag);
       ctx->resident_on = 0;
       ctx->resident_gave_up = 1;
       return ccmp_host::kResidentFallBack;
@@ -177,8 +187,8 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
     int rc = start(ctx, r, r->stock);
     if (rc != CCMP_OK) return rc;
   }
-  // ---- the request: payloads, then the three tags -------------------------------------------------------------------------------
-  const unsigned long long tag = ++r->tag;
+  // ---- the request: payloads, then the five tags ---------------------------------------------------------------------------------
+  const unsigned int tag = ++r->tag;
   volatile unsigned long long *req = word(r, kResReqOff);
   volatile unsigned long long *resp = word(r, kResRespOff);
   for (int i = 0; i < 7; i++) {
@@ -205,11 +215,7 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
     req[35] = d;
     req[36] = l;
   }
-  __atomic_store_n(&req[7], tag, __ATOMIC_RELEASE);
-  __atomic_store_n(&req[15], tag, __ATOMIC_RELEASE);
-  __atomic_store_n(&req[23], tag, __ATOMIC_RELEASE);
-  __atomic_store_n(&req[31], tag, __ATOMIC_RELEASE);
-  __atomic_store_n(&req[39], tag, __ATOMIC_RELEASE);
+  post(req, tag);
   // ---- the answer: bounded.  A kernel that left by itself between our look at its state and our request never answers: the state
   // word says so, and this one call takes the launch path (the next one starts the service again).
   bool done = false;

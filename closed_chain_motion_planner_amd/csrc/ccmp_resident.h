@@ -35,9 +35,10 @@ enum { kResStarting = 0, kResRunning = 1, kResExited = 2 };
  *                          line A: x[0..6] | tag      line B: x[7..13] | tag          (the state; `from` of an edge)
  *                          line C: to[0..6] | tag     line D: to[7..13] | tag         (an edge's target)
  *                          line E: (cmd | consts_seq << 32), (max_states | round_budget << 32), check_target, delta, lambda, 2 spare | tag
- *                        the host fills the payloads, then the five tags; a 64-byte line is read as one snapshot, x86 stores become
- *                        visible in program order, so a line whose tag is new carries its new payload — the device acts when all
- *                        five tags agree and differ from the last request it served
+ *                        a tag = the request's sequence number (low half) | a checksum of ITS line's seven payload words (high
+ *                        half).  The host fills the payloads, then the five tags (x86 stores become visible in program order); the
+ *                        device acts when the five sequence numbers agree, differ from the last request it served, and every line's
+ *                        checksum matches the payload it read — a line read in pieces while the host was writing is polled again
  *   [4608, 4608 + 192)   response: q_out[14], f[2], (ok | iters << 32), n_states, newton_iters, carry[2], 2 spare, done tag LAST
  *                        (behind a system fence)
  *   [8192, 8192 + 7168)  the states of an edge: kResMaxStates x 14 doubles */
