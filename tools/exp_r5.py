@@ -136,6 +136,48 @@ def bulk_ab(argv):
             print("%-11s E=%6d ms  %s" % (obj, E, "  ".join("%s %.3f (%+.1f %%)" % (k, v, 100 * (v / base - 1)) for k, v in best.items())), flush=True)
 
 
+def one_ctx_ab(argv):
+    """bulk_ab's comparison on ONE context whose options are switched between the calls: for option sets that make the context
+    create hardware queues of its own (CU-masked streams) — a context per set would oversubscribe the device's queues and slow
+    every one of them down, the baseline included.  R5_CFGS / R5_SIZES / R5_REPS / R5_ROUNDS as for bulk_ab."""
+    cfgs = []
+    for item in os.environ.get("R5_CFGS", "base").split(";"):
+        name, _, opts = item.partition(":")
+        cfgs.append((name, [(o.split("=")[0], int(o.split("=")[1])) for o in opts.split(",") if o]))
+    sizes = [int(v) for v in os.environ.get("R5_SIZES", "16384,65536").split(",")]
+    reps, rounds = int(os.environ.get("R5_REPS", "8")), int(os.environ.get("R5_ROUNDS", "2"))
+    L = _lib.lib()
+    ctx = Context(0)
+    r, ref_raw = Raw(L), Raw(L)
+    ref_raw.set("geodesic_group", 0)
+    keys = sorted({k for _, opts in cfgs for k, _ in opts})
+    defaults = {k: _lib.get_option(None, k) for k in keys}
+    for obj in argv or ["Wine_Bottle", "stefan"]:
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        P = c.problem
+        for E in sizes:
+            frm, to = near_edges(c, E)
+            ref = new_out(E, frm.device)
+            ref_raw.bulk(P, frm, to, ref)
+            torch.cuda.synchronize()
+            live = torch.arange(16, device=frm.device)[None, :] < ref[1].clamp(max=16)[:, None]
+            best = {}
+            for rnd in range(rounds):
+                for name, opts in cfgs:
+                    for k in keys:
+                        r.set(k, defaults[k])
+                    for k, v in opts:
+                        r.set(k, v)
+                    got = new_out(E, frm.device)
+                    r.bulk(P, frm, to, got)
+                    torch.cuda.synchronize()
+                    same = all(torch.equal(got[i], ref[i]) for i in (1, 2, 3, 4)) and torch.equal(got[0][live], ref[0][live])
+                    assert same, (obj, E, name, [bool(torch.equal(got[i], ref[i])) for i in (1, 2, 3, 4)])
+                    best[name] = min(best.get(name, 1e9), mean_ms(lambda: r.bulk(P, frm, to, got), reps))
+            base = best[cfgs[0][0]]
+            print("%-11s E=%6d ms  %s" % (obj, E, "  ".join("%s %.3f (%+.1f %%)" % (k, v, 100 * (v / base - 1)) for k, v in best.items())), flush=True)
+
+
 def timeline(argv):
     E = int(argv[0]) if argv else 16384
     obj = argv[1] if len(argv) > 1 else "Wine_Bottle"
@@ -240,5 +282,5 @@ def timeline_report(argv):
 
 
 if __name__ == "__main__":
-    {"geo_rounds": geo_rounds, "bulk_ab": bulk_ab, "timeline": timeline, "timeline_report": timeline_report, "two_contexts": two_contexts,
+    {"geo_rounds": geo_rounds, "bulk_ab": bulk_ab, "one_ctx_ab": one_ctx_ab, "timeline": timeline, "timeline_report": timeline_report, "two_contexts": two_contexts,
      "two_contexts_report": two_contexts_report, "resident_ab": resident_ab}[sys.argv[1]](sys.argv[2:])
