@@ -10,6 +10,7 @@
     python tools/measure.py sharded [n_gpus [B]]            one process, n GPUs, RCCL all-gather inside the C ABI: per-GPU stream times
     python tools/measure.py sampler                         project_batch vs the fused sampler
     python tools/measure.py soak                            25 repeats of the default policy, outputs compared bit for bit
+    python tools/measure.py soak_resident [N]               N states as single calls through the resident service kernel against the batched kernels
     python tools/measure.py scout                           FP32 scout's predictions against the true iteration counts
     python tools/measure.py run <workload> [reps]           a fixed workload for rocprofv3 (tools/profile.sh):
                                                            c3 | flat4096 | mid<B> | flat1 | geodesic | analytic | stefan | clearance
@@ -314,6 +315,71 @@ def soak(argv):
     print("proxy clearance 200000 repeats differing:", bad, flush=True)
 
 
+def soak_resident(argv):
+    """the resident service kernel under a long run: N distinct states, each through project / function / isSatisfied / jointValid as
+    single calls on the service, against the BATCHED kernels' results on the same states (both are bit-identical to the oracle, so
+    they must be to each other) — with idle exits (the service leaves after 2 ms here and restarts), batch launches and workspace
+    growth on the same context in between, and every 64th state a single checkMotion edge towards the next one"""
+    import time
+
+    N = int(argv[0]) if argv else 20000
+    ctx = Context(0)
+    for obj in ("Wine_Bottle", "stefan"):
+        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        far = c.ambient_uniform_batch(0x50C, 0, N)
+        qp, okp, _ = c.project_batch(c.ambient_uniform_batch(0x50D, 0, 4 * N))
+        near = qp[okp == 1][: N // 2] + 0.04 * (torch.rand((min(N // 2, int((okp == 1).sum())), 14), dtype=torch.float64, device=qp.device) - 0.5)
+        xs = torch.cat([far, near])[torch.randperm(N + near.shape[0], device=far.device)]
+        qb, okb, itb = c.project_batch(xs)
+        fb, sb, jb = c.function_batch(xs), c.is_satisfied_batch(xs), c.joint_valid_batch(xs)
+        torch.cuda.synchronize()
+        xs_h, qb_h, okb_h = xs.cpu().numpy(), qb.cpu().numpy(), okb.cpu().numpy()
+        fb_h, sb_h, jb_h = fb.cpu().numpy(), sb.cpu().numpy(), jb.cpu().numpy()
+        # single checkMotion edges, launched (the service off) for the expected values
+        edges = list(range(0, xs_h.shape[0] - 1, 64))
+        frm_e, to_e = qb[edges], qb[[e + 1 for e in edges]]
+        exp_e = c.discrete_geodesic_batch(frm_e, to_e, 16, check_target=True)
+        torch.cuda.synchronize()
+        frm_h, to_h = frm_e.cpu().numpy(), to_e.cpu().numpy()
+        exp_st, exp_n, exp_ok = exp_e[0].cpu().numpy(), exp_e[1].cpu().numpy(), exp_e[2].cpu().numpy()
+        L, dp = _lib.lib(), C.POINTER(C.c_double)
+        ctx.set_option("resident_idle_ms", 2)
+        ctx.set_option("resident", 1)
+        bad = restarts = 0
+        grow = 30000
+        t0 = time.perf_counter()
+        for k in range(xs_h.shape[0]):
+            x = xs_h[k]
+            y = x.copy()
+            ok = c.project(y)
+            f = c.function(x)
+            same = (np.array_equal(np.isnan(y), np.isnan(qb_h[k])) and np.array_equal(y[~np.isnan(y)].view(np.uint64), qb_h[k][~np.isnan(y)].view(np.uint64))
+                    and bool(ok) == bool(okb_h[k]) and np.array_equal(np.isnan(f), np.isnan(fb_h[k])) and np.array_equal(f[~np.isnan(f)].view(np.uint64), fb_h[k][~np.isnan(f)].view(np.uint64))
+                    and bool(c.isSatisfied(x)) == bool(sb_h[k]) and bool(c.jointValid(x)) == bool(jb_h[k]))
+            if k % 64 == 0 and k // 64 < len(edges):
+                e = k // 64
+                # one edge from host buffers, as the unchanged planner asks for it: through the service
+                st, n1, ok1 = np.zeros((16, 14)), (C.c_int32 * 1)(), (C.c_uint8 * 1)()
+                rc = L.ccmp_geodesic_host_ex(ctx.handle, C.byref(c.problem), frm_h[e].ctypes.data_as(dp), to_h[e].ctypes.data_as(dp), 1, 16,
+                                             st.ctypes.data_as(dp), n1, ok1, None, None, 0, 1)
+                n = min(int(exp_n[e]), 16)
+                same = same and rc == 0 and int(n1[0]) == int(exp_n[e]) and int(ok1[0]) == int(exp_ok[e]) and st[:n].tobytes() == exp_st[e, :n].tobytes()
+            bad += not same
+            if k % 997 == 0:
+                time.sleep(0.004)  # idle exit: the next call starts the service again
+                restarts += 1
+            if k % 4001 == 0:  # a batch and a growing workspace on the same context under the live service
+                grow += 7000
+                c.project_batch(c.ambient_uniform_batch(0x50E, k, grow))
+        dt = time.perf_counter() - t0
+        gave_up = ctx.get_option("resident_gave_up")
+        ctx.set_option("resident", 0)
+        print("%s: %d states x (project, function, isSatisfied, jointValid) + %d single checkMotion edges through the resident service, %d idle exits, "
+              "%d batch calls in between: differing from the batched kernels %d; gave up %d; %.1f s" %
+              (obj, xs_h.shape[0], len(edges), restarts, xs_h.shape[0] // 4001 + 1, bad, gave_up, dt), flush=True)
+        assert bad == 0 and gave_up == 0
+
+
 def scout(argv):
     ctx = Context(0)
     L = _lib.lib()
@@ -416,7 +482,7 @@ def run(argv):
 
 
 if __name__ == "__main__":
-    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sharded, afterload, sampler, soak, scout, clearance, run)}
+    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sharded, afterload, sampler, soak, soak_resident, scout, clearance, run)}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
     cmds[sys.argv[1]](sys.argv[2:])
