@@ -134,6 +134,14 @@ struct HostIO {
     HIP_TRY(hipMemcpyAsync(dst, dev + off, n, hipMemcpyDeviceToHost, ctx->stream));
     return CCMP_OK;
   }
+  // a failure behind the launch: earlier download copies of this call may still be writing the caller's buffers — the call
+  // returns only when its stream is quiet
+  int abandon(int rc)
+  {
+    ctx->done_armed = ctx->want_done = false;
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
   int finish()
   {
     bool done = false;
@@ -226,9 +234,9 @@ int ccmp_project_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q_in, 
   rc = ccmp_project_batch(ctx, p, (const double *)io.dev, (double *)io.dev, (uint8_t *)(io.dev + off_ok), (uint16_t *)(io.dev + off_it), B,
                           ctx->stream);
   if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
-  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return rc;
-  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
-  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return rc;
+  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return io.abandon(rc);
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return io.abandon(rc);
+  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return io.abandon(rc);
   return io.finish();
 }
 
@@ -252,7 +260,7 @@ int ccmp_function_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q, do
   ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_function_batch(ctx, p, (const double *)io.dev, (double *)(io.dev + off_f), B, ctx->stream);
   if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
-  if ((rc = io.out(f, off_f, B * 2 * sizeof(double))) != CCMP_OK) return rc;
+  if ((rc = io.out(f, off_f, B * 2 * sizeof(double))) != CCMP_OK) return io.abandon(rc);
   return io.finish();
 }
 
@@ -276,7 +284,7 @@ int ccmp_is_satisfied_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q
   ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_is_satisfied_batch(ctx, p, (const double *)io.dev, (uint8_t *)(io.dev + off_ok), B, ctx->stream);
   if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
-  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return io.abandon(rc);
   return io.finish();
 }
 
@@ -300,7 +308,7 @@ int ccmp_joint_valid_host(ccmp_ctx *ctx, const ccmp_problem *p, const double *q,
   ctx->want_done = (B == 1 && io.host != nullptr);
   rc = ccmp_joint_valid_batch(ctx, p, (const double *)io.dev, (uint8_t *)(io.dev + off_ok), B, ctx->stream);
   if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
-  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return io.abandon(rc);
   return io.finish();
 }
 
@@ -321,9 +329,9 @@ int ccmp_sample_project_host(ccmp_ctx *ctx, const ccmp_problem *p, uint64_t seed
   rc = ccmp_sample_project_batch(ctx, p, seed, first_index, (double *)io.dev, (uint8_t *)(io.dev + off_ok), (uint16_t *)(io.dev + off_it),
                                  nullptr, B, ctx->stream);
   if (rc != CCMP_OK) return rc;
-  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return rc;
-  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
-  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return rc;
+  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return io.abandon(rc);
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return io.abandon(rc);
+  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return io.abandon(rc);
   return io.finish();
 }
 
@@ -347,9 +355,9 @@ int ccmp_sample_ref_project_host(ccmp_ctx *ctx, const ccmp_problem *p, int kind,
       ctx, p, seed, first_index, (const double *)(io.dev + off_ref), 0, param, (double *)io.dev, (uint8_t *)(io.dev + off_ok),
       (uint16_t *)(io.dev + off_it), nullptr, B, ctx->stream);
   if (rc != CCMP_OK) return rc;
-  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return rc;
-  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return rc;
-  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return rc;
+  if ((rc = io.out(q_out, 0, qb)) != CCMP_OK) return io.abandon(rc);
+  if ((rc = io.out(ok, off_ok, B)) != CCMP_OK) return io.abandon(rc);
+  if (iters && (rc = io.out(iters, off_it, B * sizeof(uint16_t))) != CCMP_OK) return io.abandon(rc);
   return io.finish();
 }
 
@@ -375,9 +383,9 @@ int ccmp_clearance_host(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *
   rc = ccmp_clearance_batch(ctx, p, scene, (const double *)io.dev, nullptr, B, margin, (double *)(io.dev + off_c),
                             (int32_t *)(io.dev + off_p), (uint8_t *)(io.dev + off_f), ctx->stream);
   if (rc != CCMP_OK) { ctx->want_done = ctx->done_armed = false; return rc; }
-  if ((rc = io.out(clearance, off_c, B * sizeof(double))) != CCMP_OK) return rc;
-  if (pair && (rc = io.out(pair, off_p, B * sizeof(int32_t))) != CCMP_OK) return rc;
-  if (free_out && (rc = io.out(free_out, off_f, B)) != CCMP_OK) return rc;
+  if ((rc = io.out(clearance, off_c, B * sizeof(double))) != CCMP_OK) return io.abandon(rc);
+  if (pair && (rc = io.out(pair, off_p, B * sizeof(int32_t))) != CCMP_OK) return io.abandon(rc);
+  if (free_out && (rc = io.out(free_out, off_f, B)) != CCMP_OK) return io.abandon(rc);
   return io.finish();
 }
 
@@ -425,10 +433,10 @@ static int geodesic_host_common(ccmp_ctx *ctx, const ccmp_problem *p, const doub
                               carry_in ? (const double *)(io.dev + off_ci) : nullptr, carry_out ? (double *)(io.dev + off_co) : nullptr,
                               round_budget, check_target, ctx->stream);
   if (rc != CCMP_OK) return rc;
-  if ((rc = io.out(states, off_st, sb)) != CCMP_OK) return rc;
-  if ((rc = io.out(n_states, off_n, E * sizeof(int32_t))) != CCMP_OK) return rc;
-  if ((rc = io.out(ok, off_ok, E)) != CCMP_OK) return rc;
-  if (carry_out && (rc = io.out(carry_out, off_co, cb)) != CCMP_OK) return rc;
+  if ((rc = io.out(states, off_st, sb)) != CCMP_OK) return io.abandon(rc);
+  if ((rc = io.out(n_states, off_n, E * sizeof(int32_t))) != CCMP_OK) return io.abandon(rc);
+  if ((rc = io.out(ok, off_ok, E)) != CCMP_OK) return io.abandon(rc);
+  if (carry_out && (rc = io.out(carry_out, off_co, cb)) != CCMP_OK) return io.abandon(rc);
   return io.finish();
 }
 
