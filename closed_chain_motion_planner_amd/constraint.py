@@ -465,6 +465,12 @@ class KinematicChainConstraint:
         return out, cnt
 
     # -- single-state API with the reference's signatures ------------------------------------------
+    def setResident(self, on=True):
+        """The adapter's `KinematicChainConstraint::setResident` (include/ccmp_ompl_adapter.hpp): the single-state calls below and
+        single-edge calls from host buffers go through the context's resident service kernel (option "resident", include/ccmp.h) —
+        no launch on the call path, the same bits.  Off by default."""
+        self.ctx.set_option("resident", 1 if on else 0)
+
     def project(self, x):
         """bool project(Eigen::Ref<VectorXd> x) const — x (numpy, 14) is modified in place."""
         self._need_problem()

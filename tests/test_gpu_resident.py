@@ -53,6 +53,10 @@ def test_resident_calls_are_bitwise_the_launched_ones(obj):
     xs = np.concatenate([far, near, np.full((1, 14), np.nan)])
     want = _single_calls(c, xs)
     assert ctx.get_option("resident") == 0
+    c.setResident(True)
+    assert ctx.get_option("resident") == 1
+    c.setResident(False)
+    assert ctx.get_option("resident") == 0
     ctx.set_option("resident", 1)
     assert ctx.get_option("resident") == 1
     got = _single_calls(c, xs)
