@@ -178,6 +178,57 @@ def one_ctx_ab(argv):
             print("%-11s E=%6d ms  %s" % (obj, E, "  ".join("%s %.3f (%+.1f %%)" % (k, v, 100 * (v / base - 1)) for k, v in best.items())), flush=True)
 
 
+def front_rounds(argv):
+    """what a Newton round costs the front's blocks of a bulk extend call, by how much runs beside them (variant B built with
+    -DCCMP_GEO_TRACE, AB_UNIT=ccmp_kernels_geo.hip: per-edge start / end stamps of geodesic_flat_kernel).  The front is held at two
+    blocks per CU; geodesic_group_kernel beside it at 8, 4, 2, 1 wavefronts per CU.  If the rounds' slow-down beside the group
+    kernel is a matter of sharing issue slots or LDS, it shrinks with the group kernel's wavefronts; if it is the two kernels'
+    code not fitting the instruction cache together (42 + 32 KB against 64 KB per CU pair), it does not."""
+    E = int(argv[0]) if argv else 16384
+    LB = C.CDLL(os.environ.get("R5_LIBB", os.path.join("closed_chain_motion_planner_amd", "lib", "libccmp_B.so")))
+    LB.ccmp_debug_geo_trace.argtypes = [vp, C.c_size_t]
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    P = c.problem
+    frm, to = near_edges(c, E)
+    r = Raw(LB)
+    out = new_out(E, frm.device)
+    for waves, front, label in ((8, 8, "default"), (8, 2, ""), (4, 2, ""), (2, 2, ""), (1, 2, ""), (0, 8, "latency kernel alone (geodesic_group=0)")):
+        if waves:
+            r.set("geodesic_group", 1)
+            r.set("geodesic_group_waves_per_cu", waves)
+            r.set("geodesic_group_front_per_cu", front)
+        else:
+            r.set("geodesic_group", 0)
+        for _ in range(3):
+            r.bulk(P, frm, to, out)
+        torch.cuda.synchronize()
+        ms = mean_ms(lambda: r.bulk(P, frm, to, out), 5)
+        import time
+        time.sleep(0.02)  # a gap in front of the traced call: its stamps are the only ones of the last milliseconds
+        r.bulk(P, frm, to, out)
+        torch.cuda.synchronize()
+        tr = np.zeros(3 * E, dtype=np.uint64)
+        assert LB.ccmp_debug_geo_trace(tr.ctypes.data, E) == 0
+        tr = tr.reshape(E, 3)
+        n, its = out[1].cpu().numpy().clip(max=16), out[3].cpu().numpy()
+        rounds = (its + n - 1).astype(np.float64)
+        # stamps of this call only (an edge the group kernel finished this time keeps the stamps of an earlier call's hand-over)
+        torch.cuda.synchronize()
+        fresh = tr[:, 0].astype(np.float64) > float(tr[:, 1].max()) - ms * 1e5  # 100 MHz stamps; the call before ended about `ms` before this one
+        t0 = tr[fresh, 0].min()
+        start, end = (tr[:, 0].astype(np.float64) - t0) / 100.0, (tr[:, 1].astype(np.float64) - t0) / 100.0
+        start[~fresh] = 1e9
+        per = (end - start) / np.maximum(rounds, 1.0)
+        row = []
+        for lo, hi in ((64, 96), (96, 130), (130, 1000)):
+            m = (rounds >= lo) & (rounds < hi) & (start < 100.0) & (end > start)  # the front's own edges: started with the launch
+            row.append("%d-%d rounds: %d edges, %.2f us per round (p10 %.2f, p90 %.2f)" % (lo, hi, m.sum(), np.median(per[m]) if m.sum() else 0,
+                                                                                         np.percentile(per[m], 10) if m.sum() else 0, np.percentile(per[m], 90) if m.sum() else 0))
+        print("group wavefronts per CU %d, front blocks per CU %d %s: call %.3f ms, last stamp %.0f us; edges that started in the first 100 us — %s" %
+              (waves, front, label, ms, end[fresh].max(), "; ".join(row)), flush=True)
+
+
 def timeline(argv):
     E = int(argv[0]) if argv else 16384
     obj = argv[1] if len(argv) > 1 else "Wine_Bottle"
@@ -282,5 +333,5 @@ def timeline_report(argv):
 
 
 if __name__ == "__main__":
-    {"geo_rounds": geo_rounds, "bulk_ab": bulk_ab, "one_ctx_ab": one_ctx_ab, "timeline": timeline, "timeline_report": timeline_report, "two_contexts": two_contexts,
+    {"geo_rounds": geo_rounds, "bulk_ab": bulk_ab, "one_ctx_ab": one_ctx_ab, "front_rounds": front_rounds, "timeline": timeline, "timeline_report": timeline_report, "two_contexts": two_contexts,
      "two_contexts_report": two_contexts_report, "resident_ab": resident_ab}[sys.argv[1]](sys.argv[2:])
