@@ -229,6 +229,59 @@ def front_rounds(argv):
               (waves, front, label, ms, end[fresh].max(), "; ".join(row)), flush=True)
 
 
+def edge_costs(argv):
+    """where the time of an extend-step launch on the latency kernel alone goes, per edge (variant B with -DCCMP_GEO_TRACE as for
+    front_rounds): duration of an edge against its Newton rounds (least squares: us per round + us per edge), the gap between one
+    edge's end and the next one's start on the same block, and how busy the blocks are over the launch"""
+    E = int(argv[0]) if argv else 16384
+    LB = C.CDLL(os.environ.get("R5_LIBB", os.path.join("closed_chain_motion_planner_amd", "lib", "libccmp_B.so")))
+    LB.ccmp_debug_geo_trace.argtypes = [vp, C.c_size_t]
+    ctx = Context(0)
+    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
+    P = c.problem
+    frm, to = near_edges(c, E)
+    r = Raw(LB)
+    r.set("geodesic_group", 0)
+    out = new_out(E, frm.device)
+    for _ in range(3):
+        r.bulk(P, frm, to, out)
+    torch.cuda.synchronize()
+    ms = mean_ms(lambda: r.bulk(P, frm, to, out), 5)
+    import time
+    time.sleep(0.02)
+    r.bulk(P, frm, to, out)
+    torch.cuda.synchronize()
+    tr = np.zeros(3 * E, dtype=np.uint64)
+    assert LB.ccmp_debug_geo_trace(tr.ctypes.data, E) == 0
+    tr = tr.reshape(E, 3)
+    n, its = out[1].cpu().numpy().clip(max=16).astype(np.float64), out[3].cpu().numpy().astype(np.float64)
+    rounds = its + n - 1
+    t0 = tr[:, 0].min()
+    start, end = (tr[:, 0].astype(np.float64) - t0) / 100.0, (tr[:, 1].astype(np.float64) - t0) / 100.0
+    dur = end - start
+    A = np.stack([rounds, n, np.ones(E)], axis=1)
+    coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
+    print("E=%d, call %.3f ms, kernel spans %.0f us; %d rounds, %.1f per edge; duration of an edge = %.2f us x rounds + %.2f us x states + %.2f us (least squares, residual rms %.1f us)"
+          % (E, ms, end.max(), rounds.sum(), rounds.mean(), coef[0], coef[1], coef[2], np.sqrt(np.mean((A @ coef - dur) ** 2))))
+    for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64), (64, 1000)):
+        m = (rounds >= lo) & (rounds < hi)
+        print("   edges with %3d-%3d rounds: %6d, median duration %.1f us = %.2f us per round" % (lo, hi, m.sum(), np.median(dur[m]), np.median(dur[m] / np.maximum(rounds[m], 1))))
+    blk = (tr[:, 2] >> np.uint64(32)).astype(np.int64)
+    gaps, busy = [], 0.0
+    for b in np.unique(blk):
+        idx = np.where(blk == b)[0]
+        idx = idx[np.argsort(start[idx])]
+        gaps.extend((start[idx][1:] - end[idx][:-1]).tolist())
+        busy += dur[idx].sum()
+    gaps = np.array(gaps)
+    print("   %d blocks; inside edges %.1f %% of blocks x span; gap between an edge's end and the block's next start: median %.2f us, p90 %.2f, mean %.2f"
+          % (len(np.unique(blk)), 100.0 * busy / (len(np.unique(blk)) * end.max()), np.median(gaps), np.percentile(gaps, 90), gaps.mean()))
+    T = end.max()
+    for k in range(8):
+        lo, hi = k * T / 8, (k + 1) * T / 8
+        print("   %5.0f-%5.0f us: %5d edges in flight at some point, %5d start" % (lo, hi, ((start < hi) & (end > lo)).sum(), ((start >= lo) & (start < hi)).sum()))
+
+
 def timeline(argv):
     E = int(argv[0]) if argv else 16384
     obj = argv[1] if len(argv) > 1 else "Wine_Bottle"
@@ -333,5 +386,5 @@ def timeline_report(argv):
 
 
 if __name__ == "__main__":
-    {"geo_rounds": geo_rounds, "bulk_ab": bulk_ab, "one_ctx_ab": one_ctx_ab, "front_rounds": front_rounds, "timeline": timeline, "timeline_report": timeline_report, "two_contexts": two_contexts,
+    {"geo_rounds": geo_rounds, "bulk_ab": bulk_ab, "one_ctx_ab": one_ctx_ab, "front_rounds": front_rounds, "edge_costs": edge_costs, "timeline": timeline, "timeline_report": timeline_report, "two_contexts": two_contexts,
      "two_contexts_report": two_contexts_report, "resident_ab": resident_ab}[sys.argv[1]](sys.argv[2:])
