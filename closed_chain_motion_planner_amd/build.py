@@ -62,7 +62,7 @@ _UNITS = [
     ("ccmp_kernels_scene.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT"]),
     ("ccmp_scene.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
 ]
-_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_flat_newton.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_policy.h", "ccmp_resident.h", "ccmp_fd_newton_phase1.inc", "ccmp_fd_newton_phase2.inc", "ccmp_geo_edge.h", "ccmp_geo_edge_body.inc", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
+_HEADERS = ["ccmp_detmath.h", "ccmp_kin.h", "ccmp_solve.h", "ccmp_fd_common.h", "ccmp_flat_newton.h", "ccmp_host.h", "ccmp_ctx.h", "ccmp_policy.h", "ccmp_resident.h", "ccmp_split.h", "ccmp_fd_newton_phase1.inc", "ccmp_fd_newton_phase2.inc", "ccmp_geo_edge.h", "ccmp_geo_edge_body.inc", "ccmp_scene.h", os.path.join("..", "..", "include", "ccmp.h")]
 
 
 def hipcc_path():

@@ -15,6 +15,7 @@
 #include "ccmp_host.h"
 #include "ccmp_policy.h"
 #include "ccmp_resident.h"
+#include "ccmp_split.h"
 #include "ccmp_kin.h"
 
 using ccmp_host::AnalyticPlan;
@@ -49,7 +50,6 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
                                     unsigned int done_seq, size_t pool_records, const unsigned int *order,
                                     const unsigned long long *total_ptr, hipStream_t st);
 hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st);
-hipError_t ccmp_launch_geo_split2(const unsigned int *hist, int p_low, int p_high, int permille, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_geo_split(const unsigned int *hist, int p_min, int p_max, int permille, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
 hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
@@ -59,7 +59,8 @@ hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double
                                     int front_blocks, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipStream_t st);
 hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                    unsigned int *hist, unsigned int *order, unsigned long long *queue,
-                                   unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks, hipStream_t st);
+                                   unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks,
+                                   const ccmp_split_req *split, hipStream_t st);
 hipError_t ccmp_launch_function(const ccmp_consts *K, const double *q, double *f, size_t B, unsigned int *done_flag,
                                 unsigned int done_seq, hipStream_t st);
 hipError_t ccmp_launch_is_satisfied(const ccmp_consts *K, const double *q, uint8_t *ok, size_t B, unsigned int *done_flag,
@@ -90,7 +91,7 @@ hipError_t ccmp_launch_geodesic_order(const double *from, const double *to, size
                                       unsigned int *order, hipStream_t st);
 hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta, double lambda,
                                             int max_states, int round_cap, uint16_t *pred, unsigned int *hist, unsigned int *order, int pairs,
-                                            hipStream_t st);
+                                            const ccmp_split_req *split, hipStream_t st);
 hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st);
 hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, size_t capacity,
                                unsigned int *block_counts, unsigned long long *total, hipStream_t st);
@@ -378,7 +379,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
         if (rc != CCMP_OK) return rc;
         const ScoutBuffers sb(ctx);
         unsigned int *split = (unsigned int *)(ctx->queue + 8 + 64 + 3);
-        HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, sb.pred, sb.hist, sb.order, ctx->queue + 5, seed, first, ctx->num_cus, scout_pair_blocks, st));
+        HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, sb.pred, sb.hist, sb.order, ctx->queue + 5, seed, first, ctx->num_cus, scout_pair_blocks, nullptr, st));
         HIP_TRY(ccmp_launch_split_count(sb.hist, ctx->analytic_split_pred, (unsigned int)pl.front_blocks * 10u, split, st));
         HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, pl.lane_blocks, pl.rows_blocks,
                                          ctx->pool, pl.cap, sb.order, split, pl.front_blocks, ctx->side, ctx->fork, ctx->join, st));
@@ -423,7 +424,7 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
       const unsigned int *lat_order = nullptr;
       if (pl.latency_order) { // longest-predicted-first on the latency kernel alone
         const ScoutBuffers sb(ctx);
-        HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, sb.pred, sb.hist, sb.order, ctx->queue + 5, seed, first, ctx->num_cus, scout_pair_blocks, st));
+        HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, sb.pred, sb.hist, sb.order, ctx->queue + 5, seed, first, ctx->num_cus, scout_pair_blocks, nullptr, st));
         lat_order = sb.order;
       }
       HIP_TRY(ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, pl.latency_static ? nullptr : q_latency, seed, first,
@@ -441,7 +442,10 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if (pl.scout) { // FP32 scout pass -> predicted iteration counts -> descending counting sort -> processing order
     const ScoutBuffers sb(ctx);
     // one 256-thread block per CU, 4 samples per lane at 262144: more lanes only lengthen the per-wave maximum
-    HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, sb.pred, sb.hist, sb.order, ctx->queue + 5, seed, first, ctx->num_cus, scout_pair_blocks, st));
+    // (a split launch's cut of the order — fd_split_kernel's rule — is decided by the sort's own kernel: ccmp_split.h)
+    const ccmp_split_req cut{ctx->queue, 1, pl.shape.pred, 0, 0, pl.shape.samples, 0};
+    HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, sb.pred, sb.hist, sb.order, ctx->queue + 5, seed, first, ctx->num_cus, scout_pair_blocks,
+                                    pl.split ? &cut : nullptr, st));
     order = sb.order;
     // hand-over in two classes (scout's prediction minus the iterations done): the pool is filled from both ends and the
     // latency kernel takes the long samples first
@@ -452,7 +456,6 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     // THE START, beside the throughput kernel, which takes the rest of the order with a few wavefronts per CU fewer and hands
     // over as before.  From the fork on a failure is reported only after the side stream has been joined back (ForkJoin).
     if (pl.split) {
-      HIP_TRY(ccmp_launch_fd_split(sb.hist, pl.shape.pred, pl.shape.samples, ctx->queue, st));
       fj.fork();
       if (ctx->fail_after_fork == 1) fj.fail(hipErrorLaunchFailure, "fail_after_fork (debug option)");
       FJ_STEP(fj, ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 7, seed, first, ctx->pool, q_pool_count, mode,
@@ -567,8 +570,11 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
       if (pl.scouted) {
         // FP32 scout of every edge (the traversal in single precision with the exact Jacobian, one edge per lane, rounds
         // capped) -> predicted Newton rounds -> descending counting sort: longest-predicted-first
+        // (a bulk call's default cut of the order — apply_split's kind 2, ccmp_kernels_scout.hip — is decided, and the launch's block of queue words
+        // cleared, by the sort's own kernel: ccmp_split.h)
+        const ccmp_split_req cut{ctx->queue + kGeoGroupWords, 2, pl.low_cut, 64, ctx->geodesic_group_heavy_permille, 0u, 8};
         HIP_TRY(ccmp_launch_geodesic_scout_order(&K, from, to, E, p->delta, p->lambda, max_states, ctx->geodesic_scout_rounds, sb.pred, sb.hist,
-                                                 sb.order, pl.scout_pairs, st));
+                                                 sb.order, pl.scout_pairs, pl.bulk && pl.default_cut ? &cut : nullptr, st));
       } else {
         HIP_TRY(ccmp_launch_geodesic_order(from, to, E, ctx->geodesic_long_steps * p->delta, (unsigned int *)(ctx->queue + 4), sb.order, st));
       }
@@ -582,20 +588,19 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     unsigned long long *gq = ctx->queue + kGeoGroupWords; // [0] group kernel's ticket (starts behind the front), [3] finished edges, [4] front length, [5] front's ticket, [6] pool count, [7] pool ticket
     const ScoutBuffers sb(ctx);
     const int pct = pl.handover_pct;
-    HIP_TRY(ccmp_launch_clear_words(gq, 16, st));
+    if (!pl.default_cut) HIP_TRY(ccmp_launch_clear_words(gq, 16, st));
     // checkMotion: isSatisfied(to) of every edge up front (one lane per edge) for the group kernel; the front's blocks test their own
     uint8_t *target_ok = nullptr;
     if (check_target) {
       target_ok = (uint8_t *)sb.hist + 4096 + ctx->lpt_cap * 4;
       HIP_TRY(ccmp_launch_is_satisfied(&K, to, target_ok, E, nullptr, 0, st));
     }
-    // the cut of the order: by default one of two, by what the batch looks like (geo_split2_kernel) — at the scout's cap where the edges
-    // beyond it carry a tenth of the predicted work (stefan, dumbbell), lower where they do not (Wine_Bottle)
+    // the cut of the order: by default one of two, by what the batch looks like — at the scout's cap where the edges beyond it carry
+    // a tenth of the predicted work (stefan, dumbbell), lower where they do not (Wine_Bottle) — decided by the sort's kernel above;
+    // the options that fix it themselves get a launch of their own
     if (ctx->geodesic_group_permille > 0)
       HIP_TRY(ccmp_launch_geo_split(sb.hist, 8, ctx->geodesic_group_pred > 0 ? ctx->geodesic_group_pred : 64, ctx->geodesic_group_permille, gq, st));
-    else if (ctx->geodesic_group_pred <= 0)
-      HIP_TRY(ccmp_launch_geo_split2(sb.hist, pl.low_cut, 64, ctx->geodesic_group_heavy_permille, gq, st));
-    else
+    else if (ctx->geodesic_group_pred > 0)
       HIP_TRY(ccmp_launch_fd_split(sb.hist, ctx->geodesic_group_pred, 0xffffffffu, gq, st));
     // Fork.  From here on a failure no longer returns at once: whatever was queued on the side stream is joined back into the
     // caller's stream first (an early return left the side stream's kernels writing the caller's buffers unordered against

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "ccmp_kin.h" // ccmp_consts, ambient_uniform (double, so that MODE 1 sees the same samples)
+#include "ccmp_split.h"
 
 namespace {
 
@@ -691,13 +692,49 @@ __global__ void hist_kernel(const uint16_t *__restrict__ pred, unsigned long lon
     if (h[k]) atomicAdd(&hist[k], h[k]);
 }
 
+// The cut of the order for a split launch (ccmp_split.h), by ONE wavefront of the sort's own kernel: ge[k] = number of keys >= k for
+// every k < kBins (LDS).  Kind 1 is fd_split_kernel's rule (below: it remains for the option sets that fix the
+// cut themselves), kind 2 the extend step's default (described at geo_split_kernel).
+__device__ __forceinline__ void apply_split(const unsigned int *ge, const ccmp_split_req &req, int lane)
+{
+  unsigned long long front = 0;
+  if (req.kind == 1) {
+    const unsigned int c = ge[req.p_low < kBins ? req.p_low : kBins - 1];
+    front = c < req.limit ? c : req.limit;
+  } else {
+    const int p_high = req.p_high > kBins - 1 ? kBins - 1 : req.p_high;
+    unsigned long long all = 0, above = 0;
+    for (int j = lane; j < kBins; j += 64) {
+      const unsigned long long v = j >= 1 ? ge[j] : 0u;
+      all += v;
+      if (j > p_high) above += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      all += __shfl_down(all, off);
+      above += __shfl_down(above, off);
+    }
+    all = __shfl(all, 0);
+    above = __shfl(above, 0);
+    const bool heavy = ((unsigned long long)p_high * ge[p_high] + above) * 1000ull >= all * (unsigned long long)req.permille;
+    front = ge[heavy ? p_high : req.p_low];
+  }
+  const int n = req.clear > 5 ? req.clear : 5;
+  if (lane < n && (lane < req.clear || lane == 0 || lane == 3 || lane == 4))
+    req.queue[lane] = (lane == 0 || lane == 3 || lane == 4) ? front : 0ull;
+}
+
 // exclusive scan in DESCENDING key order: base[k] = number of samples predicted longer than k.  One wavefront: lane l
 // owns the l-th run of ceil(nbins / 64) bins from the top, sums it, the 64 sums are scanned with shuffles, every lane
 // writes its run's bases.  (A single thread walking 1024 bins took 17 us as a compile-time loop and 98 us once the bin
 // count became a run-time argument: dependent global round trips.)
-__global__ __launch_bounds__(64) void scan_desc_kernel(unsigned int *__restrict__ hist /* in: counts, out: running cursor = base */, int nbins)
+__global__ __launch_bounds__(64) void scan_desc_kernel(unsigned int *__restrict__ hist /* in: counts, out: running cursor = base */, int nbins,
+                                                       const ccmp_split_req split)
 {
+  __shared__ unsigned int ge[kBins]; // keys >= k (what hist holds once the scatter has run), for the split
   const int lane = threadIdx.x;
+  if (split.queue)
+    for (int k = lane; k < kBins; k += 64) ge[k] = 0;
+  __syncthreads();
   const int per = (nbins + 63) / 64; // <= 16 (nbins <= kBins)
   unsigned int c[16], sum = 0;
 #pragma unroll
@@ -716,7 +753,11 @@ __global__ __launch_bounds__(64) void scan_desc_kernel(unsigned int *__restrict_
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     const int k = nbins - 1 - (lane * per + i);
-    if (i < per && k >= 0) { hist[k] = run; run += c[i]; }
+    if (i < per && k >= 0) { hist[k] = run; run += c[i]; if (split.queue) ge[k] = run; }
+  }
+  if (split.queue) {
+    __syncthreads();
+    apply_split(ge, split, lane);
   }
 }
 
@@ -759,9 +800,9 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint16_t *__restrict
 // owns bin kBins - 1 - t for the descending exclusive scan (wave scan + sixteen wave sums), LDS-atomic ranks for the scatter.
 // Leaves in hist what the three-kernel form leaves: at k the number of keys >= k (the split kernels read it).
 __global__ __launch_bounds__(1024) void sort_fused_kernel(const uint16_t *__restrict__ pred, unsigned int B, unsigned int *__restrict__ hist,
-                                                          unsigned int *__restrict__ order)
+                                                          unsigned int *__restrict__ order, const ccmp_split_req split)
 {
-  __shared__ unsigned int cnt[kBins], base[kBins], wsum[16];
+  __shared__ unsigned int cnt[kBins], base[kBins], ge[kBins], wsum[16];
   const int t = threadIdx.x, lane = t & 63;
   cnt[t] = 0;
   __syncthreads();
@@ -785,8 +826,10 @@ __global__ __launch_bounds__(1024) void sort_fused_kernel(const uint16_t *__rest
   const unsigned int excl = above + incl - c; // keys in the bins above k
   base[k] = excl;
   hist[k] = excl + c;
+  ge[k] = excl + c;
   cnt[k] = 0;
   __syncthreads();
+  if (split.queue && t < 64) apply_split(ge, split, t); // the first wavefront decides the cut, then scatters with the others
   for (unsigned int i = t; i < B; i += 1024) {
     const unsigned int v = pred[i];
     const unsigned int key = v < kBins ? v : kBins - 1;
@@ -820,34 +863,11 @@ __global__ void fd_split_kernel(const unsigned int *__restrict__ hist, int pred_
   }
 }
 
-// Bulk extend calls of about one fill of the group kernel (ccmp_api.cpp: geodesic_common): one of TWO cuts, by what the batch looks
-// like.  Where the edges the scout's cap cut off (predicted >= p_high rounds) already carry permille / 1000 of the predicted work —
-// stefan, dumbbell: 17 % — they are the front; where they do not — Wine_Bottle: 5 % — the front starts at p_low rounds, or its blocks
-// would idle while the group kernel's longest edges run at a twelfth of their pace.  Words as fd_split_kernel leaves them.
-__global__ __launch_bounds__(64) void geo_split2_kernel(const unsigned int *__restrict__ hist, int p_low, int p_high, int permille,
-                                                        unsigned long long *__restrict__ queue)
-{
-  // hist[k] = edges predicted >= k rounds: the predicted work is sum_{j >= 1} hist[j], that of the edges predicted >= P is
-  // P * hist[P] + sum_{j > P} hist[j].  One wavefront, sixteen bins per lane, two shuffle reductions.
-  if (p_high > kBins - 1) p_high = kBins - 1;
-  unsigned long long all = 0, above = 0;
-  for (int j = threadIdx.x; j < kBins; j += 64) {
-    const unsigned long long v = j >= 1 ? hist[j] : 0u;
-    all += v;
-    if (j > p_high) above += v;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    all += __shfl_down(all, off);
-    above += __shfl_down(above, off);
-  }
-  if (threadIdx.x == 0) {
-    const bool heavy = ((unsigned long long)p_high * hist[p_high] + above) * 1000ull >= all * (unsigned long long)permille;
-    const unsigned long long front = hist[heavy ? p_high : p_low];
-    queue[4] = front;
-    queue[0] = front;
-    queue[3] = front;
-  }
-}
+// (The default cut of a bulk extend call — one of TWO, by what the batch looks like: where the edges the scout's cap cut off,
+// predicted >= p_high rounds, already carry permille / 1000 of the predicted work (stefan, dumbbell: 17 %) they are the front;
+// where they do not (Wine_Bottle: 5 %) the front starts at p_low rounds, or its blocks would idle while the group kernel's longest
+// edges run at a twelfth of their pace — is apply_split's kind 2 above: hist[k] = edges predicted >= k rounds, the predicted work
+// is sum_{j >= 1} hist[j], that of the edges predicted >= P is P * hist[P] + sum_{j > P} hist[j].)
 
 // Bulk extend calls (ccmp_api.cpp: geodesic_common): where to cut the scout's descending order between the latency blocks (front)
 // and the throughput layout (rest).  hist[k] = number of edges predicted >= k rounds (hist[0] = all), so the predicted work of
@@ -882,12 +902,6 @@ __global__ __launch_bounds__(64) void geo_split_kernel(const unsigned int *__res
 } // namespace
 
 extern "C" hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st); // ccmp_kernels_fd.hip
-
-extern "C" hipError_t ccmp_launch_geo_split2(const unsigned int *hist, int p_low, int p_high, int permille, unsigned long long *queue, hipStream_t st)
-{
-  hipLaunchKernelGGL(geo_split2_kernel, dim3(1), dim3(64), 0, st, hist, p_low, p_high, permille, queue);
-  return hipGetLastError();
-}
 
 extern "C" hipError_t ccmp_launch_geo_split(const unsigned int *hist, int p_min, int p_max, int permille, unsigned long long *queue, hipStream_t st)
 {
@@ -947,8 +961,10 @@ static void make_consts_f(const ccmp_consts *K, consts_f &F, bool *stock_out)
 
 extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                               unsigned int *hist, unsigned int *order, unsigned long long *queue,
-                                              unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks, hipStream_t st)
+                                              unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks,
+                                              const ccmp_split_req *split, hipStream_t st)
 {
+  const ccmp_split_req sr = split ? *split : ccmp_split_req{nullptr, 0, 0, 0, 0, 0u, 0};
   consts_f F;
   bool stock;
   make_consts_f(K, F, &stock);
@@ -980,11 +996,11 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
   }
 #undef CCMP_LAUNCH_SCOUT
   if (fused) {
-    hipLaunchKernelGGL(sort_fused_kernel, dim3(1), dim3(1024), 0, st, pred, (unsigned int)B, hist, order);
+    hipLaunchKernelGGL(sort_fused_kernel, dim3(1), dim3(1024), 0, st, pred, (unsigned int)B, hist, order, sr);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(hist_kernel, dim3(256), dim3(256), 0, st, pred, (unsigned long long)B, hist);
-  hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist, kBins);
+  hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist, kBins, sr);
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((B + 256 * kScatterPerThread - 1) / (256 * kScatterPerThread))), dim3(256), 0, st, pred,
                      (unsigned long long)B, hist, order);
   return hipGetLastError();
@@ -993,8 +1009,9 @@ extern "C" hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, co
 // extend-step order: FP32 scout of every edge (rounds capped at round_cap < 1024), then the descending counting sort
 extern "C" hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, const double *from, const double *to, size_t E, double delta,
                                                         double lambda, int max_states, int round_cap, uint16_t *pred, unsigned int *hist,
-                                                        unsigned int *order, int pairs, hipStream_t st)
+                                                        unsigned int *order, int pairs, const ccmp_split_req *split, hipStream_t st)
 {
+  const ccmp_split_req sr = split ? *split : ccmp_split_req{nullptr, 0, 0, 0, 0, 0u, 0};
   consts_f F;
   bool stock;
   make_consts_f(K, F, &stock);
@@ -1004,7 +1021,9 @@ extern "C" hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, con
   const bool fused = E <= (size_t)kSortFusedMax;
   hipError_t e = hipSuccess;
   if (!fused) {
-    e = ccmp_launch_clear_words(hist, (size_t)nbins, st);
+    // every bin, not only the nbins this sort fills: the split rules sum the histogram over all kBins, and the bins above were
+    // whatever the context's last sort left there (a projector batch's counts up to its cap of 96: a cut decided on them)
+    e = ccmp_launch_clear_words(hist, (size_t)kBins, st);
     if (e != hipSuccess) return e;
   }
   const unsigned blocks = (unsigned)((E + 63) / 64);
@@ -1018,11 +1037,11 @@ extern "C" hipError_t ccmp_launch_geodesic_scout_order(const ccmp_consts *K, con
     hipLaunchKernelGGL(scout_geodesic_kernel<false>, dim3(blocks), dim3(64), 0, st, F, from, to, (unsigned long long)E, (float)delta,
                        (float)lambda, max_states, round_cap, pred);
   if (fused) {
-    hipLaunchKernelGGL(sort_fused_kernel, dim3(1), dim3(1024), 0, st, pred, (unsigned int)E, hist, order);
+    hipLaunchKernelGGL(sort_fused_kernel, dim3(1), dim3(1024), 0, st, pred, (unsigned int)E, hist, order, sr);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(hist_kernel, dim3(64), dim3(256), 0, st, pred, (unsigned long long)E, hist);
-  hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist, nbins);
+  hipLaunchKernelGGL(scan_desc_kernel, dim3(1), dim3(64), 0, st, hist, nbins, sr);
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((E + 256 * kScatterPerThread - 1) / (256 * kScatterPerThread))), dim3(256), 0, st, pred,
                      (unsigned long long)E, hist, order);
   return hipGetLastError();

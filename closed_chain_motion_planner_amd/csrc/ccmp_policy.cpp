@@ -274,6 +274,7 @@ GeoPlan plan_geodesic(const ccmp_ctx *ctx, size_t E, int round_budget, bool cont
     if (pl.group_waves > cap) pl.group_waves = cap;
     pl.front_blocks = ctx->num_cus * (ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : 8);
     pl.low_cut = ctx->geodesic_group_low_cut > 0 ? ctx->geodesic_group_low_cut : (E < kGeoGroupHighCut ? 40 : 48);
+    pl.default_cut = ctx->geodesic_group_permille <= 0 && ctx->geodesic_group_pred <= 0;
     pl.handover_pct = ctx->geodesic_group_handover_pct;
     if (pl.handover_pct > 0) {
       const size_t lat = (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;

@@ -50,6 +50,7 @@ struct GeoPlan {
   size_t group_waves = 0;       // grid of geodesic_group_kernel
   int front_blocks = 0;         // grid of the front's launch
   int low_cut = 0;              // cut of the order where the edges beyond the scout's cap carry little work
+  bool default_cut = false;     // the cut is the default rule's (one of two by what the batch looks like), decided in the sort's kernel
   int handover_pct = 0;         // occupancy below which the group kernel gives up everything (0 = never)
   int drain_blocks = 0;         // grid of the launch behind the group kernel
 };
