@@ -47,7 +47,8 @@ struct DeviceGuard {
 // and tools/policy_check.py re-times each boundary on whatever box it runs on.
 constexpr size_t kDefaultSmallBatch = 10240;       // at or below: the latency kernel alone
 constexpr size_t kSplitWideMax = 24576;            // split launch: up to here two latency blocks per CU for the front (fd_split*)
-constexpr size_t kGeoGroupHighCut = 20480;         // bulk extend calls: the low cut of the order is 40 rounds below this many edges, 48 from here on
+constexpr size_t kGeoGroupHighCut = 20480;         // bulk extend calls: the low cut of the order is 40 rounds below this many edges, 48 from here on ...
+constexpr size_t kGeoGroupHigherCut = 65536;        // ... and 56 from here on (profiles/r05_low_cut_sweep.log: 65 536 edges -1.7 %, 131 072 -2.1 % against 48)
 constexpr int kGeoPoolDoubles = 40;                // = kGeoPoolEntry (ccmp_fd_common.h): one handed-over edge of the extend step's bulk form
 constexpr int kGeoGroupWords = 8 + 64 + 4;         // ctx->queue: first of the 8 words of the extend step's bulk form (behind the analytic kernels')
 constexpr size_t kDefaultLatencyOrderMin = 2049;   // latency kernel alone: FP32 scout order as soon as the blocks take tickets (more samples than blocks)

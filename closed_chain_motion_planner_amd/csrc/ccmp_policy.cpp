@@ -70,7 +70,7 @@ const OptionDesc kOptions[] = {
     OPT("geodesic_group", geodesic_group, kInt, 0, 1, 0, "1 = bulk calls (round budget, scout order): short edges ten to a wavefront on the throughput layout, the front of the order on latency blocks beside them"),
     OPT("geodesic_group_min", geodesic_group_min, kSize, 0, LONG_MAX, 0, "... from this many edges"),
     OPT("geodesic_group_pred", geodesic_group_pred, kInt, -1, 1023, kNotZero, "... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it carry geodesic_group_heavy_permille of the work, else geodesic_group_low_cut)"),
-    OPT("geodesic_group_low_cut", geodesic_group_low_cut, kInt, -1, 64, kNotZero, "... (-1: 40 below 20480 edges, 48 from there on)"),
+    OPT("geodesic_group_low_cut", geodesic_group_low_cut, kInt, -1, 64, kNotZero, "... (-1: 40 below 20480 edges, 48 from there on, 56 from 65536)"),
     OPT("geodesic_group_heavy_permille", geodesic_group_heavy_permille, kInt, 0, 1001, 0, "... see geodesic_group_pred"),
     OPT("geodesic_group_permille", geodesic_group_permille, kInt, 0, 1000, 0, "... > 0: instead, the largest cut whose front carries this share of the predicted work"),
     OPT("geodesic_group_front_per_cu", geodesic_group_front_per_cu, kInt, -1, 8, kNotZero, "... latency blocks per CU launched for the front (-1 = 8)"),
@@ -273,7 +273,7 @@ GeoPlan plan_geodesic(const ccmp_ctx *ctx, size_t E, int round_budget, bool cont
     const size_t cap = (size_t)ctx->num_cus * (size_t)ctx->geodesic_group_waves_per_cu;
     if (pl.group_waves > cap) pl.group_waves = cap;
     pl.front_blocks = ctx->num_cus * (ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : 8);
-    pl.low_cut = ctx->geodesic_group_low_cut > 0 ? ctx->geodesic_group_low_cut : (E < kGeoGroupHighCut ? 40 : 48);
+    pl.low_cut = ctx->geodesic_group_low_cut > 0 ? ctx->geodesic_group_low_cut : (E < kGeoGroupHighCut ? 40 : (E < kGeoGroupHigherCut ? 48 : 56));
     pl.default_cut = ctx->geodesic_group_permille <= 0 && ctx->geodesic_group_pred <= 0;
     pl.handover_pct = ctx->geodesic_group_handover_pct;
     if (pl.handover_pct > 0) {
@@ -418,8 +418,8 @@ int ccmp_ctx_describe(const ccmp_ctx *ctx_in, int call_kind, size_t n, char *buf
       } else {
         L.add("%s x %zu blocks%s", pl.latency_flavour ? "geodesic_flat_kernel_lat" : "geodesic_flat_kernel", pl.blocks, pl.queued ? ", ticket queue" : ", one per edge");
       }
-      L.add(" [geodesic_order_min=%zu geodesic_scout_min=%zu geodesic_group_min=%zu high_cut_from=%zu]", ctx->geodesic_order_min, ctx->geodesic_scout_min,
-            ctx->geodesic_group_min, kGeoGroupHighCut);
+      L.add(" [geodesic_order_min=%zu geodesic_scout_min=%zu geodesic_group_min=%zu high_cut_from=%zu higher_cut_from=%zu]", ctx->geodesic_order_min, ctx->geodesic_scout_min,
+            ctx->geodesic_group_min, kGeoGroupHighCut, kGeoGroupHigherCut);
       break;
     }
     default: return CCMP_EINVAL;

@@ -212,7 +212,7 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "geodesic_group_min"            13312     0..max        ... from this many edges
  *   "geodesic_group_pred"           -1        -1..1023      ... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it
  *                                                           carry geodesic_group_heavy_permille of the work, else geodesic_group_low_cut)
- *   "geodesic_group_low_cut"        -1        -1..64        ... (-1: 40 below 20480 edges, 48 from there on)
+ *   "geodesic_group_low_cut"        -1        -1..64        ... (-1: 40 below 20480 edges, 48 from there on, 56 from 65536)
  *   "geodesic_group_heavy_permille" 100       0..1001       ... see geodesic_group_pred
  *   "geodesic_group_permille"       0         0..1000       ... > 0: instead, the largest cut whose front carries this share of the predicted work
  *   "geodesic_group_front_per_cu"   8         -1..8         ... latency blocks per CU launched for the front (-1 = 8)

@@ -291,6 +291,7 @@ def test_describe_names_the_regime_on_both_sides_of_every_boundary(L):
     assert "ticket queue" in gb(2049) and "FP32 scout on lane pairs" in gb(2049)                 # geodesic_order_min = geodesic_scout_min: as soon as blocks take tickets
     assert "bulk form" not in gb(13311) and "bulk form" in gb(13312) and "bulk form" not in g(16384)     # geodesic_group_min
     assert "else >= 40" in gb(20479) and "else >= 48" in gb(20480)                               # kGeoGroupHighCut
+    assert "else >= 48" in gb(65535) and "else >= 56" in gb(65536)                               # kGeoGroupHigherCut
     assert "x 1639 wavefronts" in gb(16384) and "x 2048 wavefronts" in gb(65536)
     assert "lane pairs" in gb(131072) and "lane pairs" not in gb(131073)
     # truncation follows snprintf: the return value is the whole length, the buffer holds what fits
