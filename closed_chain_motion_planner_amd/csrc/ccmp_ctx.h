@@ -48,6 +48,7 @@ struct DeviceGuard {
 constexpr size_t kDefaultSmallBatch = 10240;       // at or below: the latency kernel alone
 constexpr size_t kSplitWideMax = 24576;            // split launch: up to here two latency blocks per CU for the front (fd_split*)
 constexpr size_t kGeoGroupHighCut = 20480;         // bulk extend calls: the low cut of the order is 40 rounds below this many edges, 48 from here on ...
+constexpr size_t kGeoGroupLateHandoverFrom = 32768; // bulk extend calls: the group kernel hands over below 50 % occupancy up to here, below 80 % from here on (profiles/r05_bulk_handover_sweep.log)
 constexpr size_t kGeoGroupHigherCut = 65536;        // ... and 56 from here on (profiles/r05_low_cut_sweep.log: 65 536 edges -1.7 %, 131 072 -2.1 % against 48)
 constexpr int kGeoPoolDoubles = 40;                // = kGeoPoolEntry (ccmp_fd_common.h): one handed-over edge of the extend step's bulk form
 constexpr int kGeoGroupWords = 8 + 64 + 4;         // ctx->queue: first of the 8 words of the extend step's bulk form (behind the analytic kernels')
@@ -122,7 +123,7 @@ struct ccmp_ctx {
   int geodesic_group = 1;
   size_t geodesic_group_min = 13312;  // (16384 until round 5: tools/policy_check.py found the bulk form 10-12 % ahead at 15872 edges; crossover at 13312, profiles/r05_bulk_crossover.log)
   int geodesic_group_pred = -1, geodesic_group_low_cut = -1, geodesic_group_heavy_permille = 100, geodesic_group_permille = 0;
-  int geodesic_group_front_per_cu = 8, geodesic_group_waves_per_cu = 8, geodesic_group_handover_pct = 50;
+  int geodesic_group_front_per_cu = 8, geodesic_group_waves_per_cu = 8, geodesic_group_handover_pct = -1;
   size_t clearance_per_state_max = 8192;
   int host_zero_copy = 2;
   int resident_idle_ms = 10;           // the resident service kernel leaves by itself after this long without a request

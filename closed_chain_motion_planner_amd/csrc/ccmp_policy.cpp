@@ -75,7 +75,7 @@ const OptionDesc kOptions[] = {
     OPT("geodesic_group_permille", geodesic_group_permille, kInt, 0, 1000, 0, "... > 0: instead, the largest cut whose front carries this share of the predicted work"),
     OPT("geodesic_group_front_per_cu", geodesic_group_front_per_cu, kInt, -1, 8, kNotZero, "... latency blocks per CU launched for the front (-1 = 8)"),
     OPT("geodesic_group_waves_per_cu", geodesic_group_waves_per_cu, kInt, 1, 10, 0, "... wavefronts of the throughput layout per CU at most"),
-    OPT("geodesic_group_handover_pct", geodesic_group_handover_pct, kInt, 0, 100, 0, "... with the queue dry, every wavefront gives its edges to latency blocks once those in flight fill less than this share of the slots (0 = never)"),
+    OPT("geodesic_group_handover_pct", geodesic_group_handover_pct, kInt, -1, 100, 0, "... with the queue dry, every wavefront gives its edges to latency blocks once those in flight fill less than this share of the slots (0 = never; -1: 50 below 32768 edges, 80 from there on)"),
     // other
     OPT("clearance_per_state_max", clearance_per_state_max, kSize, 0, LONG_MAX, 0, "proxy clearance: one block per state up to this many states, 64-state tiles above"),
     OPT("host_zero_copy", host_zero_copy, kInt, 0, 2, 0, "*_host calls on page-locked caller buffers: 0 = staged, 1 = q_out written in place, 2 = q_in read in place too"),
@@ -275,7 +275,7 @@ GeoPlan plan_geodesic(const ccmp_ctx *ctx, size_t E, int round_budget, bool cont
     pl.front_blocks = ctx->num_cus * (ctx->geodesic_group_front_per_cu > 0 ? ctx->geodesic_group_front_per_cu : 8);
     pl.low_cut = ctx->geodesic_group_low_cut > 0 ? ctx->geodesic_group_low_cut : (E < kGeoGroupHighCut ? 40 : (E < kGeoGroupHigherCut ? 48 : 56));
     pl.default_cut = ctx->geodesic_group_permille <= 0 && ctx->geodesic_group_pred <= 0;
-    pl.handover_pct = ctx->geodesic_group_handover_pct;
+    pl.handover_pct = ctx->geodesic_group_handover_pct >= 0 ? ctx->geodesic_group_handover_pct : (E < kGeoGroupLateHandoverFrom ? 50 : 80);
     if (pl.handover_pct > 0) {
       const size_t lat = (size_t)ctx->num_cus * (size_t)ctx->latency_blocks_per_cu;
       pl.drain_blocks = (int)(pl.group_waves * 10 < lat ? pl.group_waves * 10 : lat);
@@ -418,8 +418,8 @@ int ccmp_ctx_describe(const ccmp_ctx *ctx_in, int call_kind, size_t n, char *buf
       } else {
         L.add("%s x %zu blocks%s", pl.latency_flavour ? "geodesic_flat_kernel_lat" : "geodesic_flat_kernel", pl.blocks, pl.queued ? ", ticket queue" : ", one per edge");
       }
-      L.add(" [geodesic_order_min=%zu geodesic_scout_min=%zu geodesic_group_min=%zu high_cut_from=%zu higher_cut_from=%zu]", ctx->geodesic_order_min, ctx->geodesic_scout_min,
-            ctx->geodesic_group_min, kGeoGroupHighCut, kGeoGroupHigherCut);
+      L.add(" [geodesic_order_min=%zu geodesic_scout_min=%zu geodesic_group_min=%zu high_cut_from=%zu higher_cut_from=%zu late_handover_from=%zu]", ctx->geodesic_order_min, ctx->geodesic_scout_min,
+            ctx->geodesic_group_min, kGeoGroupHighCut, kGeoGroupHigherCut, kGeoGroupLateHandoverFrom);
       break;
     }
     default: return CCMP_EINVAL;

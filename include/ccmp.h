@@ -217,8 +217,9 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "geodesic_group_permille"       0         0..1000       ... > 0: instead, the largest cut whose front carries this share of the predicted work
  *   "geodesic_group_front_per_cu"   8         -1..8         ... latency blocks per CU launched for the front (-1 = 8)
  *   "geodesic_group_waves_per_cu"   8         1..10         ... wavefronts of the throughput layout per CU at most
- *   "geodesic_group_handover_pct"   50        0..100        ... with the queue dry, every wavefront gives its edges to latency blocks once those in
- *                                                           flight fill less than this share of the slots (0 = never)
+ *   "geodesic_group_handover_pct"   -1        -1..100       ... with the queue dry, every wavefront gives its edges to latency blocks once those in
+ *                                                           flight fill less than this share of the slots (0 = never; -1: 50 below 32768 edges, 80
+ *                                                           from there on)
  *   "clearance_per_state_max"       8192      0..max        proxy clearance: one block per state up to this many states, 64-state tiles above
  *   "host_zero_copy"                2         0..2          *_host calls on page-locked caller buffers: 0 = staged, 1 = q_out written in place, 2 =
  *                                                           q_in read in place too

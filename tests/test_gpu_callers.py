@@ -641,9 +641,8 @@ def test_bulk_extend_hybrid_is_bitwise_identical(gpu_ctx, oracle_det, variant):
             assert got_e.shape == st_cpu.shape and np.array_equal(np.ascontiguousarray(got_e).view(np.uint64), st_cpu.view(np.uint64)), e
             assert bool(ok_e) == ok_cpu and its_e == its_cpu, e
     finally:
-        for name, val in zip(opts, (1, 16384, -1, 0, 6144)):
-            gpu_ctx.set_option(name, val)
-        gpu_ctx.set_option("geodesic_group_handover_pct", 50)
+        for name in opts + ("geodesic_group_handover_pct",):  # back to the library's own defaults (the context is shared)
+            gpu_ctx.set_option(name, _lib.get_option(None, name))
 
 
 def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):

@@ -292,6 +292,7 @@ def test_describe_names_the_regime_on_both_sides_of_every_boundary(L):
     assert "bulk form" not in gb(13311) and "bulk form" in gb(13312) and "bulk form" not in g(16384)     # geodesic_group_min
     assert "else >= 40" in gb(20479) and "else >= 48" in gb(20480)                               # kGeoGroupHighCut
     assert "else >= 48" in gb(65535) and "else >= 56" in gb(65536)                               # kGeoGroupHigherCut
+    assert "hand-over below 50 %" in gb(32767) and "hand-over below 80 %" in gb(32768)           # kGeoGroupLateHandoverFrom
     assert "x 1639 wavefronts" in gb(16384) and "x 2048 wavefronts" in gb(65536)
     assert "lane pairs" in gb(131072) and "lane pairs" not in gb(131073)
     # truncation follows snprintf: the return value is the whole length, the buffer holds what fits

@@ -50,6 +50,7 @@ def boundaries(cus):
          {"geodesic_order_min": BIG, "geodesic_scout_min": BIG}),
         ("geodesic_group_min", "g", D("geodesic_group_min"), {"geodesic_group_min": 0}, {"geodesic_group_min": BIG}),
         ("low cut (kGeoGroupHighCut)", "g", 20480, {"geodesic_group_low_cut": 48}, {"geodesic_group_low_cut": 40}),
+        ("group kernel's hand-over (kGeoGroupLateHandoverFrom)", "g", 32768, {"geodesic_group_handover_pct": 80}, {"geodesic_group_handover_pct": 50}),
         ("low cut (kGeoGroupHigherCut)", "g", 65536, {"geodesic_group_low_cut": 56}, {"geodesic_group_low_cut": 48}),
     ]
 
