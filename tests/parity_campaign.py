@@ -137,7 +137,7 @@ for obj, tol, seed, mode, N, variant in cases:
         tb, _, _, _ = c.sample_near_project_batch(seed + 0x300, 0, fb, 0.6, nb, want_iters=False)
         ctx.set_option("geodesic_group_min", 0)
         sb, nbs, okb, itb, _ = c.discrete_geodesic_batch(fb, tb, 16, want_carry=True, round_budget=128)
-        ctx.set_option("geodesic_group_min", 16384)
+        ctx.set_option("geodesic_group_min", _lib.get_option(None, "geodesic_group_min"))  # the library's own default
         sb, nbs, okb, itb = sb.cpu().numpy(), nbs.cpu().numpy(), okb.cpu().numpy(), itb.cpu().numpy()
         scb, ncb, okcb, itcb = orc.discrete_geodesic_batch(P, fb.cpu().numpy(), tb.cpu().numpy(), 16, NCPU)
         liveb = okb != 2
