@@ -6,6 +6,8 @@ import pytest
 from conftest import NCPU, config_path, load_cfg, load_path_rows, load_roadmap
 from test_gpu_parity import _constraint, _oracle_problem
 
+from closed_chain_motion_planner_amd import _lib  # (option defaults are asked of the library)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -676,9 +678,9 @@ def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):
             assert torch.equal(got[0][live], ref[0][live]), (order, long_steps)
     finally:
         gpu_ctx.set_option("geodesic_order", 2)
-        gpu_ctx.set_option("geodesic_order_min", 4096)
+        gpu_ctx.set_option("geodesic_order_min", _lib.get_option(None, "geodesic_order_min"))
         gpu_ctx.set_option("geodesic_long_steps", 12)
-        gpu_ctx.set_option("geodesic_scout_min", 6144)
+        gpu_ctx.set_option("geodesic_scout_min", _lib.get_option(None, "geodesic_scout_min"))
         gpu_ctx.set_option("geodesic_scout_rounds", 64)
     sl = slice(E - 192, E)
     s_cpu, n_cpu, ok_cpu, it_cpu = oracle_det.discrete_geodesic_batch(P, frm[sl].cpu().numpy(), to[sl].cpu().numpy(), cap, NCPU)

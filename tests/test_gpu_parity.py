@@ -425,7 +425,7 @@ def test_analytic_schedules_are_bitwise_identical(gpu_ctx, oracle_det, cap, smal
             torch.cuda.synchronize()
     finally:
         gpu_ctx.set_option("analytic_cap", 96)
-        gpu_ctx.set_option("analytic_small_batch", 16384)
+        gpu_ctx.set_option("analytic_small_batch", _lib.get_option(None, "analytic_small_batch"))
         gpu_ctx.set_option("analytic_split", 1)
         gpu_ctx.set_option("analytic_split_min", 100000)
         gpu_ctx.set_option("analytic_split_pred", 90)
@@ -502,7 +502,7 @@ def test_non_finite_and_out_of_range_inputs_terminate(gpu_ctx, oracle_det):
             out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
             torch.cuda.synchronize()
         finally:
-            gpu_ctx.set_option("analytic_small_batch", 16384)
+            gpu_ctx.set_option("analytic_small_batch", _lib.get_option(None, "analytic_small_batch"))
         out, ok, it = out.cpu().numpy(), ok.cpu().numpy(), it.cpu().numpy()
         same = (out.view(np.uint64) == qa_cpu.view(np.uint64)) | (np.isnan(out) & np.isnan(qa_cpu))
         assert same.all() and np.array_equal(ok, oka_cpu) and np.array_equal(it.astype(np.int32), ita_cpu)

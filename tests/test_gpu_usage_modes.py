@@ -9,6 +9,7 @@ results, bit for bit."""
 import numpy as np
 import pytest
 
+from closed_chain_motion_planner_amd import _lib  # (option defaults are asked of the library)
 from conftest import config_path
 from test_gpu_parity import _constraint
 
@@ -110,8 +111,8 @@ def test_bulk_extend_call_replays_from_a_graph(gpu_ctx):
         st, ns, okf, its, carry = _capture_and_replay(extend)
         assert int((okf == 2).sum().item()) > 0 and int((okf == 1).sum().item()) > 0 and int(ns.max().item()) == 9
     finally:
-        gpu_ctx.set_option("geodesic_scout_min", 6144)
-        gpu_ctx.set_option("geodesic_group_min", 16384)
+        gpu_ctx.set_option("geodesic_scout_min", _lib.get_option(None, "geodesic_scout_min"))
+        gpu_ctx.set_option("geodesic_group_min", _lib.get_option(None, "geodesic_group_min"))
         gpu_ctx.set_option("geodesic_group_pred", -1)
 
 

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, ".")
 sys.path.insert(0, "tools")
-from closed_chain_motion_planner_amd import Context, KinematicChainConstraint  # noqa: E402
+from closed_chain_motion_planner_amd import Context, KinematicChainConstraint, _lib  # noqa: E402
 from measure import near_edges, timed  # noqa: E402
 
 ctx = Context(0)
@@ -33,6 +33,6 @@ for obj in sys.argv[1:] or ["Wine_Bottle", "stefan"]:
                 row.append("%s %.3f" % ({2: "scout%d" % rounds, 1: "far-first", 0: "index"}[order], timed(call, 5)))
         ctx.set_option("geodesic_order", 2)
         ctx.set_option("geodesic_order_min", 4096)
-        ctx.set_option("geodesic_scout_min", 6144)
+        ctx.set_option("geodesic_scout_min", _lib.get_option(None, "geodesic_scout_min"))
         ctx.set_option("geodesic_scout_rounds", 64)
         print("%-11s E=%6d best ms  %s" % (obj, E, "  ".join(row)), flush=True)

@@ -143,7 +143,7 @@ def analytic(argv):
                     ms = timed(lambda: c.project_batch(q, out=out), reps=5)
                     res.append("%s %7.3f ms (%.3e/s)" % ("rows-only" if small else "cap%d" % cap, ms, B / ms * 1e3))
             ctx.set_option("analytic_cap", 96)
-            ctx.set_option("analytic_small_batch", 16384)
+            ctx.set_option("analytic_small_batch", _lib.get_option(None, "analytic_small_batch"))
             ctx.set_option("analytic_handover_max", 131072)
             ms = timed(lambda: c.project_batch(q, out=out), reps=5)
             print("analytic %s B=%-8d " % (obj, B) + "  ".join(res) + "  DEFAULT %7.3f ms (%.3e/s)" % (ms, B / ms * 1e3), flush=True)
