@@ -12,6 +12,8 @@ import pytest
 
 from conftest import NCPU, OBJECTS, config_path, load_cfg, load_path_rows
 
+from closed_chain_motion_planner_amd import _lib  # (option defaults are asked of the library)
+
 pytestmark = pytest.mark.gpu
 
 _SCHED_CACHE = {}
