@@ -15,7 +15,7 @@ Translation units with deliberately different flags:
   ccmp_kernels_resident.hip -ffp-contract=off -DCCMP_USE_FMA  ... its device side, on the latency flavour's Newton routine
   ccmp_host_io.cpp                                          *_host conveniences (staging, pinned block, page-locked caller buffers), sharded host calls
   ccmp_comm.cpp                                             one process / several GPUs: RCCL communicator and sharded entry points
-  ccmp_kernels_fast.hip  -ffp-contract=off -DCCMP_USE_FMA   analytic fast mode, bit-identical to the oracle's analytic mode
+  ccmp_kernels_fast.hip  -ffp-contract=off -DCCMP_USE_FMA   analytic fast mode (one sample per lane pair), bit-identical to the oracle's analytic mode
   ccmp_kernels_scout.hip -ffast-math                        FP32 iteration-count predictor + ordering (never touches results)
   ccmp_kernels_scene.hip -ffp-contract=off -DCCMP_USE_FMA   proxy-geometry clearance (pre-filter ahead of the host's MoveIt test)
   ccmp_scene.cpp                                            proxy scenes: validation, pair list, launches
@@ -51,7 +51,9 @@ _UNITS = [
      "ccmp_kernels_geo_lat.hip.o"),
     # the resident service kernel: one block alone on its SIMDs — the latency flavour's flags (registers are free, fewest instructions per round)
     ("ccmp_kernels_resident.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_SUMS_IN_LANE", "-DCCMP_FLAT_MIN_WAVES=2", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
-    ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA"]),
+    # the analytic mode's lane-pair kernel: without machine LICM (the ~35 FP64 literals of sincos / atan would be held in
+    # registers across the Newton loop and spilled: 168 registers + 36 B of scratch instead of 142 and none)
+    ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm"]),
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_problem.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
@@ -98,7 +100,8 @@ _SCRATCH_RULES = [  # (regex on the demangled name, bound); first match wins
     (r"project_fd_kernel<1, false>", 2400),
     (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel|resident_service_kernel)<(\d+, )?true>", 0),
     (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel|resident_service_kernel)<(\d+, )?false>", 200),
-    (r"scout_|project_fast|project_rows|clearance", 400),
+    (r"project_pair_kernel|project_row16_kernel", 0),  # analytic mode, every instantiation (stock twin arms, stock, calibrated)
+    (r"scout_|clearance", 400),
     (r".", 64),
 ]
 

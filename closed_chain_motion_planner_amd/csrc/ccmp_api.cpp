@@ -52,11 +52,10 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
 hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_geo_split(const unsigned int *hist, int p_min, int p_max, int permille, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
-hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
-                                    uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
-                                    unsigned long long seed, unsigned long long first, int lane_blocks, int rows_blocks,
-                                    double *pool, int cap_iter, const unsigned int *order, const unsigned int *split_ptr,
-                                    int front_blocks, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipStream_t st);
+hipError_t ccmp_launch_project_analytic(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok, uint16_t *iters,
+                                        double *q_ambient, size_t B, unsigned long long *queue, unsigned long long seed,
+                                        unsigned long long first, int pair_blocks, int dump_below, int latency_blocks, double *pool,
+                                        hipStream_t st);
 hipError_t ccmp_launch_scout_order(const ccmp_consts *K, int mode, const double *q_in, size_t B, uint16_t *pred,
                                    unsigned int *hist, unsigned int *order, unsigned long long *queue,
                                    unsigned long long seed, unsigned long long first, int nblocks, int pair_max_blocks,
@@ -212,7 +211,7 @@ int ccmp_ctx_create(int device, ccmp_ctx **out)
   ctx->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete ctx; return hip_fail(e, "hipStreamCreate"); }
-  e = hipMalloc((void **)&ctx->queue, (kGeoGroupWords + 8) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; 64 + 3: analytic kernels; 1: split count
+  e = hipMalloc((void **)&ctx->queue, (kGeoGroupWords + 8) * sizeof(unsigned long long)); // 8 words: reference-arithmetic kernels; kAnalyticWords: analytic kernel; 1: spare; 8: bulk extend
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return hip_fail(e, "hipMalloc(queue)"); }
   // side stream of the analytic mode's split launches (latency kernel beside the throughput kernel) and the two events
   // that order it against the caller's stream
@@ -367,41 +366,14 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
   if ((((uintptr_t)q_in) | ((uintptr_t)q_out)) & 15u) return CCMP_EINVAL; // rows are moved in 16-byte pieces
   const int scout_pair_blocks = ctx->scout_pairs ? ctx->num_cus * ctx->scout_pair_blocks_per_cu : 0;
   if (p->jacobian_mode != CCMP_JAC_FD) { // analytic mode: the plan is ccmp_policy.cpp's plan_analytic_batch
-    const AnalyticPlan pl = ccmp_host::plan_analytic_batch(ctx, B, K.twin_arms != 0);
-    switch (pl.kind) {
-      case AnalyticPlan::Split: {
-        // Large batches, twin stock arms: the FP32 scout orders the batch longest-predicted-first; the samples predicted past
-        // analytic_split_pred iterations (at most the front kernel's resident capacity) run on the six-lane kernel on the side
-        // stream WHILE the one-lane kernel takes the rest, longest first, and what the one-lane kernel still hands over is
-        // finished behind both.
-        int rc = ensure_lpt_buffers(ctx, B);
-        if (rc == CCMP_OK) rc = ensure_pool(ctx, B);
-        if (rc != CCMP_OK) return rc;
-        const ScoutBuffers sb(ctx);
-        unsigned int *split = (unsigned int *)(ctx->queue + 8 + 64 + 3);
-        HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, sb.pred, sb.hist, sb.order, ctx->queue + 5, seed, first, ctx->num_cus, scout_pair_blocks, nullptr, st));
-        HIP_TRY(ccmp_launch_split_count(sb.hist, ctx->analytic_split_pred, (unsigned int)pl.front_blocks * 10u, split, st));
-        HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, pl.lane_blocks, pl.rows_blocks,
-                                         ctx->pool, pl.cap, sb.order, split, pl.front_blocks, ctx->side, ctx->fork, ctx->join, st));
-        return CCMP_OK;
-      }
-      case AnalyticPlan::LaneOnly:
-        HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, pl.lane_blocks, 0, nullptr, 0,
-                                         nullptr, nullptr, 0, nullptr, nullptr, nullptr, st));
-        return CCMP_OK;
-      case AnalyticPlan::RowsOnly:
-        HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, 0, pl.rows_blocks, nullptr, 0,
-                                         nullptr, nullptr, 0, nullptr, nullptr, nullptr, st));
-        return CCMP_OK;
-      case AnalyticPlan::LaneWithHandover: {
-        int rc = ensure_pool(ctx, B); // every sample may be handed over
-        if (rc != CCMP_OK) return rc;
-        HIP_TRY(ccmp_launch_project_fast(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, pl.lane_blocks, pl.rows_blocks,
-                                         ctx->pool, pl.cap, nullptr, nullptr, 0, nullptr, nullptr, nullptr, st));
-        return CCMP_OK;
-      }
+    const AnalyticPlan pl = ccmp_host::plan_analytic_batch(ctx, B);
+    if (pl.pool_records > 0) {
+      int rc = ensure_pool(ctx, pl.pool_records); // sized before anything of the call is in flight
+      if (rc != CCMP_OK) return rc;
     }
-    return CCMP_EINVAL;
+    HIP_TRY(ccmp_launch_project_analytic(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 8, seed, first, pl.pair_blocks, pl.dump,
+                                         pl.latency_blocks, ctx->pool, st));
+    return CCMP_OK;
   }
   // reference arithmetic: the plan is ccmp_policy.cpp's plan_fd_batch (what ccmp_ctx_describe prints)
   const FdPlan pl = ccmp_host::plan_fd_batch(ctx, B, ctx->order != nullptr);

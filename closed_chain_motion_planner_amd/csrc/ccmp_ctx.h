@@ -51,7 +51,8 @@ constexpr size_t kGeoGroupHighCut = 20480;         // bulk extend calls: the low
 constexpr size_t kGeoGroupLateHandoverFrom = 32768; // bulk extend calls: the group kernel hands over below 50 % occupancy up to here, below 80 % from here on (profiles/r05_bulk_handover_sweep.log)
 constexpr size_t kGeoGroupHigherCut = 65536;        // ... and 56 from here on (profiles/r05_low_cut_sweep.log: 65 536 edges -1.7 %, 131 072 -2.1 % against 48)
 constexpr int kGeoPoolDoubles = 40;                // = kGeoPoolEntry (ccmp_fd_common.h): one handed-over edge of the extend step's bulk form
-constexpr int kGeoGroupWords = 8 + 64 + 4;         // ctx->queue: first of the 8 words of the extend step's bulk form (behind the analytic kernels')
+constexpr int kAnalyticWords = 64 + 2;            // ctx->queue + 8: 64 ticket words of the analytic mode's lane-pair kernel, the hand-over pool's fill count, the latency kernel's ticket word
+constexpr int kGeoGroupWords = 8 + kAnalyticWords + 1; // ctx->queue: first of the 8 words of the extend step's bulk form (behind the analytic kernel's)
 constexpr size_t kDefaultLatencyOrderMin = 2049;   // latency kernel alone: FP32 scout order as soon as the blocks take tickets (more samples than blocks)
 constexpr size_t kDefaultLptMinBatch = 16384;      // throughput kernel: the scout's order pays from here on
 constexpr size_t kOccupancyHandoverBelow = 53248;  // below: the throughput kernel hands over by occupancy, from here on at once
@@ -109,11 +110,9 @@ struct ccmp_ctx {
   size_t fd_split_min = 0, fd_split_max = 90112;
   int fd_split_pred = -1, fd_split_front = -1, fd_split_group_cut = -1;
   long long fd_split_samples = -1;
-  int analytic_cap = 96;
-  size_t analytic_small_batch = 16384, analytic_handover_max = 131072;
-  int analytic_split = 1;
-  size_t analytic_split_min = 100000, analytic_split_max = 300000;
-  int analytic_split_front = 128, analytic_split_cap = 160, analytic_split_pred = 90;
+  size_t analytic_small_batch = 8192;  // analytic mode: at or below, the sixteen-lanes-per-sample latency kernel alone
+  int analytic_waves_per_cu = 12;      // ... persistent wavefronts of the lane-pair kernel per CU (142 registers, 13 KB of LDS: three per SIMD)
+  int analytic_handover = 8;           // ... one of them hands over to the latency kernel once its tickets are gone and it holds at most this many samples (0: never)
   int scout_pairs = 1, scout_pair_blocks_per_cu = 1;
   size_t scout_pair_max_edges = 131072;
   int geodesic_blocks_per_cu = 4, geodesic_flavour = 0, geodesic_order = 2;

@@ -1,18 +1,25 @@
 // ccmp_kernels_fast.hip — analytic-Jacobian projector for gfx950 (jacobian_mode = CCMP_JAC_ANALYTIC).
 //
 // Same Newton iteration, stopping rule and quirks as KinematicChainConstraint::project
-// (include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:57-82), but the 2x14
-// Jacobian is the exact derivative of the residual instead of OMPL's 84-evaluation
-// finite-difference stencil: ~35x less arithmetic per iteration.  Built in the canonical rounding model
-// (-ffp-contract=off -DCCMP_USE_FMA, like the reference-arithmetic units): bit-identical to the CPU oracle run with
-// ORC_JAC_ANALYTIC (oracle/ccmp_oracle.c: orc_jacobian_analytic restates this file's operation order), which is
-// how the mode is verified.  NOT bit-comparable with the REFERENCE arithmetic: the reference iteration amplifies
-// 1e-8 Jacobian differences along the trajectory, so this mode lands on a different
-// point of the same manifold for ~20 % of uniform samples.  It is an opt-in fast mode; the default
-// mode is the FD-faithful kernel in ccmp_kernels_fd.hip.
+// (include/closed_chain_motion_planner/base/constraints/ConstraintFunction.h:57-82), but the 2x14 Jacobian is the exact
+// derivative of the residual — G(2x6) times the 6x14 closed-loop geometric Jacobian, whose single-arm half the reference
+// itself carries as PandaModel::getJacobianMatrix (src/kinematics/panda_rbdl.cpp:9-22, never called there) — instead of
+// OMPL's 84-evaluation finite-difference stencil, and the step is SURVEY.md §7.3's x -= 0.30 J^T (J J^T)^-1 f on the 2x2
+// Gram matrix (the SVD-equivalent routine of the reference arithmetic only where the two rows are nearly parallel).
+// Built in the canonical rounding model (-ffp-contract=off -DCCMP_USE_FMA): bit-identical to the CPU oracle run with
+// ORC_JAC_ANALYTIC (oracle/ccmp_oracle.c: orc_jacobian_analytic + orc_solve_gram restate this file's operation order),
+// which is how the mode is verified.  NOT bit-comparable with the REFERENCE arithmetic: the reference iteration amplifies
+// 1e-8 Jacobian differences along the trajectory, so this mode lands on a different point of the same
+// manifold for ~20 % of uniform samples.  Opt-in; the default mode is the FD-faithful kernel in ccmp_kernels_fd.hip.
 //
-// Decomposition: one sample per lane, state in registers; lanes that finish a sample are refilled together from
-// wave-level ticket queues while their neighbours keep iterating (iteration counts spread 15..250).
+// Layout (round 6): ONE SAMPLE PER LANE PAIR, 32 samples per wavefront.  The even lane carries arm 0, the odd lane arm 1:
+// each runs its own 7-joint chain (sines, cosines, frames, joint axes z_i and origins o_i in the arm's base frame) and its
+// seven Jacobian columns; the two tool poses cross inside the pair by DPP quad_perm broadcasts, the three Gram sums by a
+// quad_perm swap.  Half the per-lane state of a one-sample-per-lane layout (round 5: 256 VGPRs + 198 AGPRs of spill
+// space, one wavefront per SIMD, 34 % VALU issue): three to four wavefronts per SIMD, no scratch, no AGPR traffic.
+// Lanes whose sample is done are refilled from ticket queues while their neighbours keep iterating (iteration counts
+// spread 15..250); when the queues are dry a wavefront that is mostly empty hands its live samples over (x, index,
+// counters, at the loop top) to a pool that a later launch of this same kernel packs into full wavefronts again.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,376 +31,228 @@ using namespace ccmp;
 namespace {
 
 constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
-constexpr int kFastQueues = 64; // queue words of the analytic kernel (ccmp_api.cpp allocates and clears as many)
+constexpr int kFastQueues = 64; // ticket words of one generation (ccmp_api.cpp allocates and clears as many per generation)
 constexpr int kPoolEntry = 18;  // hand-over record: x[14], idx, (iter, updates), norm1, norm2 (as ccmp_fd_common.h)
 
-// Forward chain of one arm in its own base frame, keeping every joint's axis z_i and origin o_i; joint indices are
-// compile-time so that the STOCK instantiation can skip the products with the stock Panda's exact zeros (ccmp_kin.h).
+// value of the pair's even (arm 0) / odd (arm 1) lane in both lanes; the partner's value
+__device__ __forceinline__ double pair_even(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xA0 /* quad_perm:[0,0,2,2] */, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xA0, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pair_odd(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xF5 /* quad_perm:[1,1,3,3] */, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xF5, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pair_swap(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// A value the optimiser cannot see through: what is derived from it inside the Newton loop is recomputed where it is used
+// instead of being hoisted in front of the loop and held (or spilled) across it.
+__device__ __forceinline__ int opaque(int v)
+{
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// KinematicChainSpace::enforceBounds (ccmp_kin.h: wrap_pi): fmod(q, 2 pi) is q itself when |q| < 2 pi — where a Newton
+// iterate practically always is — and the library call's ~120 instructions run only for the lanes beyond (same bits).
+__device__ __forceinline__ double wrap_pi_near(double q)
+{
+  const double pi = 3.14159265358979323846;
+  double v = q;
+  if (!(ccmp_abs(q) < 2.0 * pi)) v = __builtin_fmod(q, 2.0 * pi);
+  if (v < -pi) v += 2.0 * pi;
+  else if (v >= pi) v -= 2.0 * pi;
+  return v;
+}
+__device__ __forceinline__ int pair_swap_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false); }
+
+// Forward chain of this lane's arm in the arm's base frame, keeping every joint's axis z_i and origin o_i; joint indices are
+// compile-time so that the STOCK instantiation skips the products with the stock Panda's exact zeros (ccmp_kin.h).  `ac` is
+// the arm whose constants are read: the lane's own arm, or 0 for twin arms (one LDS address for the whole wavefront).
+// The axes go to this lane's column of an LDS array (zs[k * 64], k = 3 i + component: consecutive lanes, consecutive words)
+// — 42 more live registers across the chain otherwise; the origins stay in registers (with the stock structure joints 1
+// and 5 share the origin of the joint before them, and joint 0's is a constant).
 template <bool STOCK, int I>
-__device__ __forceinline__ void chain_frames_from(const ccmp_consts &K, const int arm, const double *q, double (*z)[3], double (*oj)[3],
+__device__ __forceinline__ void chain_frames_from(const ccmp_consts &K, const int ac, const double *q, double *zs, double (*oj)[3],
                                                   double *R, double *o)
 {
   if constexpr (I < 7) {
     asm volatile("" ::: "memory"); // the joint's constants are read from LDS here, not hoisted out of the Newton loop into registers
+    // one joint after the other: the angle is made to depend on the frame the joint before left behind (no instruction
+    // is emitted), or all seven sines and cosines are formed up front and the chain is interleaved across joints at
+    // a cost of ~150 registers
+    double qi = q[I];
+    if constexpr (I > 0) asm volatile("" : "+v"(qi) : "v"(R[0]), "v"(R[4]), "v"(R[8]), "v"(o[0]), "v"(o[1]), "v"(o[2]));
     double s, c;
-    ccmp_sincos(q[I], &s, &c);
-    mulvec_acc_nz<STOCK ? kStockOff[I] : 7>(R, K.offset[arm][I], o);
-    const double *a = K.axis[arm][I];
+    ccmp_sincos(qi, &s, &c);
+    mulvec_acc_nz<STOCK ? kStockOff[I] : 7>(R, K.offset[ac][I], o);
+    const double *a = K.axis[ac][I];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      z[I][k] = (STOCK && kStockZ[I]) ? R[3 * k + 2] : dot3(R[3 * k], a[0], R[3 * k + 1], a[1], R[3 * k + 2], a[2]);
+      zs[(3 * I + k) * 64] = (STOCK && kStockZ[I]) ? R[3 * k + 2] : dot3(R[3 * k], a[0], R[3 * k + 1], a[1], R[3 * k + 2], a[2]);
       oj[I][k] = o[k];
     }
     double Rn[9];
-    chain_rot<I, STOCK>(a, K.aprod[arm][I], s, c, R, Rn);
+    chain_rot<I, STOCK>(a, K.aprod[ac][I], s, c, R, Rn);
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = Rn[k];
-    chain_frames_from<STOCK, I + 1>(K, arm, q, z, oj, R, o);
+    chain_frames_from<STOCK, I + 1>(K, ac, q, zs, oj, R, o);
   }
 }
-template <bool STOCK>
-__device__ __forceinline__ void chain_frames(const ccmp_consts &K, const int arm, const double *q, double (*z)[3],
-                                             double (*oj)[3], double *R, double *o)
-{
-  R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
-  o[0] = 0; o[1] = 0; o[2] = 0;
-  chain_frames_from<STOCK, 0>(K, arm, q, z, oj, R, o);
-}
 
-template <int MODE, bool STOCK>
-__global__ __launch_bounds__(64) void project_fast_kernel(const ccmp_consts K_arg, const double *__restrict__ q_in,
+// Sources: 0 q_in; 1 the ambient sampler (sampleUniform fused, output wrapped).
+// STOCK: both arms carry the stock Panda's exact zeros; TWIN: and bit-identical chain constants with diag(+-1) base frames.
+template <bool STOCK, bool TWIN>
+__global__ __launch_bounds__(64, 3) void project_pair_kernel(const ccmp_consts K_arg, const int srcmode, const double *__restrict__ q_in,
                                                           double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
-                                                          uint16_t *__restrict__ iters_out,
-                                                          double *__restrict__ q_ambient, unsigned long long B,
-                                                          unsigned long long *queue, unsigned long long seed,
-                                                          unsigned long long first_index, double *__restrict__ pool,
-                                                          unsigned long long *pool_count, int cap_iter,
-                                                          const unsigned int *__restrict__ order,
-                                                          const unsigned int *__restrict__ split_ptr)
+                                                          uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient,
+                                                          unsigned long long B, unsigned long long *queue, unsigned long long seed,
+                                                          unsigned long long first_index, double *__restrict__ pool_out,
+                                                          unsigned long long *pool_out_count, const int dump_below)
 {
   // the constants as an LDS copy read by broadcast: with compile-time joint indices the compiler would otherwise hoist
-  // every scalar load of the kernarg copy out of the Newton loop and spill ~300 SGPRs into VGPR lanes (1170 v_readlane /
-  // v_writelane of 4600 vector instructions); the compiler barriers in chain_frames_from keep the LDS reads at their joints (they also keep the
-  // scheduler from interleaving all fourteen joints at once, which costs 512 registers and scratch)
+  // every scalar load of the kernarg copy out of the Newton loop and spill hundreds of SGPRs into VGPR lanes; the compiler
+  // barriers in chain_frames_from keep the LDS reads at their joints
   __shared__ double ktab[kConstsDoubles + 1];
+  __shared__ double zpark[21 * 64];
   {
-    const double *src = reinterpret_cast<const double *>(&K_arg);
-    for (int k = threadIdx.x; k < kConstsDoubles; k += 64) ktab[k] = src[k];
+    const double *srcp = reinterpret_cast<const double *>(&K_arg);
+    for (int k = threadIdx.x; k < kConstsDoubles; k += 64) ktab[k] = srcp[k];
   }
   __syncthreads();
   const ccmp_consts &K = *reinterpret_cast<const ccmp_consts *>(ktab);
-  double x[14];
+  const int src = srcmode & 15;          // where the samples come from
+  const bool wrap = (srcmode >> 4) == 1; // the call is a fused sampleUniform: enforceBounds on the way out
+  const int lane = threadIdx.x;
+  const int arm = lane & 1;
+  const int ac = TWIN ? 0 : arm;
+  double x[7];
   unsigned long long idx = 0;
   int iter = 0, updates = 0;
   double norm1 = 0.0, norm2 = 0.0;
   bool active = false, drained = false;
-  // Work distribution: iteration counts spread 15..250, so a fixed list of samples per lane leaves most lanes idle
-  // while the unluckiest one works through its list (at 262144 samples: 23 % lane utilisation at 8 wavefronts per CU).
-  // Lanes that need a sample are served together: one atomic per wavefront and refill event takes as many tickets as
-  // lanes are free.  kFastQueues queue words, each owning a contiguous slice of the batch, keep the atomics off a
-  // single address; a wavefront starts on its own word and moves on to the next ones when that slice is used up.
-  const int lane = threadIdx.x;
-  int qk = blockIdx.x % kFastQueues, tried = 0;
-  // With a processing order (longest predicted first, ccmp_kernels_scout.hip) this kernel takes positions [split, B) of it
-  // — the front goes to the six-lane kernel on a second stream — and the queue words own INTERLEAVED positions
-  // (word k: split + k, split + k + 64, …), so that every wavefront, whichever word it starts on, begins with the longest
-  // samples left and the launch ends on the shortest.
-  const unsigned long long split = (order != nullptr && split_ptr != nullptr) ? (unsigned long long)*split_ptr : 0ull;
-  const unsigned long long n_mine = B > split ? B - split : 0ull;
+  // Work distribution: one atomic per wavefront and refill event takes as many tickets as pairs are free.  kFastQueues
+  // ticket words, each owning a contiguous slice of the batch (or of the pool), keep the atomics off a single address — a
+  // same-address atomic costs ~12 ns chip-wide on this part (tools/ubench/atomic_rate.hip); a wavefront starts on its own
+  // word and moves on to the next ones when that slice is used up.
+  const unsigned long long total = B;
+  static_assert(kFastQueues == 64, "one ticket word per lane");
+  int qk = blockIdx.x % kFastQueues;
+  const unsigned long long below_pair = (1ull << (lane & ~1)) - 1ull;
+  constexpr unsigned long long kEven = 0x5555555555555555ull;
 
   for (;;) {
-    // ---- hand-over: this kernel runs a sample on ONE lane at ~7 us per iteration whatever the occupancy, so the serial
-    // chain of its longest sample bounds the launch (250 iterations: 1.85 ms).  A sample that has used cap_iter iterations
-    // leaves its state (x, index, counters — at the loop top, where function(x) and the loop test come next) in the pool
-    // for the six-lanes-per-sample kernel below, which iterates ~3x faster per sample.
-    if (pool != nullptr && active && iter >= cap_iter) {
-      const unsigned long long slot = atomicAdd(pool_count, 1ull);
-      double *ent = pool + slot * kPoolEntry;
+    // ---- hand-over --------------------------------------------------------------------------------------------------
+    // When the tickets are used up and at most dump_below pairs of this wavefront still carry a sample, all of them leave and
+    // the wavefront retires: the latency kernel launched behind finishes them, four to a wavefront.  State at the loop top:
+    // function(x) and the loop test come next.
+    if (pool_out != nullptr && drained) {
+      const unsigned long long lv = __builtin_amdgcn_ballot_w64(active) & kEven;
+      if (lv != 0ull && __builtin_popcountll(lv) <= dump_below) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(pool_out_count, (unsigned long long)__builtin_popcountll(lv));
+        base = __shfl(base, 0);
+        if (active) {
+          const int a7 = 7 * (opaque(lane) & 1);
+          double *ent = pool_out + (base + (unsigned long long)__builtin_popcountll(lv & below_pair)) * kPoolEntry + a7;
 #pragma unroll
-      for (int e = 0; e < 14; e++) ent[e] = x[e];
-      ent[14] = __longlong_as_double((long long)idx);
-      ent[15] = __hiloint2double(updates, iter);
-      ent[16] = norm1;
-      ent[17] = norm2;
-      active = false; // the refill below gives the lane its next sample in this same pass
+          for (int e = 0; e < 7; e++) ent[e] = x[e];
+          if (a7 == 0) {
+            ent[14] = __longlong_as_double((long long)idx);
+            ent[15] = __hiloint2double(updates, iter);
+            ent[16] = norm1;
+            ent[17] = norm2;
+          }
+          active = false;
+        }
+      }
     }
-    unsigned long long need = __builtin_amdgcn_ballot_w64(!active && !drained);
+    // ---- refill -------------------------------------------------------------------------------------------------------
+    unsigned long long need = __builtin_amdgcn_ballot_w64(!active && !drained) & kEven;
     while (need != 0ull) {
       const int n = __builtin_popcountll(need);
       unsigned long long base = 0;
       if (lane == 0) base = atomicAdd(queue + qk, (unsigned long long)n);
-      base = __shfl(base, 0);  // ticket of the first free lane, relative to the word's share
-      const bool mine = (need >> lane) & 1ull;
-      const unsigned long long j = base + (unsigned long long)__builtin_popcountll(need & ((1ull << lane) - 1ull));
-      unsigned long long t, hi;
-      if (order != nullptr) { // interleaved positions of the order
-        t = (unsigned long long)qk + kFastQueues * j;
-        hi = n_mine;
-      } else { // a contiguous slice of the batch
-        const unsigned long long lo = B * (unsigned long long)qk / kFastQueues;
-        t = lo + j;
-        hi = B * (unsigned long long)(qk + 1) / kFastQueues;
-      }
+      base = __shfl(base, 0); // ticket of the first free pair, relative to the word's share
+      const bool mine = (need >> (lane & ~1)) & 1ull;
+      const unsigned long long lo = total * (unsigned long long)qk / kFastQueues;
+      const unsigned long long hi = total * (unsigned long long)(qk + 1) / kFastQueues;
+      const unsigned long long t = lo + base + (unsigned long long)__builtin_popcountll(need & below_pair);
       if (mine && t < hi) {
-        idx = order != nullptr ? (unsigned long long)order[split + t] : t;
-        active = true; iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+        active = true;
+        const int a7 = 7 * (opaque(lane) & 1);
+        idx = t;
+        iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
 #pragma unroll
-        for (int e = 0; e < 14; e++) {
-          if (MODE == 0) x[e] = q_in[idx * 14 + e];
+        for (int e = 0; e < 7; e++) {
+          if (src == 0) x[e] = q_in[idx * 14 + a7 + e];
           else {
-            x[e] = ambient_uniform(K_arg, seed, first_index + idx, e);
-            if (q_ambient) q_ambient[idx * 14 + e] = x[e];
+            x[e] = ambient_uniform_at(K, seed, first_index + idx, a7 + e, e);
+            if (q_ambient) q_ambient[idx * 14 + a7 + e] = x[e];
           }
         }
       }
-      need = __builtin_amdgcn_ballot_w64(!active && !drained);
-      if (need != 0ull) { // this slice is used up: try the next one; after a full round every slice is dry
-        if (++tried >= kFastQueues) { drained = true; break; }
-        qk = (qk + 1) % kFastQueues;
+      need = __builtin_amdgcn_ballot_w64(!active && !drained) & kEven;
+      if (need != 0ull) {
+        // this slice is used up.  One load brings all kFastQueues (= 64, one per lane) ticket words: go on with the next slice
+        // that still has tickets; a word only grows, so when none has any left the batch is handed out for good.  (Trying
+        // the words one by one cost every wavefront 64 serial atomic round trips at the end of a launch.)
+        const unsigned long long taken = __hip_atomic_load(queue + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long lo_l = total * (unsigned long long)lane / kFastQueues, hi_l = total * (unsigned long long)(lane + 1) / kFastQueues;
+        const unsigned long long avail = __builtin_amdgcn_ballot_w64(lo_l + taken < hi_l);
+        if (avail == 0ull) { drained = true; break; }
+        const int r = (qk + 1) & 63;
+        const unsigned long long rot = r ? ((avail >> r) | (avail << (64 - r))) : avail;
+        qk = (r + __builtin_ctzll(rot)) & 63;
       }
     }
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
 
-    // ---- function(x) with joint frames kept for the Jacobian --------------------------------
-    double z[2][7][3], oj[2][7][3], Rw[2][9], pw[2][3];
+    // ---- function(x): this lane's chain with its joint frames kept for the Jacobian, tool poses crossed in the pair -----
+    double oj[7][3], Rw[9], pw[3];
+    double *const zs = zpark + lane;
+    {
+      double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+      chain_frames_from<STOCK, 0>(K, ac, x, zs, oj, R, o);
+      asm volatile("" ::: "memory");
+      // tool_pose_t with this lane's base frame (ccmp_kin.h): TWIN bases are diag(+-1) — d_r * Rf[r][c] and
+      // fma(d_r, pf[r], base_p[r]), to which the general product only adds exact zeros
+      double pf[3] = {o[0], o[1], o[2]}, Rf[9];
+      mulvec_acc_nz<STOCK ? kStockEe : 7>(R, K.ee[ac], pf);
+      mul33(R, K.R_tool[ac], Rf);
+      if (TWIN) {
 #pragma unroll
-    for (int arm = 0; arm < 2; arm++) {
-      double R[9], o[3];
-      chain_frames<STOCK>(K, arm, x + 7 * arm, z[arm], oj[arm], R, o);
-      tool_pose_t<STOCK>(K, arm, R, o, Rw[arm], pw[arm]);
+        for (int r = 0; r < 3; r++) {
+          const double d = K.base_R[arm][4 * r];
+#pragma unroll
+          for (int c = 0; c < 3; c++) Rw[3 * r + c] = d * Rf[3 * r + c];
+          pw[r] = CCMP_FMA(d, pf[r], K.base_p[arm][r]);
+        }
+      } else {
+        mul33(K.base_R[arm], Rf, Rw);
+        pw[0] = K.base_p[arm][0]; pw[1] = K.base_p[arm][1]; pw[2] = K.base_p[arm][2];
+        mulvec_acc(K.base_R[arm], pf, pw);
+      }
     }
+    double R1[9], p1[3], R2[9], p2[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { R1[k] = pair_even(Rw[k]); R2[k] = pair_odd(Rw[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { p1[k] = pair_even(pw[k]); p2[k] = pair_odd(pw[k]); }
     double f[2], dq[4], pc[3];
-    chain_residual(K, Rw[0], pw[0], Rw[1], pw[1], f, dq, pc);
+    chain_residual(K, R1, p1, R2, p2, f, dq, pc);
 
-    bool cont = false;
-    if (active) {
-      const bool c1 = f[0] > K.tol_pos;
-      norm1 = c1 ? 1.0 : 0.0;
-      bool resid = c1;
-      if (!c1) { norm2 = f[1]; resid = f[1] > K.tol_rot; }
-      if (resid) { cont = iter < K.max_iter; iter++; }
-    }
-    if (active && !cont) {
-      bool good = true;
-#pragma unroll
-      for (int e = 0; e < 14; e++) {
-        if (x[e] < K.lbe[e % 7]) good = false;
-        if (x[e] > K.ube[e % 7]) good = false;
-        q_out[idx * 14 + e] = (MODE == 1) ? wrap_pi(x[e]) : x[e];
-      }
-      ok_out[idx] = (uint8_t)(good && (norm1 < K.tol_pos) && (norm2 < K.tol_rot));
-      if (iters_out) iters_out[idx] = (uint16_t)updates;
-      active = false;
-    }
-    if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue;
-
-    // ---- analytic 2x14 Jacobian ----------------------------------------------------------------
-    // u = dp/|dp| (chain frame), n = axis of R_c R_0^T with w >= 0; both taken to the world frame
-    // through R_2, then into each arm's base frame through base_R^T.
-    double u[3] = {0, 0, 0}, n[3] = {0, 0, 0};
-    if (f[0] > 0.0) {
-      const double inv = 1.0 / f[0];
-#pragma unroll
-      for (int k = 0; k < 3; k++) u[k] = (pc[k] - K.init_p[k]) * inv;
-    }
-    const double vn = ccmp_sqrt(dot3(dq[0], dq[0], dq[1], dq[1], dq[2], dq[2]));
-    if (vn > 0.0) {
-      const double sg = (dq[3] < 0.0 ? -1.0 : 1.0) / vn;
-#pragma unroll
-      for (int k = 0; k < 3; k++) n[k] = dq[k] * sg;
-    }
-    double aw[3], bw[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      aw[k] = dot3(Rw[1][3 * k], u[0], Rw[1][3 * k + 1], u[1], Rw[1][3 * k + 2], u[2]);
-      bw[k] = dot3(Rw[1][3 * k], n[0], Rw[1][3 * k + 1], n[1], Rw[1][3 * k + 2], n[2]);
-    }
-    double J[28];
-#pragma unroll
-    for (int arm = 0; arm < 2; arm++) {
-      // probe vectors in this arm's base frame: a' = Rb^T a, b' = Rb^T b, p' = Rb^T (p1 - pb)
-      double al[3], bl[3], pl[3], dp[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) dp[k] = pw[0][k] - K.base_p[arm][k];
-      mulTvec(K.base_R[arm], aw, al);
-      mulTvec(K.base_R[arm], bw, bl);
-      mulTvec(K.base_R[arm], dp, pl);
-      const double sgn = arm == 0 ? 1.0 : -1.0;
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 7; i++) {
-        const double *zi = z[arm][i];
-        const double r0 = pl[0] - oj[arm][i][0], r1 = pl[1] - oj[arm][i][1], r2 = pl[2] - oj[arm][i][2];
-        const double cx = CCMP_FMA(zi[1], r2, -(zi[2] * r1));
-        const double cy = CCMP_FMA(zi[2], r0, -(zi[0] * r2));
-        const double cz = CCMP_FMA(zi[0], r1, -(zi[1] * r0));
-        J[arm * 7 + i] = sgn * dot3(al[0], cx, al[1], cy, al[2], cz);
-        J[14 + arm * 7 + i] = sgn * dot3(bl[0], zi[0], bl[1], zi[1], bl[2], zi[2]);
-      }
-    }
-    double dx[14];
-    solve_minnorm(J, f[0], f[1], dx);
-    if (cont) {
-#pragma unroll
-      for (int e = 0; e < 14; e++) x[e] = CCMP_FMA(-K.step, dx[e], x[e]);
-      updates++;
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------------------
-// project_fast_rows_kernel — the analytic mode's LATENCY kernel: six lanes per sample, ten samples per wavefront.
-// Lane r of a group carries row r % 3 of arm r / 3's chain frame (the decomposition of the reference-arithmetic
-// throughput kernel's phase 1, ccmp_kernels_fd.hip): per joint the lane computes the joint's rotation matrix (13
-// operations, all lanes alike) and ONE row of the frame product, its component of the joint axis z_i = R axis_i and of the
-// joint origin; axes and origins of all fourteen joints, the two tool poses and the Jacobian pass through LDS.  An
-// iteration is ~1.35 k instructions per lane instead of ~3.6 k (2.3 us instead of 7.4 us when a wave has its SIMD to
-// itself), at 2.5x the SIMD-cycles per sample-iteration: used for the samples the one-lane kernel hands over, and alone for
-// small batches.  Every value is produced by the same operations on the same operands as in the one-lane kernel and in
-// the oracle (orc_jacobian_analytic): bit-identical.  Twin stock arms and diag(+-1) base frames only (K.twin_arms).
-// SRC 0: q_in; SRC 1: ambient sampler; SRC 2: the hand-over pool.
-constexpr int rGroup = 6, rGroups = 10;
-constexpr int rX = 0, rSC = 14, rZO = 42, rT = 126, rJ = 150, rRec = 179; // doubles per group: x, sin/cos, (z, o)[2][7], poses, J; odd stride
-
-template <int I>
-__device__ __forceinline__ void rows_chain_from(const ccmp_consts &K, double *rec, const double *sc, int arm, int row, bool live,
-                                                double &R0, double &R1, double &R2, double &o)
-{
-  if constexpr (I < 7) {
-    asm volatile("" ::: "memory");
-    constexpr int NZ = kStockOff[I];
-    if (NZ & 1) o = CCMP_FMA(R0, K.offset[0][I][0], o);
-    if (NZ & 2) o = CCMP_FMA(R1, K.offset[0][I][1], o);
-    if (NZ & 4) o = CCMP_FMA(R2, K.offset[0][I][2], o);
-    const double *a = K.axis[0][I];
-    // this lane's component of z_i = R axis_i (a stock z joint: the third column of R) and of the joint origin
-    const double zr = kStockZ[I] ? R2 : dot3(R0, a[0], R1, a[1], R2, a[2]);
-    if (live) {
-      rec[rZO + (arm * 7 + I) * 6 + row] = zr;
-      rec[rZO + (arm * 7 + I) * 6 + 3 + row] = o;
-    }
-    const double s = sc[2 * I], c = sc[2 * I + 1];
-    double n0, n1, n2;
-    if constexpr (kStockZ[I] != 0) { // mul_zrot, one row
-      const double t = 1.0 - c;
-      const double w = t + c;
-      const double ns = -s;
-      n0 = CCMP_FMA(R1, s, R0 * c);
-      n1 = CCMP_FMA(R1, c, R0 * ns);
-      n2 = R2 * w;
-    } else { // rot_sc + one row of mul33
-      double Rj[9];
-      rot_sc(a, K.aprod[0][I], s, c, Rj);
-      n0 = dot3(R0, Rj[0], R1, Rj[3], R2, Rj[6]);
-      n1 = dot3(R0, Rj[1], R1, Rj[4], R2, Rj[7]);
-      n2 = dot3(R0, Rj[2], R1, Rj[5], R2, Rj[8]);
-    }
-    R0 = n0; R1 = n1; R2 = n2;
-    rows_chain_from<I + 1>(K, rec, sc, arm, row, live, R0, R1, R2, o);
-  }
-}
-
-template <int SRC>
-__global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
-    const ccmp_consts K_arg, const double *__restrict__ q_in, double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
-    uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient, unsigned long long B, unsigned long long *queue,
-    unsigned long long seed, unsigned long long first_index, const double *__restrict__ pool,
-    const unsigned long long *__restrict__ pool_count, int wrap_output, const unsigned int *__restrict__ order,
-    const unsigned int *__restrict__ split_ptr)
-{
-  __shared__ double ktab[kConstsDoubles + 1];
-  __shared__ double lds[rGroups * rRec];
-  {
-    const double *src = reinterpret_cast<const double *>(&K_arg);
-    for (int k = threadIdx.x; k < kConstsDoubles; k += 64) ktab[k] = src[k];
-  }
-  __syncthreads();
-  const ccmp_consts &K = *reinterpret_cast<const ccmp_consts *>(ktab);
-  const int lane = threadIdx.x;
-  const int g = lane / rGroup, r = lane - rGroup * g;
-  const bool live = g < rGroups;
-  const int leader = live ? rGroup * g : 0;
-  double *rec = lds + (live ? g : 0) * rRec; // idle lanes alias group 0 for reads, never write
-  const int arm = r < 3 ? 0 : 1, row = r < 3 ? r : r - 3;
-  const double d_lane = K.base_R[arm][4 * row], bp_lane = K.base_p[arm][row];
-  // SRC 0 / 1 with a processing order: the first *split_ptr positions of it (the samples predicted longest)
-  const unsigned long long total = (SRC == 2) ? *pool_count : ((order != nullptr && split_ptr != nullptr) ? (unsigned long long)*split_ptr : B);
-
-  unsigned long long idx = 0;
-  int iter = 0, updates = 0;
-  double norm1 = 0.0, norm2 = 0.0;
-  bool active = false, drained = false;
-
-  for (;;) {
-    // ---- refill: groups without a sample pull the next ticket ---------------------------------------------------
-    {
-      const bool want = live && !active && !drained;
-      unsigned long long t = 0;
-      if (want && r == 0) t = atomicAdd(queue, 1ull);
-      t = __shfl(t, leader);
-      if (want) {
-        if (t < total) {
-          active = true;
-          if (SRC == 2) {
-            const double *ent = pool + t * kPoolEntry;
-            idx = (unsigned long long)__double_as_longlong(ent[14]);
-            iter = __double2hiint(ent[15]);
-            updates = __double2loint(ent[15]);
-            norm1 = ent[16];
-            norm2 = ent[17];
-            for (int e = r; e < 14; e += rGroup) rec[rX + e] = ent[e];
-          } else {
-            idx = order != nullptr ? (unsigned long long)order[t] : t;
-            iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
-            for (int e = r; e < 14; e += rGroup) {
-              double v;
-              if (SRC == 0) v = q_in[idx * 14 + e];
-              else {
-                v = ambient_uniform(K, seed, first_index + idx, e);
-                if (q_ambient) q_ambient[idx * 14 + e] = v;
-              }
-              rec[rX + e] = v;
-            }
-          }
-        } else drained = true;
-      }
-    }
-    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-    __syncthreads();
-    // ---- function(x): sines / cosines (6 lanes, 3 rounds), both chains by rows, tool poses by rows ------------------
-    for (int e = r; e < 14; e += rGroup) {
-      double s, c;
-      ccmp_sincos(rec[rX + e], &s, &c);
-      if (live) { rec[rSC + 2 * e] = s; rec[rSC + 2 * e + 1] = c; }
-    }
-    __syncthreads();
-    {
-      double R0 = row == 0 ? 1.0 : 0.0, R1 = row == 1 ? 1.0 : 0.0, R2 = row == 2 ? 1.0 : 0.0, o = 0.0;
-      rows_chain_from<0>(K, rec, rec + rSC + 14 * arm, arm, row, live, R0, R1, R2, o);
-      asm volatile("" ::: "memory");
-      double pf = o; // tool_pose_t<true>, diag(+-1) base frame, one row
-      if (kStockEe & 1) pf = CCMP_FMA(R0, K.ee[0][0], pf);
-      if (kStockEe & 2) pf = CCMP_FMA(R1, K.ee[0][1], pf);
-      if (kStockEe & 4) pf = CCMP_FMA(R2, K.ee[0][2], pf);
-      const double *Rt = K.R_tool[0];
-      const double f0 = dot3(R0, Rt[0], R1, Rt[3], R2, Rt[6]);
-      const double f1 = dot3(R0, Rt[1], R1, Rt[4], R2, Rt[7]);
-      const double f2 = dot3(R0, Rt[2], R1, Rt[5], R2, Rt[8]);
-      if (live) {
-        double *T = rec + rT + 12 * arm;
-        T[3 * row] = d_lane * f0;
-        T[3 * row + 1] = d_lane * f1;
-        T[3 * row + 2] = d_lane * f2;
-        T[9 + row] = CCMP_FMA(d_lane, pf, bp_lane);
-      }
-    }
-    __syncthreads();
-    double T0[12], T1[12], f[2], dq[4], pc[3];
-#pragma unroll
-    for (int k = 0; k < 12; k++) { T0[k] = rec[rT + k]; T1[k] = rec[rT + 12 + k]; }
-    chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, dq, pc);
-    // ---- loop condition of ConstraintFunction.h:68, quirks included ----------------------------------------------
+    // ---- loop condition of ConstraintFunction.h:68, quirks included (both lanes of a pair decide alike) -------------------
     bool cont = false;
     if (active) {
       const bool c1 = f[0] > K.tol_pos;
@@ -404,26 +263,303 @@ __global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
     }
     {
       const bool fin = active && !cont;
-      bool bad = false;
+      int good = 1;
+      const int a7 = 7 * (opaque(lane) & 1);
       if (fin) {
-        for (int e = r; e < 14; e += rGroup) {
-          const double v = rec[rX + e];
-          const int jj = e < 7 ? e : e - 7;
-          if (v < K.lbe[jj]) bad = true;
-          if (v > K.ube[jj]) bad = true;
-          q_out[idx * 14 + e] = wrap_output ? wrap_pi(v) : v;
+        double *row = q_out + idx * 14 + a7;
+#pragma unroll
+        for (int e = 0; e < 7; e++) {
+          if (x[e] < K.lbe[e]) good = 0;
+          if (x[e] > K.ube[e]) good = 0;
+          row[e] = wrap ? wrap_pi_near(x[e]) : x[e];
         }
       }
-      const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);
-      if (fin && r == 0) {
-        const bool gbad = ((badmask >> leader) & 0x3Full) != 0ull;
-        ok_out[idx] = (uint8_t)((!gbad) && (norm1 < K.tol_pos) && (norm2 < K.tol_rot));
+      good &= pair_swap_i(good);
+      if (fin && a7 == 0) {
+        ok_out[idx] = (uint8_t)(good && (norm1 < K.tol_pos) && (norm2 < K.tol_rot));
         if (iters_out) iters_out[idx] = (uint16_t)updates;
       }
       if (fin) active = false;
     }
     if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue;
-    // ---- analytic Jacobian: probes (every lane, its arm), then this lane's 2-3 joints of its arm ---------------------
+
+    // ---- analytic Jacobian, this lane's seven columns ----------------------------------------------------------------------
+    // u = dp/|dp| (chain frame), n = axis of R_c R_0^T with w >= 0; both taken to the world frame through R_2, then into
+    // this lane's arm base frame through base_R^T (oracle/ccmp_oracle.c: orc_jacobian_analytic).
+    double J0[7], J1[7];
+    {
+      double u[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+      if (f[0] > 0.0) {
+        const double inv = 1.0 / f[0];
+#pragma unroll
+        for (int k = 0; k < 3; k++) u[k] = (pc[k] - K.init_p[k]) * inv;
+      }
+      const double vn = ccmp_sqrt(dot3(dq[0], dq[0], dq[1], dq[1], dq[2], dq[2]));
+      if (vn > 0.0) {
+        const double sg = (dq[3] < 0.0 ? -1.0 : 1.0) / vn;
+#pragma unroll
+        for (int k = 0; k < 3; k++) n[k] = dq[k] * sg;
+      }
+      double aw[3], bw[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        aw[k] = dot3(R2[3 * k], u[0], R2[3 * k + 1], u[1], R2[3 * k + 2], u[2]);
+        bw[k] = dot3(R2[3 * k], n[0], R2[3 * k + 1], n[1], R2[3 * k + 2], n[2]);
+      }
+      double al[3], bl[3], pl[3], dp[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) dp[k] = p1[k] - K.base_p[arm][k];
+      mulTvec(K.base_R[arm], aw, al);
+      mulTvec(K.base_R[arm], bw, bl);
+      mulTvec(K.base_R[arm], dp, pl);
+      asm volatile("" ::: "memory");
+      const double sgn = (opaque(lane) & 1) ? -1.0 : 1.0; // + arm 0, - arm 1
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        const double zi[3] = {zs[(3 * i) * 64], zs[(3 * i + 1) * 64], zs[(3 * i + 2) * 64]};
+        const double r0 = pl[0] - oj[i][0], r1 = pl[1] - oj[i][1], r2 = pl[2] - oj[i][2];
+        const double cx = CCMP_FMA(zi[1], r2, -(zi[2] * r1));
+        const double cy = CCMP_FMA(zi[2], r0, -(zi[0] * r2));
+        const double cz = CCMP_FMA(zi[0], r1, -(zi[1] * r0));
+        J0[i] = sgn * dot3(al[0], cx, al[1], cy, al[2], cz);
+        J1[i] = sgn * dot3(bl[0], zi[0], bl[1], zi[1], bl[2], zi[2]);
+      }
+    }
+    // ---- Newton step on the Gram matrix (orc_solve_gram): per-arm partial sums, added across the pair ---------------------
+    double dx[7];
+    {
+      double pa = 0.0, pd = 0.0, pb = 0.0;
+#pragma unroll
+      for (int j = 0; j < 7; j++) {
+        pa = CCMP_FMA(J0[j], J0[j], pa);
+        pd = CCMP_FMA(J1[j], J1[j], pd);
+        pb = CCMP_FMA(J0[j], J1[j], pb);
+      }
+      // arm 0's sum + arm 1's sum: IEEE addition commutes, both lanes hold the same bits
+      const double a = pa + pair_swap(pa), d = pd + pair_swap(pd), b = pb + pair_swap(pb);
+      double y0, y1;
+      const bool well = gram_coeffs(a, d, b, f[0], f[1], y0, y1);
+#pragma unroll
+      for (int j = 0; j < 7; j++) dx[j] = CCMP_FMA(y1, J1[j], y0 * J0[j]);
+      if (__builtin_amdgcn_ballot_w64(cont && !well) != 0ull) {
+        // nearly parallel rows (or a NaN): the reference arithmetic's SVD-equivalent solve on the full rows, both lanes alike
+        double Jf[28], dxf[14];
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+          Jf[j] = pair_even(J0[j]); Jf[7 + j] = pair_odd(J0[j]);
+          Jf[14 + j] = pair_even(J1[j]); Jf[21 + j] = pair_odd(J1[j]);
+        }
+        solve_minnorm(Jf, f[0], f[1], dxf);
+        if (!well) {
+#pragma unroll
+          for (int j = 0; j < 7; j++) dx[j] = (opaque(lane) & 1) ? dxf[7 + j] : dxf[j];
+        }
+      }
+    }
+    if (cont) {
+#pragma unroll
+      for (int e = 0; e < 7; e++) x[e] = CCMP_FMA(-K.step, dx[e], x[e]);
+      updates++;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// project_row16_kernel — the analytic mode's LATENCY kernel: sixteen lanes (one DPP row) per sample, four samples per
+// wavefront, one wavefront per block.  A wavefront that has its SIMD to itself pays ~4.6 cycles for ANY instruction
+// (tools/ubench/), so a Newton round of the lane-pair kernel (~2 100 instructions) lasts ~5 us however few samples are
+// left — 250 rounds of a sample that never converges: 1.2 ms.  Here a round is ~900 instructions on the critical path:
+//   lane l < 14 owns joint l (arm l / 7): its angle, sine / cosine and joint rotation (rot_sc), its Jacobian column,
+//               its component of the Newton step — the joint's constants stay in the lane's registers;
+//   lane l < 6 also carries row l % 3 of arm l / 3's chain frame: per joint one row of R * Rot, its component of the
+//               joint's axis z_i = R axis_i and of the joint's origin (the decomposition of the reference-arithmetic
+//               throughput kernel's phase 1, ccmp_kernels_fd.hip), then one row of the tool pose;
+//   all lanes   the residual, the probe vectors and the 2x2 Gram step (every lane needs their results).
+// Joint rotations, axes / origins, the two tool poses and the Jacobian pass through the sample's LDS record; with one
+// wavefront per block the LDS queue orders writes and reads, no barrier is needed.  Every value is produced by the same
+// operations on the same operands as in the lane-pair kernel and in the oracle (general formulas: what the STOCK
+// instantiations skip are products with exact zeros): bit-identical.  DIAG: both base frames are diag(+-1) (every shipped
+// t_wb); otherwise the base-frame product is formed from the whole hand poses by every lane.
+// Sources: 0 q_in, 1 ambient sampler, 2 the hand-over pool of the generation before.
+constexpr int qRJ = 0, qZO = 126, qT = 210, qJ = 234, qDX = 262, qRec = 277; // doubles per sample: Rot[14][9], (z, o)[14][6], poses[2][12], J[28], fallback dx[14]; odd stride
+
+template <bool DIAG>
+__global__ __launch_bounds__(64, 2) void project_row16_kernel(const ccmp_consts K_arg, const int srcmode, const double *__restrict__ q_in,
+                                                              double *__restrict__ q_out, uint8_t *__restrict__ ok_out,
+                                                              uint16_t *__restrict__ iters_out, double *__restrict__ q_ambient,
+                                                              unsigned long long B, unsigned long long *queue, unsigned long long seed,
+                                                              unsigned long long first_index, const double *__restrict__ pool_in,
+                                                              const unsigned long long *__restrict__ pool_in_count)
+{
+  __shared__ double ktab[kConstsDoubles + 1];
+  __shared__ double lds[4 * qRec];
+  {
+    const double *srcp = reinterpret_cast<const double *>(&K_arg);
+    for (int k = threadIdx.x; k < kConstsDoubles; k += 64) ktab[k] = srcp[k];
+  }
+  __syncthreads();
+  const ccmp_consts &K = *reinterpret_cast<const ccmp_consts *>(ktab);
+  const int src = srcmode & 15;
+  const bool wrap = (srcmode >> 4) == 1;
+  const int lane = threadIdx.x, l = lane & 15;
+  double *const rec = lds + (lane >> 4) * qRec;
+  // joint role (lanes 14, 15 shadow joint 13 and never store)
+  const bool jl = l < 14;
+  const int lj = jl ? l : 13;
+  const int aj = lj >= 7 ? 1 : 0, ij = lj - 7 * aj;
+  double ax[3], ap[6];
+#pragma unroll
+  for (int k = 0; k < 3; k++) ax[k] = K.axis[aj][ij][k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) ap[k] = K.aprod[aj][ij][k];
+  const double lbe = K.lbe[ij], ube = K.ube[ij];
+  const double sgn = aj ? -1.0 : 1.0;
+  // chain role: lanes 6..15 shadow the rows of lanes 0..5 — the same operands, the same results, stored to the same words
+  const int ac = (l / 3) & 1, rc = l % 3;
+  double cee[3], cRt[9]; // this lane's arm: loop-invariant, kept in registers
+#pragma unroll
+  for (int k = 0; k < 3; k++) cee[k] = K.ee[ac][k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) cRt[k] = K.R_tool[ac][k];
+  const double cd = K.base_R[ac][4 * rc], cbp = K.base_p[ac][rc];
+  const unsigned long long total = src == 2 ? *pool_in_count : B;
+
+  double x = 0.0;
+  unsigned long long idx = 0;
+  int iter = 0, updates = 0;
+  double norm1 = 0.0, norm2 = 0.0;
+  bool active = false, drained = false;
+
+  for (;;) {
+    // ---- refill: rows without a sample take the next ticket ------------------------------------------------------------
+    {
+      const bool want = !active && !drained;
+      unsigned long long t = 0;
+      if (want && l == 0) t = atomicAdd(queue, 1ull);
+      t = __shfl(t, lane & ~15);
+      if (want) {
+        if (t < total) {
+          active = true;
+          if (src == 2) {
+            const double *ent = pool_in + t * kPoolEntry;
+            idx = (unsigned long long)__double_as_longlong(ent[14]);
+            iter = __double2hiint(ent[15]);
+            updates = __double2loint(ent[15]);
+            norm1 = ent[16];
+            norm2 = ent[17];
+            x = ent[lj];
+          } else {
+            idx = t;
+            iter = 0; updates = 0; norm1 = 0.0; norm2 = 0.0;
+            if (src == 0) x = q_in[idx * 14 + lj];
+            else {
+              x = ambient_uniform_at(K, seed, first_index + idx, lj, ij);
+              if (q_ambient && jl) q_ambient[idx * 14 + lj] = x;
+            }
+          }
+        } else drained = true;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+
+    // ---- function(x).  Joint lanes: sine, cosine, joint rotation (lanes 14, 15 shadow lane 13: same values, same words) ------
+    {
+      double s, c, Rj[9];
+      ccmp_sincos(x, &s, &c);
+      rot_sc(ax, ap, s, c, Rj);
+#pragma unroll
+      for (int k = 0; k < 9; k++) rec[qRJ + 9 * lj + k] = Rj[k];
+    }
+    // ---- chain lanes: one row of the arm's frame through the seven joints, then one row of the hand pose ---------------------
+    {
+      double R0 = rc == 0 ? 1.0 : 0.0, R1 = rc == 1 ? 1.0 : 0.0, R2 = rc == 2 ? 1.0 : 0.0, o = 0.0;
+      // the arm's joint rotations in two batches (four joints, then three): two LDS latencies instead of seven
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        constexpr int kFirst[2] = {0, 4}, kCount[2] = {4, 3};
+        double Rj[4][9];
+#pragma unroll
+        for (int i = 0; i < kCount[h]; i++)
+#pragma unroll
+          for (int k = 0; k < 9; k++) Rj[i][k] = rec[qRJ + 9 * (ac * 7 + kFirst[h] + i) + k];
+#pragma unroll
+        for (int ii = 0; ii < kCount[h]; ii++) {
+          const int i = kFirst[h] + ii;
+          const double *off = K.offset[ac][i], *a = K.axis[ac][i];
+          o = dot3acc(o, R0, off[0], R1, off[1], R2, off[2]);
+          const double zr = dot3(R0, a[0], R1, a[1], R2, a[2]);
+          rec[qZO + (ac * 7 + i) * 6 + rc] = zr;
+          rec[qZO + (ac * 7 + i) * 6 + 3 + rc] = o;
+          const double n0 = dot3(R0, Rj[ii][0], R1, Rj[ii][3], R2, Rj[ii][6]);
+          const double n1 = dot3(R0, Rj[ii][1], R1, Rj[ii][4], R2, Rj[ii][7]);
+          const double n2 = dot3(R0, Rj[ii][2], R1, Rj[ii][5], R2, Rj[ii][8]);
+          R0 = n0; R1 = n1; R2 = n2;
+        }
+      }
+      // the hand frame in the arm's base frame (getTranslation / getRotation), one row
+      const double pf = dot3acc(o, R0, cee[0], R1, cee[1], R2, cee[2]);
+      const double f0 = dot3(R0, cRt[0], R1, cRt[3], R2, cRt[6]);
+      const double f1 = dot3(R0, cRt[1], R1, cRt[4], R2, cRt[7]);
+      const double f2 = dot3(R0, cRt[2], R1, cRt[5], R2, cRt[8]);
+      double *T = rec + qT + 12 * ac;
+      if (DIAG) { // t_wb * T with t_wb.linear() = diag(d): d_r * Rf[r][c], fma(d_r, pf[r], base_p[r]) (the general product adds exact zeros)
+        T[3 * rc] = cd * f0;
+        T[3 * rc + 1] = cd * f1;
+        T[3 * rc + 2] = cd * f2;
+        T[9 + rc] = CCMP_FMA(cd, pf, cbp);
+      } else {
+        T[3 * rc] = f0;
+        T[3 * rc + 1] = f1;
+        T[3 * rc + 2] = f2;
+        T[9 + rc] = pf;
+      }
+    }
+    // ---- all lanes: the two world poses, the residual, the loop condition ------------------------------------------------------
+    double T0[12], T1[12], f[2], dq[4], pc[3];
+    if (DIAG) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) { T0[k] = rec[qT + k]; T1[k] = rec[qT + 12 + k]; }
+    } else {
+#pragma unroll
+      for (int arm = 0; arm < 2; arm++) {
+        double Rf[9], pf[3], *Tw = arm ? T1 : T0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rf[k] = rec[qT + 12 * arm + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pf[k] = rec[qT + 12 * arm + 9 + k];
+        mul33(K.base_R[arm], Rf, Tw);
+        Tw[9] = K.base_p[arm][0]; Tw[10] = K.base_p[arm][1]; Tw[11] = K.base_p[arm][2];
+        mulvec_acc(K.base_R[arm], pf, Tw + 9);
+      }
+    }
+    chain_residual(K, &T0[0], &T0[9], &T1[0], &T1[9], f, dq, pc);
+    bool cont = false;
+    if (active) { // ConstraintFunction.h:68, quirks included; the sixteen lanes of a row decide alike
+      const bool c1 = f[0] > K.tol_pos;
+      norm1 = c1 ? 1.0 : 0.0;
+      bool resid = c1;
+      if (!c1) { norm2 = f[1]; resid = f[1] > K.tol_rot; }
+      if (resid) { cont = iter < K.max_iter; iter++; }
+    }
+    {
+      const bool fin = active && !cont;
+      bool bad = false;
+      if (fin && jl) {
+        if (x < lbe) bad = true;
+        if (x > ube) bad = true;
+        q_out[idx * 14 + lj] = wrap ? wrap_pi_near(x) : x;
+      }
+      const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);
+      if (fin && l == 0) {
+        const bool rbad = ((badmask >> (lane & ~15)) & 0xFFFFull) != 0ull;
+        ok_out[idx] = (uint8_t)((!rbad) && (norm1 < K.tol_pos) && (norm2 < K.tol_rot));
+        if (iters_out) iters_out[idx] = (uint16_t)updates;
+      }
+      if (fin) active = false;
+    }
+    if (__builtin_amdgcn_ballot_w64(cont) == 0ull) continue;
+    // ---- analytic Jacobian: probes (every lane, its joint's arm), then this lane's column --------------------------------------
+    double J0, J1;
     {
       double u[3] = {0, 0, 0}, n[3] = {0, 0, 0}, aw[3], bw[3];
       if (f[0] > 0.0) {
@@ -442,45 +578,46 @@ __global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
         aw[k] = dot3(T1[3 * k], u[0], T1[3 * k + 1], u[1], T1[3 * k + 2], u[2]);
         bw[k] = dot3(T1[3 * k], n[0], T1[3 * k + 1], n[1], T1[3 * k + 2], n[2]);
       }
-      // base_R[arm] is diag(d0, d1, d2) here, but the probes take the general transposed product (the oracle's
-      // m3t_vec): exact zeros are added, the bits are those of the one-lane kernel
       double al[3], bl[3], pl[3], dp[3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) dp[k] = T0[9 + k] - K.base_p[arm][k];
-      mulTvec(K.base_R[arm], aw, al);
-      mulTvec(K.base_R[arm], bw, bl);
-      mulTvec(K.base_R[arm], dp, pl);
-      const double sgn = arm == 0 ? 1.0 : -1.0;
-#pragma unroll
-      for (int nn = 0; nn < 3; nn++) {
-        const int i = row + 3 * nn; // joints row, row + 3, row + 6 of this lane's arm
-        if (i < 7 && live) {
-          const double *zo = rec + rZO + (arm * 7 + i) * 6;
-          const double z0 = zo[0], z1 = zo[1], z2 = zo[2];
-          const double r0 = pl[0] - zo[3], r1 = pl[1] - zo[4], r2 = pl[2] - zo[5];
-          const double cx = CCMP_FMA(z1, r2, -(z2 * r1));
-          const double cy = CCMP_FMA(z2, r0, -(z0 * r2));
-          const double cz = CCMP_FMA(z0, r1, -(z1 * r0));
-          rec[rJ + arm * 7 + i] = sgn * dot3(al[0], cx, al[1], cy, al[2], cz);
-          rec[rJ + 14 + arm * 7 + i] = sgn * dot3(bl[0], z0, bl[1], z1, bl[2], z2);
-        }
-      }
+      for (int k = 0; k < 3; k++) dp[k] = T0[9 + k] - K.base_p[aj][k];
+      mulTvec(K.base_R[aj], aw, al);
+      mulTvec(K.base_R[aj], bw, bl);
+      mulTvec(K.base_R[aj], dp, pl);
+      const double *zo = rec + qZO + 6 * lj;
+      const double z0 = zo[0], z1 = zo[1], z2 = zo[2];
+      const double r0 = pl[0] - zo[3], r1 = pl[1] - zo[4], r2 = pl[2] - zo[5];
+      const double cx = CCMP_FMA(z1, r2, -(z2 * r1));
+      const double cy = CCMP_FMA(z2, r0, -(z0 * r2));
+      const double cz = CCMP_FMA(z0, r1, -(z1 * r0));
+      J0 = sgn * dot3(al[0], cx, al[1], cy, al[2], cz);
+      J1 = sgn * dot3(bl[0], z0, bl[1], z1, bl[2], z2);
+      rec[qJ + lj] = J0;
+      rec[qJ + 14 + lj] = J1;
     }
-    __syncthreads();
-    // ---- Newton update: x -= 0.30 * J.jacobiSvd().solve(f) ---------------------------------------------------------
+    // ---- Newton update on the Gram matrix (orc_solve_gram): every lane the three sums, its own component of the step ----------
     {
-      double Jr[28], dx[14];
+      double Jr[28], a, d, b, y0, y1;
 #pragma unroll
-      for (int k = 0; k < 28; k++) Jr[k] = rec[rJ + k];
-      solve_minnorm(Jr, f[0], f[1], dx);
+      for (int k = 0; k < 28; k++) Jr[k] = rec[qJ + k];
+      gram_sums(Jr, a, d, b);
+      const bool well = gram_coeffs(a, d, b, f[0], f[1], y0, y1);
+      double dx = CCMP_FMA(y1, J1, y0 * J0);
+      if (__builtin_amdgcn_ballot_w64(cont && !well) != 0ull) { // nearly parallel rows (or a NaN): the SVD-equivalent solve, through LDS
+        double dxf[14];
+        solve_minnorm(Jr, f[0], f[1], dxf);
+        if (l == 0) {
+#pragma unroll
+          for (int k = 0; k < 14; k++) rec[qDX + k] = dxf[k];
+        }
+        const double own = rec[qDX + lj];
+        if (!well) dx = own;
+      }
       if (cont) {
-#pragma unroll
-        for (int e = 0; e < 14; e++)
-          if (e % rGroup == r) rec[rX + e] = CCMP_FMA(-K.step, dx[e], rec[rX + e]);
+        x = CCMP_FMA(-K.step, dx, x);
         updates++;
       }
     }
-    __syncthreads();
   }
 }
 
@@ -488,60 +625,40 @@ __global__ __launch_bounds__(64, 2) void project_fast_rows_kernel(
 
 extern "C" hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st); // ccmp_kernels_fd.hip
 
-// One-lane kernel (+ hand-over of the samples past cap_iter iterations to the rows kernel when pool != NULL), or the
-// rows kernel alone (lane_blocks == 0).  queue: kFastQueues words for the one-lane kernel, then one word for the rows
-// kernel's tickets, one for the pool's fill count and one for the rows kernel's tickets of a split launch.
-//
-// Split launch (order != NULL): the batch is processed in `order` (longest predicted first); its first *split_ptr
-// positions — the samples predicted longest — run on the six-lane kernel on stream `side` WHILE the one-lane kernel takes
-// the rest on `st`, longest first; what the one-lane kernel still hands over past cap_iter (mispredictions) is finished
-// by a second pass of the six-lane kernel behind both.  fork / join order the two streams (no host synchronisation).
-extern "C" hipError_t ccmp_launch_project_fast(const ccmp_consts *K, int mode, const double *q_in, double *q_out,
-                                               uint8_t *ok, uint16_t *iters, double *q_ambient, size_t B,
-                                               unsigned long long *queue, unsigned long long seed,
-                                               unsigned long long first, int lane_blocks, int rows_blocks, double *pool,
-                                               int cap_iter, const unsigned int *order, const unsigned int *split_ptr,
-                                               int front_blocks, hipStream_t side, hipEvent_t fork, hipEvent_t join, hipStream_t st)
+// One call of the analytic mode on one stream: the lane-pair kernel with pair_blocks wavefronts (0: none) and behind it, or
+// alone, the latency kernel with latency_blocks wavefronts (0: none).  With both, a wavefront of the lane-pair kernel whose
+// tickets are used up and that holds at most dump_below samples hands them over through `pool` (kPoolEntry doubles per
+// sample; the fill count is read on the device: surplus wavefronts of the latency kernel exit at once).  queue: kFastQueues
+// ticket words of the lane-pair kernel, the pool's fill count, the ticket word of the latency kernel.
+extern "C" hipError_t ccmp_launch_project_analytic(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok,
+                                                   uint16_t *iters, double *q_ambient, size_t B, unsigned long long *queue,
+                                                   unsigned long long seed, unsigned long long first, int pair_blocks, int dump_below,
+                                                   int latency_blocks, double *pool, hipStream_t st)
 {
-  hipError_t e = ccmp_launch_clear_words(queue, (kFastQueues + 3) * 2, st); // a kernel, so that a stream capture replays it
+  if (pair_blocks <= 0 && latency_blocks <= 0) return hipErrorInvalidValue;
+  hipError_t e = ccmp_launch_clear_words(queue, (kFastQueues + 2) * 2, st); // a kernel, so that a stream capture replays it
   if (e != hipSuccess) return e;
-  unsigned long long *rows_queue = queue + kFastQueues, *pool_count = queue + kFastQueues + 1, *front_queue = queue + kFastQueues + 2;
-  const bool split = order != nullptr && split_ptr != nullptr && front_blocks > 0 && lane_blocks > 0;
-  if (split) {
-    if ((e = hipEventRecord(fork, st)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return e;
-    if (mode == 0)
-      hipLaunchKernelGGL((project_fast_rows_kernel<0>), dim3(front_blocks), dim3(64), 0, side, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, front_queue, seed, first, pool, pool_count, mode, order, split_ptr);
-    else
-      hipLaunchKernelGGL((project_fast_rows_kernel<1>), dim3(front_blocks), dim3(64), 0, side, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, front_queue, seed, first, pool, pool_count, mode, order, split_ptr);
-    if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
+  unsigned long long *count = queue + kFastQueues, *lat_tickets = queue + kFastQueues + 1;
+  const bool both = pair_blocks > 0 && latency_blocks > 0;
+  if (pair_blocks > 0) {
+#define CCMP_LAUNCH_PAIR(STOCK, TWIN)                                                                                                  \
+  hipLaunchKernelGGL((project_pair_kernel<STOCK, TWIN>), dim3(pair_blocks), dim3(64), 0, st, *K, mode | (mode << 4), q_in, q_out, ok, iters, \
+                     q_ambient, (unsigned long long)B, queue, seed, first, both ? pool : nullptr, count, dump_below)
+    if (K->twin_arms) CCMP_LAUNCH_PAIR(true, true);
+    else if (K->stock) CCMP_LAUNCH_PAIR(true, false);
+    else CCMP_LAUNCH_PAIR(false, false);
+#undef CCMP_LAUNCH_PAIR
   }
-  const unsigned int *lane_order = split ? order : nullptr, *lane_split = split ? split_ptr : nullptr;
-  if (lane_blocks > 0) {
-#define CCMP_LAUNCH_FAST(MODE, STOCK)                                                                                                \
-  hipLaunchKernelGGL((project_fast_kernel<MODE, STOCK>), dim3(lane_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient, \
-                     (unsigned long long)B, queue, seed, first, pool, pool_count, cap_iter, lane_order, lane_split)
-    if (mode == 0) {
-      if (K->stock) CCMP_LAUNCH_FAST(0, true);
-      else CCMP_LAUNCH_FAST(0, false);
-    } else {
-      if (K->stock) CCMP_LAUNCH_FAST(1, true);
-      else CCMP_LAUNCH_FAST(1, false);
-    }
-#undef CCMP_LAUNCH_FAST
-    if (split && (e = hipStreamWaitEvent(st, join, 0)) != hipSuccess) return e;
-    if (pool != nullptr && rows_blocks > 0) // the pool's fill count is read on the device: surplus waves exit at once
-      hipLaunchKernelGGL((project_fast_rows_kernel<2>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode, nullptr, nullptr);
-  } else {
-    if (mode == 0)
-      hipLaunchKernelGGL((project_fast_rows_kernel<0>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode, nullptr, nullptr);
+  if (latency_blocks > 0) {
+    // srcmode: low nibble = where the samples come from (2: the pool), high nibble = the call's mode (a sample of a fused
+    // sampleUniform is wrapped by whichever kernel finishes it)
+    const int srcmode = (both ? 2 : mode) | (mode << 4);
+    if (K->base_diag == 3)
+      hipLaunchKernelGGL((project_row16_kernel<true>), dim3(latency_blocks), dim3(64), 0, st, *K, srcmode, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, lat_tickets, seed, first, pool, count);
     else
-      hipLaunchKernelGGL((project_fast_rows_kernel<1>), dim3(rows_blocks), dim3(64), 0, st, *K, q_in, q_out, ok, iters, q_ambient,
-                         (unsigned long long)B, rows_queue, seed, first, pool, pool_count, mode, nullptr, nullptr);
+      hipLaunchKernelGGL((project_row16_kernel<false>), dim3(latency_blocks), dim3(64), 0, st, *K, srcmode, q_in, q_out, ok, iters, q_ambient,
+                         (unsigned long long)B, lat_tickets, seed, first, pool, count);
   }
   return hipGetLastError();
 }

@@ -350,11 +350,15 @@ CCMP_HD uint64_t splitmix64(uint64_t z)
   return z ^ (z >> 31);
 }
 /* dimension j of ambient sample `index`: RNG::uniformReal(low, high) = (high-low)*u + low */
-CCMP_HD double ambient_uniform(const ccmp_consts &K, uint64_t seed, uint64_t index, int j)
+CCMP_HD double ambient_uniform_at(const ccmp_consts &K, uint64_t seed, uint64_t index, int j, int joint /* = j % 7 */)
 {
   uint64_t r = splitmix64(seed ^ (index * 14ULL + (uint64_t)j));
   double u = (double)(r >> 11) * 1.1102230246251565e-16; /* 2^-53 */
-  return CCMP_FMA(K.span[j % 7], u, K.lb[j % 7]);
+  return CCMP_FMA(K.span[joint], u, K.lb[joint]);
+}
+CCMP_HD double ambient_uniform(const ccmp_consts &K, uint64_t seed, uint64_t index, int j)
+{
+  return ambient_uniform_at(K, seed, index, j, j % 7);
 }
 
 /* RealVectorStateSampler::sampleUniformNear: uniformReal(max(low, near-d), min(high, near+d)) */

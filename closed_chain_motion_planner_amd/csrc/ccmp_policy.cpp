@@ -46,15 +46,9 @@ const OptionDesc kOptions[] = {
     OPT("fd_split_samples", fd_split_samples, kLongLong, -1, 0x7fffffffl, 0, "samples of the front at most (-1: four per CU up to 24576 samples, three to four above; 0 = one per block)"),
     OPT("fd_split_group_cut", fd_split_group_cut, kInt, -1, 8, 0, "throughput wavefronts per CU left out for the front's blocks (-1: 3 up to 24576 samples, 2 above)"),
     // projector, analytic mode
-    OPT("analytic_small_batch", analytic_small_batch, kSize, 0, LONG_MAX, 0, "analytic mode: at or below, the six-lanes-per-sample kernel alone"),
-    OPT("analytic_cap", analytic_cap, kInt, 0, 65535, 0, "analytic mode: samples past this many iterations leave the one-lane kernel for the six-lane kernel (0 = never)"),
-    OPT("analytic_handover_max", analytic_handover_max, kSize, 0, LONG_MAX, 0, "analytic mode: that hand-over for batches up to this size"),
-    OPT("analytic_split", analytic_split, kInt, 0, 1, 0, "analytic mode: 1 = scout order + six-lane kernel beside the one-lane kernel for large batches"),
-    OPT("analytic_split_min", analytic_split_min, kSize, 0, LONG_MAX, 0, "... from this many samples"),
-    OPT("analytic_split_max", analytic_split_max, kSize, 0, LONG_MAX, 0, "... up to this many"),
-    OPT("analytic_split_pred", analytic_split_pred, kInt, 1, 1023, 0, "... samples predicted past this many iterations go to the six-lane kernel"),
-    OPT("analytic_split_front", analytic_split_front, kInt, 1, 512, 0, "... which gets this many wavefronts"),
-    OPT("analytic_split_cap", analytic_split_cap, kInt, 1, 65535, 0, "... and the one-lane kernel hands over past this many iterations"),
+    OPT("analytic_small_batch", analytic_small_batch, kSize, 0, LONG_MAX, 0, "analytic mode: at or below, the sixteen-lanes-per-sample latency kernel alone"),
+    OPT("analytic_waves_per_cu", analytic_waves_per_cu, kInt, 1, 12, 0, "analytic mode: persistent wavefronts of the lane-pair kernel per CU"),
+    OPT("analytic_handover", analytic_handover, kInt, 0, 32, 0, "analytic mode: a wavefront of the lane-pair kernel whose tickets are gone hands over to the latency kernel once it holds at most this many samples (0 = never: one launch)"),
     // FP32 scouts
     OPT("scout_pairs", scout_pairs, kInt, 0, 1, 0, "1 = two lanes per sample / edge, one arm each, where lanes are plentiful (stock twin arms)"),
     OPT("scout_pair_blocks_per_cu", scout_pair_blocks_per_cu, kInt, 1, 64, 0, "... projector: up to 128 x this x CUs samples"),
@@ -211,38 +205,31 @@ FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order)
   return pl;
 }
 
-// Analytic mode.  One sample per lane (one wavefront per SIMD) is the throughput kernel; it runs a sample at ~7 us per iteration
-// whatever the occupancy, so its longest sample bounds the launch.  With twin stock arms the six-lanes-per-sample rows kernel
-// (~4 us per iteration, 2.5x the SIMD-cycles per sample-iteration) takes small batches alone and, for mid-size batches, the
-// samples that pass analytic_cap iterations; large batches: scout order, the predicted-longest on the rows kernel beside it.
-AnalyticPlan plan_analytic_batch(const ccmp_ctx *ctx, size_t B, bool twin_arms)
+// Analytic mode (ccmp_kernels_fast.hip).  Throughput: one sample per lane pair, 32 per wavefront, three wavefronts per SIMD.  A
+// wavefront alone on its SIMD pays ~4.6 cycles per instruction whatever it holds, so a Newton round there lasts 4.2 us and a call
+// would end on wavefronts that hold one or two long samples each: once the tickets are gone a wavefront that holds at most
+// analytic_handover samples hands them over (x, index, counters) to the sixteen-lanes-per-sample latency kernel launched behind
+// (2.7 us per round, four samples per wavefront), which also takes small batches alone.  (Round 6 measured and dropped: a cap on
+// the iterations a sample does in the lane-pair kernel, a second lane-pair generation in between — DESIGN_experiments.md §13.)
+AnalyticPlan plan_analytic_batch(const ccmp_ctx *ctx, size_t B)
 {
   AnalyticPlan pl;
-  pl.lane_blocks = projector_blocks(ctx, B, 64, 4);
-  const size_t rows_cap = (size_t)ctx->num_cus * 8; // waves of the rows kernel: two per SIMD (16.5 KB of LDS each)
-  if (twin_arms && ctx->analytic_split && ctx->analytic_cap > 0 && ctx->lpt > 0 && !ctx->order && B >= ctx->analytic_split_min &&
-      B <= ctx->analytic_split_max && B < 0xffffffffull) {
-    pl.kind = AnalyticPlan::Split;
-    // the front kernel gets analytic_split_front wavefronts, one SIMD each (a one-lane wave fills a SIMD's registers, so the
-    // one-lane kernel is launched that many wavefronts short); ten samples per wavefront, one round
-    pl.front_blocks = ctx->analytic_split_front;
-    const int room = ctx->num_cus * 4 - pl.front_blocks;
-    if (pl.lane_blocks > room) pl.lane_blocks = room < 1 ? 1 : room;
-    pl.rows_blocks = (int)rows_cap;
-    pl.cap = ctx->analytic_split_cap;
+  const size_t lat_resident = (size_t)ctx->num_cus * 8; // the latency kernel: two wavefronts per SIMD, four samples per wavefront
+  auto lat_blocks = [&](size_t samples) {
+    const size_t w = (samples + 3) / 4;
+    return (int)(w < lat_resident ? (w < 1 ? 1 : w) : lat_resident); // (surplus wavefronts read the pool's fill count and exit at once)
+  };
+  if (B <= ctx->analytic_small_batch) { // the latency kernel alone
+    pl.latency_blocks = lat_blocks(B);
     return pl;
   }
-  if (!twin_arms || ctx->analytic_cap <= 0 || (B > ctx->analytic_handover_max && B > ctx->analytic_small_batch)) return pl; // LaneOnly
-  if (B <= ctx->analytic_small_batch) {
-    pl.kind = AnalyticPlan::RowsOnly;
-    const size_t want = (B + 9) / 10;
-    pl.lane_blocks = 0;
-    pl.rows_blocks = (int)(want < rows_cap ? want : rows_cap);
-    return pl;
+  const size_t resident = (size_t)ctx->num_cus * (size_t)ctx->analytic_waves_per_cu, want = (B + 31) / 32;
+  pl.pair_blocks = (int)(want < resident ? want : resident);
+  if (ctx->analytic_handover > 0) {
+    pl.dump = ctx->analytic_handover;
+    pl.pool_records = (size_t)pl.pair_blocks * (size_t)pl.dump;
+    pl.latency_blocks = lat_blocks(pl.pool_records);
   }
-  pl.kind = AnalyticPlan::LaneWithHandover;
-  pl.rows_blocks = (int)rows_cap;
-  pl.cap = ctx->analytic_cap;
   return pl;
 }
 
@@ -386,21 +373,15 @@ int ccmp_ctx_describe(const ccmp_ctx *ctx_in, int call_kind, size_t n, char *buf
       break;
     }
     case CCMP_CALL_PROJECT_ANALYTIC: {
-      const AnalyticPlan pl = plan_analytic_batch(ctx, n, true);
-      L.add("project (analytic mode, twin stock arms) B=%zu: ", n);
-      switch (pl.kind) {
-        case AnalyticPlan::LaneOnly: L.add("project_fast_kernel one sample per lane x %d wavefronts", pl.lane_blocks); break;
-        case AnalyticPlan::RowsOnly: L.add("six-lanes-per-sample kernel alone x %d wavefronts", pl.rows_blocks); break;
-        case AnalyticPlan::LaneWithHandover:
-          L.add("one-lane kernel x %d wavefronts, samples past %d iterations to the six-lane kernel (%d wavefronts)", pl.lane_blocks, pl.cap, pl.rows_blocks);
-          break;
-        case AnalyticPlan::Split:
-          L.add("FP32 scout order; samples predicted > %d iterations on %d six-lane wavefronts beside the one-lane kernel x %d, hand-over past %d",
-                ctx->analytic_split_pred, pl.front_blocks, pl.lane_blocks, pl.cap);
-          break;
-      }
-      L.add(" [analytic_small_batch=%zu analytic_handover_max=%zu analytic_split=%d:%zu..%zu]", ctx->analytic_small_batch, ctx->analytic_handover_max,
-            ctx->analytic_split, ctx->analytic_split_min, ctx->analytic_split_max);
+      const AnalyticPlan pl = plan_analytic_batch(ctx, n);
+      L.add("project (analytic mode) B=%zu: ", n);
+      if (pl.pair_blocks > 0) {
+        L.add("project_pair_kernel (one sample per lane pair) x %d wavefronts", pl.pair_blocks);
+        if (pl.latency_blocks > 0)
+          L.add(", each handing over once the tickets are gone and it holds <= %d samples, then project_row16_kernel (sixteen lanes per sample) x %d wavefronts",
+                pl.dump, pl.latency_blocks);
+      } else L.add("project_row16_kernel (sixteen lanes per sample) alone x %d wavefronts", pl.latency_blocks);
+      L.add(" [analytic_small_batch=%zu analytic_waves_per_cu=%d analytic_handover=%d]", ctx->analytic_small_batch, ctx->analytic_waves_per_cu, ctx->analytic_handover);
       break;
     }
     case CCMP_CALL_GEODESIC:

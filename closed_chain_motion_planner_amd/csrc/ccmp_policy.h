@@ -32,11 +32,12 @@ FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order);
 
 /* an analytic-mode projector batch */
 struct AnalyticPlan {
-  enum Kind { LaneOnly, RowsOnly, LaneWithHandover, Split } kind = LaneOnly;
-  int lane_blocks = 0, rows_blocks = 0, front_blocks = 0;
-  int cap = 0; // iterations past which the one-lane kernel hands a sample over
+  int pair_blocks = 0;      // wavefronts of project_pair_kernel (one sample per lane pair); 0: the latency kernel alone
+  int latency_blocks = 0;   // wavefronts of project_row16_kernel (sixteen lanes per sample) behind it, or alone; 0: none
+  int dump = 0;             // a wavefront of the lane-pair kernel hands over once its tickets are gone and it holds at most this many samples
+  size_t pool_records = 0;  // capacity that hand-over needs
 };
-AnalyticPlan plan_analytic_batch(const ccmp_ctx *ctx, size_t B, bool twin_arms);
+AnalyticPlan plan_analytic_batch(const ccmp_ctx *ctx, size_t B);
 
 /* an extend-step call */
 struct GeoPlan {

@@ -54,6 +54,36 @@ __device__ __forceinline__ void solve_minnorm(const double *J /*28, registers*/,
   for (int j = 0; j < 14; j++) dx[j] = CCMP_FMA(k1, r1[j], k0 * r0[j]);
 }
 
+// The analytic mode's step (oracle/ccmp_oracle.c: orc_solve_gram — same operations, same order): dx = J^T (J J^T)^-1 f
+// through the 2x2 Gram matrix [[a, b], [b, d]] in closed form: dx_j = y1 J1_j + y0 J0_j.  `false` where the two rows are
+// nearly parallel (det / (a d) = sin^2 of their angle <= 2^-20) or something is NaN: solve_minnorm takes over there.
+__device__ __forceinline__ bool gram_coeffs(double a, double d, double b, double f0, double f1, double &y0, double &y1)
+{
+  const double det = CCMP_FMA(a, d, -(b * b));
+  const bool well = det > (a * d) * 9.5367431640625e-07; // 2^-20
+  const double inv = 1.0 / det;
+  y0 = CCMP_FMA(d, f0, -(b * f1)) * inv;
+  y1 = CCMP_FMA(a, f1, -(b * f0)) * inv;
+  return well;
+}
+// the three Gram sums of a full 2x14 Jacobian held by one lane: each arm's seven columns summed from zero, the two partial
+// sums added (ccmp_kernels_fast.hip's lane-pair kernel holds one arm per lane)
+__device__ __forceinline__ void gram_sums(const double *J /*28*/, double &a, double &d, double &b)
+{
+  double pa[2], pd[2], pb[2];
+#pragma unroll
+  for (int arm = 0; arm < 2; arm++) {
+    double sa = 0.0, sd = 0.0, sb = 0.0;
+#pragma unroll
+    for (int j = 7 * arm; j < 7 * arm + 7; j++) {
+      sa = CCMP_FMA(J[j], J[j], sa);
+      sd = CCMP_FMA(J[14 + j], J[14 + j], sd);
+      sb = CCMP_FMA(J[j], J[14 + j], sb);
+    }
+    pa[arm] = sa; pd[arm] = sd; pb[arm] = sb;
+  }
+  a = pa[0] + pa[1]; d = pd[0] + pd[1]; b = pb[0] + pb[1];
+}
 
 } /* namespace ccmp */
 #endif

@@ -182,17 +182,10 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *                                                            0 = one per block)
  *   "fd_split_group_cut"            -1        -1..8         throughput wavefronts per CU left out for the front's blocks (-1: 3 up to 24576 samples,
  *                                                           2 above)
- *   "analytic_small_batch"          16384     0..max        analytic mode: at or below, the six-lanes-per-sample kernel alone
- *   "analytic_cap"                  96        0..65535      analytic mode: samples past this many iterations leave the one-lane kernel for the six-
- *                                                           lane kernel (0 = never)
- *   "analytic_handover_max"         131072    0..max        analytic mode: that hand-over for batches up to this size
- *   "analytic_split"                1         0..1          analytic mode: 1 = scout order + six-lane kernel beside the one-lane kernel for large
- *                                                           batches
- *   "analytic_split_min"            100000    0..max        ... from this many samples
- *   "analytic_split_max"            300000    0..max        ... up to this many
- *   "analytic_split_pred"           90        1..1023       ... samples predicted past this many iterations go to the six-lane kernel
- *   "analytic_split_front"          128       1..512        ... which gets this many wavefronts
- *   "analytic_split_cap"            160       1..65535      ... and the one-lane kernel hands over past this many iterations
+ *   "analytic_small_batch"          8192      0..max        analytic mode: at or below, the sixteen-lanes-per-sample latency kernel alone
+ *   "analytic_waves_per_cu"         12        1..12         analytic mode: persistent wavefronts of the lane-pair kernel per CU
+ *   "analytic_handover"             8         0..32         analytic mode: a wavefront of the lane-pair kernel whose tickets are gone hands over to
+ *                                                           the latency kernel once it holds at most this many samples (0 = never: one launch)
  *   "scout_pairs"                   1         0..1          1 = two lanes per sample / edge, one arm each, where lanes are plentiful (stock twin
  *                                                           arms)
  *   "scout_pair_blocks_per_cu"      1         1..64         ... projector: up to 128 x this x CUs samples

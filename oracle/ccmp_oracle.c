@@ -530,6 +530,36 @@ void orc_solve_minnorm(const double J[28], const double f[2], double dx[14])
   for (int j = 0; j < 14; j++) dx[j] = FMA(k1, r1[j], k0 * r0[j]);
 }
 
+/* The analytic mode's step (jacobian_mode = ORC_JAC_ANALYTIC; this library's own extension): the same
+ * minimum-norm solution dx = J^T (J J^T)^-1 f through the 2x2 Gram matrix in closed form, operation for operation in the
+ * order csrc/ccmp_kernels_fast.hip runs it — each arm's seven columns summed from zero (one lane per arm there), the two
+ * partial sums added — wherever the two rows are not nearly parallel: det / (a d) = sin^2 of the angle between them, and
+ * above 2^-20 the closed form's cancellation costs at most ~1e-10 relative.  Below that (or on a NaN) the SVD-equivalent
+ * routine above takes over, so that rank handling stays what Eigen's JacobiSVD::solve gives the reference. */
+void orc_solve_gram(const double J[28], const double f[2], double dx[14])
+{
+  double pa[2], pd[2], pb[2];
+  for (int arm = 0; arm < 2; arm++) {
+    double a = 0.0, d = 0.0, b = 0.0;
+    for (int j = 7 * arm; j < 7 * arm + 7; j++) {
+      a = FMA(J[j], J[j], a);
+      d = FMA(J[14 + j], J[14 + j], d);
+      b = FMA(J[j], J[14 + j], b);
+    }
+    pa[arm] = a; pd[arm] = d; pb[arm] = b;
+  }
+  const double a = pa[0] + pa[1], d = pd[0] + pd[1], b = pb[0] + pb[1];
+  const double det = FMA(a, d, -(b * b));
+  if (!(det > (a * d) * 9.5367431640625e-07)) { /* 2^-20 */
+    orc_solve_minnorm(J, f, dx);
+    return;
+  }
+  const double inv = 1.0 / det;
+  const double y0 = FMA(d, f[0], -(b * f[1])) * inv;
+  const double y1 = FMA(a, f[1], -(b * f[0])) * inv;
+  for (int j = 0; j < 14; j++) dx[j] = FMA(y1, J[14 + j], y0 * J[j]);
+}
+
 /* ---- the projector --------------------------------------------------------------------------- */
 /* KinematicChainConstraint::jointValid, ConstraintFunction.h:43-55 */
 int orc_joint_valid(const orc_problem *P, const double q[14])
@@ -555,9 +585,13 @@ int orc_project(const orc_problem *P, double x[14], int32_t *iters)
   orc_function(P, x, f);
   while (((norm1 = (double)(f[0] > P->tol_pos)) != 0.0 || (norm2 = f[1]) > P->tol_rot) &&
          iter++ < (unsigned int)P->max_iter) {
-    if (P->jacobian_mode == ORC_JAC_ANALYTIC) orc_jacobian_analytic(P, x, J);
-    else orc_jacobian_fd(P, x, J);
-    orc_solve_minnorm(J, f, dx);
+    if (P->jacobian_mode == ORC_JAC_ANALYTIC) {
+      orc_jacobian_analytic(P, x, J);
+      orc_solve_gram(J, f, dx);
+    } else {
+      orc_jacobian_fd(P, x, J);
+      orc_solve_minnorm(J, f, dx);
+    }
     for (int i = 0; i < 14; i++) x[i] = FMA(-P->step, dx[i], x[i]); /* x -= 0.30*dx */
     orc_function(P, x, f);
     updates++;

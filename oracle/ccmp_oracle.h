@@ -125,6 +125,9 @@ void orc_jacobian_analytic(const orc_problem *P, const double x[14], double J[28
 /* the same derivative formulated in world coordinates: independent cross-check (agrees to ~1e-13, not bitwise) */
 void orc_jacobian_analytic_world(const orc_problem *P, const double x[14], double J[28]);
 void orc_solve_minnorm(const double J[28], const double f[2], double dx[14]);
+/* the analytic mode's step: the same minimum-norm solution through the 2x2 Gram matrix in closed form,
+ * orc_solve_minnorm where the two rows are nearly parallel */
+void orc_solve_gram(const double J[28], const double f[2], double dx[14]);
 int orc_project(const orc_problem *P, double x[14], int32_t *iters); /* 1 = true, 0 = false */
 int orc_joint_valid(const orc_problem *P, const double x[14]);
 int orc_is_satisfied(const orc_problem *P, const double x[14]);

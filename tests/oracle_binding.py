@@ -99,6 +99,7 @@ class Oracle:
         lib.orc_jacobian_analytic.argtypes = [pp, dp, dp]
         lib.orc_jacobian_analytic_world.argtypes = [pp, dp, dp]
         lib.orc_solve_minnorm.argtypes = [dp, dp, dp]
+        lib.orc_solve_gram.argtypes = [dp, dp, dp]
         lib.orc_project.argtypes = [pp, dp, C.POINTER(C.c_int32)]
         lib.orc_project.restype = C.c_int
         lib.orc_joint_valid.argtypes = [pp, dp]
@@ -214,6 +215,13 @@ class Oracle:
         f = np.ascontiguousarray(f, dtype=np.float64)
         dx = np.empty(14)
         self.lib.orc_solve_minnorm(_dptr(J), _dptr(f), _dptr(dx))
+        return dx
+
+    def solve_gram(self, J, f):
+        J = np.ascontiguousarray(J, dtype=np.float64).reshape(28)
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        dx = np.empty(14)
+        self.lib.orc_solve_gram(_dptr(J), _dptr(f), _dptr(dx))
         return dx
 
     def project(self, P, x):

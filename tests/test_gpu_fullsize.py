@@ -162,10 +162,9 @@ def test_default_policy_at_mid_sizes_is_bitwise_the_oracle(gpu_ctx, oracle_det, 
 
 @pytest.mark.parametrize("obj,n", [("Wine_Bottle", 262144), ("stefan", 131072), ("Wine_Bottle", 70000)])
 def test_analytic_default_policy_at_full_size_is_bitwise_the_oracle(gpu_ctx, oracle_det, obj, n):
-    """analytic mode under its default policy at the sizes where the split launch is on (100 000 .. 300 000 samples: scout
-    order, six-lane kernel on the side stream beside the one-lane kernel, hand-over pass behind both) and just below it
-    (hand-over only) — every sample against the oracle's analytic mode, bit for bit, twice (the second launch reuses
-    the queues, the pool and the events of the first)"""
+    """analytic mode under its default policy (lane-pair kernel, hand-over of the last samples to the latency kernel) at full
+    size — every sample against the oracle's analytic mode, bit for bit, twice (the second launch reuses the ticket words and
+    the pool of the first)"""
     import torch
 
     c = _constraint(obj, gpu_ctx, mode=1)

@@ -396,49 +396,46 @@ def test_analytic_mode_bitwise(gpu_ctx, oracle_det, obj, B):
     assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
 
 
-@pytest.mark.parametrize("cap,small,split_pred", [(0, 0, 0), (20, 0, 0), (64, 0, 0), (96, 1 << 30, 0), (96, 0, 90), (40, 0, 25), (96, 0, 1)])
-def test_analytic_schedules_are_bitwise_identical(gpu_ctx, oracle_det, cap, small, split_pred):
-    """analytic mode's kernels: the one-lane kernel alone / with hand-over of the samples past `cap` iterations to the
-    six-lanes-per-sample kernel (lanes hand over at different times: the refill after a hand-over is what once lost
-    samples) / the six-lane kernel alone with several samples per group / the split launch (scout order, the samples
-    predicted past `split_pred` iterations on the six-lane kernel on the side stream beside the one-lane kernel, which
-    takes the rest longest first and still hands over past `cap`; split_pred 1 = the front kernel is offered everything
-    and takes its capacity) — all bit-identical to the oracle's analytic mode"""
+_ANALYTIC_OPTIONS = ("analytic_small_batch", "analytic_waves_per_cu", "analytic_handover")
+
+
+def _restore_analytic_options(ctx):
+    for name in _ANALYTIC_OPTIONS:
+        ctx.set_option(name, _lib.get_option(None, name))
+
+
+@pytest.mark.parametrize("small,waves,handover", [(1 << 30, 12, 8), (0, 12, 0), (0, 12, 8), (0, 12, 32), (0, 12, 1), (0, 3, 16), (0, 1, 31)])
+def test_analytic_schedules_are_bitwise_identical(gpu_ctx, oracle_det, small, waves, handover):
+    """analytic mode's two kernels under every shape of a call: the sixteen-lanes-per-sample latency kernel alone (`small`); the
+    lane-pair kernel alone (hand-over 0); the lane-pair kernel handing its last samples over at the loop top (x, index,
+    counters) to the latency kernel once a wavefront's tickets are gone and it holds at most `handover` of them — 32: as soon
+    as the tickets are gone, 1: the last sample of a wavefront only; with few wavefronts per CU (every wavefront refills many
+    times, every ticket word runs dry early) — all bit-identical to the oracle's analytic mode"""
     import torch
 
     c = _constraint("stefan", gpu_ctx, mode=1)
     P = _oracle_problem(oracle_det, c)
-    B = 60000  # > 20480 group slots of the six-lane kernel: its groups refill
+    B = 60000
     q = c.ambient_uniform_batch(0xA9, 0, B)
     q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q.cpu().numpy(), NCPU)
-    gpu_ctx.set_option("analytic_cap", cap)
-    gpu_ctx.set_option("analytic_small_batch", small)
-    gpu_ctx.set_option("analytic_split", 1 if split_pred else 0)
-    gpu_ctx.set_option("analytic_split_min", 0)
-    if split_pred:
-        gpu_ctx.set_option("analytic_split_pred", split_pred)
-        gpu_ctx.set_option("analytic_split_cap", cap)  # 40 with split_pred 25: the one-lane kernel of the split launch hands over too
+    for name, v in zip(_ANALYTIC_OPTIONS, (small, waves, handover)):
+        gpu_ctx.set_option(name, v)
     try:
+        text = gpu_ctx.describe(_lib.CALL_PROJECT_ANALYTIC, B)
+        assert ("alone" in text) == bool(small) and ("then project_row16_kernel" in text) == bool(handover and not small)
         out = torch.full_like(q, 777.0)
         _, ok, it = c.project_batch(q, out=out)
         torch.cuda.synchronize()
-        if split_pred:  # the fused sampler through the same launch shape
-            qs, oks, its, _ = c.sample_project_batch(0xA8, 5, 30000)
-            torch.cuda.synchronize()
+        qs, oks, its, _ = c.sample_project_batch(0xA8, 5, 30000)  # the fused sampler through the same launch shape
+        torch.cuda.synchronize()
     finally:
-        gpu_ctx.set_option("analytic_cap", 96)
-        gpu_ctx.set_option("analytic_small_batch", _lib.get_option(None, "analytic_small_batch"))
-        gpu_ctx.set_option("analytic_split", 1)
-        gpu_ctx.set_option("analytic_split_min", 100000)
-        gpu_ctx.set_option("analytic_split_pred", 90)
-        gpu_ctx.set_option("analytic_split_cap", 160)
+        _restore_analytic_options(gpu_ctx)
     assert np.array_equal(out.cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))
     assert np.array_equal(ok.cpu().numpy(), ok_cpu) and np.array_equal(it.cpu().numpy().astype(np.int32), it_cpu)
     assert it_cpu.max() == 250 and (it_cpu < 20).any()
-    if split_pred:
-        e_q, e_ok, e_it = oracle_det.sample_project_batch(P, 0xA8, 5, 30000, NCPU)
-        assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
-        assert np.array_equal(its.cpu().numpy().astype(np.int32), e_it)
+    e_q, e_ok, e_it = oracle_det.sample_project_batch(P, 0xA8, 5, 30000, NCPU)
+    assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
+    assert np.array_equal(its.cpu().numpy().astype(np.int32), e_it)
 
 
 def test_analytic_mode_statistics(gpu_ctx, oracle_det):
@@ -494,17 +491,18 @@ def test_non_finite_and_out_of_range_inputs_terminate(gpu_ctx, oracle_det):
         same = (out.view(np.uint64) == q_cpu.view(np.uint64)) | (np.isnan(out) & np.isnan(q_cpu))
         assert same.all() and np.array_equal(ok, ok_cpu) and np.array_equal(it.astype(np.int32), it_cpu)
     assert not c.isSatisfied(q[3]) and not c.isSatisfied(q[17])  # f.allFinite() is part of isSatisfied
-    # the analytic mode's kernels (six lanes per sample at this size; one lane per sample) terminate the same way
+    # the analytic mode's kernels terminate the same way
     c.setJacobianMode(1)
     Pa = _oracle_problem(oracle_det, c)
     qa_cpu, oka_cpu, ita_cpu = oracle_det.project_batch(Pa, q, 4)
-    for small in (1 << 30, 0):
+    for small, handover in ((1 << 30, 8), (0, 0), (0, 32)):  # the latency kernel alone; the lane-pair kernel alone; a NaN sample handed over
         gpu_ctx.set_option("analytic_small_batch", small)
+        gpu_ctx.set_option("analytic_handover", handover)
         try:
             out, ok, it = c.project_batch(torch.as_tensor(q).cuda())
             torch.cuda.synchronize()
         finally:
-            gpu_ctx.set_option("analytic_small_batch", _lib.get_option(None, "analytic_small_batch"))
+            _restore_analytic_options(gpu_ctx)
         out, ok, it = out.cpu().numpy(), ok.cpu().numpy(), it.cpu().numpy()
         same = (out.view(np.uint64) == qa_cpu.view(np.uint64)) | (np.isnan(out) & np.isnan(qa_cpu))
         assert same.all() and np.array_equal(ok, oka_cpu) and np.array_equal(it.astype(np.int32), ita_cpu)

@@ -40,10 +40,10 @@ def _capture_and_replay(work, replays=3):
     return ref
 
 
-@pytest.mark.parametrize("mode,B", [(0, 1), (0, 4096), (0, 40000), (0, 70000), (1, 30000), (1, 120000)])
+@pytest.mark.parametrize("mode,B", [(0, 1), (0, 4096), (0, 40000), (0, 70000), (1, 3000), (1, 120000)])
 def test_projector_calls_replay_from_a_graph(gpu_ctx, mode, B):
     """single state, latency kernel with its queue, scout + throughput kernel + hand-over (occupancy-driven and at once),
-    analytic mode with hand-over and with the split launch on the side stream"""
+    analytic mode: the latency kernel alone, the lane-pair kernel with its hand-over"""
     c = _constraint("Wine_Bottle", gpu_ctx, mode=mode)
 
     def work():
@@ -119,7 +119,7 @@ def test_bulk_extend_call_replays_from_a_graph(gpu_ctx):
 def test_two_contexts_on_two_streams_run_side_by_side(gpu_ctx):
     """"use one context per stream for concurrency" (include/ccmp.h): two contexts of one device, each on its own stream,
     launched back to back without synchronising in between — reference arithmetic with scout and hand-over on one, the
-    analytic split launch (which brings its own side stream) on the other — give what they give alone"""
+    analytic mode's two kernels on the other — give what they give alone"""
     import torch
     from closed_chain_motion_planner_amd import Context
 

@@ -123,62 +123,34 @@ def geodesic(argv):
               % (E, "; ".join(row), n.clamp(max=cap).float().mean().item(), cap, (okg == 1).float().mean().item(), its.float().mean().item()), flush=True)
 
 
+_ANALYTIC = ("analytic_small_batch", "analytic_waves_per_cu", "analytic_handover")
+
+
 def analytic(argv):
+    """analytic mode: run time against batch size — the latency kernel alone ('lat'), the lane-pair kernel alone (h0) and with
+    its hand-over to the latency kernel at <= h samples per wavefront, for w wavefronts per CU; argv: sizes"""
     ctx = Context(0)
-    c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
-    c.setJacobianMode(1)
-    caps = [int(a) for a in argv] or [0, 32, 48, 64]
+    sizes_ = [int(a) for a in argv] or [1024, 4096, 8192, 16384, 32768, 65536, 262144, 2097152]
+    shapes = [(12, 0), (12, 4), (12, 8), (12, 12), (12, 16), (12, 24), (8, 8), (10, 8)]
     for obj in ("Wine_Bottle", "stefan"):
         c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
         c.setJacobianMode(1)
-        for B in (1024, 4096, 16384, 65536, 262144, 1048576):
+        for B in sizes_:
             q = c.ambient_uniform_batch(0xC3, 0, B)
             out = torch.empty_like(q)
             res = []
-            ctx.set_option("analytic_handover_max", 1 << 40)
-            for cap in caps:  # 0: one-lane kernel alone; else hand-over past `cap` iterations
-                ctx.set_option("analytic_cap", cap)
-                for small in ((0, 1 << 30) if cap == caps[-1] and B <= 65536 else (0,)):
-                    ctx.set_option("analytic_small_batch", small)
-                    ms = timed(lambda: c.project_batch(q, out=out), reps=5)
-                    res.append("%s %7.3f ms (%.3e/s)" % ("rows-only" if small else "cap%d" % cap, ms, B / ms * 1e3))
-            ctx.set_option("analytic_cap", 96)
-            ctx.set_option("analytic_small_batch", _lib.get_option(None, "analytic_small_batch"))
-            ctx.set_option("analytic_handover_max", 131072)
-            ms = timed(lambda: c.project_batch(q, out=out), reps=5)
-            print("analytic %s B=%-8d " % (obj, B) + "  ".join(res) + "  DEFAULT %7.3f ms (%.3e/s)" % (ms, B / ms * 1e3), flush=True)
-
-
-def split(argv):
-    """analytic mode, large batches: the split launch (scout order, six-lane kernel beside the one-lane kernel) against the
-    one-lane kernel alone / with hand-over, for several split thresholds"""
-    ctx = Context(0)
-    for obj in ("Wine_Bottle", "stefan"):
-        c = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
-        c.setJacobianMode(1)
-        for B in (131072, 262144, 393216):
-            q = c.ambient_uniform_batch(0xC3, 0, B)
-            out = torch.empty_like(q)
-            ctx.set_option("analytic_split_min", 0)
-            ctx.set_option("analytic_split_max", 1 << 40)
-            ctx.set_option("analytic_handover_max", 1 << 40)
+            if B <= 65536:
+                ctx.set_option("analytic_small_batch", 1 << 40)
+                res.append("lat %.3f" % timed(lambda: c.project_batch(q, out=out), reps=7))
             ctx.set_option("analytic_small_batch", 0)
-            res = []
-            ctx.set_option("analytic_split", 0)
-            for cap in (0, 96):
-                ctx.set_option("analytic_cap", cap)
-                res.append("nosplit cap%d %.3f" % (cap, timed(lambda: c.project_batch(q, out=out), reps=5)))
-            ctx.set_option("analytic_split", 1)
-            for pred, cap, front in ((90, 128, 64), (90, 128, 96), (90, 128, 128), (90, 128, 192), (80, 128, 128), (90, 160, 128), (96, 128, 128)):
-                ctx.set_option("analytic_split_pred", pred)
-                ctx.set_option("analytic_split_cap", cap)
-                ctx.set_option("analytic_split_front", front)
-                res.append("split p%d cap%d f%d %.3f" % (pred, cap, front, timed(lambda: c.project_batch(q, out=out), reps=5)))
-            print("%s B=%-8d " % (obj, B) + "  ".join(res), flush=True)
-    for name, v in (("analytic_split_min", 100000), ("analytic_split_max", 300000), ("analytic_handover_max", 131072),
-                    ("analytic_small_batch", 16384), ("analytic_cap", 96), ("analytic_split_pred", 90), ("analytic_split_front", 128),
-                    ("analytic_split_cap", 160)):
-        ctx.set_option(name, v)
+            for w, h in shapes:
+                ctx.set_option("analytic_waves_per_cu", w)
+                ctx.set_option("analytic_handover", h)
+                res.append("w%d h%d %.3f" % (w, h, timed(lambda: c.project_batch(q, out=out), reps=7)))
+            for name in _ANALYTIC:
+                ctx.set_option(name, _lib.get_option(None, name))
+            ms = timed(lambda: c.project_batch(q, out=out), reps=7)
+            print("analytic %s B=%-8d DEFAULT %7.3f ms (%.3e/s) | " % (obj, B, ms, B / ms * 1e3) + "  ".join(res), flush=True)
 
 
 def host(argv):
@@ -447,9 +419,9 @@ def run(argv):
     elif what.startswith("geodesic"):  # geodesic (16384 edges: bench.py's first pass), geodesic65536 (a bulk call) ...
         frm, to = near_edges(c, int(what[8:] or 16384))
         fn = lambda: c.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128)  # bench.py's first pass
-    elif what == "analytic":
+    elif what.startswith("analytic"):  # analytic (C3's batch), analytic4096, analytic2097152 ...
         c.setJacobianMode(1)
-        q = c.ambient_uniform_batch(0xC3, 0, 262144)
+        q = c.ambient_uniform_batch(0xC3, 0, int(what[8:] or 262144))
         fn = lambda: c.project_batch(q)
     elif what == "clearance":
         from closed_chain_motion_planner_amd.scene import ProxyValidityChecker
@@ -459,6 +431,10 @@ def run(argv):
         fn = lambda: sc.clearance_batch(q, 0.0)
     else:
         raise SystemExit(__doc__)
+    import os
+
+    for kv in filter(None, os.environ.get("CCMP_OPTS", "").split(",")):  # CCMP_OPTS=name=value,...: options of the context for this run
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     # >= 3 warm-up calls (the profile's summary drops their dispatches), then `reps` calls, each bracketed by HIP events on the
     # launch stream (a call that forks to the context's side stream joins it back before it returns, so the second event is behind
     # everything) and followed by a synchronise — the idle gap that tells two calls apart in the kernel trace.  The per-call times
@@ -482,7 +458,7 @@ def run(argv):
 
 
 if __name__ == "__main__":
-    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, split, host, sharded, afterload, sampler, soak, soak_resident, scout, clearance, run)}
+    cmds = {f.__name__: f for f in (sizes, single, geodesic, analytic, host, sharded, afterload, sampler, soak, soak_resident, scout, clearance, run)}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
     cmds[sys.argv[1]](sys.argv[2:])
