@@ -268,10 +268,10 @@ def cpu_baseline(obj, seed, gpu_check=None):
     t0 = time.perf_counter()
     O.project_batch(Pa, q, cores)
     wall_a = time.perf_counter() - t0
-    # in-run parity evidence: the det build of the oracle vs the GPU on the first 2048 samples of the batch
+    # in-run parity evidence: the det build of the oracle vs the GPU on the first 8192 samples of the batch (< 1 s on 16 threads)
     parity, vs_libm = None, None
     if gpu_check is not None:
-        m = 2048
+        m = 8192
         parity = det_parity(obj, gpu_check["problem"], gpu_check["q_in"][:m], gpu_check["q_out"][:m], gpu_check["ok"][:m],
                             gpu_check["iters"][:m], cores)
         # how far the GPU's results are from what the reference's libm gives — the glibc build timed
@@ -515,7 +515,7 @@ def main():
         return
 
     value = world * B * args.steps / elapsed
-    kernel = "project_fd_kernel+project_fd_flat_kernel+scout_kernel" if args.mode == "fd" else "project_fast_kernel"
+    kernel = "project_fd_kernel+project_fd_flat_kernel+scout_kernel" if args.mode == "fd" else "project_pair_kernel+project_row16_kernel"
     achieved_gbs = BYTES_PER_PROJECTION * B / (kms * 1e-3) / 1e9
     traffic, valu, executed, profile_kernel = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -659,7 +659,14 @@ def flatten_for_the_driver(line, B):
             "one_edge_check_motion_resident_us": get(sec, "single_project_c_abi", "one_edge_check_motion_resident_median_us"),
             "host_buffer_pageable_per_s": get(sec, "host_buffer", "pageable", "projections_per_s"),
             "host_buffer_pinned_per_s": get(sec, "host_buffer", "pinned", "projections_per_s"),
+            "c3_calibrated_per_s": get(sec, "c3_calibrated", "projections_per_s"),
+            "c3_calibrated_bitwise": get(sec, "c3_calibrated", "parity_vs_det_oracle", "bit_identical"),
+            "c3_calibrated_analytic_per_s": get(sec, "c3_calibrated", "analytic_projections_per_s"),
             "analytic_mode_per_s": sec.get("analytic_mode_projections_per_s"),
+            "analytic_bitwise": get(sec, "analytic_mode", "parity_vs_det_oracle", "bit_identical"),
+            "analytic_bitwise_samples": get(sec, "analytic_mode", "parity_vs_det_oracle", "samples"),
+            "analytic_mode_2m_per_s": get(sec, "analytic_mode_batch2097152", "projections_per_s"),
+            "analytic_mode_4096_per_s": get(sec, "analytic_mode_batch4096", "projections_per_s"),
             "proxy_clearance_states_per_s": get(sec, "proxy_clearance", "states_per_s"),
             "one_process_gpus": get(sec, "one_process", "gpus"),
             "one_process_direct_per_s": get(sec, "one_process", "direct", "projections_per_s"),
@@ -711,11 +718,12 @@ def secondary(args, c, ctx, B, torch, cfg_path):
         qo = torch.empty_like(qi)
         sec = timed(lambda: con.project_batch(qi, out=qo), reps)
         res = {"projections_per_s": b / sec, "ms": sec * 1e3}
-        if check and mode == CCMP_JAC_FD:
+        if check:  # reference arithmetic: against the det oracle; analytic mode: against the det oracle's analytic mode
+            m = 1024 if mode == CCMP_JAC_FD else 4096
             _, ok, it = con.project_batch(qi, out=qo)
             try:
-                res["parity_vs_det_oracle"] = det_parity(obj or args.obj, con.problem, qi[:1024].cpu().numpy(), qo[:1024].cpu().numpy(),
-                                                         ok[:1024].cpu().numpy(), it[:1024].cpu().numpy().astype("int32"), threads)
+                res["parity_vs_det_oracle"] = det_parity(obj or args.obj, con.problem, qi[:m].cpu().numpy(), qo[:m].cpu().numpy(),
+                                                         ok[:m].cpu().numpy(), it[:m].cpu().numpy().astype("int32"), threads)
             except Exception as e:
                 res["parity_vs_det_oracle"] = {"error": repr(e)}
             res["mean_newton_iters"] = float(it.to(torch.float64).mean().item())
@@ -1060,6 +1068,38 @@ def secondary(args, c, ctx, B, torch, cfg_path):
             res["parity_vs_det_oracle"] = {"error": repr(e)}
         return res
 
+    def c3_calibrated():
+        # C3 on CALIBRATED arms: PandaModel::initModel(dh) with DH offsets that differ per arm (src/kinematics/panda_rbdl.cpp:80-99;
+        # the reference has the call commented out at ConstrainedPlanningCommon.cpp:97) — the kernels' general instantiations
+        # (no exact zeros to skip, two sets of chain constants), checked against the det oracle on the problem's own bytes
+        import ctypes as C
+        from closed_chain_motion_planner_amd import _lib
+
+        cal = KinematicChainConstraint.from_yaml(cfg_path(args.obj), ctx=ctx)
+        for arm in (0, 1):
+            dh = (C.c_double * 28)(*[(1e-3 if arm == 0 else -7e-4) * ((5 * i + 3 * arm) % 7 - 3) for i in range(28)])
+            if _lib.lib().ccmp_set_calibration(C.byref(cal.problem), arm, dh) != 0:
+                raise RuntimeError("ccmp_set_calibration failed")
+        cal.setJacobianMode(CCMP_JAC_FD)
+        qi = cal.ambient_uniform_batch(0xC3, 0, B)
+        qo = torch.empty_like(qi)
+        sec = timed(lambda: cal.project_batch(qi, out=qo), 3)
+        _, ok, it = cal.project_batch(qi, out=qo)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_binding import Oracle
+
+        Od = Oracle("det")
+        Pd = Od.problem_from_bytes(bytes(cal.problem))  # a problem this bench modified after loading: adopted as bytes
+        m = 2048
+        qd, okd, itd = Od.project_batch(Pd, qi[:m].cpu().numpy(), threads)
+        res = {"projections_per_s": B / sec, "ms": sec * 1e3, "mean_newton_iters": float(it.to(torch.float64).mean().item()),
+               "parity_vs_det_oracle": {"samples": m, "bit_identical": bool(np.array_equal(qd.view(np.uint64), qo[:m].cpu().numpy().view(np.uint64))
+                                                                                 and np.array_equal(okd, ok[:m].cpu().numpy())
+                                                                                 and np.array_equal(itd, it[:m].cpu().numpy().astype("int32")))}}
+        cal.setJacobianMode(CCMP_JAC_ANALYTIC)
+        res["analytic_projections_per_s"] = B / timed(lambda: cal.project_batch(qi, out=qo), 3)
+        return res
+
     out = {}
     s4 = quick(c, main_mode, 4096, 10, check=True)
     s32 = quick(c, main_mode, 32768, 10)
@@ -1068,7 +1108,13 @@ def secondary(args, c, ctx, B, torch, cfg_path):
     out["batch32768_projections_per_s"] = s32["projections_per_s"]
     out["single_project_call_median_us"] = single_latency_us()
     out["single_project_c_abi"] = single_latency_c_abi_us()
-    out[("analytic" if args.mode == "fd" else "fd") + "_mode_projections_per_s"] = quick(c, other, B, 5)["projections_per_s"]
+    om = "analytic" if args.mode == "fd" else "fd"
+    so = quick(c, other, B, 5, check=True)
+    out[om + "_mode_projections_per_s"] = so["projections_per_s"]
+    out[om + "_mode"] = so
+    if other == CCMP_JAC_ANALYTIC:  # the fast mode where its tail is amortised (C3's batch ends on the serial chain of its longest samples) and at C2's size
+        out["analytic_mode_batch2097152"] = quick(c, other, 2097152, 3)
+        out["analytic_mode_batch4096"] = quick(c, other, 4096, 10)
     c.setJacobianMode(main_mode)
     # BASELINE configs[3]: stefan (arms left + top), the reference's tolerances and the tighter set the baseline asks for
     st = KinematicChainConstraint.from_yaml(cfg_path("stefan"), ctx=ctx)
@@ -1077,7 +1123,7 @@ def secondary(args, c, ctx, B, torch, cfg_path):
     out["stefan_batch%d_tol_5e-4_2.5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True, obj="stefan")
     out["discrete_geodesic"] = geodesic()
     out["proxy_clearance"] = proxy_clearance()
-    for name, fn in (("host_buffer", host_buffer), ("c1_dumbbell", c1_dumbbell)):
+    for name, fn in (("host_buffer", host_buffer), ("c1_dumbbell", c1_dumbbell), ("c3_calibrated", c3_calibrated)):
         try:
             out[name] = fn()
         except Exception as e:  # secondaries must not take the headline line down

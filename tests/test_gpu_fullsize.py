@@ -66,9 +66,9 @@ def test_full_batch_properties(gpu_ctx, oracle_det, obj, seed, tol, mean_lo, mea
             gpu_ctx.set_schedule(1)
             gpu_ctx.set_lpt(1)
         assert torch.equal(out_g, out) and torch.equal(ok_g, ok) and torch.equal(it_g, it), (sched, lpt)
-    # 6. spot-check 192 random samples against the oracle, bit for bit
+    # 6. spot-check 8 192 random samples against the oracle, bit for bit (< 1 s of the 16-thread oracle; 192 until round 6)
     rng = np.random.default_rng(1)
-    idx = np.sort(rng.choice(B, 192, replace=False))
+    idx = np.sort(rng.choice(B, 8192, replace=False))
     P = _oracle_problem(oracle_det, c)
     q_cpu, ok_cpu, it_cpu = oracle_det.project_batch(P, q[idx].cpu().numpy(), NCPU)
     assert np.array_equal(out[idx].cpu().numpy().view(np.uint64), q_cpu.view(np.uint64))

@@ -11,6 +11,11 @@
     1e-6 rad must be shown to be ill-conditioned — a last-bit perturbation of its endpoints moves the det oracle's own result
     by > 1e-7 rad — and is counted as a threshold flip when the iteration totals differ (SURVEY.md §7.4);
     a well-conditioned edge that differs fails the test.
+(3) The same two pins for the ANALYTIC fast mode (exact Jacobian, closed-form Gram step): the extend step exists in reference
+    arithmetic only inside the library, so the traversal is composed here from the reference's loop
+    (jy_ProjectedStateSpace.cpp:32-96: interpolate, the break tests, the state list — the oracle's interpolate / distance on the
+    host) around the GPU's analytic-mode `project` of every step, all edges of a step in one batch, through both of the
+    mode's kernels.
 """
 import numpy as np
 import pytest
@@ -30,15 +35,74 @@ def _gpu_geodesic(c, frm, to, maxs):
     return st.cpu().numpy(), n.cpu().numpy(), ok.cpu().numpy(), its.cpu().numpy()
 
 
+def _gpu_geodesic_stepwise(c, O, P, frm, to, maxs):
+    """discreteGeodesic(interpolate = true) of every pair with `project` on the GPU (whatever jacobian mode `c` is in), one batch
+    per step over the edges still under way; the loop around it is jy_ProjectedStateSpace.cpp:32-96 as oracle/ccmp_oracle.c:
+    orc_discrete_geodesic_ex states it, with the oracle's interpolate / distance"""
+    import torch
+
+    E = len(frm)
+    delta, lam = P.delta, P.lambda_
+    st = np.zeros((E, maxs, 14))
+    st[:, 0] = frm
+    n, its = np.ones(E, dtype=np.int64), np.zeros(E, dtype=np.int64)
+    dist = np.array([O.distance(frm[e], to[e]) for e in range(E)])
+    mx, total = dist * lam, np.zeros(E)
+    prev = np.array(frm, dtype=np.float64)
+    live = ~(dist <= delta)
+    while live.any():
+        idx = np.where(live)[0]
+        scratch = np.array([O.interpolate(prev[e], to[e], delta / dist[e]) for e in idx])
+        q, okp, itp = c.project_batch(torch.as_tensor(scratch).cuda())
+        q, okp, itp = q.cpu().numpy(), okp.cpu().numpy(), itp.cpu().numpy()
+        for k, e in enumerate(idx):
+            its[e] += int(itp[k])
+            live[e] = False  # every `break` below ends the edge
+            if not okp[k]:
+                continue
+            step = O.distance(prev[e], q[k])
+            if step > lam * delta:
+                continue
+            total[e] += step
+            if total[e] > mx[e]:
+                continue
+            nd = O.distance(q[k], to[e])
+            if nd >= dist[e]:
+                continue
+            assert n[e] < maxs, "state list too short for this test"
+            dist[e], prev[e] = nd, q[k]
+            st[e, n[e]] = q[k]
+            n[e] += 1
+            live[e] = bool(dist[e] >= delta)
+    return st, n, dist <= delta, its
+
+
+@pytest.mark.parametrize("mode", ["fd", "analytic-latency-kernel", "analytic-lane-pair-kernel"])
 @pytest.mark.parametrize("obj", sorted(RECORDED_SEGMENTS))
-def test_recorded_paths_are_reproduced_on_the_gpu(gpu_ctx, oracle_det, obj):
-    c = _constraint(obj, gpu_ctx)
+def test_recorded_paths_are_reproduced_on_the_gpu(gpu_ctx, oracle_det, obj, mode):
+    """debug/Wine_Bottle_path.txt:1-30, debug/dumbbell_path.txt:1-9 — outputs of the reference's own discreteGeodesic + project —
+    reproduced with the projector on the GPU: the recorded number of states exactly, every state to the print precision of the
+    file, bit for bit the oracle's traversal in the same jacobian mode; in reference arithmetic (the library's extend kernel)
+    and in the analytic fast mode (both of its kernels; module docstring (3))"""
+    from closed_chain_motion_planner_amd import _lib
+
+    c = _constraint(obj, gpu_ctx, mode=0 if mode == "fd" else 1)
     delta, segs = RECORDED_SEGMENTS[obj]
     c.problem.delta = delta
     P = _oracle_problem(oracle_det, c)
+    assert P.jacobian_mode == (0 if mode == "fd" else 1)
     rows = load_path_rows(obj)
     frm = np.array([rows[a] for a, _ in segs])
     to = np.array([rows[b] for _, b in segs])
+    gpu_ctx.set_option("analytic_small_batch", 0 if mode == "analytic-lane-pair-kernel" else _lib.get_option(None, "analytic_small_batch"))
+    geodesic = _gpu_geodesic if mode == "fd" else (lambda c_, f_, t_, m_: _gpu_geodesic_stepwise(c_, oracle_det, P, f_, t_, m_))
+    try:
+        _recorded_paths_body(c, oracle_det, P, obj, segs, rows, frm, to, geodesic)
+    finally:
+        gpu_ctx.set_option("analytic_small_batch", _lib.get_option(None, "analytic_small_batch"))
+
+
+def _recorded_paths_body(c, oracle_det, P, obj, segs, rows, frm, to, _gpu_geodesic):
     st, n, ok, its = _gpu_geodesic(c, frm, to, 16)
     worst = 0.0
     for e, (a, b) in enumerate(segs):
@@ -59,10 +123,10 @@ def test_recorded_paths_are_reproduced_on_the_gpu(gpu_ctx, oracle_det, obj):
         st2, n2, _, _ = _gpu_geodesic(c, f2, t2, 16)
         assert np.array_equal(n2, n)
         assert max(np.abs(st2[e, : n[e]] - st[e, : n[e]]).max() for e in range(len(segs))) <= 2e-5
-    print("%s: recorded geodesic rows reproduced on the GPU, max |dq| = %.2e rad" % (obj, worst))
+    print("%s (jacobian mode %d): recorded geodesic rows reproduced on the GPU, max |dq| = %.2e rad" % (obj, P.jacobian_mode, worst))
 
 
-def _compare_with_libm(c, oracle_det, oracle_libm, frm, to, maxs, label):
+def _compare_with_libm(c, oracle_det, oracle_libm, frm, to, maxs, label, analytic=False):
     """GPU geodesics vs the glibc oracle.  Every edge above 1e-6 rad must be ill-conditioned in the sense that a
     last-bit perturbation of its endpoints moves the det oracle's own result by > 1e-7 rad (condition number
     > 1e8: the Newton iteration multiplies tangent perturbations by 1.4-2 per iteration); among
@@ -70,7 +134,12 @@ def _compare_with_libm(c, oracle_det, oracle_libm, frm, to, maxs, label):
     edge that differs fails the test."""
     Pl = _oracle_problem(oracle_libm, c)
     Pd = _oracle_problem(oracle_det, c)
-    st, n, ok, its = _gpu_geodesic(c, frm, to, maxs)
+    if analytic:  # the GPU runs the fast mode; the yardstick stays the glibc build of the REFERENCE arithmetic
+        st, n, ok, its = _gpu_geodesic_stepwise(c, oracle_det, Pd, frm, to, maxs)
+        Pl.jacobian_mode = 0
+        Pd.jacobian_mode = 0
+    else:
+        st, n, ok, its = _gpu_geodesic(c, frm, to, maxs)
     sl, nl, okl, itl = oracle_libm.discrete_geodesic_batch(Pl, frm, to, maxs, NCPU)
     assert n.max() <= maxs and nl.max() <= maxs
     E = len(frm)
@@ -91,17 +160,20 @@ def _compare_with_libm(c, oracle_det, oracle_libm, frm, to, maxs, label):
     return len(out), flips, d
 
 
+@pytest.mark.parametrize("mode", ["fd", "analytic"])
 @pytest.mark.parametrize("obj", ["Wine_Bottle", "dumbbell"])
-def test_roadmap_edges_match_the_glibc_oracle_to_1e6(gpu_ctx, oracle_det, oracle_libm, obj):
+def test_roadmap_edges_match_the_glibc_oracle_to_1e6(gpu_ctx, oracle_det, oracle_libm, obj, mode):
     """the reference's own extend workload (every directed edge of its dumped roadmaps).  Wine_Bottle: no edge above
     1e-6 rad.  dumbbell (~20 Newton iterations per state): the two libms themselves part by 2e-5..4e-4 rad there
     (tests/test_oracle_golden.py::test_det_and_libm_builds_on_the_recorded_extend_workload); every such edge must be
-    ill-conditioned, which _compare_with_libm asserts."""
-    c = _constraint(obj, gpu_ctx)
+    ill-conditioned, which _compare_with_libm asserts.  mode "analytic": the GPU projects in the fast mode (exact Jacobian,
+    Gram step; the traversal composed around it, module docstring (3)) and is held to the same yardstick — the glibc build of
+    the reference arithmetic (ConstrainedPlanningCommon.cpp:217-222 is what wrote the roadmaps)."""
+    c = _constraint(obj, gpu_ctx, mode=0 if mode == "fd" else 1)
     nodes, edges = load_roadmap(obj)
     frm = np.array([nodes[a] for a, _ in edges])
     to = np.array([nodes[b] for _, b in edges])
-    n_out, _, d = _compare_with_libm(c, oracle_det, oracle_libm, frm, to, 64, obj + " roadmap")
+    n_out, _, d = _compare_with_libm(c, oracle_det, oracle_libm, frm, to, 64, obj + " roadmap (" + mode + ")", analytic=mode != "fd")
     if obj == "Wine_Bottle":
         assert n_out == 0 and d.max() <= TOL_RAD
     else:
