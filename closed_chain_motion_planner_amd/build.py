@@ -92,14 +92,16 @@ def _stale(target, sources):
 #     under the bound of three wavefronts per SIMD; they are now recomputed where they are used or kept in LDS.  Without the bound
 #     the kernel takes 181 registers, no scratch, and is 5 % SLOWER at 16 384 - 32 768 edges — profiles/r05_bulk_live_ab.log, B/r4
 #     of version 1: the front's latency blocks lose the register space.)
-#   * the general instantiations (calibrated arms, tilted bases): at most 200 B, except the fused-sampler throughput kernel
-#     project_fd_kernel<1,false>, which spills 2.3 KB (its sampler prologue and the general chain's pose arrays overlap; the
-#     path is the fused sampler x a calibrated model, which nothing in the reference's configuration reaches);
+#   * the general instantiations (calibrated arms, tilted bases): at most 136 B of PRIVATE SEGMENT and not one scratch
+#     instruction — the 96-132 B that project_fd_kernel<0,false>, geodesic_group_kernel<false> and geodesic_flat_kernel<false>
+#     declare are stack slots of SGPR spills that the allocator then kept in VGPR lanes (v_writelane / v_readlane; the ISA of
+#     those kernels contains no scratch_load / scratch_store: tests/test_host_cabi.py checks the objects).  The fused-sampler
+#     general instantiation project_fd_kernel<1,false> (2.3 KB of real spills) was removed in round 6: sampleUniform on
+#     calibrated arms runs unfused (ccmp_api.cpp: project_common);
 #   * everything else (scouts, small per-lane kernels, analytic mode, scene): at most 64 B unless listed.
 _SCRATCH_RULES = [  # (regex on the demangled name, bound); first match wins
-    (r"project_fd_kernel<1, false>", 2400),
     (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel|resident_service_kernel)<(\d+, )?true>", 0),
-    (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel|resident_service_kernel)<(\d+, )?false>", 200),
+    (r"(project_fd_kernel|project_fd_flat_kernel|project_fd_wave_kernel|geodesic_flat_kernel(_lat)?|geodesic_group_kernel|resident_service_kernel)<(\d+, )?false>", 136),
     (r"project_pair_kernel|project_row16_kernel", 0),  # analytic mode, every instantiation (stock twin arms, stock, calibrated)
     (r"scout_|clearance", 400),
     (r".", 64),

@@ -375,7 +375,19 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
                                          pl.latency_blocks, ctx->pool, st));
     return CCMP_OK;
   }
-  // reference arithmetic: the plan is ccmp_policy.cpp's plan_fd_batch (what ccmp_ctx_describe prints)
+  // Reference arithmetic.  sampleUniform on arms WITHOUT the stock structure (calibrated arms, tilted bases) is not fused: the
+  // ambient sampler writes the states, the projector runs on them in place, enforceBounds wraps them — the same values through
+  // 60 MB more traffic at C3 (0.03 ms beside a 20 ms kernel).  The fused general instantiation project_fd_kernel<1, false>
+  // spilled 2.3 KB per lane (its sampler prologue and the general chain's pose arrays overlap) and was removed in round 6.
+  if (mode == 1 && !(K.stock && K.twin_arms)) {
+    double *amb = q_ambient ? q_ambient : q_out;
+    HIP_TRY(ccmp_launch_ambient_uniform(&K, seed, first, amb, B, st));
+    const int rc = project_common(ctx, p, 0, amb, q_out, ok, iters, nullptr, B, seed, first, hip_stream);
+    if (rc != CCMP_OK) return rc;
+    HIP_TRY(ccmp_launch_enforce_bounds(q_out, B, st));
+    return CCMP_OK;
+  }
+  // the plan is ccmp_policy.cpp's plan_fd_batch (what ccmp_ctx_describe prints)
   const FdPlan pl = ccmp_host::plan_fd_batch(ctx, B, ctx->order != nullptr);
   // every workspace of the call is sized before anything of it is in flight
   if (pl.scout || pl.latency_order) {

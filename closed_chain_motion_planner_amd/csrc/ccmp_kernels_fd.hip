@@ -1019,8 +1019,8 @@ hipError_t ccmp_launch_project_group(const ccmp_consts *K, int mode, const doubl
     if (K->stock && K->twin_arms) CCMP_LAUNCH_GROUP(0, true);
     else CCMP_LAUNCH_GROUP(0, false);
   } else {
-    if (K->stock && K->twin_arms) CCMP_LAUNCH_GROUP(1, true);
-    else CCMP_LAUNCH_GROUP(1, false);
+    if (!(K->stock && K->twin_arms)) return hipErrorInvalidValue; // the fused sampler exists for the stock structure only (ccmp_api.cpp: project_common)
+    CCMP_LAUNCH_GROUP(1, true);
   }
 #undef CCMP_LAUNCH_GROUP
   return hipGetLastError();

@@ -130,8 +130,8 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
     if (K->stock) CCMP_LAUNCH_FLAT(0, true);
     else CCMP_LAUNCH_FLAT(0, false);
   } else if (src == 1) {
-    if (K->stock) CCMP_LAUNCH_FLAT(1, true);
-    else CCMP_LAUNCH_FLAT(1, false);
+    if (!K->stock) return hipErrorInvalidValue; // the fused sampler exists for the stock structure only (ccmp_api.cpp: project_common)
+    CCMP_LAUNCH_FLAT(1, true);
   } else {
     if (K->stock) CCMP_LAUNCH_FLAT(2, true);
     else CCMP_LAUNCH_FLAT(2, false);

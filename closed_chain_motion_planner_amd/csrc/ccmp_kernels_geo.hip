@@ -33,7 +33,9 @@ namespace {
 // is then the distance of that state to the target, recomputed from the same operands as the value the first call held,
 // so first call + continuation produce the states, flags and counts of one uninterrupted traversal bit for bit.
 template <bool STOCK>
-__global__ __launch_bounds__(128, CCMP_FLAT_MIN_WAVES) void geodesic_flat_kernel(
+// (the general instantiation — calibrated arms, tilted bases — gets the register budget of three wavefronts per SIMD: under the
+// stock one's 128 registers it spilled 33 of them, 96 B per lane)
+__global__ __launch_bounds__(128, (STOCK || CCMP_FLAT_MIN_WAVES < 4) ? CCMP_FLAT_MIN_WAVES : 3) void geodesic_flat_kernel(
     const ccmp_consts K, const double delta, const double lambda, const double *__restrict__ from,
     const double *__restrict__ to, unsigned long long E, int max_states, double *__restrict__ states,
     int *__restrict__ n_states, uint8_t *__restrict__ ok_out, int *__restrict__ newton_iters, int check_target,

@@ -621,3 +621,35 @@ def test_stock_structure_kernels_and_general_kernels(gpu_ctx, oracle_det, calibr
                 continue
             assert int(gok[e]) == int(ok_c) and int(n[e]) == len(st_c), (calibrated, stock, e)
             assert np.array_equal(st[e, : n[e]].view(np.uint64), st_c.view(np.uint64))
+
+
+@pytest.mark.parametrize("B", [1, 700, 20000, 70000])
+def test_sample_uniform_on_calibrated_arms_runs_unfused_and_bitwise(gpu_ctx, oracle_det, B):
+    """sampleUniform (jy_ProjectedStateSpace.cpp:10-15) on arms WITHOUT the stock structure — PandaModel::initModel(dh) with
+    calibration offsets that differ per arm (panda_rbdl.cpp:80-99) — is ambient sampler -> projector in place -> enforceBounds
+    as three launches (ccmp_api.cpp: project_common; the fused general instantiation spilled 2.3 KB per lane and was removed):
+    samples, flags, iteration counts and the ambient states bit for bit the oracle's fused loop, for a single state, the latency
+    kernel, the split launch and the throughput kernel; and the general kernels under the stock model give the same"""
+    import torch
+
+    c = _constraint("Wine_Bottle", gpu_ctx)
+    for arm in (0, 1):
+        dh = (C.c_double * 28)(*[(1e-3 if arm == 0 else -7e-4) * ((5 * i + 3 * arm) % 7 - 3) for i in range(28)])
+        assert _lib.lib().ccmp_set_calibration(C.byref(c.problem), arm, dh) == 0
+    P = _oracle_problem(oracle_det, c)
+    e_q, e_ok, e_it = oracle_det.sample_project_batch(P, 0xCA1, 11, B, NCPU)
+    amb = oracle_det.ambient_uniform_batch(P, 0xCA1, 11, B)
+    q, ok, it, q_amb = c.sample_project_batch(0xCA1, 11, B, want_ambient=True)
+    assert np.array_equal(q.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(ok.cpu().numpy(), e_ok)
+    assert np.array_equal(it.cpu().numpy().astype(np.int32), e_it) and np.array_equal(q_amb.cpu().numpy().view(np.uint64), amb.view(np.uint64))
+    q2, ok2, it2, _ = c.sample_project_batch(0xCA1, 11, B)  # without the ambient output: projected in place in q_out
+    assert torch.equal(q2, q) and torch.equal(ok2, ok) and torch.equal(it2, it)
+    if B == 20000:  # stock model, general kernels (option): the same unfused path, the same bits as the fused stock kernels
+        s = _constraint("Wine_Bottle", gpu_ctx)
+        ref = s.sample_project_batch(0xCA2, 0, B)
+        gpu_ctx.set_option("stock_kernels", 0)
+        try:
+            gen = s.sample_project_batch(0xCA2, 0, B)
+        finally:
+            gpu_ctx.set_option("stock_kernels", 1)
+        assert all(torch.equal(a, b) for a, b in zip(ref[:3], gen[:3]))

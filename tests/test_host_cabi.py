@@ -306,8 +306,7 @@ def test_describe_names_the_regime_on_both_sides_of_every_boundary(L):
 def test_stock_kernels_do_not_spill(ccmp_built):
     """build.py keeps the compiler's own account of every kernel (-Rpass-analysis=kernel-resource-usage -> build/*.resources.json)
     and FAILS the build when a kernel exceeds its scratch bound; here the record is read back: the stock instantiations of the
-    projector kernels, of the extend step's kernels and of the resident service kernel use no scratch at all, the general ones stay
-    under 200 B per lane — except the one instantiation DESIGN.md names (fused sampler x calibrated model: 2.3 KB)."""
+    projector kernels, of the extend step's kernels and of the resident service kernel use no scratch at all, the general ones spill no vector register."""
     from closed_chain_motion_planner_amd.build import check_resources, resource_report
 
     rep = resource_report()
@@ -325,7 +324,15 @@ def test_stock_kernels_do_not_spill(ccmp_built):
     for name in ("project_row16_kernel<true>", "project_row16_kernel<false>"):  # its latency kernel: two per SIMD
         k = by_name[name]
         assert k["scratch"] == 0 and k["scratch_bound"] == 0 and k["agprs"] == 0 and k["occupancy"] >= 2, (name, k)
-    spill = {n: k["scratch"] for n, k in by_name.items() if k["scratch"] > 200}
-    assert set(spill) == {"project_fd_kernel<1, false>"}, spill
+    # the general instantiations (calibrated arms, tilted bases) of the reference-arithmetic kernels: no VGPR goes to scratch; what two of
+    # them declare as private segment (132 B) are stack slots of SGPR spills that live in VGPR lanes — their ISA holds no scratch
+    # instruction (build.py: _SCRATCH_RULES).  The fused sampler's general instantiations (2.3 KB of spills) are gone.
+    general = [n for n in by_name if n.endswith("false>") and n.split("<")[0] in ("project_fd_kernel", "project_fd_flat_kernel", "geodesic_flat_kernel",
+                                                                                   "geodesic_flat_kernel_lat", "geodesic_group_kernel", "resident_service_kernel")]
+    assert "project_fd_kernel<0, false>" in general and "project_fd_kernel<1, false>" not in by_name and "project_fd_flat_kernel<1, false>" not in by_name
+    for name in general:
+        assert by_name[name]["vgpr_spill"] == 0 and by_name[name]["scratch"] <= 136, (name, by_name[name])
+    assert by_name["geodesic_flat_kernel<false>"]["scratch"] == 0 and by_name["project_fd_flat_kernel<0, false>"]["scratch"] == 0
+    assert not {n: k["scratch"] for n, k in by_name.items() if k["scratch"] > 136}
     with pytest.raises(RuntimeError):  # and the check itself bites
         check_resources([{"name": "project_fd_kernel<0, true>", "scratch": 8, "vgprs": 168, "vgpr_spill": 2}], "ccmp_kernels_fd.hip.o")

@@ -13,7 +13,7 @@
     python tools/measure.py soak_resident [N]               N states as single calls through the resident service kernel against the batched kernels
     python tools/measure.py scout                           FP32 scout's predictions against the true iteration counts
     python tools/measure.py run <workload> [reps]           a fixed workload for rocprofv3 (tools/profile.sh):
-                                                           c3 | flat4096 | mid<B> | flat1 | geodesic | analytic | stefan | clearance
+                                                           c3 | flat4096 | mid<B> | flat1 | geodesic | analytic[<B>] | stefan | stefan_tight | calibrated | clearance
 """
 import ctypes as C
 import sys
@@ -403,8 +403,14 @@ def run(argv):
     what = argv[0]
     reps = int(argv[1]) if len(argv) > 1 else 12
     ctx = Context(0)
-    c = KinematicChainConstraint.from_yaml(CFG % ("stefan" if what == "stefan" else "Wine_Bottle"), ctx=ctx)
-    if what in ("c3", "stefan"):
+    c = KinematicChainConstraint.from_yaml(CFG % ("stefan" if what.startswith("stefan") else "Wine_Bottle"), ctx=ctx)
+    if what == "stefan_tight":  # BASELINE configs[3] read as "tighter loop tol": half the reference's tolerances
+        c.setTolerance(5e-4, 2.5e-3)
+    if what == "calibrated":  # C3 on calibrated arms (PandaModel::initModel(dh), offsets differing per arm): the general instantiations
+        for arm in (0, 1):
+            dh = (C.c_double * 28)(*[(1e-3 if arm == 0 else -7e-4) * ((5 * i + 3 * arm) % 7 - 3) for i in range(28)])
+            assert _lib.lib().ccmp_set_calibration(C.byref(c.problem), arm, dh) == 0
+    if what in ("c3", "stefan", "stefan_tight", "calibrated"):
         q = c.ambient_uniform_batch(0xC3, 0, 262144)
         fn = lambda: c.project_batch(q)
     elif what.startswith("flat") and what[4:].isdigit() and int(what[4:]) > 1:  # flat4096 (C2), flat14336 ...: the latency kernel alone

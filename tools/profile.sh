@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over one workload; run on the GPU box from the repo root:
 #   bash tools/profile.sh <tag>                      bench.py at its default configuration (C3)
-#   bash tools/profile.sh <tag> <workload> [reps]    tools/measure.py run <workload>: flat4096 | flat1 | geodesic | geodesic65536 | analytic | stefan | clearance (reps: profiled calls, default 12, behind 3 warm-ups)
+#   bash tools/profile.sh <tag> <workload> [reps]    tools/measure.py run <workload>: flat4096 | flat1 | geodesic | geodesic65536 | analytic[<B>] | stefan | stefan_tight | calibrated | clearance (reps: profiled calls, default 12, behind 3 warm-ups)
 # -> gpurun_out/prof_<tag>/{trace,pmc_*}/...; condense with: python tools/summarize_profile.py <tag> <kernel,...> <units per launch>
 # The program after `--` is python3 itself (no env / bash -c / launcher hop: the profiler's library initialises the GPU
 # before the program starts).  Counters are collected in their own passes, never together with a trace domain other
