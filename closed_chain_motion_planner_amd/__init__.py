@@ -13,4 +13,4 @@ from .space import (check_motion, format_graphml, format_graphviz, format_path_m
 
 from .scene import ProxyScene, ProxyValidityChecker, default_allowed, skeleton_spheres  # noqa: F401
 
-__version__ = "0.5.0"
+__version__ = "0.6.0"

@@ -69,13 +69,16 @@ EXPORTS = [
     "ccmp_sample_project_batch", "ccmp_sample_near_project_batch", "ccmp_sample_gaussian_project_batch",
     "ccmp_compute_t_wo_batch", "ccmp_geodesic_batch", "ccmp_check_motion_batch", "ccmp_geodesic_batch_ex", "ccmp_geodesic_host_ex", "ccmp_check_motion_host", "ccmp_ambient_uniform_batch", "ccmp_enforce_bounds_batch", "ccmp_compact_valid", "ccmp_compact_valid_capped",
     "ccmp_project_host", "ccmp_function_host", "ccmp_is_satisfied_host", "ccmp_joint_valid_host", "ccmp_sample_project_host", "ccmp_sample_ref_project_host", "ccmp_geodesic_host", "ccmp_project_sharded_host", "ccmp_sample_project_sharded_host", "ccmp_sharded_host_last_timing",
-    "ccmp_comm_create", "ccmp_comm_destroy", "ccmp_comm_last_timing", "ccmp_project_sharded", "ccmp_sample_project_sharded", "ccmp_ctx_set_order_experimental",
+    "ccmp_comm_create", "ccmp_comm_destroy", "ccmp_comm_last_timing", "ccmp_project_sharded", "ccmp_sample_project_sharded",
     "ccmp_scene_create", "ccmp_scene_destroy", "ccmp_scene_num_pairs", "ccmp_clearance_batch", "ccmp_clearance_host",
-    "ccmp_ctx_debug_lpt_pred", "ccmp_detmath_probe", "ccmp_strerror",
+    "ccmp_strerror",
     "ccmp_last_hip_error", "ccmp_version", "ccmp_problem_sizeof",
 ]
 
 _lib = None
+# include/ccmp_debug.h: exported by lib/libccmp_debug.so only (the same sources with -DCCMP_DEBUG_HOOKS; select it with CCMP_LIBRARY)
+DEBUG_EXPORTS = ["ccmp_detmath_probe", "ccmp_ctx_set_order_experimental", "ccmp_ctx_debug_lpt_pred", "ccmp_debug_fail_calls"]
+DEBUG_LIBPATH = os.path.join(os.path.dirname(LIBPATH), "libccmp_debug.so")
 
 
 def lib():
@@ -160,9 +163,6 @@ def lib():
         "ccmp_scene_num_pairs": ([vp], C.c_int),
         "ccmp_clearance_batch": ([vp, pp, vp, vp, vp, C.c_size_t, C.c_double, vp, vp, vp, vp], C.c_int),
         "ccmp_clearance_host": ([vp, pp, vp, dp, C.c_size_t, C.c_double, dp, C.POINTER(C.c_int32), u8p], C.c_int),
-        "ccmp_ctx_set_order_experimental": ([vp, vp], C.c_int),
-        "ccmp_ctx_debug_lpt_pred": ([vp, vp, C.c_size_t], C.c_int),
-        "ccmp_detmath_probe": ([vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
         "ccmp_strerror": ([C.c_int], C.c_char_p),
         "ccmp_last_hip_error": ([], C.c_char_p),
         "ccmp_version": ([], C.c_int),
@@ -172,6 +172,17 @@ def lib():
         fn = getattr(L, name)  # AttributeError here = library out of date with the header
         fn.argtypes = args
         fn.restype = res
+    debug_sig = {
+        "ccmp_ctx_set_order_experimental": ([vp, vp], C.c_int),
+        "ccmp_ctx_debug_lpt_pred": ([vp, vp, C.c_size_t], C.c_int),
+        "ccmp_detmath_probe": ([vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+        "ccmp_debug_fail_calls": ([vp, C.c_int], C.c_int),
+    }
+    for name, (args, res) in debug_sig.items():  # present in the debug build only (include/ccmp_debug.h)
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
     if L.ccmp_problem_sizeof() != C.sizeof(CcmpProblem):
         raise ImportError("ccmp_problem layout mismatch between libccmp.so and the Python binding")
     _lib = L

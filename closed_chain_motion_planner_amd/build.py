@@ -9,8 +9,8 @@ Translation units with deliberately different flags:
                          like the flat unit (throughput flavour) and -DCCMP_GEO_LATENCY with machine LICM and a 256-register
                          budget (latency flavour)
   ccmp_problem.cpp       -ffp-contract=off -DCCMP_USE_FMA   host set-up (problem, constants) in the same rounding model
-  ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   context, launches
-  ccmp_policy.cpp                                           option table (set / get / info), scheduling plans, ccmp_ctx_describe
+  ccmp_api.cpp           -ffp-contract=off -DCCMP_USE_FMA   context, launches            } compiled a second time with -DCCMP_DEBUG_HOOKS for
+  ccmp_policy.cpp                                           option table, plans, describe } lib/libccmp_debug.so (include/ccmp_debug.h)
   ccmp_resident.cpp                                         opt-in resident service kernel for single-state calls (host side)
   ccmp_kernels_resident.hip -ffp-contract=off -DCCMP_USE_FMA  ... its device side, on the latency flavour's Newton routine
   ccmp_host_io.cpp                                          *_host conveniences (staging, pinned block, page-locked caller buffers), sharded host calls
@@ -29,6 +29,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 # CCMP_LIBRARY: another build of the same library (tools/sanitize_cpu.py: host code under ASan/UBSan); never set in production
 LIBPATH = os.environ.get("CCMP_LIBRARY") or os.path.join(LIBDIR, "libccmp.so")
+# the same sources with the test / tool hooks of include/ccmp_debug.h (-DCCMP_DEBUG_HOOKS on the two host units that carry them)
+DEBUG_LIBPATH = os.path.join(LIBDIR, "libccmp_debug.so")
+_DEBUG_UNITS = ("ccmp_api.cpp", "ccmp_policy.cpp")
+_DEBUG_ONLY_UNITS = [("ccmp_kernels_debug.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT", "-mllvm", "-disable-machine-licm"])]  # the device probe of ccmp_detmath.h
 ARCH = "gfx950"
 
 _UNITS = [
@@ -169,15 +173,28 @@ def build_library(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     hipcc = hipcc_path()
     headers = [os.path.join(CSRC, h) for h in _HEADERS]
-    objs, jobs = [], []
+    objs, dbg_objs, jobs = [], [], []
     relink = force
     for src, flags, *obj in _UNITS:  # optional third entry: object name (a source built twice)
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, obj[0] if obj else src + ".o")
         objs.append(op)
+        variants = [(op, [])]
+        if src in _DEBUG_UNITS:  # the debug library's copy of the unit
+            dp = os.path.join(objdir, src + ".dbg.o")
+            dbg_objs.append(dp)
+            variants.append((dp, ["-DCCMP_DEBUG_HOOKS"]))
+        else:
+            dbg_objs.append(op)
+        for target, extra in variants:
+            if force or _stale(target, [sp] + headers):
+                jobs.append([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags + extra +
+                            (["-Rpass-analysis=kernel-resource-usage"] if src.endswith(".hip") else []) + ["-c", sp, "-o", target])
+    for src, flags in _DEBUG_ONLY_UNITS:
+        sp, op = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
+        dbg_objs.append(op)
         if force or _stale(op, [sp] + headers):
-            jobs.append([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags +
-                        (["-Rpass-analysis=kernel-resource-usage"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op])
+            jobs.append([hipcc, "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", op])
     if jobs:  # the units are independent: compile them side by side (hipcc is one process per unit)
         import json
         from concurrent.futures import ThreadPoolExecutor
@@ -204,11 +221,13 @@ def build_library(force=False, verbose=False):
         with ThreadPoolExecutor(workers) as pool:
             list(pool.map(run, jobs))
         relink = True
-    if relink or _stale(LIBPATH, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIBPATH] + objs
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+    default_lib = os.path.join(LIBDIR, "libccmp.so")
+    for target, members in ((default_lib, objs), (DEBUG_LIBPATH, dbg_objs)):
+        if relink or _stale(target, members):
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", target] + members
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
     return LIBPATH
 
 

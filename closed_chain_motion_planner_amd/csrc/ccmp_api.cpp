@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
 
 #include "../../include/ccmp.h"
 #include "ccmp_ctx.h"
@@ -190,6 +192,17 @@ const char *ccmp_strerror(int code)
 }
 
 // ---- context ---------------------------------------------------------------------------------------
+// the contexts that exist (ccmp_host::context_alive): +1 registers, -1 removes, 0 asks
+static bool live_contexts(const ccmp_ctx *ctx, int op)
+{
+  static std::mutex mu;
+  static std::set<const ccmp_ctx *> live;
+  std::lock_guard<std::mutex> hold(mu);
+  if (op > 0) live.insert(ctx);
+  else if (op < 0) live.erase(ctx);
+  return live.count(ctx) != 0;
+}
+
 int ccmp_ctx_create(int device, ccmp_ctx **out)
 {
   if (!out) return CCMP_EINVAL;
@@ -230,6 +243,7 @@ int ccmp_ctx_create(int device, ccmp_ctx **out)
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming);
   if (e != hipSuccess) { ccmp_ctx_destroy(ctx); return hip_fail(e, "side stream / events"); }
+  live_contexts(ctx, +1);
   *out = ctx;
   return CCMP_OK;
 }
@@ -237,6 +251,7 @@ int ccmp_ctx_create(int device, ccmp_ctx **out)
 void ccmp_ctx_destroy(ccmp_ctx *ctx)
 {
   if (!ctx) return;
+  live_contexts(ctx, -1);
   DeviceGuard guard(ctx->device);
   ccmp_host::resident_destroy(ctx); // first: hipFree below waits for the whole device, a resident kernel included
   (void)hipStreamSynchronize(ctx->stream);
@@ -281,6 +296,7 @@ int ccmp_ctx_set_lpt(ccmp_ctx *ctx, int mode, size_t min_batch)
   ctx->lpt_min_batch = min_batch == CCMP_DEFAULT ? kDefaultLptMinBatch : min_batch;
   return CCMP_OK;
 }
+#ifdef CCMP_DEBUG_HOOKS // include/ccmp_debug.h: lib/libccmp_debug.so only
 int ccmp_ctx_debug_lpt_pred(ccmp_ctx *ctx, uint16_t *host_out, size_t B)
 {
   if (!ctx || !host_out || !ctx->lpt_buf || B > ctx->lpt_cap) return CCMP_EINVAL;
@@ -296,11 +312,26 @@ int ccmp_ctx_set_order_experimental(ccmp_ctx *ctx, const unsigned int *order_dev
   ctx->order = order_dev;
   return CCMP_OK;
 }
+int ccmp_debug_fail_calls(ccmp_ctx *ctx, int n)
+{
+  if (!ctx || n < 0) return CCMP_EINVAL;
+  ctx->debug_fail_calls = n;
+  return CCMP_OK;
+}
+#endif
 int ccmp_ctx_device(const ccmp_ctx *ctx) { return ctx ? ctx->device : -1; }
 int ccmp_ctx_num_cus(const ccmp_ctx *ctx) { return ctx ? ctx->num_cus : 0; }
 
+#ifdef CCMP_DEBUG_HOOKS
+#define CCMP_DEBUG_FAIL_POINT() if (ctx->debug_fail_calls > 0) { ctx->debug_fail_calls--; return CCMP_EHIP; }
+#define CCMP_FAIL_AFTER_FORK(fj, where) if (ctx->fail_after_fork == (where)) (fj).fail(hipErrorLaunchFailure, "fail_after_fork (debug option)")
+#else
+#define CCMP_DEBUG_FAIL_POINT()
+#define CCMP_FAIL_AFTER_FORK(fj, where)
+#endif
 #define CCMP_PROLOGUE()                                        \
   if (!ctx) return CCMP_EINVAL;                                \
+  CCMP_DEBUG_FAIL_POINT()                                      \
   { int rc_ = check_problem(p); if (rc_ != CCMP_OK) return rc_; } \
   DeviceGuard guard(ctx->device);                              \
   if (!guard.ok) return CCMP_ENODEV;                           \
@@ -441,11 +472,11 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     // over as before.  From the fork on a failure is reported only after the side stream has been joined back (ForkJoin).
     if (pl.split) {
       fj.fork();
-      if (ctx->fail_after_fork == 1) fj.fail(hipErrorLaunchFailure, "fail_after_fork (debug option)");
+      CCMP_FAIL_AFTER_FORK(fj, 1);
       FJ_STEP(fj, ccmp_launch_project_flat(&K, mode, q_in, q_out, ok, iters, q_ambient, B, ctx->queue + 7, seed, first, ctx->pool, q_pool_count, mode,
                                            pl.shape.blocks, nullptr, 0, 0, sb.order, ctx->queue + 4, ctx->side));
       fj.side_done();
-      if (ctx->fail_after_fork == 2) fj.fail(hipErrorLaunchFailure, "fail_after_fork (debug option)");
+      CCMP_FAIL_AFTER_FORK(fj, 2);
     }
   }
   const size_t pool_records = pred ? (size_t)pl.group_blocks * 10 : 0;
@@ -591,11 +622,11 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
     // `st`), then the first error is reported.
     ForkJoin fj(ctx, st);
     fj.fork();
-    if (ctx->fail_after_fork == 1) fj.fail(hipErrorLaunchFailure, "fail_after_fork (debug option)");
+    CCMP_FAIL_AFTER_FORK(fj, 1);
     FJ_STEP(fj, ccmp_launch_geodesic(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, check_target,
                                      pl.front_blocks, gq + 5, order, carry_in, carry_out, round_budget, gq + 4, nullptr, nullptr, ctx->side));
     fj.side_done();
-    if (ctx->fail_after_fork == 2) fj.fail(hipErrorLaunchFailure, "fail_after_fork (debug option)");
+    CCMP_FAIL_AFTER_FORK(fj, 2);
     FJ_STEP(fj, ccmp_launch_geodesic_group(&K, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, (int)pl.group_waves, gq,
                                            order, carry_out, round_budget, pct > 0 ? ctx->geo_pool : nullptr, gq + 6, pct, target_ok, st));
     if (pct > 0) // the handed-over edges: latency blocks behind the group kernel; the pool's fill count is read on the device
@@ -703,6 +734,7 @@ int ccmp_compact_valid_capped(ccmp_ctx *ctx, const double *q, const uint8_t *ok,
   return CCMP_OK;
 }
 
+#ifdef CCMP_DEBUG_HOOKS
 int ccmp_detmath_probe(ccmp_ctx *ctx, const double *x_dev, const double *y_dev, double *out_dev, size_t n, void *hip_stream)
 {
   if (!ctx || !x_dev || !y_dev || !out_dev) return CCMP_EINVAL;
@@ -713,5 +745,10 @@ int ccmp_detmath_probe(ccmp_ctx *ctx, const double *x_dev, const double *y_dev, 
   HIP_TRY(ccmp_launch_detmath_probe(x_dev, y_dev, out_dev, n, st));
   return CCMP_OK;
 }
+#endif
 
 } // extern "C"
+
+namespace ccmp_host {
+bool context_alive(const ccmp_ctx *ctx) { return ctx && live_contexts(ctx, 0); }
+}  // namespace ccmp_host

@@ -14,6 +14,7 @@
 
 #include "../../include/ccmp.h"
 #include "ccmp_ctx.h"
+#include "ccmp_resident.h"
 
 using ccmp_host::DeviceGuard;
 using ccmp_host::ensure_stage;
@@ -136,6 +137,7 @@ void ccmp_comm_destroy(ccmp_comm *c)
   if (!c) return;
   for (int g = 0; g < c->n; g++) {
     DeviceGuard guard(c->ctxs[g]->device);
+    ccmp_host::quiesce(c->ctxs[g]); // (hipFree waits for the whole device: a resident service kernel of the context must be gone first)
     (void)hipStreamSynchronize(c->ctxs[g]->stream);
     if (c->comms[g]) (void)rccl().CommDestroy(c->comms[g]);
     for (int k = 0; k < 3; k++)
@@ -155,6 +157,7 @@ static int comm_ensure_blocks(ccmp_comm *c, size_t cap)
   for (int g = 0; g < c->n; g++) {
     DeviceGuard guard(c->ctxs[g]->device);
     if (!guard.ok) return CCMP_ENODEV;
+    ccmp_host::quiesce(c->ctxs[g]); // ccmp_resident.h rule (2): before every hipFree / hipMalloc of the library's own
     if (c->send[g]) (void)hipFree(c->send[g]);
     if (c->recv[g]) (void)hipFree(c->recv[g]);
     c->send[g] = c->recv[g] = nullptr;

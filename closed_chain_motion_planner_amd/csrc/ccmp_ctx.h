@@ -92,7 +92,7 @@ struct ccmp_ctx {
   // resident service kernel (opt-in, option "resident"; ccmp_resident.h)
   struct ccmp_resident *resident = nullptr;
   int resident_on = 0;
-  int resident_gave_up = 0;            // the service kernel did not get to run within 2 ms of a start (its queue is shared): option turned off
+  int resident_gave_up = 0;            // how often a start of the service kernel gave up (it did not get to run within 5 ms: that ONE call took the launch path; ccmp_resident.cpp)
 
   // ---- tuning (option table: ccmp_policy.cpp) ----------------------------------------------------------------------------
   int waves_per_cu = 0;                // persistent wavefronts of the throughput kernels per CU (0 = 12)
@@ -126,7 +126,8 @@ struct ccmp_ctx {
   size_t clearance_per_state_max = 8192;
   int host_zero_copy = 2;
   int resident_idle_ms = 10;           // the resident service kernel leaves by itself after this long without a request
-  int fail_after_fork = 0;             // debug (tests): 1 / 2 = the split launches report a failure in front of / behind their side-stream part
+  int fail_after_fork = 0;             // debug build only (include/ccmp_debug.h): 1 / 2 = the split launches report a failure in front of / behind their side-stream part
+  int debug_fail_calls = 0;            // debug build only: the next so many compute entry points return CCMP_EHIP before anything is launched
 };
 
 namespace ccmp_host {

@@ -909,20 +909,6 @@ __global__ void enforce_bounds_kernel(double *__restrict__ q, size_t n)
   q[t] = wrap_pi(q[t]);
 }
 
-__global__ void detmath_probe_kernel(const double *__restrict__ x, const double *__restrict__ y,
-                                     double *__restrict__ out, size_t n)
-{
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s, c;
-  ccmp_sincos(x[i], &s, &c);
-  out[5 * i + 0] = s;
-  out[5 * i + 1] = c;
-  out[5 * i + 2] = ccmp_atan2_nn(ccmp_abs(x[i]), ccmp_abs(y[i]));
-  out[5 * i + 3] = ccmp_sqrt(ccmp_abs(x[i]));
-  out[5 * i + 4] = x[i] / y[i];
-}
-
 // Stable stream compaction of valid rows: block-local scan + one atomic per block would reorder
 // blocks, so this is the ordered two-pass form: (1) per-block counts, (2) single-block exclusive
 // scan of the counts, (3) scatter.  B/256 counts fit one block's loop comfortably (1024 at 262144).
@@ -1076,11 +1062,6 @@ hipError_t ccmp_launch_enforce_bounds(double *q, size_t B, hipStream_t st)
 {
   size_t n = B * 14;
   hipLaunchKernelGGL(enforce_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q, n);
-  return hipGetLastError();
-}
-hipError_t ccmp_launch_detmath_probe(const double *x, const double *y, double *out, size_t n, hipStream_t st)
-{
-  hipLaunchKernelGGL(detmath_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, out, n);
   return hipGetLastError();
 }
 hipError_t ccmp_launch_compact(const double *q, const uint8_t *ok, size_t B, double *out, size_t capacity,

@@ -74,7 +74,9 @@ const OptionDesc kOptions[] = {
     OPT("clearance_per_state_max", clearance_per_state_max, kSize, 0, LONG_MAX, 0, "proxy clearance: one block per state up to this many states, 64-state tiles above"),
     OPT("host_zero_copy", host_zero_copy, kInt, 0, 2, 0, "*_host calls on page-locked caller buffers: 0 = staged, 1 = q_out written in place, 2 = q_in read in place too"),
     OPT("resident_idle_ms", resident_idle_ms, kInt, 1, 10000, 0, "the resident service kernel (option \"resident\") leaves by itself after this many milliseconds without a request"),
+#ifdef CCMP_DEBUG_HOOKS // lib/libccmp_debug.so only (include/ccmp_debug.h)
     OPT("fail_after_fork", fail_after_fork, kInt, 0, 2, kDebug, "debug: the split launches report a failure in front of (1) / behind (2) their side-stream part"),
+#endif
 };
 #undef OPT
 constexpr int kNumOptions = (int)(sizeof kOptions / sizeof kOptions[0]);
@@ -320,7 +322,7 @@ int ccmp_ctx_get_option(const ccmp_ctx *ctx, const char *name, long *value)
     return CCMP_OK;
   }
   if (!strcmp(name, "resident")) { *value = ctx ? ctx->resident_on : 0; return CCMP_OK; }
-  if (!strcmp(name, "resident_gave_up")) { *value = ctx ? ctx->resident_gave_up : 0; return CCMP_OK; } // 1: its queue was shared, the option turned itself off
+  if (!strcmp(name, "resident_gave_up")) { *value = ctx ? ctx->resident_gave_up : 0; return CCMP_OK; } // how often a start gave up (that call took the launch path; the option stays on)
   const OptionDesc *o = find_option(name);
   if (!o) return CCMP_EINVAL;
   *value = read_option(ctx ? ctx : &ccmp_host::default_ctx(), *o);

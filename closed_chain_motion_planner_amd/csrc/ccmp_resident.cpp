@@ -21,6 +21,9 @@ struct ccmp_resident {
   void *box_dev = nullptr;
   hipStream_t stream = nullptr;
   bool launched = false;    // a kernel was put on `stream` and has not been waited for
+  bool abandoned = false;   // ... and did not get to run within the start bound: told to stop, not waited for (it leaves as soon as it runs)
+  bool broken = false;      // a request was not answered within its bound: the service is not used again by this context
+  double retry_after_ms = 0, backoff_ms = 0; // no new start before this time (steady clock); doubled by every start that gave up
   int stock = -1;           // which instantiation runs
   unsigned int tag = 0;     // sequence number of the last request
   unsigned int consts_seq = 0;
@@ -62,12 +65,24 @@ void drain(ccmp_resident *r)
   if (!r->launched) return;
   (void)hipStreamSynchronize(r->stream);
   r->launched = false;
+  r->abandoned = false;
 }
 
+// Has the kernel on the stream ended?  (kResExited is the last thing it writes.)
+bool exited(ccmp_resident *r) { return __atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) == (unsigned long long)kResExited; }
+
+// Every wait on the host is bounded (ccmp_resident.h rule 4).  A kernel that was ABANDONED — queued behind another context's
+// resident kernel on a shared hardware queue, told to stop, never seen running — or one that stopped answering is not waited for
+// by quiesce(): it holds no CU until it runs, and it leaves at once when it does; what the caller's hipFree / hipMalloc then waits
+// for is at most the OTHER kernel's idle time, which is HIP's business, not a spin of ours.
 void stop(ccmp_resident *r)
 {
   if (!r || !r->launched) return;
-  if (__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) != (unsigned long long)kResExited) {
+  if (r->abandoned || r->broken) {
+    if (exited(r)) drain(r); // it got to run meanwhile and is gone: the stream is idle, nothing to wait for
+    return;
+  }
+  if (!exited(r)) {
     // a request whose command is "stop": payload first, the five tags last (ccmp_resident.h)
     const unsigned int tag = ++r->tag;
     volatile unsigned long long *req = word(r, kResReqOff);
@@ -99,26 +114,43 @@ int start(ccmp_ctx *ctx, ccmp_resident *r, int stock)
   HIP_TRY(ccmp_launch_resident(stock, r->box_dev, r->tag, idle_ticks, r->stream));
   r->launched = true;
   r->stock = stock;
-  // The kernel reports itself running with its first instructions (~20 us behind the launch).  If it does not within 2 ms its
-  // stream is queued behind something that does not end — another context's resident kernel on the same hardware queue (streams
-  // of one priority share a few) — and every start would wait for that one's idle exit: this context then gives the option up
-  // (the kernel, told to stop, leaves as soon as it gets to run) and its calls take the launch path.
+  // The kernel reports itself running with its first instructions (~20 us behind the launch).  If it does not within 5 ms — two
+  // orders of magnitude above launch jitter — its stream is queued behind something that does not end soon: another context's
+  // resident kernel on the same hardware queue (streams of one priority share a few), or this process's own persistent batch
+  // kernels filling every CU.  THIS CALL then takes the launch path and the kernel is abandoned: told to stop (it leaves as soon
+  // as it gets to run), not waited for; a later call starts the service again once that kernel is gone and a back-off has passed
+  // (10 ms, doubled by every start that gave up, at most 1 s).  The option stays on; "resident_gave_up" counts the occasions.
   const double t0 = now_ms();
   while (__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) == (unsigned long long)kResStarting) {
-    if (now_ms() - t0 > 2.0) {
+    if (now_ms() - t0 > 5.0) {
       const unsigned int tag = ++r->tag;
       volatile unsigned long long *req = word(r, kResReqOff);
       req[32] = (unsigned long long)kResStop;
       post(req, tag);
-      ctx->resident_on = 0;
-      ctx->resident_gave_up = 1;
+      r->abandoned = true;
+      r->backoff_ms = r->backoff_ms > 0 ? (r->backoff_ms * 2 > 1000.0 ? 1000.0 : r->backoff_ms * 2) : 10.0;
+      r->retry_after_ms = now_ms() + r->backoff_ms;
+      ctx->resident_gave_up++;
       return ccmp_host::kResidentFallBack;
     }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
   }
+  r->backoff_ms = 0;
   return CCMP_OK;
+}
+
+// May the service be (re)started now?  Not while an abandoned kernel is still queued, not before the back-off has passed, never
+// again once a request went unanswered.
+bool may_start(ccmp_resident *r)
+{
+  if (r->broken) return false;
+  if (r->abandoned) {
+    if (!exited(r)) return false;
+    drain(r); // gone: the stream is idle
+  }
+  return now_ms() >= r->retry_after_ms;
 }
 
 }  // namespace
@@ -135,8 +167,22 @@ void resident_destroy(ccmp_ctx *ctx)
   ccmp_resident *r = ctx ? ctx->resident : nullptr;
   if (!r) return;
   stop(r);
-  if (r->stream) (void)hipStreamDestroy(r->stream);
-  if (r->box) (void)hipHostFree(r->box);
+  if (r->launched) {
+    // an abandoned (or unresponsive) kernel is still on the stream: it may yet run and read its mailbox.  Give it 100 ms to be gone;
+    // otherwise the mailbox (64 KB of pinned memory) and the stream are LEFT to the process rather than freed under a kernel or
+    // waited for without bound.
+    const double t0 = now_ms();
+    while (!exited(r) && now_ms() - t0 < 100.0) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    if (exited(r)) drain(r);
+  }
+  if (!r->launched) {
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->box) (void)hipHostFree(r->box);
+  }
   delete r;
   ctx->resident = nullptr;
 }
@@ -156,6 +202,9 @@ int resident_set(ccmp_ctx *ctx, long on)
     if (!ctx->resident) return CCMP_ENOMEM;
   }
   ctx->resident_on = 1; // started by the first single-state call: it brings the problem the kernel is instantiated for
+  ctx->resident_gave_up = 0; // (turning the option on again is also how a caller asks for a fresh try at once)
+  ctx->resident->backoff_ms = 0;
+  ctx->resident->retry_after_ms = 0;
   return CCMP_OK;
 }
 
@@ -163,6 +212,12 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
 {
   ccmp_resident *r = ctx->resident;
   if (!ctx->resident_on || !r || !p || p->jacobian_mode != CCMP_JAC_FD) return kResidentFallBack; // reference arithmetic only
+  if (r->broken) return kResidentFallBack;
+  if (r->abandoned && !may_start(r)) return kResidentFallBack; // an abandoned kernel is still queued, or the back-off has not passed
+  // a request whose worst case (max_iter rounds for each of max_states states, ~20 us each under load) exceeds what the answer is
+  // waited for goes to the launch path instead of timing out spuriously
+  const double worst_ms = 0.02 * (double)p->max_iter * (double)(call.cmd == kResGeodesic ? (call.max_states > 0 ? call.max_states : 1) : 1);
+  if (worst_ms > 1500.0) return kResidentFallBack;
   // the problem in force: its kernel constants go into the mailbox when it changes (a planner sets its problem up once)
   if (!r->have_problem || r->stock_kernels != ctx->stock_kernels || memcmp(&r->problem, p, sizeof *p) != 0) {
     if (!(p->tol_pos > 0) || !(p->tol_rot > 0) || p->max_iter < 0 || p->max_iter > 65535) return CCMP_EINVAL;
@@ -172,6 +227,7 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
     if (r->launched && r->stock != (K.stock ? 1 : 0)) stop(r); // the other instantiation of the kernel
     static_assert(sizeof(ccmp_consts) <= kResStateOff, "the constants fit in front of the state word");
     if (!r->box) { // (first use: the mailbox comes with the first start)
+      if (!may_start(r)) return kResidentFallBack;
       int rc = start(ctx, r, K.stock ? 1 : 0);
       if (rc != CCMP_OK) return rc; // (kResidentFallBack: the service could not get a queue of its own)
     }
@@ -184,6 +240,7 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
   }
   // (re)start: never started, stopped by quiesce(), or left by itself after its idle time
   if (!r->launched || __atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE) == (unsigned long long)kResExited) {
+    if (!may_start(r)) return kResidentFallBack;
     int rc = start(ctx, r, r->stock);
     if (rc != CCMP_OK) return rc;
   }
@@ -236,8 +293,14 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
 #endif
   }
   if (!done) {
-    snprintf(g_hip_err, sizeof g_hip_err, "resident service kernel: no answer within 2 s (state %llu)",
+    // never post into a service that stopped answering: told to stop, marked unusable (later calls take the launch path; quiesce()
+    // and destroy do not wait for it)
+    snprintf(g_hip_err, sizeof g_hip_err, "resident service kernel: no answer within 2 s (state %llu); the service is not used again by this context",
              (unsigned long long)__atomic_load_n(word(r, kResStateOff), __ATOMIC_ACQUIRE));
+    const unsigned int stop_tag = ++r->tag;
+    req[32] = (unsigned long long)kResStop;
+    post(req, stop_tag);
+    r->broken = true;
     return CCMP_EHIP;
   }
   const unsigned long long flags = resp[kResRespFlags];

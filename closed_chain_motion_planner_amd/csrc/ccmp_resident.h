@@ -71,6 +71,9 @@ int resident_call(ccmp_ctx *ctx, const ccmp_problem *p, const ResidentCall &call
 /* stops the service and waits for its stream (before hipFree / hipMalloc / device-wide synchronisation; idempotent, cheap when
  * nothing runs); the next single-state call starts it again if the option is still on */
 void quiesce(ccmp_ctx *ctx);
+/* is `ctx` a context ccmp_ctx_create made and ccmp_ctx_destroy has not yet taken?  (objects that remember their context — scenes — ask before
+ * touching it: a scene may outlive the context it was created on) */
+bool context_alive(const ccmp_ctx *ctx);
 /* option "resident": 1 = on (started lazily by the first single-state *_host call), 0 = stop and release */
 int resident_set(ccmp_ctx *ctx, long on);
 /* ccmp_ctx_destroy */

@@ -116,6 +116,7 @@ int ccmp_scene_create(ccmp_ctx *ctx, const ccmp_sphere *spheres, int n_spheres, 
     delete sc;
     return hip_fail(e, "ccmp_scene_create");
   }
+  sc->ctx = ctx;
   *out = sc;
   return CCMP_OK;
 }
@@ -125,6 +126,7 @@ void ccmp_scene_destroy(ccmp_scene *scene)
   if (!scene) return;
   {
     DeviceGuard guard(scene->device);
+    if (scene->ctx && ccmp_host::context_alive(scene->ctx)) ccmp_host::quiesce(scene->ctx);
     if (scene->dev) (void)hipFree(scene->dev);
   }
   delete scene;

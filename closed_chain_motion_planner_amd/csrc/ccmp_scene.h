@@ -35,6 +35,7 @@ struct scene_dev {
 
 struct ccmp_scene {
   int device = 0;
+  ccmp_ctx *ctx = nullptr; // the context the scene was created on: its resident service kernel is stopped before the scene's hipFree (ccmp_resident.h rule 2); the context must outlive the scene or be destroyed first with the service off
   ccmp::scene_dev host;
   ccmp::scene_dev *dev = nullptr;
 };

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CCMP_VERSION 500
+#define CCMP_VERSION 600
 
 enum {
   CCMP_OK = 0,
@@ -218,8 +218,6 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *                                                           q_in read in place too
  *   "resident_idle_ms"              10        1..10000      the resident service kernel (option "resident") leaves by itself after this many
  *                                                           milliseconds without a request
- *   "fail_after_fork"               0         0..2          debug: the split launches report a failure in front of (1) / behind (2) their side-stream
- *                                                           part
  * END OPTION TABLE */
 /* Resident service kernel (option "resident", 0 / 1, default 0): with it on, the one-at-a-time calls the unchanged planner makes —
  * ccmp_project_host, ccmp_function_host, ccmp_is_satisfied_host, ccmp_joint_valid_host with B == 1, and ccmp_geodesic_host /
@@ -231,10 +229,12 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  * synchronise of its own and in ccmp_ctx_destroy (and takes the launch path while it is stopped), so every entry point of this
  * header can be mixed with resident calls; the APPLICATION's own hipDeviceSynchronize / hipFree waits until the service leaves by
  * itself, after "resident_idle_ms" (default 10) without a request — bounded, never for ever; the next call starts it again.  Its
- * stream has the lowest priority (a hardware queue of its own); should the kernel not get to run within 2 ms of a start — its queue
- * is shared with something that does not end, e.g. another context's service — the context turns the option off by itself
- * ("resident_gave_up" reads 1) and its calls take the launch path.  Every host-side wait is bounded: CCMP_EHIP after 2 s without
- * an answer. */
+ * stream has the lowest priority (a hardware queue of its own); should the kernel not get to run within 5 ms of a start — its queue
+ * is shared with something that does not end soon, e.g. another context's service — THAT CALL takes the launch path, the kernel is
+ * told to stop and abandoned (never waited for), and a later call starts the service again behind a back-off (10 ms, doubling up
+ * to 1 s; "resident_gave_up" counts the occasions; setting "resident" to 1 again clears both).  Every host-side wait is bounded:
+ * a request whose worst case exceeds 1.5 s goes to the launch path, CCMP_EHIP after 2 s without an answer (the service is then not
+ * used again by the context). */
 /* What the policy does with a call: writes ONE line into buf (NUL-terminated, truncated to cap) naming the kernels a call of
  * kind call_kind over n samples / edges runs on under the context's present settings, and the thresholds that delimit that
  * regime — computed by the same functions the launches use (csrc/ccmp_policy.cpp), so it cannot disagree with them.  ctx == NULL:
@@ -459,14 +459,8 @@ int ccmp_clearance_host(ccmp_ctx *ctx, const ccmp_problem *p, const ccmp_scene *
                         double *clearance, int32_t *pair, uint8_t *free_out);
 
 /* ---- diagnostics ---------------------------------------------------------------------------------- */
-/* runs ccmp_detmath.h's sincos/atan2/sqrt/div on the device: out[i] = {sin,cos,atan2_nn(|x|,|y|),
- * sqrt(|x|), x/y} — used by tests to prove the device arithmetic is bit-identical to the host's */
-int ccmp_detmath_probe(ccmp_ctx *ctx, const double *x_dev, const double *y_dev, double *out_dev, size_t n,
-                       void *hip_stream);
-/* experimental / diagnostic hooks used by tools/: an externally supplied processing order (device array of B
- * sample indices, NULL = none) and a copy of the scout's predicted iteration counts of the last large call */
-int ccmp_ctx_set_order_experimental(ccmp_ctx *ctx, const unsigned int *order_dev);
-int ccmp_ctx_debug_lpt_pred(ccmp_ctx *ctx, uint16_t *host_out, size_t B);
+/* (test and tool hooks — the device probe of ccmp_detmath.h, an externally supplied processing order, the scout's predictions, fault
+ * injection — are not part of this library: include/ccmp_debug.h, lib/libccmp_debug.so) */
 const char *ccmp_strerror(int code);
 const char *ccmp_last_hip_error(void);
 int ccmp_version(void);

@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <limits>
 #include <mutex>
 #include <ostream>
 #include <random>
@@ -191,7 +192,7 @@ public:
   // writes 14 doubles; returns project()'s result for that sample (the reference ignores it)
   bool next(double *state14)
   {
-    if (pos_ >= buf_.size() / 14) refill();
+    if (pos_ >= filled_) refill();
     std::memcpy(state14, &buf_[14 * pos_], 14 * sizeof(double));
     return ok_[pos_++] != 0;
   }
@@ -199,17 +200,19 @@ public:
 private:
   void refill()
   {
+    filled_ = 0;  // a refill that throws leaves the buffer EMPTY (the next call tries again with the same indices), never half-valid
+    pos_ = 0;
     buf_.resize(batch_ * 14);
     ok_.resize(batch_);
     std::lock_guard<std::mutex> hold(proj_.mutex());
     check(ccmp_sample_project_host(proj_.ctx(), &proj_.problem(), seed_, next_index_, buf_.data(), ok_.data(), nullptr, batch_),
           "ccmp_sample_project_host");
     next_index_ += batch_;
-    pos_ = 0;
+    filled_ = batch_;
   }
   const Projector &proj_;
   uint64_t seed_, next_index_ = 0;
-  size_t batch_, pos_ = 0;
+  size_t batch_, pos_ = 0, filled_ = 0;
   std::vector<double> buf_;
   std::vector<uint8_t> ok_;
 };
@@ -239,6 +242,8 @@ public:
 private:
   void refill(const double *ref14, double param)
   {
+    filled_ = 0;  // a refill that throws leaves the buffer EMPTY, never filled with samples around another state
+    pos_ = 0;
     std::memcpy(ref_, ref14, sizeof ref_);
     param_ = param;
     buf_.resize(lookahead_ * 14);
@@ -604,19 +609,26 @@ public:
       throw ompl::Exception("ompl::base::Constraint::setProjectionTolerance(): tolerance must be positive.");
     }
   }
+  // The reference's overrides return plain bool / void and are called from the planner's main thread AND its solution-checker
+  // thread (src/planner/stefanBiPRM.cpp:848-849): nothing may be thrown out of them — a transient HIP error would otherwise
+  // std::terminate the planner.  A failed call keeps the reference's contract for "no": project / isSatisfied / jointValid return
+  // false and leave the state as it was, function writes NaN (so that isSatisfied(f) is false); the error stays readable through
+  // lastError() / lastErrorMessage() until clearError().  setTolerance above remains the only thrower, as in the reference
+  // (ConstraintFunction.h:104-108).
   bool project(Eigen::Ref<Eigen::VectorXd> x) const override
   {
     double buf[14];
     for (int i = 0; i < 14; ++i) buf[i] = x[i];
-    const bool ok = impl_->project(buf);
+    bool ok = false;
+    if (!guarded([&] { ok = impl_->project(buf); })) return false;  // x untouched
     for (int i = 0; i < 14; ++i) x[i] = buf[i];
     return ok;
   }
   void function(const Eigen::Ref<const Eigen::VectorXd> &x, Eigen::Ref<Eigen::VectorXd> out) const override
   {
-    double buf[14], f[2];
+    double buf[14], f[2] = {std::numeric_limits<double>::quiet_NaN(), std::numeric_limits<double>::quiet_NaN()};
     for (int i = 0; i < 14; ++i) buf[i] = x[i];
-    impl_->function(buf, f);
+    guarded([&] { impl_->function(buf, f); });
     out[0] = f[0];
     out[1] = f[1];
   }
@@ -624,18 +636,65 @@ public:
   {
     double buf[14];
     for (int i = 0; i < 14; ++i) buf[i] = x[i];
-    return impl_->isSatisfied(buf);
+    bool ok = false;
+    return guarded([&] { ok = impl_->isSatisfied(buf); }) && ok;
   }
   bool jointValid(const Eigen::Ref<const Eigen::VectorXd> &q) const
   {
     double buf[14];
     for (int i = 0; i < 14; ++i) buf[i] = q[i];
-    return impl_->jointValid(buf);
+    bool ok = false;
+    return guarded([&] { ok = impl_->jointValid(buf); }) && ok;
+  }
+  // 0 (CCMP_OK) or the code of the first error since the last clearError() (CCMP_EHIP, CCMP_ENODEV, ...) — sticky, thread-safe
+  int lastError() const
+  {
+    std::lock_guard<std::mutex> hold(err_mu_);
+    return err_code_;
+  }
+  std::string lastErrorMessage() const
+  {
+    std::lock_guard<std::mutex> hold(err_mu_);
+    return err_what_;
+  }
+  void clearError() const
+  {
+    std::lock_guard<std::mutex> hold(err_mu_);
+    err_code_ = CCMP_OK;
+    err_what_.clear();
+  }
+  // runs `body`; an exception of the library (or any other) is recorded, never passed on: false = it failed.  Used by the space and
+  // the samplers below for their own GPU calls too.
+  template <class F>
+  bool guarded(F &&body) const noexcept
+  {
+    try {
+      body();
+      return true;
+    } catch (const ccmp::Error &e) {
+      record(e.code, e.what());
+    } catch (const std::exception &e) {
+      record(CCMP_EHIP, e.what());
+    } catch (...) {
+      record(CCMP_EHIP, "unknown exception");
+    }
+    return false;
   }
   ccmp::Projector &impl() const { return *impl_; }
 
 private:
+  void record(int code, const char *what) const noexcept
+  {
+    try {
+      std::lock_guard<std::mutex> hold(err_mu_);
+      if (err_code_ == CCMP_OK) { err_code_ = code; err_what_ = what; }
+    } catch (...) {
+    }
+  }
   std::shared_ptr<ccmp::Projector> impl_;
+  mutable std::mutex err_mu_;
+  mutable int err_code_ = CCMP_OK;
+  mutable std::string err_what_;
 };
 typedef std::shared_ptr<KinematicChainConstraint> ChainConstraintPtr;
 
@@ -655,7 +714,7 @@ public:
   {
     auto &&x = *state->as<ompl::base::ConstrainedStateSpace::StateType>();
     double buf[14];
-    buffer_.next(buf);  // already projected and wrapped by enforceBounds on the GPU
+    if (!constraint_->guarded([&] { buffer_.next(buf); })) return;  // already projected and wrapped by enforceBounds on the GPU; a failed refill leaves the state as it was (lastError() of the constraint)
     for (int i = 0; i < 14; ++i) x[i] = buf[i];
   }
   void sampleUniformNear(ompl::base::State *state, const ompl::base::State *near, const double distance) override
@@ -674,7 +733,7 @@ protected:
     auto &&x = *state->as<ompl::base::ConstrainedStateSpace::StateType>();
     double rb[14], out[14];
     for (int i = 0; i < 14; ++i) rb[i] = r[i];
-    buf.next(out, rb, param);  // ambient draw, project (result ignored, as the reference does) and enforceBounds on the GPU
+    if (!constraint_->guarded([&] { buf.next(out, rb, param); })) return;  // ambient draw, project (result ignored, as the reference does) and enforceBounds on the GPU
     for (int i = 0; i < 14; ++i) x[i] = out[i];
   }
   const std::shared_ptr<KinematicChainConstraint> constraint_;
@@ -731,14 +790,21 @@ public:
     auto &&svc = si_->getStateValidityChecker();
     std::vector<std::vector<std::vector<double>>> lists;
     ompl::base::State *scratch = allocState();
-    ccmp::discreteGeodesicBatch(proj, a.data(), b.data(), E, interpolate,
-                                [&](const double *q) {
-                                  auto &x = *scratch->as<StateType>();
-                                  for (int i = 0; i < 14; ++i) x[i] = q[i];
-                                  return svc->isValid(scratch);
-                                },
-                                geodesics ? &lists : nullptr, reached, 64, false, delta_, lambda_); // setDelta / setLambda of the base class
+    const bool done = chain_->guarded([&] {
+      ccmp::discreteGeodesicBatch(proj, a.data(), b.data(), E, interpolate,
+                                  [&](const double *q) {
+                                    auto &x = *scratch->as<StateType>();
+                                    for (int i = 0; i < 14; ++i) x[i] = q[i];
+                                    return svc->isValid(scratch);
+                                  },
+                                  geodesics ? &lists : nullptr, reached, 64, false, delta_, lambda_); // setDelta / setLambda of the base class
+    });
     freeState(scratch);
+    if (!done) {  // the GPU call failed (KinematicChainConstraint::lastError()): no edge was extended
+      if (geodesics) geodesics->assign(E, {});
+      if (reached) reached->assign(E, 0);
+      return;
+    }
     if (geodesics) {
       geodesics->assign(E, {});
       for (size_t e = 0; e < E; ++e)
@@ -763,15 +829,22 @@ private:
     auto &&svc = si_->getStateValidityChecker();
     std::vector<std::vector<double>> states;
     ompl::base::State *scratch = allocState();
-    const bool ok = ccmp::discreteGeodesic(proj, a, b, interpolate,
-                                           [&](const double *q) {
-                                             auto &x = *scratch->as<StateType>();
-                                             for (int i = 0; i < 14; ++i) x[i] = q[i];
-                                             return svc->isValid(scratch);
-                                           },
-                                           geodesic ? &states : nullptr, 64, check_target, delta_,
-                                           lambda_);  // setDelta / setLambda of the base class stay the source of truth
+    bool ok = false;
+    const bool done = chain_->guarded([&] {
+      ok = ccmp::discreteGeodesic(proj, a, b, interpolate,
+                                  [&](const double *q) {
+                                    auto &x = *scratch->as<StateType>();
+                                    for (int i = 0; i < 14; ++i) x[i] = q[i];
+                                    return svc->isValid(scratch);
+                                  },
+                                  geodesic ? &states : nullptr, 64, check_target, delta_,
+                                  lambda_);  // setDelta / setLambda of the base class stay the source of truth
+    });
     freeState(scratch);
+    if (!done) {  // the GPU call failed (KinematicChainConstraint::lastError()): "not reached", no states
+      if (geodesic) geodesic->clear();
+      return false;
+    }
     if (geodesic) {
       geodesic->clear();
       for (const auto &st : states) {

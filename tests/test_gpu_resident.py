@@ -156,8 +156,9 @@ def test_resident_latency_is_reported():
 def test_two_contexts_with_a_service_each():
     """two constraints, two contexts, both resident, called in turn (a planner with a second constraint object): each service has
     its own low-priority stream; either they get hardware queues of their own — then no call waits for the other's idle exit — or
-    a context that finds its kernel queued behind the other's gives the option up by itself ("resident_gave_up") and goes on on
-    the launch path.  Either way: the same bits, and no call anywhere near the idle time."""
+    a call that finds its kernel queued behind the other's takes the launch path, abandons that kernel and tries again behind a
+    back-off ("resident_gave_up" counts the occasions; the option stays on).  Either way: the same bits, and no call anywhere near
+    the idle time."""
     import torch
 
     (ca, xa), (cb, xb) = _constraint(), _constraint("stefan")
@@ -176,6 +177,9 @@ def test_two_contexts_with_a_service_each():
             assert _same(want[2 * k: 2 * k + 2], got)
     print("two services: worst batch of 14 single-state calls %.2f ms; gave up: %d %d" % (worst * 1e3, xa.get_option("resident_gave_up"), xb.get_option("resident_gave_up")))
     assert worst < 0.05, worst  # 14 calls of ~0.1 ms; a wait for the other service's idle exit would be 200 ms
+    assert xa.get_option("resident") == 1 and xb.get_option("resident") == 1  # giving a start up is for one call, not for the context's life
+    xa.set_option("resident", 1)
+    assert xa.get_option("resident_gave_up") == 0  # ... and asking again clears the count and the back-off
     xa.set_option("resident", 0)
     xb.set_option("resident", 0)
     torch.cuda.synchronize()

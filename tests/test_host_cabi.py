@@ -26,7 +26,19 @@ def test_exports_every_declared_symbol(L, ccmp_built):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ccmp_version() == 500
+    assert L.ccmp_version() == 600
+    # the test / tool hooks live in include/ccmp_debug.h and in lib/libccmp_debug.so only: the product library exports none of them
+    # (nor any other symbol that says debug / probe / experimental), and knows no debug option
+    import subprocess
+
+    dbg_hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ccmp_debug.h")).read(), flags=re.S)
+    dbg_declared = set(re.findall(r"\b(ccmp_[a-z0-9_]+)\s*\(", dbg_hdr))
+    assert dbg_declared == set(_lib.DEBUG_EXPORTS) and not (dbg_declared & declared)
+    syms = lambda path: set(re.findall(r" T (\w+)", subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout))
+    default_syms, debug_syms = syms(ccmp_built), syms(_lib.DEBUG_LIBPATH)
+    assert not [n for n in default_syms if re.search(r"debug|probe|experimental", n)], default_syms
+    assert dbg_declared <= debug_syms and declared <= debug_syms and declared <= default_syms
+    assert all(o["name"] != "fail_after_fork" and not o["doc"].startswith("debug") for o in _lib.option_table())
 
 
 def test_library_does_not_link_rccl(ccmp_built):

@@ -7,6 +7,8 @@ import sys
 import numpy as np
 import torch
 
+import os
+os.environ.setdefault("CCMP_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "closed_chain_motion_planner_amd", "lib", "libccmp_debug.so"))  # reads the scout's predictions: a hook of include/ccmp_debug.h
 sys.path.insert(0, ".")
 sys.path.insert(0, "tools")
 from closed_chain_motion_planner_amd import Context, KinematicChainConstraint, _lib  # noqa: E402
