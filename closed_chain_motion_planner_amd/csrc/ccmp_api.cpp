@@ -437,6 +437,10 @@ static int project_common(ccmp_ctx *ctx, const ccmp_problem *p, int mode, const 
     if (ctx->flat_kernel) {
       unsigned int *flag = arm_done_word(ctx, B);
       const unsigned int *lat_order = nullptr;
+      // (Round 6 measured and dropped a head start — the first resident-blocks samples in index order on this stream while scout
+      // and sort of the rest, and then the rest, ran on the side stream: 4 096 Wine_Bottle samples 0.656 -> 0.704 ms, stefan 0.977 ->
+      // 1.163 ms over six seeds, bit-identical; the longest sample is as likely in the rest, where it then starts later than behind
+      // the scout — profiles/r06_head_start_ab.log.)
       if (pl.latency_order) { // longest-predicted-first on the latency kernel alone
         const ScoutBuffers sb(ctx);
         HIP_TRY(ccmp_launch_scout_order(&K, mode, q_in, B, sb.pred, sb.hist, sb.order, ctx->queue + 5, seed, first, ctx->num_cus, scout_pair_blocks, nullptr, st));

@@ -31,5 +31,7 @@ def rounds(argv):
             print("%s: %5d wavefronts (%6d samples, %d rounds each): %.3f ms = %.2f us per round" % (kernel, waves, B, int(it.max()), ms, ms * 1e3 / 251), flush=True)
 
 
+
+
 if __name__ == "__main__":
     {"rounds": rounds}[sys.argv[1]](sys.argv[2:])
