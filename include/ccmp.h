@@ -171,9 +171,6 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "pool_long_remaining"           24        0..1000       hand-over in two classes: samples predicted to need at least this many more iterations
  *                                                           are taken first (0 = one class)
  *   "latency_blocks_per_cu"         8         1..32         persistent blocks of the latency kernel per CU (8 are resident)
- *   "latency_head_start"            0         0..1          latency kernel alone, ordered: 1 = the first resident-blocks samples start at once in
- *                                                           index order while scout and sort of the rest run on the side stream (round-6 experiment,
- *                                                           measured and left off)
  *   "fd_split"                      1         0..1          1 = split launch: above small_batch, the predicted-longest samples run on latency blocks
  *                                                           on a side stream beside the throughput kernel
  *   "fd_split_min"                  0         0..max        split launch from this many samples ...
