@@ -25,6 +25,8 @@ struct OptionDesc {
 
 #define OPT(name, member, kind, lo, hi, flags, doc) {name, offsetof(ccmp_ctx, member), kind, lo, hi, flags, doc}
 // The order is the order of the table in include/ccmp.h (tests/test_host_cabi.py compares the two).
+// Round 6 removed seventeen options whose sweeps had one setting winning everywhere (DESIGN_experiments.md §11, §13): their members
+// of ccmp_ctx keep the winning value as a constant of the build.
 const OptionDesc kOptions[] = {
     // projector, reference arithmetic
     OPT("hand_over", wave_kernel, kInt, 0, 2, 0, "0 = throughput kernel (10 samples per wavefront) only, 1 = that kernel until its queue drains, then the latency kernel on what is in flight, 2 = latency kernel only (= ccmp_ctx_set_schedule)"),
@@ -36,8 +38,6 @@ const OptionDesc kOptions[] = {
     OPT("flat_kernel", flat_kernel, kInt, 0, 1, 0, "latency work: 1 = one sample per 128-thread block, an iteration's evaluations in one round, 0 = one wavefront per sample"),
     OPT("stock_kernels", stock_kernels, kInt, 0, 1, 0, "1 = kernels that skip the exact zeros of the uncalibrated Panda when both arms carry them (same bits), 0 = always the general kernels"),
     OPT("handover_threshold", dump_threshold, kInt, -1, 110, 0, "-1 = automatic; 0..10: a wavefront hands over once the queue is dry and at most this many of its 10 groups are busy; 11..110: all hand over once the samples in flight fill less than (value - 10) % of the group slots"),
-    OPT("pool_long_remaining", pool_long_remaining, kInt, 0, 1000, 0, "hand-over in two classes: samples predicted to need at least this many more iterations are taken first (0 = one class)"),
-    OPT("latency_blocks_per_cu", latency_blocks_per_cu, kInt, 1, 32, 0, "persistent blocks of the latency kernel per CU (8 are resident)"),
     OPT("fd_split", fd_split, kInt, 0, 1, 0, "1 = split launch: above small_batch, the predicted-longest samples run on latency blocks on a side stream beside the throughput kernel"),
     OPT("fd_split_min", fd_split_min, kSize, 0, LONG_MAX, 0, "split launch from this many samples ..."),
     OPT("fd_split_max", fd_split_max, kSize, 0, LONG_MAX, 0, "... up to this many"),
@@ -51,11 +51,8 @@ const OptionDesc kOptions[] = {
     OPT("analytic_handover", analytic_handover, kInt, 0, 32, 0, "analytic mode: a wavefront of the lane-pair kernel whose tickets are gone hands over to the latency kernel once it holds at most this many samples (0 = never: one launch)"),
     // FP32 scouts
     OPT("scout_pairs", scout_pairs, kInt, 0, 1, 0, "1 = two lanes per sample / edge, one arm each, where lanes are plentiful (stock twin arms)"),
-    OPT("scout_pair_blocks_per_cu", scout_pair_blocks_per_cu, kInt, 1, 64, 0, "... projector: up to 128 x this x CUs samples"),
-    OPT("scout_pair_max_edges", scout_pair_max_edges, kSize, 0, LONG_MAX, 0, "... extend step: up to this many edges"),
     // extend step
     OPT("geodesic_flavour", geodesic_flavour, kInt, 0, 2, 0, "two builds, same bits: 0 = throughput build for calls with a round budget beyond the latency build's blocks, latency build otherwise; 1 / 2 = always the throughput / latency build"),
-    OPT("geodesic_blocks_per_cu", geodesic_blocks_per_cu, kInt, 1, 32, 0, "persistent blocks of the latency build per CU (4 are resident)"),
     OPT("geodesic_order", geodesic_order, kInt, 0, 2, 0, "batches beyond the resident blocks: 0 = index order, 1 = far-apart edges first, 2 = FP32 scout order from geodesic_scout_min edges on"),
     OPT("geodesic_order_min", geodesic_order_min, kSize, 0, LONG_MAX, 0, "no ordering pass below this many edges"),
     OPT("geodesic_long_steps", geodesic_long_steps, kDouble, 0, LONG_MAX, 0, "order 1: edges further apart than this many delta count as long"),
@@ -65,10 +62,7 @@ const OptionDesc kOptions[] = {
     OPT("geodesic_group_min", geodesic_group_min, kSize, 0, LONG_MAX, 0, "... from this many edges"),
     OPT("geodesic_group_pred", geodesic_group_pred, kInt, -1, 1023, kNotZero, "... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it carry geodesic_group_heavy_permille of the work, else geodesic_group_low_cut)"),
     OPT("geodesic_group_low_cut", geodesic_group_low_cut, kInt, -1, 64, kNotZero, "... (-1: 40 below 20480 edges, 48 from there on, 56 from 65536)"),
-    OPT("geodesic_group_heavy_permille", geodesic_group_heavy_permille, kInt, 0, 1001, 0, "... see geodesic_group_pred"),
     OPT("geodesic_group_permille", geodesic_group_permille, kInt, 0, 1000, 0, "... > 0: instead, the largest cut whose front carries this share of the predicted work"),
-    OPT("geodesic_group_front_per_cu", geodesic_group_front_per_cu, kInt, -1, 8, kNotZero, "... latency blocks per CU launched for the front (-1 = 8)"),
-    OPT("geodesic_group_waves_per_cu", geodesic_group_waves_per_cu, kInt, 1, 10, 0, "... wavefronts of the throughput layout per CU at most"),
     OPT("geodesic_group_handover_pct", geodesic_group_handover_pct, kInt, -1, 100, 0, "... with the queue dry, every wavefront gives its edges to latency blocks once those in flight fill less than this share of the slots (0 = never; -1: 50 below 32768 edges, 80 from there on)"),
     // other
     OPT("clearance_per_state_max", clearance_per_state_max, kSize, 0, LONG_MAX, 0, "proxy clearance: one block per state up to this many states, 64-state tiles above"),

@@ -168,9 +168,6 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "handover_threshold"            -1        -1..110       -1 = automatic; 0..10: a wavefront hands over once the queue is dry and at most this many
  *                                                           of its 10 groups are busy; 11..110: all hand over once the samples in flight fill less
  *                                                           than (value - 10) % of the group slots
- *   "pool_long_remaining"           24        0..1000       hand-over in two classes: samples predicted to need at least this many more iterations
- *                                                           are taken first (0 = one class)
- *   "latency_blocks_per_cu"         8         1..32         persistent blocks of the latency kernel per CU (8 are resident)
  *   "fd_split"                      1         0..1          1 = split launch: above small_batch, the predicted-longest samples run on latency blocks
  *                                                           on a side stream beside the throughput kernel
  *   "fd_split_min"                  0         0..max        split launch from this many samples ...
@@ -188,12 +185,9 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *                                                           the latency kernel once it holds at most this many samples (0 = never: one launch)
  *   "scout_pairs"                   1         0..1          1 = two lanes per sample / edge, one arm each, where lanes are plentiful (stock twin
  *                                                           arms)
- *   "scout_pair_blocks_per_cu"      1         1..64         ... projector: up to 128 x this x CUs samples
- *   "scout_pair_max_edges"          131072    0..max        ... extend step: up to this many edges
  *   "geodesic_flavour"              0         0..2          two builds, same bits: 0 = throughput build for calls with a round budget beyond the
  *                                                           latency build's blocks, latency build otherwise; 1 / 2 = always the throughput / latency
  *                                                           build
- *   "geodesic_blocks_per_cu"        4         1..32         persistent blocks of the latency build per CU (4 are resident)
  *   "geodesic_order"                2         0..2          batches beyond the resident blocks: 0 = index order, 1 = far-apart edges first, 2 = FP32
  *                                                           scout order from geodesic_scout_min edges on
  *   "geodesic_order_min"            2049      0..max        no ordering pass below this many edges
@@ -206,10 +200,7 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *   "geodesic_group_pred"           -1        -1..1023      ... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it
  *                                                           carry geodesic_group_heavy_permille of the work, else geodesic_group_low_cut)
  *   "geodesic_group_low_cut"        -1        -1..64        ... (-1: 40 below 20480 edges, 48 from there on, 56 from 65536)
- *   "geodesic_group_heavy_permille" 100       0..1001       ... see geodesic_group_pred
  *   "geodesic_group_permille"       0         0..1000       ... > 0: instead, the largest cut whose front carries this share of the predicted work
- *   "geodesic_group_front_per_cu"   8         -1..8         ... latency blocks per CU launched for the front (-1 = 8)
- *   "geodesic_group_waves_per_cu"   8         1..10         ... wavefronts of the throughput layout per CU at most
  *   "geodesic_group_handover_pct"   -1        -1..100       ... with the queue dry, every wavefront gives its edges to latency blocks once those in
  *                                                           flight fill less than this share of the slots (0 = never; -1: 50 below 32768 edges, 80
  *                                                           from there on)

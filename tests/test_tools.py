@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_tools_compile(tmp_path):
     files = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
-    assert len(files) > 10
+    assert len(files) >= 8
     for f in files:
         py_compile.compile(f, cfile=str(tmp_path / (os.path.basename(f) + "c")), doraise=True)
 
