@@ -60,7 +60,7 @@ const OptionDesc kOptions[] = {
     OPT("geodesic_scout_rounds", geodesic_scout_rounds, kInt, 1, 1023, 0, "the scout stops an edge after this many Newton rounds"),
     OPT("geodesic_group", geodesic_group, kInt, 0, 1, 0, "1 = bulk calls (round budget, scout order): short edges ten to a wavefront on the throughput layout, the front of the order on latency blocks beside them"),
     OPT("geodesic_group_min", geodesic_group_min, kSize, 0, LONG_MAX, 0, "... from this many edges"),
-    OPT("geodesic_group_pred", geodesic_group_pred, kInt, -1, 1023, kNotZero, "... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it carry geodesic_group_heavy_permille of the work, else geodesic_group_low_cut)"),
+    OPT("geodesic_group_pred", geodesic_group_pred, kInt, -1, 1023, kNotZero, "... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it carry a tenth of the predicted work, else geodesic_group_low_cut)"),
     OPT("geodesic_group_low_cut", geodesic_group_low_cut, kInt, -1, 64, kNotZero, "... (-1: 40 below 20480 edges, 48 from there on, 56 from 65536)"),
     OPT("geodesic_group_permille", geodesic_group_permille, kInt, 0, 1000, 0, "... > 0: instead, the largest cut whose front carries this share of the predicted work"),
     OPT("geodesic_group_handover_pct", geodesic_group_handover_pct, kInt, -1, 100, 0, "... with the queue dry, every wavefront gives its edges to latency blocks once those in flight fill less than this share of the slots (0 = never; -1: 50 below 32768 edges, 80 from there on)"),

@@ -198,7 +198,7 @@ int ccmp_ctx_option_info(int index, const char **name, long *dflt, long *lo, lon
  *                                                           throughput layout, the front of the order on latency blocks beside them
  *   "geodesic_group_min"            13312     0..max        ... from this many edges
  *   "geodesic_group_pred"           -1        -1..1023      ... cut of the order in predicted rounds (-1: the scout's cap where the edges beyond it
- *                                                           carry geodesic_group_heavy_permille of the work, else geodesic_group_low_cut)
+ *                                                           carry a tenth of the predicted work, else geodesic_group_low_cut)
  *   "geodesic_group_low_cut"        -1        -1..64        ... (-1: 40 below 20480 edges, 48 from there on, 56 from 65536)
  *   "geodesic_group_permille"       0         0..1000       ... > 0: instead, the largest cut whose front carries this share of the predicted work
  *   "geodesic_group_handover_pct"   -1        -1..100       ... with the queue dry, every wavefront gives its edges to latency blocks once those in
