@@ -15,7 +15,7 @@ Translation units with deliberately different flags:
   ccmp_kernels_resident.hip -ffp-contract=off -DCCMP_USE_FMA  ... its device side, on the latency flavour's Newton routine
   ccmp_host_io.cpp                                          *_host conveniences (staging, pinned block, page-locked caller buffers), sharded host calls
   ccmp_comm.cpp                                             one process / several GPUs: RCCL communicator and sharded entry points
-  ccmp_kernels_fast.hip  -ffp-contract=off -DCCMP_USE_FMA   analytic fast mode (one sample per lane pair), bit-identical to the oracle's analytic mode
+  ccmp_kernels_fast.hip  -ffp-contract=off -DCCMP_USE_FMA -DCCMP_LEAN_SQRT   analytic fast mode (one sample per lane pair), bit-identical to the oracle's analytic mode
   ccmp_kernels_scout.hip -ffast-math                        FP32 iteration-count predictor + ordering (never touches results)
   ccmp_kernels_scene.hip -ffp-contract=off -DCCMP_USE_FMA   proxy-geometry clearance (pre-filter ahead of the host's MoveIt test)
   ccmp_scene.cpp                                            proxy scenes: validation, pair list, launches
@@ -57,7 +57,7 @@ _UNITS = [
     ("ccmp_kernels_resident.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_SUMS_IN_LANE", "-DCCMP_FLAT_MIN_WAVES=2", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     # the analytic mode's lane-pair kernel: without machine LICM (the ~35 FP64 literals of sincos / atan would be held in
     # registers across the Newton loop and spilled: 168 registers + 36 B of scratch instead of 142 and none)
-    ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-mllvm", "-disable-machine-licm"]),
+    ("ccmp_kernels_fast.hip", ["-O3", "-ffp-contract=off", "-DCCMP_USE_FMA", "-DCCMP_LEAN_SQRT", "-mllvm", "-disable-machine-licm"]),
     ("ccmp_kernels_scout.hip", ["-O3", "-ffp-contract=fast", "-ffast-math", "-fno-slp-vectorize"]),  # SLP packs into v_pk_* and spills 310 dwords
     ("ccmp_problem.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
     ("ccmp_api.cpp", ["-O2", "-ffp-contract=off", "-DCCMP_USE_FMA", "-x", "hip"]),
