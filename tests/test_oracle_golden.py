@@ -533,3 +533,31 @@ def test_a_continued_geodesic_is_the_uninterrupted_one(oracle_det):
             assert got.shape == full.shape and np.array_equal(got.view(np.uint64), full.view(np.uint64))
             assert ok == full_ok and total_its == full_its
     assert cuts > 50
+
+
+def test_gram_step_is_the_minimum_norm_solution(oracle_det, oracle_libm):
+    """orc_solve_gram — the analytic mode's step, SURVEY.md §7.3: dx = J^T (J J^T)^-1 f through the 2x2 Gram matrix in closed form —
+    against numpy's minimum-norm least-squares solution and against the SVD-equivalent routine of the reference arithmetic
+    (orc_solve_minnorm = Eigen's JacobiSVD.solve, ConstraintFunction.h:71) on Jacobians of the real problem: the same solution to
+    1e-10 relative wherever the two rows are not nearly parallel; and where they are (sin^2 of their angle <= 2^-20), or the matrix
+    is rank-deficient, or something is NaN, it IS orc_solve_minnorm, bit for bit — rank handling stays Eigen's."""
+    for O in (oracle_det, oracle_libm):
+        P = O.problem(load_cfg("Wine_Bottle"))
+        rng = np.random.default_rng(11)
+        worst = 0.0
+        for k in range(200):
+            x = O.ambient_uniform(P, 0x6A, k)
+            J = O.jacobian(P, x, analytic=True)
+            f = O.function(P, x)
+            dx = O.solve_gram(J, f)
+            ref = np.linalg.lstsq(J, f, rcond=None)[0]
+            worst = max(worst, np.abs(dx - ref).max() / np.abs(ref).max())
+            assert np.abs(dx - O.solve_minnorm(J, f)).max() <= 1e-10 * np.abs(ref).max()
+        assert worst < 1e-10, worst
+        # nearly parallel rows, exactly parallel rows, a zero row, a NaN: the fallback, bit for bit
+        base = rng.standard_normal(14)
+        for J in (np.stack([base, base * (1 + 1e-9) + 1e-9 * rng.standard_normal(14)]), np.stack([base, 2.0 * base]), np.stack([base, np.zeros(14)]),
+                  np.stack([base, np.where(np.arange(14) == 3, np.nan, base)])):
+            f = np.array([0.3, 0.2])
+            a, b = O.solve_gram(J, f), O.solve_minnorm(J, f)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) or (np.isnan(a).all() and np.isnan(b).all()), J
