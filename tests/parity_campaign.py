@@ -25,7 +25,7 @@ build_oracle()
 orc = Oracle("det")
 ctx = Context(0)
 # (object, tolerances, seed, jacobian mode, samples); the analytic mode (its own extension) against the oracle's analytic
-# mode: above and inside the batch sizes of its split launch (100 000 .. 300 000 samples)
+# mode (lane-pair kernel + hand-over to the latency kernel; a 2-million-sample case where the hand-over is a sliver of the call)
 # variants (the general kernel instantiations at scale — every shipped configuration takes the stock-structure ones):
 # "calibrated" = DH calibration offsets, different for the two arms (ccmp_set_calibration: axes tilt, offsets fill in, the
 # arms stop being twins); "tilted" = arm 2 on a base rotated about two axes and arm 1 on a 1-ulp-off identity (tool_pose's
@@ -34,6 +34,7 @@ cases = [("Wine_Bottle", None, 0xA1, 0, N, None), ("stefan", None, 0xA2, 0, N, N
          ("stefan", (5e-4, 2.5e-3), 0xA4, 0, N, None),
          ("Wine_Bottle", None, 0xA8, 0, N // 2, "calibrated"), ("stefan", None, 0xA9, 0, N // 2, "tilted"),
          ("Wine_Bottle", None, 0xA5, 1, N, None), ("Wine_Bottle", None, 0xA6, 1, min(N, 250000), None), ("stefan", None, 0xA7, 1, min(N, 250000), None),
+         ("dumbbell", None, 0xAB, 1, N // 2, None), ("stefan", None, 0xAC, 1, N // 2, "tilted"),
          ("Wine_Bottle", None, 0xAA, 1, N // 2, "calibrated")]
 report = {"samples_per_case": N, "host_threads": NCPU, "cases": []}
 from closed_chain_motion_planner_amd.scene import ProxyValidityChecker  # noqa: E402
@@ -82,9 +83,10 @@ for obj, tol, seed, mode, N, variant in cases:
     }
     # the same samples again in mid-size batches — the sizes of the split launch (round 4: the predicted-longest samples on latency
     # blocks beside the throughput kernel, 12288 .. 90112 samples) — against the oracle rows already computed
-    if mode == 0:
+    # (analytic mode: 4 096 — the latency kernel alone — and the lane-pair kernel with its hand-over at two sizes)
+    if True:
         mid_same, mid_n = 0, 0
-        for chunk in (20000, 60000, 13000):
+        for chunk in ((20000, 60000, 13000) if mode == 0 else (4096, 20000, 60000)):
             for a in range(0, min(N, 180000) - chunk + 1, chunk):
                 o2, k2, i2 = c.project_batch(q[a:a + chunk].contiguous())
                 mid_same += int(((o2.cpu().numpy().view(np.uint64) == q_cpu[a:a + chunk].view(np.uint64)).all(axis=1)

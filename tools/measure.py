@@ -264,7 +264,7 @@ def soak(argv):
         ref = c.project_batch(q)
         bad = sum(not all(torch.equal(a, b) for a, b in zip(c.project_batch(q), ref)) for _ in range(25))
         print(obj, B, "repeats differing from the first run:", bad, flush=True)
-    # the analytic mode's split launch (two streams, scout order) and the proxy clearance, the same way
+    # the analytic mode (lane-pair kernel + hand-over to the latency kernel) and the proxy clearance, the same way
     from closed_chain_motion_planner_amd.scene import ProxyValidityChecker
 
     c = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
@@ -272,7 +272,7 @@ def soak(argv):
     q = c.ambient_uniform_batch(0x50B, 0, 200000)
     ref = c.project_batch(q)
     bad = sum(not all(torch.equal(a, b) for a, b in zip(c.project_batch(q), ref)) for _ in range(25))
-    print("Wine_Bottle analytic 200000 (split launch) repeats differing:", bad, flush=True)
+    print("Wine_Bottle analytic 200000 (lane-pair kernel + latency kernel) repeats differing:", bad, flush=True)
     # the extend step beyond the resident blocks: ticket queue + FP32 scout order (atomics decide who takes which edge,
     # the sort's ties fall as they fall) — counts, flags, Newton counts and every listed state, the same 25 times over
     cg = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
