@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))  # oracle_binding lives next to this file
 import torch  # noqa: E402
-from closed_chain_motion_planner_amd import Context, KinematicChainConstraint  # noqa: E402
+from closed_chain_motion_planner_amd import Context, KinematicChainConstraint, _lib  # noqa: E402
 from oracle_binding import Oracle, build_oracle  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
