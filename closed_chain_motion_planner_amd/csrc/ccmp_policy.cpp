@@ -401,6 +401,9 @@ int ccmp_ctx_describe(const ccmp_ctx *ctx_in, int call_kind, size_t n, char *buf
     }
     default: return CCMP_EINVAL;
   }
+  // without a context the plan is the built-in policy on an ASSUMED device: say so (block counts and the thresholds that mark
+  // "as soon as the resident blocks take tickets" follow the CU count)
+  if (!ctx_in) L.add(" {no context: a %d-CU device assumed}", ctx->num_cus);
   return (int)L.len; // the length the whole line needs (snprintf's convention); the buffer holds what fitted, NUL-terminated
 }
 
