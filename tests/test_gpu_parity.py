@@ -307,6 +307,11 @@ def test_analytic_mode_bitwise(gpu_ctx, oracle_det, obj, B):
     qs, oks, its, _ = c.sample_project_batch(0xA7, 0, 777)
     e_q, e_ok, e_it = oracle_det.sample_project_batch(P, 0xA7, 0, 777, NCPU)
     assert np.array_equal(qs.cpu().numpy().view(np.uint64), e_q.view(np.uint64)) and np.array_equal(oks.cpu().numpy(), e_ok)
+    # the reference signature, one state through the host entry point (one wavefront of the latency kernel)
+    for k in range(3):
+        x = q[k].copy()
+        ok1 = c.project(x)
+        assert ok1 == bool(ok_cpu[k]) and np.array_equal(x.view(np.uint64), q_cpu[k].view(np.uint64)), k
 
 
 _ANALYTIC_OPTIONS = ("analytic_small_batch", "analytic_waves_per_cu", "analytic_handover")
