@@ -202,7 +202,7 @@ FdPlan plan_fd_batch(const ccmp_ctx *ctx, size_t B, bool external_order)
 }
 
 // Analytic mode (ccmp_kernels_fast.hip).  Throughput: one sample per lane pair, 32 per wavefront, three wavefronts per SIMD.  A
-// wavefront alone on its SIMD pays ~4.6 cycles per instruction whatever it holds, so a Newton round there lasts 4.2 us and a call
+// wavefront alone on its SIMD pays ~4.6 cycles per instruction whatever it holds, so a Newton round there lasts 4 us and a call
 // would end on wavefronts that hold one or two long samples each: once the tickets are gone a wavefront that holds at most
 // analytic_handover samples hands them over (x, index, counters) to the sixteen-lanes-per-sample latency kernel launched behind
 // (2.7 us per round, four samples per wavefront), which also takes small batches alone.  (Round 6 measured and dropped: a cap on
