@@ -273,6 +273,13 @@ def soak(argv):
     ref = c.project_batch(q)
     bad = sum(not all(torch.equal(a, b) for a, b in zip(c.project_batch(q), ref)) for _ in range(25))
     print("Wine_Bottle analytic 200000 (lane-pair kernel + latency kernel) repeats differing:", bad, flush=True)
+    for obj, B in (("stefan", 262144), ("Wine_Bottle", 2097152), ("dumbbell", 5000)):  # the hand-over's order is decided by atomics; the latency kernel alone
+        ca = KinematicChainConstraint.from_yaml(CFG % obj, ctx=ctx)
+        ca.setJacobianMode(1)
+        qa = ca.ambient_uniform_batch(0x50E, 0, B)
+        ra = ca.project_batch(qa)
+        bad = sum(not all(torch.equal(a, b) for a, b in zip(ca.project_batch(qa), ra)) for _ in range(25))
+        print(obj, "analytic", B, "repeats differing:", bad, flush=True)
     # the extend step beyond the resident blocks: ticket queue + FP32 scout order (atomics decide who takes which edge,
     # the sort's ties fall as they fall) — counts, flags, Newton counts and every listed state, the same 25 times over
     cg = KinematicChainConstraint.from_yaml(CFG % "Wine_Bottle", ctx=ctx)
