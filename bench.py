@@ -662,6 +662,8 @@ def flatten_for_the_driver(line, B):
             "c3_calibrated_per_s": get(sec, "c3_calibrated", "projections_per_s"),
             "c3_calibrated_bitwise": get(sec, "c3_calibrated", "parity_vs_det_oracle", "bit_identical"),
             "c3_calibrated_analytic_per_s": get(sec, "c3_calibrated", "analytic_projections_per_s"),
+            "extend_calibrated_first_pass_edges_per_s": get(sec, "c3_calibrated", "extend_first_pass_edges_per_s"),
+            "extend_calibrated_bitwise": get(sec, "c3_calibrated", "extend_parity_vs_det_oracle", "bit_identical"),
             "analytic_mode_per_s": sec.get("analytic_mode_projections_per_s"),
             "analytic_bitwise": get(sec, "analytic_mode", "parity_vs_det_oracle", "bit_identical"),
             "analytic_bitwise_samples": get(sec, "analytic_mode", "parity_vs_det_oracle", "samples"),
@@ -1098,6 +1100,31 @@ def secondary(args, c, ctx, B, torch, cfg_path):
                                                                                  and np.array_equal(itd, it[:m].cpu().numpy().astype("int32")))}}
         cal.setJacobianMode(CCMP_JAC_ANALYTIC)
         res["analytic_projections_per_s"] = B / timed(lambda: cal.project_batch(qi, out=qo), 3)
+        # the extend step on the same model (geodesic_flat_kernel<false> + geodesic_group_kernel<false>): the first pass of the
+        # growTree-shaped workload above, 16 384 edges, lists of 16 states, 128 Newton rounds per edge; 256 edges against the oracle
+        cal.setJacobianMode(CCMP_JAC_FD)
+        ne = 16384
+        q2, ok2, _, _ = cal.sample_project_batch(0x6E0, 0, 8 * ne, want_iters=False)
+        frm = q2[ok2 == 1][:ne].contiguous()
+        to, _, _, _ = cal.sample_near_project_batch(0x6E1, 0, frm, 0.6, ne, want_iters=False)
+        call = lambda: cal.discrete_geodesic_batch(frm, to, 16, want_carry=True, round_budget=128)
+        sec_g = timed(call, 5)
+        st, n, gok, its, _ = call()
+        done = int(((n <= 16) & (gok != 2)).sum().item())
+        res["extend_first_pass_edges_per_s"] = done / sec_g
+        res["extend_first_pass_ms"] = sec_g * 1e3
+        m = 256
+        sc, nc, okc, itc = Od.discrete_geodesic_batch(Pd, frm[:m].cpu().numpy(), to[:m].cpu().numpy(), 16, threads)
+        same = 0
+        st_h, n_h, ok_h = st[:m].cpu().numpy(), n[:m].cpu().numpy(), gok[:m].cpu().numpy()
+        for e in range(m):
+            if ok_h[e] == 2:  # the round budget was spent: the oracle's traversal (no budget) is longer, its prefix must agree
+                k = min(int(n_h[e]), 16)
+                same += int(np.array_equal(st_h[e, :k].view(np.uint64), sc[e, :k].view(np.uint64)))
+                continue
+            k = min(int(n_h[e]), 16)
+            same += int(n_h[e] == nc[e] and bool(ok_h[e]) == bool(okc[e]) and np.array_equal(st_h[e, :k].view(np.uint64), sc[e, :k].view(np.uint64)))
+        res["extend_parity_vs_det_oracle"] = {"edges": m, "bit_identical": bool(same == m)}
         return res
 
     out = {}
