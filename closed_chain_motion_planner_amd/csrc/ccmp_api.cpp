@@ -54,6 +54,10 @@ hipError_t ccmp_launch_project_flat(const ccmp_consts *K, int src, const double 
 hipError_t ccmp_launch_fd_split(const unsigned int *hist, int pred_min, unsigned int limit, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_geo_split(const unsigned int *hist, int p_min, int p_max, int permille, unsigned long long *queue, hipStream_t st);
 hipError_t ccmp_launch_split_count(const unsigned int *hist, int pred_min, unsigned int limit, unsigned int *out, hipStream_t st);
+hipError_t ccmp_launch_geodesic_analytic_step(int which, double delta, double lambda, const double *from, const double *to, size_t E,
+                                              int max_states, double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters,
+                                              const double *carry_in, double *carry_out, const uint8_t *target_ok, void *const *ws,
+                                              const double *start14, hipStream_t st);
 hipError_t ccmp_launch_project_analytic(const ccmp_consts *K, int mode, const double *q_in, double *q_out, uint8_t *ok, uint16_t *iters,
                                         double *q_ambient, size_t B, unsigned long long *queue, unsigned long long seed,
                                         unsigned long long first, int pair_blocks, int dump_below, int latency_blocks, double *pool,
@@ -256,6 +260,7 @@ void ccmp_ctx_destroy(ccmp_ctx *ctx)
   ccmp_host::resident_destroy(ctx); // first: hipFree below waits for the whole device, a resident kernel included
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->geo_pool) (void)hipFree(ctx->geo_pool);
+  if (ctx->geo_an) (void)hipFree(ctx->geo_an);
   if (ctx->queue) (void)hipFree(ctx->queue);
   if (ctx->pool) (void)hipFree(ctx->pool);
   if (ctx->lpt_buf) (void)hipFree(ctx->lpt_buf);
@@ -558,12 +563,47 @@ static int geodesic_common(ccmp_ctx *ctx, const ccmp_problem *p, const double *f
   if (E == 0) return CCMP_OK;
   if (!from || !to || !states || !n_states || !ok || max_states < 1 || round_budget < 0) return CCMP_EINVAL;
   if (!(p->delta > 0) || !(p->lambda > 0)) return CCMP_EINVAL;
-  if (p->jacobian_mode != CCMP_JAC_FD) return CCMP_EINVAL; // the extend step exists in reference arithmetic only
+  if (newton_iters == nullptr && p->jacobian_mode != CCMP_JAC_FD) return CCMP_EINVAL; // (the analytic step loop keeps its counts there)
   if (carry_in && check_target) return CCMP_EINVAL;        // a continuation's target was tested by the call it continues
   if (round_budget > 0 && !carry_out) return CCMP_EINVAL;  // a suspended edge is useless without what its continuation needs
   // a resumable call needs room for one state besides `from`: with a one-entry list the first accepted state already reports
   // max_states + 1 with `from` as its last stored state, and a caller following the protocol would continue from `from` for ever
   if ((carry_in || carry_out || round_budget > 0) && max_states < 2) return CCMP_EINVAL;
+  if (p->jacobian_mode != CCMP_JAC_FD) {
+    // Analytic mode (round 6): the traversal is a step loop around the batched analytic projector (ccmp_kernels_fast.hip) — per
+    // step: every live edge's interpolated state, the projection of all of them in place, the reference's bookkeeping — at most
+    // max_states steps, no host synchronisation, capturable.  A round budget is not enforced here (ok is never 2).
+    if (ctx->geo_an_cap < E) { // (grows outside any stream capture: the first call at a size is never captured)
+      ccmp_host::quiesce(ctx);
+      if (ctx->geo_an) (void)hipFree(ctx->geo_an);
+      ctx->geo_an = nullptr;
+      ctx->geo_an_cap = 0;
+      HIP_TRY(hipMalloc(&ctx->geo_an, E * ((14 + 14 + 3) * sizeof(double) + 2 + 1 + 1 + 1)));
+      ctx->geo_an_cap = E;
+    }
+    char *base = (char *)ctx->geo_an;
+    const size_t cap = ctx->geo_an_cap;
+    double *prev = (double *)base, *scr = prev + cap * 14, *dtm = scr + cap * 14;
+    uint16_t *itp = (uint16_t *)(dtm + cap * 3);
+    uint8_t *okp = (uint8_t *)(itp + cap), *live = okp + cap, *tok = live + cap;
+    void *ws[6] = {prev, scr, dtm, itp, okp, live};
+    const uint8_t *target_ok = nullptr;
+    if (check_target) { // ConstrainedMotionValidator::checkMotion: isSatisfied(to) first
+      HIP_TRY(ccmp_launch_is_satisfied(&K, to, tok, E, nullptr, 0, st));
+      target_ok = tok;
+    }
+    HIP_TRY(ccmp_launch_geodesic_analytic_step(0, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, carry_in, carry_out,
+                                               target_ok, ws, p->start_joint, st));
+    for (int s = 0; s < max_states; s++) {
+      HIP_TRY(ccmp_launch_geodesic_analytic_step(1, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, nullptr, carry_out,
+                                                 nullptr, ws, p->start_joint, st));
+      const int rc = project_common(ctx, p, 0, scr, scr, okp, itp, nullptr, E, 0, 0, hip_stream);
+      if (rc != CCMP_OK) return rc;
+      HIP_TRY(ccmp_launch_geodesic_analytic_step(2, p->delta, p->lambda, from, to, E, max_states, states, n_states, ok, newton_iters, nullptr, carry_out,
+                                                 nullptr, ws, p->start_joint, st));
+    }
+    return CCMP_OK;
+  }
   // what the call is going to launch is decided (ccmp_policy.cpp: plan_geodesic — what ccmp_ctx_describe prints) and every workspace
   // it needs is sized before anything of it is in flight
   const GeoPlan pl = ccmp_host::plan_geodesic(ctx, E, round_budget, carry_in != nullptr);

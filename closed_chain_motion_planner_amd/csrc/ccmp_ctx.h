@@ -75,6 +75,8 @@ struct ccmp_ctx {
   size_t lpt_cap = 0;                  // in samples
   double *geo_pool = nullptr;          // bulk extend hand-over: kGeoPoolDoubles per edge
   size_t geo_pool_cap = 0;
+  void *geo_an = nullptr;              // the analytic-mode extend step's per-edge state (ccmp_kernels_fast.hip: geo_an_ws) + target flags
+  size_t geo_an_cap = 0;               // in edges
   unsigned int *scan = nullptr;        // compaction block counts
   size_t scan_cap = 0;
   void *stage = nullptr;               // device staging of the *_host conveniences

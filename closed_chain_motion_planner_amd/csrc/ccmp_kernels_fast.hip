@@ -621,6 +621,143 @@ __global__ __launch_bounds__(64, 2) void project_row16_kernel(const ccmp_consts 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The extend step in analytic mode (round 6): jy_ProjectedStateSpace::discreteGeodesic (src/base/jy_ProjectedStateSpace.cpp:32-96)
+// as a STEP LOOP around the batched projector — per step one launch that writes every live edge's interpolated state, the
+// analytic-mode projection of all of them (the kernels above, whatever the policy picks for E states), one launch that does
+// the reference's bookkeeping between two projections (the four break tests, the state list, the running lengths) — instead
+// of a traversal kernel of its own.  max_states steps at most (an edge appends one state per step), no host synchronisation:
+// an edge that has ended projects a state that is already on the manifold (the problem's start_joint: zero iterations).
+// Operation for operation oracle/ccmp_oracle.c: orc_discrete_geodesic_ex with interpolate = true (the host truncates the list
+// at the first state its StateValidityChecker rejects — where the reference's loop breaks), resumable through carry_in /
+// carry_out like the reference-arithmetic kernel; a round budget is not enforced in this mode (ok is never 2).
+struct geo_an_ws { // the step loop's per-edge state (device workspace of the context)
+  double *prev, *scr, *dtm; // [E][14] last accepted state, [E][14] the state under projection, [E][3] dist / total / max
+  uint16_t *itp;            // [E] iterations of the step's projection
+  uint8_t *okp, *live;      // [E] its result; is the edge still under way
+};
+
+__device__ __forceinline__ double geo_distance(const double *a, const double *b)
+{ // RealVectorStateSpace::distance: sqrt of the squares summed left to right (oracle: orc_distance)
+  double d = 0.0;
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    const double diff = a[i] - b[i];
+    d = CCMP_FMA(diff, diff, d);
+  }
+  return ccmp_sqrt(d);
+}
+
+__global__ void geo_an_init_kernel(const double delta, const double lambda, const double *__restrict__ from, const double *__restrict__ to,
+                                   unsigned long long E, int max_states, double *__restrict__ states, int32_t *__restrict__ n_states,
+                                   uint8_t *__restrict__ ok, int32_t *__restrict__ newton_iters, const double *__restrict__ carry_in,
+                                   double *__restrict__ carry_out, const uint8_t *__restrict__ target_ok, geo_an_ws W)
+{
+  const unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double a[14], b[14];
+#pragma unroll
+  for (int i = 0; i < 14; i++) { a[i] = from[e * 14 + i]; b[i] = to[e * 14 + i]; }
+  if (max_states > 0) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) states[e * (unsigned long long)max_states * 14 + i] = a[i];
+  }
+  const double dist = geo_distance(a, b);
+  double total = 0.0, mx = dist * lambda;
+  if (carry_in) { total = carry_in[2 * e]; mx = carry_in[2 * e + 1]; }
+  if (carry_out) { carry_out[2 * e] = total; carry_out[2 * e + 1] = mx; }
+  newton_iters[e] = 0;
+  n_states[e] = 1;
+  bool live = true;
+  if (target_ok && !target_ok[e]) { ok[e] = 0; live = false; } // checkMotion: isSatisfied(to) failed — false, only `from` in the list
+  else if (carry_in ? !(dist >= delta) : dist <= delta) { ok[e] = (uint8_t)(dist <= delta); live = false; }
+  W.live[e] = live ? 1 : 0;
+  W.dtm[3 * e] = dist; W.dtm[3 * e + 1] = total; W.dtm[3 * e + 2] = mx;
+#pragma unroll
+  for (int i = 0; i < 14; i++) W.prev[e * 14 + i] = a[i];
+}
+
+struct geo_an_start { double q[14]; };
+
+// the next state of every live edge: WrapperStateSpace::interpolate(previous, to, delta / dist) (KinematicChain.h:145-171; oracle:
+// orc_interpolate); an edge that has ended gets the problem's start state (f = 0 exactly: the projector leaves at once)
+__global__ void geo_an_prepare_kernel(const double delta, const double *__restrict__ to, unsigned long long E, const geo_an_start S, geo_an_ws W)
+{
+  const unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const double pi = 3.14159265358979323846;
+  if (!W.live[e]) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) W.scr[e * 14 + i] = S.q[i];
+    return;
+  }
+  const double t = delta / W.dtm[3 * e];
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    const double f = W.prev[e * 14 + i];
+    double diff = to[e * 14 + i] - f, v;
+    if (ccmp_abs(diff) <= pi) v = CCMP_FMA(diff, t, f);
+    else {
+      if (diff > 0.0) diff = 2.0 * pi - diff;
+      else diff = -2.0 * pi - diff;
+      v = CCMP_FMA(-diff, t, f);
+      if (v > pi) v -= 2.0 * pi;
+      else if (v < -pi) v += 2.0 * pi;
+    }
+    W.scr[e * 14 + i] = v;
+  }
+}
+
+// between two projections: jy_ProjectedStateSpace.cpp:65-92 (the break tests, the list, the running lengths)
+__global__ void geo_an_book_kernel(const double delta, const double lambda, const double *__restrict__ to, unsigned long long E, int max_states,
+                                   double *__restrict__ states, int32_t *__restrict__ n_states, uint8_t *__restrict__ ok,
+                                   int32_t *__restrict__ newton_iters, double *__restrict__ carry_out, geo_an_ws W)
+{
+  const unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E || !W.live[e]) return;
+  double prev[14], sc[14], tg[14];
+#pragma unroll
+  for (int i = 0; i < 14; i++) { prev[i] = W.prev[e * 14 + i]; sc[i] = W.scr[e * 14 + i]; tg[i] = to[e * 14 + i]; }
+  double dist = W.dtm[3 * e], total = W.dtm[3 * e + 1];
+  const double mx = W.dtm[3 * e + 2];
+  const int it = (int)W.itp[e];
+  int its = newton_iters[e] + it, n = n_states[e];
+  bool go_on = W.okp[e] != 0; // !project(scratch) -> break (interpolate = true: no validity test on the device)
+  double step = 0.0;
+  if (go_on) { step = geo_distance(prev, sc); go_on = !(step > lambda * delta); }
+  const double total_before = total;
+  if (go_on) { total += step; go_on = !(total > mx); }
+  double new_dist = dist;
+  if (go_on) { new_dist = geo_distance(sc, tg); go_on = !(new_dist >= dist); }
+  if (go_on && n >= max_states) { // the accepted state finds the list full: the continuation projects it again
+    n_states[e] = max_states + 1;
+    newton_iters[e] = its - it;
+    if (carry_out) { carry_out[2 * e] = total_before; carry_out[2 * e + 1] = mx; }
+    ok[e] = 0;
+    W.live[e] = 0;
+    return;
+  }
+  if (go_on) {
+    dist = new_dist;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+      W.prev[e * 14 + i] = sc[i];
+      states[(e * (unsigned long long)max_states + (unsigned long long)n) * 14 + i] = sc[i];
+    }
+    n++;
+    go_on = dist >= delta; // } while (dist >= tolerance)
+  }
+  n_states[e] = n;
+  newton_iters[e] = its;
+  W.dtm[3 * e] = dist; W.dtm[3 * e + 1] = total;
+  if (!go_on) {
+    if (carry_out) { carry_out[2 * e] = total; carry_out[2 * e + 1] = mx; }
+    ok[e] = (uint8_t)(dist <= delta);
+    W.live[e] = 0;
+  }
+}
+
 } // namespace
 
 extern "C" hipError_t ccmp_launch_clear_words(void *words, size_t n_u32, hipStream_t st); // ccmp_kernels_fd.hip
@@ -660,5 +797,27 @@ extern "C" hipError_t ccmp_launch_project_analytic(const ccmp_consts *K, int mod
       hipLaunchKernelGGL((project_row16_kernel<false>), dim3(latency_blocks), dim3(64), 0, st, *K, srcmode, q_in, q_out, ok, iters, q_ambient,
                          (unsigned long long)B, lat_tickets, seed, first, pool, count);
   }
+  return hipGetLastError();
+}
+
+// the extend step's step loop in analytic mode: which = 0 init, 1 prepare, 2 bookkeeping (ws: seven device pointers of the
+// context's workspace — prev, scr, dtm, itp, okp, live; start14: the problem's start_joint)
+extern "C" hipError_t ccmp_launch_geodesic_analytic_step(int which, double delta, double lambda, const double *from, const double *to, size_t E,
+                                                         int max_states, double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters,
+                                                         const double *carry_in, double *carry_out, const uint8_t *target_ok, void *const *ws,
+                                                         const double *start14, hipStream_t st)
+{
+  geo_an_ws W{(double *)ws[0], (double *)ws[1], (double *)ws[2], (uint16_t *)ws[3], (uint8_t *)ws[4], (uint8_t *)ws[5]};
+  const dim3 grid((unsigned)((E + 127) / 128)), block(128);
+  if (which == 0)
+    hipLaunchKernelGGL(geo_an_init_kernel, grid, block, 0, st, delta, lambda, from, to, (unsigned long long)E, max_states, states, n_states, ok,
+                       newton_iters, carry_in, carry_out, target_ok, W);
+  else if (which == 1) {
+    geo_an_start S;
+    for (int i = 0; i < 14; i++) S.q[i] = start14[i];
+    hipLaunchKernelGGL(geo_an_prepare_kernel, grid, block, 0, st, delta, to, (unsigned long long)E, S, W);
+  } else
+    hipLaunchKernelGGL(geo_an_book_kernel, grid, block, 0, st, delta, lambda, to, (unsigned long long)E, max_states, states, n_states, ok,
+                       newton_iters, carry_out, W);
   return hipGetLastError();
 }

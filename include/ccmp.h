@@ -285,7 +285,11 @@ int ccmp_compute_t_wo_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *
  * max_states + 1 (ok[e] = 0): repeat it with a larger buffer before anything is concluded from it (the adapter and the
  * Python mirror do) — a creeping edge (observed: 952 accepted states, each a hair closer to the target) must not hold
  * a whole launch, and a cut list must never look complete.  Runs as the reference does with interpolate == true; for
- * interpolate == false the host truncates at the first state its StateValidityChecker rejects. */
+ * interpolate == false the host truncates at the first state its StateValidityChecker rejects.
+ * With jacobian_mode = CCMP_JAC_ANALYTIC the traversal is a step loop around the batched analytic projector (at most max_states steps of
+ * three launches each, no host synchronisation): the same lists, counts, flags and carries as the analytic mode's CPU restatement, bit for
+ * bit; newton_iters must be given, a round budget (ccmp_geodesic_batch_ex) is not enforced in that mode (ok is never 2), the resident
+ * service does not serve it. */
 int ccmp_geodesic_batch(ccmp_ctx *ctx, const ccmp_problem *p, const double *from, const double *to, size_t E, int max_states,
                         double *states, int32_t *n_states, uint8_t *ok, int32_t *newton_iters, void *hip_stream);
 /* The same, resumable.  carry_out (nullable, [E][2]) receives what a continuation needs: the running length and the

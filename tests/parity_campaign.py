@@ -102,7 +102,7 @@ for obj, tol, seed, mode, N, variant in cases:
     entry["sampler_rows_bit_identical"] = int((sq.cpu().numpy().view(np.uint64) == sq_cpu.view(np.uint64)).all(axis=1).sum())
     entry["sampler_samples"] = n2
     entry["sampler_ok_mismatches"] = int((sok.cpu().numpy() != sok_cpu).sum())
-    # extend step (reference arithmetic only): near-neighbour edges from valid projected states, GPU batch vs the oracle's
+    # extend step (reference arithmetic; the analytic mode's step loop is covered by tests/test_gpu_callers.py): near-neighbour edges from valid projected states, GPU batch vs the oracle's
     # batch driver; a list that does not fit is reported as max_states + 1 by both
     ne, same_edges, nst = 0, 0, np.zeros(1)
     if mode == 0:

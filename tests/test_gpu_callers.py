@@ -689,3 +689,53 @@ def test_geodesic_batches_beyond_the_resident_blocks(gpu_ctx, oracle_det):
     for k in range(192):
         m = min(int(n_cpu[k]), cap)
         assert np.array_equal(got[0][E - 192 + k, :m].cpu().numpy().view(np.uint64), s_cpu[k, :m].view(np.uint64))
+
+
+@pytest.mark.parametrize("E,small", [(700, None), (3000, 0), (20000, None)])
+def test_extend_step_in_analytic_mode_is_bitwise_the_oracles(gpu_ctx, oracle_det, E, small):
+    """discreteGeodesic / checkMotion with jacobian_mode = CCMP_JAC_ANALYTIC (round 6): the library runs the reference's traversal
+    (jy_ProjectedStateSpace.cpp:32-96) as a step loop around the batched analytic projector — interpolated states of every live edge,
+    their projection in place, the bookkeeping between two projections — through the latency kernel alone and through the lane-pair
+    kernel with its hand-over.  State lists, counts, flags and Newton totals bit for bit the oracle's traversal in its analytic mode,
+    on growTree-shaped edges (src/planner/stefanBiPRM.cpp:307-351); a list that is full reports max_states + 1 and is CONTINUED
+    from its last stored state through carry_in to the states of one uninterrupted traversal; checkMotion tests isSatisfied(to) first."""
+    import torch
+    from test_gpu_parity import _constraint, _oracle_problem
+    from closed_chain_motion_planner_amd import _lib
+
+    c = _constraint("Wine_Bottle", gpu_ctx, mode=1)
+    P = _oracle_problem(oracle_det, c)
+    assert P.jacobian_mode == 1
+    q, okq, _, _ = c.sample_project_batch(0x7E0, 0, 8 * E, want_iters=False)
+    frm = q[okq == 1][:E].contiguous()
+    assert frm.shape[0] == E
+    to, _, _, _ = c.sample_near_project_batch(0x7E1, 0, frm, 0.6, E, want_iters=False)
+    to[5] = frm[5] + 0.01          # an edge within delta: true at once, only `from`
+    to[6] = to[6] + 0.4            # a target off the manifold (checkMotion's first test)
+    maxs = 6                       # short lists: several edges overflow
+    if small is not None:
+        gpu_ctx.set_option("analytic_small_batch", small)
+    try:
+        st, n, ok, its, carry = c.discrete_geodesic_batch(frm, to, maxs, want_carry=True)
+        stc, nc_, okc, itc = c.discrete_geodesic_batch(frm, to, maxs, check_target=True)
+        whole = c.continue_geodesics(to, st, n, ok, its, carry, maxs)
+    finally:
+        gpu_ctx.set_option("analytic_small_batch", _lib.get_option(None, "analytic_small_batch"))
+    torch.cuda.synchronize()
+    f_h, t_h = frm.cpu().numpy(), to.cpu().numpy()
+    so, no, oko, ito = oracle_det.discrete_geodesic_batch(P, f_h, t_h, maxs, NCPU)
+    st_h, n_h, ok_h, it_h = st.cpu().numpy(), n.cpu().numpy(), ok.cpu().numpy(), its.cpu().numpy()
+    assert np.array_equal(n_h, no) and np.array_equal(ok_h, oko) and np.array_equal(it_h, ito)
+    assert int((n_h == maxs + 1).sum()) > 0 and n_h[5] == 1 and ok_h[5] == 1
+    live = np.arange(maxs)[None, :] < np.minimum(n_h, maxs)[:, None]
+    assert np.array_equal(st_h[live].view(np.uint64), so[live].view(np.uint64))
+    # checkMotion: the same, except where isSatisfied(to) fails
+    sat = np.array([oracle_det.is_satisfied(P, t_h[e]) for e in range(E)], dtype=bool)
+    nc_h, okc_h = nc_.cpu().numpy(), okc.cpu().numpy()
+    assert not sat[6] and nc_h[6] == 1 and okc_h[6] == 0
+    assert np.array_equal(nc_h[sat], n_h[sat]) and np.array_equal(okc_h[sat], ok_h[sat]) and (nc_h[~sat] == 1).all() and (okc_h[~sat] == 0).all()
+    # continuation: every edge that did not fit, whole, against the oracle's uninterrupted traversal
+    assert len(whole) == int((n_h == maxs + 1).sum())
+    for e, (st_e, ok_e, its_e) in list(whole.items())[:200]:
+        okf, stf, itf = oracle_det.discrete_geodesic(P, f_h[e], t_h[e], interpolate=True, max_states=4096)
+        assert stf.shape == st_e.shape and np.array_equal(np.ascontiguousarray(st_e).view(np.uint64), stf.view(np.uint64)) and bool(ok_e) == okf and its_e == itf, e

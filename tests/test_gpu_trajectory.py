@@ -11,11 +11,11 @@
     1e-6 rad must be shown to be ill-conditioned — a last-bit perturbation of its endpoints moves the det oracle's own result
     by > 1e-7 rad — and is counted as a threshold flip when the iteration totals differ (SURVEY.md §7.4);
     a well-conditioned edge that differs fails the test.
-(3) The same two pins for the ANALYTIC fast mode (exact Jacobian, closed-form Gram step): the extend step exists in reference
-    arithmetic only inside the library, so the traversal is composed here from the reference's loop
+(3) The same two pins for the ANALYTIC fast mode (exact Jacobian, closed-form Gram step): through the library's own extend step
+    in that mode (a step loop around the batched projector), and with the traversal composed here from the reference's loop
     (jy_ProjectedStateSpace.cpp:32-96: interpolate, the break tests, the state list — the oracle's interpolate / distance on the
-    host) around the GPU's analytic-mode `project` of every step, all edges of a step in one batch, through both of the
-    mode's kernels.
+    host) around the GPU's analytic-mode `project` of every step, all edges of a step in one batch, through each of the
+    mode's two kernels.
 """
 import numpy as np
 import pytest
@@ -77,7 +77,7 @@ def _gpu_geodesic_stepwise(c, O, P, frm, to, maxs):
     return st, n, dist <= delta, its
 
 
-@pytest.mark.parametrize("mode", ["fd", "analytic-latency-kernel", "analytic-lane-pair-kernel"])
+@pytest.mark.parametrize("mode", ["fd", "analytic-latency-kernel", "analytic-lane-pair-kernel", "analytic-library-extend-step"])
 @pytest.mark.parametrize("obj", sorted(RECORDED_SEGMENTS))
 def test_recorded_paths_are_reproduced_on_the_gpu(gpu_ctx, oracle_det, obj, mode):
     """debug/Wine_Bottle_path.txt:1-30, debug/dumbbell_path.txt:1-9 — outputs of the reference's own discreteGeodesic + project —
@@ -95,7 +95,9 @@ def test_recorded_paths_are_reproduced_on_the_gpu(gpu_ctx, oracle_det, obj, mode
     frm = np.array([rows[a] for a, _ in segs])
     to = np.array([rows[b] for _, b in segs])
     gpu_ctx.set_option("analytic_small_batch", 0 if mode == "analytic-lane-pair-kernel" else _lib.get_option(None, "analytic_small_batch"))
-    geodesic = _gpu_geodesic if mode == "fd" else (lambda c_, f_, t_, m_: _gpu_geodesic_stepwise(c_, oracle_det, P, f_, t_, m_))
+    # "analytic-library-extend-step": the library's own discreteGeodesic in analytic mode (a step loop around the batched projector,
+    # csrc/ccmp_kernels_fast.hip); the other two analytic variants compose the traversal here, around `project`, one kernel each
+    geodesic = _gpu_geodesic if mode in ("fd", "analytic-library-extend-step") else (lambda c_, f_, t_, m_: _gpu_geodesic_stepwise(c_, oracle_det, P, f_, t_, m_))
     try:
         _recorded_paths_body(c, oracle_det, P, obj, segs, rows, frm, to, geodesic)
     finally:
@@ -135,7 +137,10 @@ def _compare_with_libm(c, oracle_det, oracle_libm, frm, to, maxs, label, analyti
     Pl = _oracle_problem(oracle_libm, c)
     Pd = _oracle_problem(oracle_det, c)
     if analytic:  # the GPU runs the fast mode; the yardstick stays the glibc build of the REFERENCE arithmetic
-        st, n, ok, its = _gpu_geodesic_stepwise(c, oracle_det, Pd, frm, to, maxs)
+        st, n, ok, its = _gpu_geodesic(c, frm, to, maxs)  # the library's extend step in analytic mode
+        st2, n2, ok2, its2 = _gpu_geodesic_stepwise(c, oracle_det, Pd, frm, to, maxs)  # ... and the traversal composed around `project`: the same
+        assert np.array_equal(n, n2) and np.array_equal(its, its2) and np.array_equal(ok.astype(bool), ok2)
+        assert all(np.array_equal(st[e, : n[e]].view(np.uint64), st2[e, : n[e]].view(np.uint64)) for e in range(len(frm)))
         Pl.jacobian_mode = 0
         Pd.jacobian_mode = 0
     else:
