@@ -664,6 +664,8 @@ def flatten_for_the_driver(line, B):
             "c3_calibrated_analytic_per_s": get(sec, "c3_calibrated", "analytic_projections_per_s"),
             "extend_calibrated_first_pass_edges_per_s": get(sec, "c3_calibrated", "extend_first_pass_edges_per_s"),
             "extend_calibrated_bitwise": get(sec, "c3_calibrated", "extend_parity_vs_det_oracle", "bit_identical"),
+            "extend_analytic_edges_per_s": get(sec, "extend_analytic", "edges_per_s"),
+            "extend_analytic_bitwise": get(sec, "extend_analytic", "parity_vs_det_oracle", "bit_identical"),
             "analytic_mode_per_s": sec.get("analytic_mode_projections_per_s"),
             "analytic_bitwise": get(sec, "analytic_mode", "parity_vs_det_oracle", "bit_identical"),
             "analytic_bitwise_samples": get(sec, "analytic_mode", "parity_vs_det_oracle", "samples"),
@@ -1149,8 +1151,38 @@ def secondary(args, c, ctx, B, torch, cfg_path):
     st.setTolerance(5e-4, 2.5e-3)
     out["stefan_batch%d_tol_5e-4_2.5e-3" % B] = quick(st, CCMP_JAC_FD, B, 3, check=True, obj="stefan")
     out["discrete_geodesic"] = geodesic()
+
+    def extend_analytic(n_edges=16384, first_pass=16):
+        # the same growTree-shaped workload through the extend step in ANALYTIC mode (a step loop around the batched analytic
+        # projector): lists of 16 states, no round budget in that mode; 256 edges against the oracle's analytic traversal
+        c.setJacobianMode(CCMP_JAC_FD)
+        q, ok, _, _ = c.sample_project_batch(0x6E0, 0, 8 * n_edges, want_iters=False)
+        frm = q[ok == 1][:n_edges].contiguous()
+        to, _, _, _ = c.sample_near_project_batch(0x6E1, 0, frm, 0.6, n_edges, want_iters=False)
+        c.setJacobianMode(CCMP_JAC_ANALYTIC)
+        try:
+            call = lambda: c.discrete_geodesic_batch(frm, to, first_pass)
+            sec = timed(call, 5)
+            st, n, gok, its = call()
+            res = {"edges_per_s": int((n <= first_pass).sum().item()) / sec, "ms": sec * 1e3, "edges": n_edges, "overflowed_edges": int((n > first_pass).sum().item())}
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_binding import Oracle
+
+            Od = Oracle("det")
+            Pd = checker_problem(Od, args.obj, c.problem)
+            m = 256
+            sc, nc, okc, itc = Od.discrete_geodesic_batch(Pd, frm[:m].cpu().numpy(), to[:m].cpu().numpy(), first_pass, threads)
+            st_h, n_h = st[:m].cpu().numpy(), n[:m].cpu().numpy()
+            live = np.arange(first_pass)[None, :] < np.minimum(n_h, first_pass)[:, None]
+            res["parity_vs_det_oracle"] = {"edges": m, "bit_identical": bool(np.array_equal(n_h, nc) and np.array_equal(gok[:m].cpu().numpy(), okc)
+                                                                                 and np.array_equal(its[:m].cpu().numpy(), itc)
+                                                                                 and np.array_equal(st_h[live].view(np.uint64), sc[live].view(np.uint64)))}
+            return res
+        finally:
+            c.setJacobianMode(main_mode)
+
     out["proxy_clearance"] = proxy_clearance()
-    for name, fn in (("host_buffer", host_buffer), ("c1_dumbbell", c1_dumbbell), ("c3_calibrated", c3_calibrated)):
+    for name, fn in (("host_buffer", host_buffer), ("c1_dumbbell", c1_dumbbell), ("c3_calibrated", c3_calibrated), ("extend_analytic", extend_analytic)):
         try:
             out[name] = fn()
         except Exception as e:  # secondaries must not take the headline line down

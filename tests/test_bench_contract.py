@@ -109,7 +109,7 @@ FLAT_CONFIG = ("c1_dumbbell_cpu_single_thread_per_s", "c1_dumbbell_gpu_per_s", "
                "c4_stefan_per_s", "c4_stefan_tight_per_s", "c4_bitwise", "extend_first_pass_edges_per_s", "extend_first_pass_ms",
                "extend_unfinished_edges", "extend_complete_ms", "extend_bitwise", "growtree_5_edges_ms", "single_project_us",
                "single_project_near_manifold_us", "host_buffer_pageable_per_s", "host_buffer_pinned_per_s", "analytic_mode_per_s",
-               "c3_calibrated_per_s", "c3_calibrated_bitwise", "c3_calibrated_analytic_per_s", "extend_calibrated_first_pass_edges_per_s", "extend_calibrated_bitwise", "analytic_bitwise", "analytic_bitwise_samples", "analytic_mode_2m_per_s", "analytic_mode_4096_per_s",
+               "c3_calibrated_per_s", "c3_calibrated_bitwise", "c3_calibrated_analytic_per_s", "extend_calibrated_first_pass_edges_per_s", "extend_calibrated_bitwise", "extend_analytic_edges_per_s", "extend_analytic_bitwise", "analytic_bitwise", "analytic_bitwise_samples", "analytic_mode_2m_per_s", "analytic_mode_4096_per_s",
                "proxy_clearance_states_per_s", "extend_bulk_65536_edges_per_s", "extend_bulk_65536_ms", "extend_bulk_bitwise", "extend_cpu_edges_per_s", "extend_cpu_threads", "growtree_5_edges_cpu_single_thread_ms",
                "single_project_cpu_us", "single_project_near_manifold_cpu_us", "single_project_resident_us", "single_project_near_manifold_resident_us",
                "single_is_satisfied_us", "single_is_satisfied_resident_us", "single_function_us", "single_function_resident_us", "single_resident_bitwise",
@@ -145,6 +145,7 @@ def test_flat_keys_are_first_level_scalars():
                                   "bulk": {"edges_per_s": 15.9e6, "ms": 4.1, "parity_vs_det_oracle": {"bit_identical": True}},
                                   "parity_vs_det_oracle": {"bit_identical": True, "continued_edges": {"bit_identical": True}}},
             "proxy_clearance": {"states_per_s": 6.6e8},
+            "extend_analytic": {"edges_per_s": 2.0e7, "ms": 0.8, "parity_vs_det_oracle": {"edges": 256, "bit_identical": True}},
             "c3_calibrated": {"projections_per_s": 14.0e6, "analytic_projections_per_s": 1.5e8, "parity_vs_det_oracle": {"bit_identical": True, "samples": 2048},
                               "extend_first_pass_edges_per_s": 9.0e6, "extend_parity_vs_det_oracle": {"bit_identical": True, "edges": 256}},
             "host_buffer": {"pageable": {"projections_per_s": 14.5e6}, "pinned": {"projections_per_s": 13.2e6}},
