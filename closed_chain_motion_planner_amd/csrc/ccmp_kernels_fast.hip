@@ -16,10 +16,12 @@
 // each runs its own 7-joint chain (sines, cosines, frames, joint axes z_i and origins o_i in the arm's base frame) and its
 // seven Jacobian columns; the two tool poses cross inside the pair by DPP quad_perm broadcasts, the three Gram sums by a
 // quad_perm swap.  Half the per-lane state of a one-sample-per-lane layout (round 5: 256 VGPRs + 198 AGPRs of spill
-// space, one wavefront per SIMD, 34 % VALU issue): three to four wavefronts per SIMD, no scratch, no AGPR traffic.
+// space, one wavefront per SIMD, 34 % VALU issue): 142 registers, three wavefronts per SIMD, no scratch, no AGPR traffic.
 // Lanes whose sample is done are refilled from ticket queues while their neighbours keep iterating (iteration counts
 // spread 15..250); when the queues are dry a wavefront that is mostly empty hands its live samples over (x, index,
-// counters, at the loop top) to a pool that a later launch of this same kernel packs into full wavefronts again.
+// counters, at the loop top) to a pool that the LATENCY kernel below — sixteen lanes per sample, 2.7 us per Newton round
+// where this layout needs 4 — finishes; that kernel also takes small batches alone.  The extend step in this mode is a step
+// loop around these projectors (end of the file).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -31,7 +33,7 @@ using namespace ccmp;
 namespace {
 
 constexpr int kConstsDoubles = (int)((sizeof(ccmp_consts) + 7) / 8);
-constexpr int kFastQueues = 64; // ticket words of one generation (ccmp_api.cpp allocates and clears as many per generation)
+constexpr int kFastQueues = 64; // ticket words of the lane-pair kernel: one per lane of a wavefront (ccmp_ctx.h: kAnalyticWords)
 constexpr int kPoolEntry = 18;  // hand-over record: x[14], idx, (iter, updates), norm1, norm2 (as ccmp_fd_common.h)
 
 // value of the pair's even (arm 0) / odd (arm 1) lane in both lanes; the partner's value
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(64, 3) void project_pair_kernel(const ccmp_consts K
 // operations on the same operands as in the lane-pair kernel and in the oracle (general formulas: what the STOCK
 // instantiations skip are products with exact zeros): bit-identical.  DIAG: both base frames are diag(+-1) (every shipped
 // t_wb); otherwise the base-frame product is formed from the whole hand poses by every lane.
-// Sources: 0 q_in, 1 ambient sampler, 2 the hand-over pool of the generation before.
+// Sources: 0 q_in, 1 ambient sampler, 2 the hand-over pool of the lane-pair kernel launched in front.
 constexpr int qRJ = 0, qZO = 126, qT = 210, qJ = 234, qDX = 262, qRec = 277; // doubles per sample: Rot[14][9], (z, o)[14][6], poses[2][12], J[28], fallback dx[14]; odd stride
 
 template <bool DIAG>
